@@ -1,0 +1,159 @@
+/*
+ * qhbm_engine.h -- C ABI of the MI355X-native expectation engine.
+ *
+ * This is the drop-in boundary for the hot path of google/qhbm-library:
+ *
+ *   qhbmlib/inference/qnn.py:82-84   QuantumInference._expectation(circuits,
+ *       symbol_names, symbol_values, observables)            <- qhbm_expectation
+ *   qhbmlib/inference/qnn.py:134-138 tfq.layers.Expectation()(circuits,
+ *       symbol_names, symbol_values, operators) forward       <- qhbm_expectation
+ *   qhbmlib/inference/qnn.py:90-99   adjoint backward of that op (VJP w.r.t.
+ *       symbol_values, summed through the tile of qnn.py:75-76) <- qhbm_expectation_vjp
+ *   qhbmlib/inference/qnn.py:168,192-194 ParameterShift gradient circuits
+ *       (rule restated in baselines/train.py:190-240)          <- qhbm_expectation_vjp(method=1)
+ *   qhbmlib/models/circuit.py:129-136 bit-injection X**bit     <- `bits` argument
+ *   qhbmlib/models/circuit.py:138-178 append / inverse         <- gate list passed to qhbm_set_circuit
+ *
+ * Conventions
+ *   - qubit q in [0, n_qubits). Qubit 0 is the MOST significant bit of a basis
+ *     index (cirq big-endian; qhbmlib/inference/ebm.py:445-447).
+ *   - `bits` is row-major [U, n_qubits] int8; column j initialises qubit j.
+ *   - exponent of a gate: t = scalar * params[param_idx] + offset
+ *     (param_idx < 0: t = offset).  Inverse circuit = reversed gate list with
+ *     scalar and offset negated (circuit.py:164-176).
+ *   - Pauli masks are in QUBIT space: bit q of x_mask set  <=> X or Y on qubit q,
+ *     bit q of z_mask set <=> Z or Y on qubit q.
+ *   - All pointers named d_* are DEVICE pointers (HBM); the others are host
+ *     pointers.  Work is enqueued on `stream` (a hipStream_t cast to void*;
+ *     NULL = default stream) and is asynchronous with respect to the host.
+ *   - Every function returns 0 on success, non-zero on error;
+ *     qhbm_last_error() gives the message.  No exceptions cross the ABI.
+ *   - One engine per device; an engine is not thread-safe, distinct engines are
+ *     independent.
+ */
+#ifndef QHBM_ENGINE_H_
+#define QHBM_ENGINE_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QHBM_ABI_VERSION 1
+
+/* Gate kinds: the one-parameter "power gate" families of cirq 0.14.1 that
+ * tensorflow-quantum 0.6.1 serialises.  A gate is
+ * G**t with the cirq matrix convention
+ *     G**t = sum_k exp(i*pi*t*e_k) P_k      (eigen-exponents e_k, projectors P_k)
+ * Global phases exp(i*pi*t*global_shift) never change an expectation value and
+ * are not represented.  rx/ry/rz(theta) are XPOW/YPOW/ZPOW with scalar = 1/pi.
+ * PhasedXPow, FSim and PhasedISwapPow are lowered by the host to products of
+ * these kinds. */
+enum qhbm_gate_kind {
+  QHBM_GATE_I = 0,
+  QHBM_GATE_XPOW = 1,
+  QHBM_GATE_YPOW = 2,
+  QHBM_GATE_ZPOW = 3,
+  QHBM_GATE_HPOW = 4,
+  QHBM_GATE_CZPOW = 5,
+  QHBM_GATE_CNOTPOW = 6,  /* q0 = control, q1 = target */
+  QHBM_GATE_SWAPPOW = 7,
+  QHBM_GATE_ISWAPPOW = 8,
+  QHBM_GATE_XXPOW = 9,
+  QHBM_GATE_YYPOW = 10,
+  QHBM_GATE_ZZPOW = 11,
+  QHBM_GATE_KIND_COUNT = 12
+};
+
+typedef struct qhbm_gate {
+  int32_t kind;      /* enum qhbm_gate_kind */
+  int32_t q0;        /* first qubit */
+  int32_t q1;        /* second qubit, -1 for one-qubit gates */
+  int32_t param_idx; /* index into params[], -1 = constant exponent */
+  float scalar;      /* exponent = scalar * params[param_idx] + offset */
+  float offset;
+} qhbm_gate;
+
+/* Gradient method for qhbm_expectation_vjp. */
+enum qhbm_grad_method {
+  QHBM_GRAD_ADJOINT = 0,        /* adjoint sweep, what tfq.layers.Expectation uses */
+  QHBM_GRAD_PARAMETER_SHIFT = 1 /* two shifted forwards per gate occurrence */
+};
+
+typedef struct qhbm_engine qhbm_engine;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int qhbm_abi_version(void);
+/* Creates an engine bound to HIP device `device`. */
+int qhbm_create(int device, qhbm_engine** out);
+void qhbm_destroy(qhbm_engine* h);
+/* Message of the last failing call on this engine (or of qhbm_create when
+ * h == NULL).  Valid until the next call. */
+const char* qhbm_last_error(const qhbm_engine* h);
+
+/* ---- model ------------------------------------------------------------- */
+/* Installs the total circuit (bit-injector excluded: it is the `bits`
+ * argument).  Replaces tfq serialisation + append_circuit
+ * (circuit.py:129-160).  The gate list is copied. */
+int qhbm_set_circuit(qhbm_engine* h, int n_qubits, int n_gates,
+                     const qhbm_gate* gates, int n_params);
+
+/* Installs n_ops observables; op k is sum_{j in [term_offsets[k],
+ * term_offsets[k+1])} coeffs[j] * Pauli(x_masks[j], z_masks[j]).
+ * Replaces the tiled PauliSum protos of qnn.py:133.  Arrays are copied. */
+int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
+                         const float* coeffs, const uint64_t* x_masks,
+                         const uint64_t* z_masks);
+
+/* ---- tuning ------------------------------------------------------------ */
+/* Optional knobs (name -> value); unknown names are an error.
+ *   "tile_qubits"   log2 amplitudes of one LDS tile (10..14), 0 = auto
+ *   "chunk_states"  states simulated per launch group, 0 = auto
+ */
+int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value);
+
+/* Bytes of device workspace the engine will hold for a batch of U states
+ * (forward only, or forward + adjoint when with_vjp != 0). */
+int qhbm_workspace_bytes(qhbm_engine* h, int U, int with_vjp, size_t* out);
+
+/* ---- hot path ---------------------------------------------------------- */
+/* out[u, k] = <x_u| C(params)^dagger  O_k  C(params) |x_u>
+ *   d_bits   [U, n_qubits] int8   (device)
+ *   d_params [n_params]    float  (device)
+ *   d_out    [U, n_ops]    float  (device) */
+int qhbm_expectation(qhbm_engine* h, const int8_t* d_bits, int U,
+                     const float* d_params, float* d_out, void* stream);
+
+/* Values plus one vector-Jacobian product:
+ *   d_grad[p] = sum_{u,k} d_upstream[u,k] * d out[u,k] / d params[p]
+ *   d_upstream [U, n_ops] float, d_out_vals [U, n_ops] float (may be NULL),
+ *   d_grad [n_params] float (overwritten). */
+int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U,
+                         const float* d_params, const float* d_upstream,
+                         float* d_out_vals, float* d_grad, int method,
+                         void* stream);
+
+/* Full Jacobian d_jac[u, k, p] (tests / small n only; adjoint). */
+int qhbm_expectation_jacobian(qhbm_engine* h, const int8_t* d_bits, int U,
+                              const float* d_params, float* d_out_vals,
+                              float* d_jac, void* stream);
+
+/* ---- introspection (tests, bench, DESIGN.md numbers) ------------------- */
+/* Number of HBM passes (kernel launches over the state) the scheduler emits
+ * for one forward of the installed circuit + observables. */
+int qhbm_num_passes(qhbm_engine* h, int* forward_passes, int* backward_passes);
+/* Human-readable description of the schedule, written into buf. */
+int qhbm_describe_schedule(qhbm_engine* h, char* buf, size_t buf_len);
+/* Accumulated HIP-event time (ms) and launch count of the pass kernels since
+ * the last call with reset != 0.  Timing is only recorded when the option
+ * "profile_events" is non-zero; it synchronises the stream. */
+int qhbm_kernel_time_ms(qhbm_engine* h, int reset, double* fwd_ms,
+                        int64_t* fwd_launches, double* bwd_ms,
+                        int64_t* bwd_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QHBM_ENGINE_H_ */
