@@ -1,0 +1,504 @@
+// engine.cpp -- C ABI (include/qhbm_engine.h) on top of the scheduler and the
+// gfx950 kernels.  This is the boundary a QuantumInference subclass binds
+// (/root/reference/qhbmlib/inference/qnn.py:82-84,114-139).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/qhbm_engine.h"
+#include "kernels.h"
+#include "program.h"
+#include "schedule.h"
+
+using namespace qhbm;
+
+namespace {
+
+std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t reserve(size_t count) {
+    if (count <= n) return hipSuccess;
+    release();
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  hipError_t upload(const std::vector<T>& h) {
+    hipError_t e = reserve(h.size());
+    if (e != hipSuccess || h.empty()) return e;
+    return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+  }
+};
+
+struct DevicePlan {
+  Plan plan;
+  std::vector<PassArgs> args;
+  DevBuf<uint32_t> prog, tables;
+  DevBuf<CoefJob> jobs;
+  DevBuf<float> coef;
+  DevBuf<double> angles;
+  bool uploaded = false;
+};
+
+struct TimedEvent {
+  hipEvent_t a, b;
+  int kind;  // 0 forward pass, 1 adjoint pass
+};
+
+}  // namespace
+
+struct qhbm_engine {
+  int device = -1;
+  std::string err;
+  Model model;
+  bool have_circuit = false;
+  // options
+  int opt_tile = 0, opt_adj_tile = 0, opt_profile = 0;
+  int64_t opt_chunk = 0;
+  int64_t opt_budget_mb = 16384;
+  // plans
+  bool plans_valid = false;
+  DevicePlan fwd, adj;
+  DevBuf<DevTerm> terms;
+  DevBuf<float2> psi, lam;
+  DevBuf<float> state_grad, slot_factor, vals_tmp, vals_p, vals_m, upstream_tmp;
+  DevBuf<int> param_slot_begin, param_slots;
+  std::vector<TimedEvent> events;
+  std::vector<TimedEvent> free_events;
+};
+
+namespace {
+
+int fail(qhbm_engine* h, const std::string& msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return 1;
+}
+
+#define HIPCHK(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess)                                                              \
+      return fail(h, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+  } while (0)
+
+int need_device(qhbm_engine* h) {
+  if (h->device < 0)
+    return fail(h, "engine was created without a device (planning only); no CPU fallback exists");
+  HIPCHK(hipSetDevice(h->device));
+  return 0;
+}
+
+void fill_args(const Plan& plan, const Model& m, std::vector<PassArgs>* args, std::vector<uint32_t>* prog,
+               std::vector<uint32_t>* tables) {
+  args->clear();
+  prog->clear();
+  tables->clear();
+  for (const Pass& p : plan.passes) {
+    PassArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.flags = p.flags;
+    a.n = uint32_t(plan.n_eff);
+    a.c = uint32_t(p.c);
+    a.n_nonlocal = uint32_t(p.nonlocal_pos.size());
+    a.prog_off = uint32_t(prog->size());
+    a.spread_off = uint32_t(tables->size());
+    a.n_ops = uint32_t(m.n_ops);
+    a.slot_base = uint32_t(p.slot_base);
+    a.n_slots = uint32_t(p.n_slots);
+    for (size_t i = 0; i < p.nonlocal_pos.size(); ++i) a.nonlocal_pos[i] = uint8_t(p.nonlocal_pos[i]);
+    for (size_t i = 0; i < p.local_pos.size(); ++i) a.local_pos[i] = uint8_t(p.local_pos[i]);
+    prog->insert(prog->end(), p.prog.begin(), p.prog.end());
+    tables->insert(tables->end(), p.spread.begin(), p.spread.end());
+    args->push_back(a);
+  }
+}
+
+int build_plans(qhbm_engine* h) {
+  if (h->plans_valid) return 0;
+  if (!h->have_circuit) return fail(h, "qhbm_set_circuit has not been called");
+  if (h->model.n_ops > kMaxOps) return fail(h, "too many observables (max 1024)");
+  std::string err;
+  if (!build_plan(h->model, h->opt_tile, false, &h->fwd.plan, &err)) return fail(h, "forward plan: " + err);
+  if (!build_plan(h->model, h->opt_adj_tile, true, &h->adj.plan, &err)) return fail(h, "adjoint plan: " + err);
+  h->fwd.uploaded = h->adj.uploaded = false;
+  h->plans_valid = true;
+  return 0;
+}
+
+int upload_plan(qhbm_engine* h, DevicePlan* d) {
+  if (d->uploaded) return 0;
+  std::vector<uint32_t> prog, tables;
+  fill_args(d->plan, h->model, &d->args, &prog, &tables);
+  HIPCHK(d->prog.upload(prog));
+  HIPCHK(d->tables.upload(tables));
+  HIPCHK(d->jobs.upload(d->plan.jobs));
+  HIPCHK(d->coef.reserve(size_t(d->plan.n_coef_floats) + 64));
+  HIPCHK(d->angles.reserve(size_t(d->plan.n_angles) + 1));
+  d->uploaded = true;
+  return 0;
+}
+
+int upload_model(qhbm_engine* h) {
+  if (int rc = build_plans(h)) return rc;
+  if (int rc = upload_plan(h, &h->fwd)) return rc;
+  if (int rc = upload_plan(h, &h->adj)) return rc;
+  if (!h->terms.p) {
+    std::vector<DevTerm> t;
+    for (const PauliTerm& pt : h->model.terms)
+      t.push_back(DevTerm{pt.coeff, pt.x, pt.z, uint32_t(pt.ny), uint32_t(pt.op)});
+    HIPCHK(h->terms.upload(t));
+  }
+  // parameter -> slots map for the adjoint reduction
+  const Plan& ap = h->adj.plan;
+  std::vector<int> begin(size_t(h->model.n_params) + 1, 0), slots(ap.slot_gate.size());
+  for (int g : ap.slot_gate) ++begin[size_t(h->model.gates[g].param_idx) + 1];
+  for (size_t p = 0; p < size_t(h->model.n_params); ++p) begin[p + 1] += begin[p];
+  std::vector<int> cursor(begin.begin(), begin.end() - 1);
+  for (size_t s = 0; s < ap.slot_gate.size(); ++s) slots[size_t(cursor[h->model.gates[ap.slot_gate[s]].param_idx]++)] = int(s);
+  HIPCHK(h->param_slot_begin.upload(begin));
+  HIPCHK(h->param_slots.upload(slots));
+  HIPCHK(h->slot_factor.upload(ap.slot_factor));
+  return 0;
+}
+
+size_t state_bytes(const qhbm_engine* h) { return size_t(8) << h->fwd.plan.n_eff; }
+
+uint32_t chunk_states(const qhbm_engine* h, int U) {
+  if (h->opt_chunk > 0) return uint32_t(std::min<int64_t>(h->opt_chunk, U));
+  const size_t budget = size_t(h->opt_budget_mb) << 20;
+  const size_t fit = std::max<size_t>(1, budget / state_bytes(h));
+  return uint32_t(std::min<size_t>(fit, size_t(U)));
+}
+
+hipEvent_t* timer_begin(qhbm_engine* h, int kind, hipStream_t s) {
+  if (!h->opt_profile) return nullptr;
+  TimedEvent ev;
+  if (!h->free_events.empty()) { ev = h->free_events.back(); h->free_events.pop_back(); }
+  else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
+  ev.kind = kind;
+  (void)hipEventRecord(ev.a, s);
+  h->events.push_back(ev);
+  return &h->events.back().b;
+}
+void timer_end(hipEvent_t* e, hipStream_t s) { if (e) (void)hipEventRecord(*e, s); }
+
+// Forward passes for one chunk.
+int run_forward_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_t cs, float* d_out,
+                      bool keep_state, hipStream_t stream) {
+  DevicePlan& d = h->fwd;
+  const size_t np = d.plan.passes.size();
+  bool measure_only_after = false;
+  for (const Pass& p : d.plan.passes) measure_only_after |= p.is_measure_only;
+  for (size_t i = 0; i < np; ++i) {
+    const Pass& p = d.plan.passes[i];
+    PassArgs a = d.args[i];
+    a.flags = p.flags & PASS_INIT_BASIS;
+    if (!p.is_measure_only && (!p.completes_circuit || keep_state || measure_only_after)) a.flags |= PASS_STORE;
+    hipEvent_t* ev = timer_begin(h, 0, stream);
+    HIPCHK(launch_pass_fwd(d.plan.K, a, cs, h->psi.p, d_bits, h->model.n, d.prog.p, d.tables.p, d.coef.p,
+                           d.angles.p, d_out, s0, stream));
+    timer_end(ev, stream);
+  }
+  return 0;
+}
+
+int ensure_state_buffers(qhbm_engine* h, uint32_t cs, bool with_lam) {
+  const size_t amps = size_t(cs) << h->fwd.plan.n_eff;
+  HIPCHK(h->psi.reserve(amps));
+  if (with_lam) HIPCHK(h->lam.reserve(amps));
+  return 0;
+}
+
+int forward(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, float* d_out,
+            int shift_gate, double shift, hipStream_t stream) {
+  DevicePlan& d = h->fwd;
+  HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, d.angles.p, shift_gate,
+                           shift, stream));
+  if (h->model.n_ops) HIPCHK(hipMemsetAsync(d_out, 0, size_t(U) * h->model.n_ops * sizeof(float), stream));
+  const uint32_t cs = chunk_states(h, U);
+  if (int rc = ensure_state_buffers(h, cs, false)) return rc;
+  for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += cs) {
+    const uint32_t c = std::min<uint32_t>(cs, uint32_t(U) - s0);
+    if (int rc = run_forward_chunk(h, d_bits, s0, c, d_out, false, stream)) return rc;
+  }
+  return 0;
+}
+
+// values + per-state gradient slots (adjoint) for a given upstream.
+int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params,
+                  const float* d_upstream, float* d_out_vals, hipStream_t stream) {
+  DevicePlan& f = h->fwd;
+  DevicePlan& b = h->adj;
+  const uint32_t n_slots = uint32_t(b.plan.slot_gate.size());
+  HIPCHK(launch_prep_coefs(f.jobs.p, int(f.plan.jobs.size()), d_params, f.coef.p, f.angles.p, -1, 0.0, stream));
+  HIPCHK(launch_prep_coefs(b.jobs.p, int(b.plan.jobs.size()), d_params, b.coef.p, b.angles.p, -1, 0.0, stream));
+  HIPCHK(hipMemsetAsync(d_out_vals, 0, size_t(U) * h->model.n_ops * sizeof(float), stream));
+  HIPCHK(h->state_grad.reserve(size_t(U) * std::max<uint32_t>(n_slots, 1)));
+  HIPCHK(hipMemsetAsync(h->state_grad.p, 0, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), stream));
+  uint32_t cs = chunk_states(h, U);
+  if (h->opt_chunk <= 0) cs = std::max<uint32_t>(1, cs / 2);  // two buffers per state
+  if (int rc = ensure_state_buffers(h, cs, true)) return rc;
+  const uint32_t n_eff = uint32_t(f.plan.n_eff);
+  for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += cs) {
+    const uint32_t c = std::min<uint32_t>(cs, uint32_t(U) - s0);
+    if (int rc = run_forward_chunk(h, d_bits, s0, c, d_out_vals, true, stream)) return rc;
+    HIPCHK(launch_apply_observable(h->psi.p, h->lam.p, n_eff, c, h->terms.p, uint32_t(h->model.terms.size()),
+                                   d_upstream, uint32_t(h->model.n_ops), s0, stream));
+    for (size_t i = 0; i < b.plan.passes.size(); ++i) {
+      hipEvent_t* ev = timer_begin(h, 1, stream);
+      HIPCHK(launch_pass_adj(b.plan.K, b.args[i], c, h->psi.p, h->lam.p, b.prog.p, b.tables.p, b.coef.p,
+                             b.angles.p, h->state_grad.p, n_slots, s0, stream));
+      timer_end(ev, stream);
+    }
+  }
+  return 0;
+}
+
+int check_call(qhbm_engine* h, int U) {
+  if (!h) return 1;
+  if (int rc = need_device(h)) return rc;
+  if (U < 0) return fail(h, "negative batch size");
+  if (h->model.n_ops <= 0) return fail(h, "qhbm_set_observables has not been called");
+  return upload_model(h);
+}
+
+}  // namespace
+
+// ================================================================================
+extern "C" {
+
+int qhbm_abi_version(void) { return QHBM_ABI_VERSION; }
+
+int qhbm_create(int device, qhbm_engine** out) {
+  if (!out) return fail(nullptr, "out is NULL");
+  std::unique_ptr<qhbm_engine> h(new qhbm_engine());
+  h->device = device;
+  if (device >= 0) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || device >= count)
+      return fail(nullptr, std::string("no HIP device ") + std::to_string(device) + ": " +
+                               (e != hipSuccess ? hipGetErrorString(e) : "index out of range"));
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  }
+  *out = h.release();
+  return 0;
+}
+
+void qhbm_destroy(qhbm_engine* h) {
+  if (!h) return;
+  if (h->device >= 0) (void)hipSetDevice(h->device);
+  for (auto& ev : h->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  for (auto& ev : h->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  delete h;
+}
+
+const char* qhbm_last_error(const qhbm_engine* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int qhbm_set_circuit(qhbm_engine* h, int n_qubits, int n_gates, const qhbm_gate* gates, int n_params) {
+  if (!h) return 1;
+  if (n_qubits < 1 || n_qubits > 31) return fail(h, "n_qubits must be in [1, 31]");
+  if (n_gates < 0 || n_params < 0 || (n_gates > 0 && !gates)) return fail(h, "bad gate list");
+  static_assert(sizeof(qhbm_gate) == sizeof(Gate), "ABI gate layout");
+  Model m = h->model;
+  if (m.n != n_qubits) { m.terms.clear(); m.n_ops = 0; }
+  m.n = n_qubits;
+  m.n_params = n_params;
+  m.gates.resize(size_t(n_gates));
+  if (n_gates) std::memcpy(m.gates.data(), gates, size_t(n_gates) * sizeof(Gate));
+  Plan probe;
+  std::string err;
+  Model no_obs = m;
+  no_obs.terms.clear();
+  no_obs.n_ops = 0;
+  if (!build_plan(no_obs, h->opt_tile, false, &probe, &err)) return fail(h, err);
+  h->model = std::move(m);
+  h->have_circuit = true;
+  h->plans_valid = false;
+  return 0;
+}
+
+int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets, const float* coeffs,
+                         const uint64_t* x_masks, const uint64_t* z_masks) {
+  if (!h) return 1;
+  if (!h->have_circuit) return fail(h, "call qhbm_set_circuit first");
+  if (n_ops < 1 || n_ops > kMaxOps || !term_offsets) return fail(h, "n_ops must be in [1, 1024]");
+  const int n = h->model.n;
+  std::vector<PauliTerm> terms;
+  for (int k = 0; k < n_ops; ++k) {
+    if (term_offsets[k + 1] < term_offsets[k]) return fail(h, "term_offsets must be non-decreasing");
+    for (int j = term_offsets[k]; j < term_offsets[k + 1]; ++j) {
+      const uint64_t x = x_masks[j], z = z_masks[j];
+      if ((x | z) >> n) return fail(h, "Pauli mask addresses a qubit >= n_qubits");
+      PauliTerm t;
+      t.coeff = coeffs[j];
+      t.x = t.z = 0;
+      for (int q = 0; q < n; ++q) {
+        if (x >> q & 1) t.x |= 1u << (n - 1 - q);
+        if (z >> q & 1) t.z |= 1u << (n - 1 - q);
+      }
+      t.ny = __builtin_popcountll(x & z);
+      t.op = k;
+      terms.push_back(t);
+    }
+  }
+  h->model.n_ops = n_ops;
+  h->model.terms = std::move(terms);
+  h->plans_valid = false;
+  h->terms.release();
+  return 0;
+}
+
+int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
+  if (!h || !name) return 1;
+  const std::string k(name);
+  if (k == "tile_qubits") { h->opt_tile = int(value); h->plans_valid = false; }
+  else if (k == "adjoint_tile_qubits") { h->opt_adj_tile = int(value); h->plans_valid = false; }
+  else if (k == "chunk_states") h->opt_chunk = value;
+  else if (k == "workspace_budget_mb") h->opt_budget_mb = std::max<int64_t>(1, value);
+  else if (k == "profile_events") h->opt_profile = int(value);
+  else return fail(h, "unknown option '" + k + "'");
+  return 0;
+}
+
+int qhbm_workspace_bytes(qhbm_engine* h, int U, int with_vjp, size_t* out) {
+  if (!h || !out) return 1;
+  if (int rc = build_plans(h)) return rc;
+  uint32_t cs = chunk_states(h, U);
+  if (with_vjp && h->opt_chunk <= 0) cs = std::max<uint32_t>(1, cs / 2);
+  size_t b = size_t(cs) * state_bytes(h) * (with_vjp ? 2 : 1);
+  if (with_vjp) b += size_t(U) * h->adj.plan.slot_gate.size() * sizeof(float);
+  *out = b;
+  return 0;
+}
+
+int qhbm_expectation(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, float* d_out,
+                     void* stream) {
+  if (int rc = check_call(h, U)) return rc;
+  if (U == 0) return 0;
+  return forward(h, d_bits, U, d_params, d_out, -1, 0.0, static_cast<hipStream_t>(stream));
+}
+
+int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params,
+                         const float* d_upstream, float* d_out_vals, float* d_grad, int method,
+                         void* stream) {
+  if (int rc = check_call(h, U)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int P = h->model.n_params;
+  if (U == 0) {
+    if (P) HIPCHK(hipMemsetAsync(d_grad, 0, size_t(P) * sizeof(float), s));
+    return 0;
+  }
+  const size_t nv = size_t(U) * h->model.n_ops;
+  if (!d_out_vals) {
+    HIPCHK(h->vals_tmp.reserve(nv));
+    d_out_vals = h->vals_tmp.p;
+  }
+  if (method == QHBM_GRAD_ADJOINT) {
+    if (int rc = adjoint_sweep(h, d_bits, U, d_params, d_upstream, d_out_vals, s)) return rc;
+    HIPCHK(launch_reduce_grad(h->state_grad.p, uint32_t(U), uint32_t(h->adj.plan.slot_gate.size()),
+                              h->param_slot_begin.p, h->param_slots.p, h->slot_factor.p, d_grad, P, 0, s));
+    return 0;
+  }
+  if (method != QHBM_GRAD_PARAMETER_SHIFT) return fail(h, "unknown gradient method");
+  // tfq ParameterShift / baselines/train.py:190-240: exponent c*s -> shift the gate's
+  // exponent by +-1/2, weight +-pi*c/2, one pair of forwards per gate occurrence.
+  if (int rc = forward(h, d_bits, U, d_params, d_out_vals, -1, 0.0, s)) return rc;
+  if (P) HIPCHK(hipMemsetAsync(d_grad, 0, size_t(P) * sizeof(float), s));
+  HIPCHK(h->vals_p.reserve(nv));
+  HIPCHK(h->vals_m.reserve(nv));
+  for (size_t g = 0; g < h->model.gates.size(); ++g) {
+    const Gate& G = h->model.gates[g];
+    if (G.param_idx < 0 || G.kind == QHBM_GATE_I) continue;
+    if (G.kind == QHBM_GATE_ISWAPPOW)
+      return fail(h, "the two-term parameter-shift rule does not apply to ISWAPPOW; use the adjoint method");
+    if (int rc = forward(h, d_bits, U, d_params, h->vals_p.p, int(g), +0.5, s)) return rc;
+    if (int rc = forward(h, d_bits, U, d_params, h->vals_m.p, int(g), -0.5, s)) return rc;
+    HIPCHK(launch_shift_accumulate(h->vals_p.p, h->vals_m.p, d_upstream, uint32_t(nv),
+                                   float(1.5707963267948966 * double(G.scalar)), d_grad + G.param_idx, s));
+  }
+  return 0;
+}
+
+int qhbm_expectation_jacobian(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params,
+                              float* d_out_vals, float* d_jac, void* stream) {
+  if (int rc = check_call(h, U)) return rc;
+  if (U == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int T = h->model.n_ops, P = h->model.n_params;
+  const size_t nv = size_t(U) * T;
+  HIPCHK(h->upstream_tmp.reserve(nv));
+  if (!d_out_vals) {
+    HIPCHK(h->vals_tmp.reserve(nv));
+    d_out_vals = h->vals_tmp.p;
+  }
+  std::vector<float> up(nv);
+  for (int k = 0; k < T; ++k) {
+    for (size_t i = 0; i < nv; ++i) up[i] = (int(i % size_t(T)) == k) ? 1.f : 0.f;
+    HIPCHK(hipMemcpyAsync(h->upstream_tmp.p, up.data(), nv * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (int rc = adjoint_sweep(h, d_bits, U, d_params, h->upstream_tmp.p, d_out_vals, s)) return rc;
+    HIPCHK(launch_scatter_jac(h->state_grad.p, uint32_t(U), uint32_t(h->adj.plan.slot_gate.size()),
+                              h->param_slot_begin.p, h->param_slots.p, h->slot_factor.p, d_jac, uint32_t(T),
+                              uint32_t(k), uint32_t(P), s));
+  }
+  return 0;
+}
+
+int qhbm_num_passes(qhbm_engine* h, int* forward_passes, int* backward_passes) {
+  if (!h) return 1;
+  if (int rc = build_plans(h)) return rc;
+  if (forward_passes) *forward_passes = int(h->fwd.plan.passes.size());
+  if (backward_passes) *backward_passes = int(h->adj.plan.passes.size());
+  return 0;
+}
+
+int qhbm_describe_schedule(qhbm_engine* h, char* buf, size_t buf_len) {
+  if (!h || !buf || !buf_len) return 1;
+  if (int rc = build_plans(h)) return rc;
+  const std::string s = describe_plan(h->fwd.plan) + describe_plan(h->adj.plan);
+  std::snprintf(buf, buf_len, "%s", s.c_str());
+  return 0;
+}
+
+int qhbm_kernel_time_ms(qhbm_engine* h, int reset, double* fwd_ms, int64_t* fwd_launches, double* bwd_ms,
+                        int64_t* bwd_launches) {
+  if (!h) return 1;
+  double ms[2] = {0.0, 0.0};
+  int64_t cnt[2] = {0, 0};
+  if (h->device >= 0 && !h->events.empty()) {
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventSynchronize(h->events.back().b));
+    for (auto& ev : h->events) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, ev.a, ev.b) == hipSuccess) { ms[ev.kind] += t; ++cnt[ev.kind]; }
+    }
+  }
+  if (fwd_ms) *fwd_ms = ms[0];
+  if (fwd_launches) *fwd_launches = cnt[0];
+  if (bwd_ms) *bwd_ms = ms[1];
+  if (bwd_launches) *bwd_launches = cnt[1];
+  if (reset) {
+    h->free_events.insert(h->free_events.end(), h->events.begin(), h->events.end());
+    h->events.clear();
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// kernels.h -- launch entry points of kernels.hip (host side).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "program.h"
+#include "schedule.h"
+
+namespace qhbm {
+
+struct DevTerm {  // one Pauli term, amplitude-index bit space
+  float coeff;
+  uint32_t x, z;
+  uint32_t ny;
+  uint32_t op;
+};
+
+size_t fwd_lds_bytes(int K);
+size_t adj_lds_bytes(int K);
+
+hipError_t launch_pass_fwd(int K, const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
+                           int n_user, const uint32_t* prog, const uint32_t* tables, const float* coef,
+                           const double* angles, float* out, uint32_t state0, hipStream_t stream);
+hipError_t launch_pass_adj(int K, const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
+                           const uint32_t* prog, const uint32_t* tables, const float* coef,
+                           const double* angles, float* state_grad, uint32_t n_slots_total,
+                           uint32_t state0, hipStream_t stream);
+hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
+                                   const DevTerm* terms, uint32_t n_terms, const float* upstream,
+                                   uint32_t n_ops, uint32_t state0, hipStream_t stream);
+hipError_t launch_prep_coefs(const CoefJob* jobs, int n_jobs, const float* params, float* coef,
+                             double* angles, int shift_gate, double shift, hipStream_t stream);
+hipError_t launch_reduce_grad(const float* state_grad, uint32_t U, uint32_t n_slots,
+                              const int* param_slot_begin, const int* param_slots,
+                              const float* slot_factor, float* grad, int n_params, int accumulate,
+                              hipStream_t stream);
+hipError_t launch_scatter_jac(const float* state_grad, uint32_t U, uint32_t n_slots,
+                              const int* param_slot_begin, const int* param_slots,
+                              const float* slot_factor, float* jac, uint32_t n_ops, uint32_t op,
+                              uint32_t n_params, hipStream_t stream);
+hipError_t launch_shift_accumulate(const float* vp, const float* vm, const float* upstream,
+                                   uint32_t count, float weight, float* grad_p, hipStream_t stream);
+
+}  // namespace qhbm

@@ -1,0 +1,98 @@
+// schedule.h -- host-side lowering of a circuit + observables into passes.
+//
+// Replaces what the reference leaves to TFQ's op: proto parsing, symbol
+// resolution and qsim gate fusion per circuit per call
+// (/root/reference/qhbmlib/inference/qnn.py:134-138).
+// Here the structure is scheduled ONCE per circuit; only the small
+// coefficient buffer changes from call to call.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "program.h"
+
+namespace qhbm {
+
+struct Gate {  // layout-compatible with the C ABI's qhbm_gate
+  int32_t kind, q0, q1, param_idx;
+  float scalar, offset;
+};
+
+struct PauliTerm {
+  float coeff;
+  uint32_t x, z;  // masks in amplitude-index bit space
+  int ny;         // number of Y factors
+  int op;         // observable this term belongs to
+};
+
+struct LoweredOp {
+  int type = LOW_SKIP;  // LoweredType
+  int kind = 0;         // qhbm_gate_kind
+  int gate = -1;        // index into the circuit
+  uint32_t bits = 0;    // index bits touched
+  int b0 = -1, b1 = -1; // index bit of q0 / q1
+  bool par = false;     // LOW_DIAG: parity term (ZZPOW) instead of AND term
+  int angle_idx = -1;   // LOW_DIAG: index into the angle buffer
+};
+
+// One entry of the per-call coefficient preparation.
+struct CoefJob {
+  int32_t op_kind;    // qhbm_gate_kind
+  int32_t mop;        // MOP_X / MOP_Y / MOP_MAT1 / MOP_MAT2 / 0 = diagonal angle
+  int32_t gate;       // circuit gate (for exponent and parameter-shift)
+  int32_t param_idx;
+  float scalar, offset;
+  int32_t out_off;    // float offset in the coefficient buffer (or angle index)
+  int32_t swap;       // MAT2: matrix index bits swapped
+  int32_t dagger;     // write U^dagger (adjoint plan), followed by the generator
+};
+
+struct Pass {
+  int K = 0, R = 0, c = 0;
+  uint32_t flags = 0;
+  std::vector<int> local_pos;     // ascending index-bit positions, size K
+  std::vector<int> nonlocal_pos;  // ascending, size n - K
+  std::vector<uint32_t> prog;     // instruction words, OP_END terminated
+  std::vector<uint32_t> spread;   // spread_hi[2^(K-c)]
+  bool is_measure_only = false;
+  bool completes_circuit = false;
+  // statistics (DESIGN.md / bench roofline accounting)
+  int n_mat_ops = 0, n_diag_terms = 0, n_rounds = 0, n_diag_ops = 0;
+  int n_meas_groups = 0, n_meas_terms = 0;
+  int slot_base = 0, n_slots = 0;
+};
+
+struct Plan {
+  int n = 0, n_eff = 0, K = 0, R = 0;
+  bool adjoint = false;
+  std::vector<Pass> passes;
+  std::vector<CoefJob> jobs;
+  int n_coef_floats = 0;
+  int n_angles = 0;
+  // adjoint: gradient slot -> (gate, chain-rule factor to the exponent)
+  std::vector<int> slot_gate;
+  std::vector<float> slot_factor;
+};
+
+struct Model {
+  int n = 0;
+  int n_params = 0;
+  std::vector<Gate> gates;
+  int n_ops = 0;
+  std::vector<PauliTerm> terms;
+};
+
+// Tile geometry for a given tile size.
+inline int round_bits_for(int K) { return K >= 13 ? 5 : 4; }
+inline int threads_for(int K) { return 1 << (K - round_bits_for(K)); }
+
+// Builds the forward plan (circuit passes + measurement) or, with adjoint =
+// true, the backward plan over (psi, lambda) tile pairs.  `tile_bits` = 0
+// selects automatically.  Returns false and fills `err` on failure.
+bool build_plan(const Model& m, int tile_bits, bool adjoint, Plan* out,
+                std::string* err);
+
+std::string describe_plan(const Plan& p);
+
+}  // namespace qhbm

@@ -1,0 +1,248 @@
+"""ctypes binding of the HIP engine's C ABI (include/qhbm_engine.h).
+
+There is no CPU fallback: if `libqhbm_engine.so` is missing or no GPU is
+present, every compute call raises.  torch is used for device memory and
+streams only.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libqhbm_engine.so")
+
+# Gate kinds: values of enum qhbm_gate_kind.
+GATE_I = 0
+GATE_XPOW = 1
+GATE_YPOW = 2
+GATE_ZPOW = 3
+GATE_HPOW = 4
+GATE_CZPOW = 5
+GATE_CNOTPOW = 6
+GATE_SWAPPOW = 7
+GATE_ISWAPPOW = 8
+GATE_XXPOW = 9
+GATE_YYPOW = 10
+GATE_ZZPOW = 11
+
+GRAD_ADJOINT = 0
+GRAD_PARAMETER_SHIFT = 1
+
+ABI_SYMBOLS = (
+    "qhbm_abi_version", "qhbm_create", "qhbm_destroy", "qhbm_last_error",
+    "qhbm_set_circuit", "qhbm_set_observables", "qhbm_set_option",
+    "qhbm_workspace_bytes", "qhbm_expectation", "qhbm_expectation_vjp",
+    "qhbm_expectation_jacobian", "qhbm_num_passes", "qhbm_describe_schedule",
+    "qhbm_kernel_time_ms",
+)
+
+
+class QhbmGate(ctypes.Structure):
+  _fields_ = [("kind", ctypes.c_int32), ("q0", ctypes.c_int32),
+              ("q1", ctypes.c_int32), ("param_idx", ctypes.c_int32),
+              ("scalar", ctypes.c_float), ("offset", ctypes.c_float)]
+
+
+class EngineError(RuntimeError):
+  pass
+
+
+_lib = None
+
+
+def load_library():
+  """Loads libqhbm_engine.so (built by `__graft_entry__.build()`)."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise EngineError(
+        f"{LIB_PATH} not found: build the HIP extension first "
+        "(python -c 'import __graft_entry__ as g; g.build()'); "
+        "there is no CPU fallback.")
+  lib = ctypes.CDLL(LIB_PATH)
+  vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+  lib.qhbm_abi_version.restype = i32
+  lib.qhbm_create.argtypes = [i32, ctypes.POINTER(vp)]
+  lib.qhbm_destroy.argtypes = [vp]
+  lib.qhbm_destroy.restype = None
+  lib.qhbm_last_error.argtypes = [vp]
+  lib.qhbm_last_error.restype = ctypes.c_char_p
+  lib.qhbm_set_circuit.argtypes = [vp, i32, i32, ctypes.POINTER(QhbmGate), i32]
+  lib.qhbm_set_observables.argtypes = [vp, i32, vp, vp, vp, vp]
+  lib.qhbm_set_option.argtypes = [vp, ctypes.c_char_p, i64]
+  lib.qhbm_workspace_bytes.argtypes = [vp, i32, i32,
+                                       ctypes.POINTER(ctypes.c_size_t)]
+  lib.qhbm_expectation.argtypes = [vp, vp, i32, vp, vp, vp]
+  lib.qhbm_expectation_vjp.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp]
+  lib.qhbm_expectation_jacobian.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+  lib.qhbm_num_passes.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+  lib.qhbm_describe_schedule.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
+  lib.qhbm_kernel_time_ms.argtypes = [
+      vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64),
+      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
+  _lib = lib
+  return lib
+
+
+class Engine:
+  """One engine per device.  `device=None` makes a planning-only engine
+  (schedules can be inspected, compute calls raise)."""
+
+  def __init__(self, device=0):
+    self._lib = load_library()
+    self._h = ctypes.c_void_p()
+    dev = -1 if device is None else int(device)
+    if self._lib.qhbm_create(dev, ctypes.byref(self._h)) != 0:
+      raise EngineError(self._lib.qhbm_last_error(None).decode())
+    self.device = None if device is None else torch.device("cuda", dev)
+    self.n_qubits = 0
+    self.n_params = 0
+    self.n_ops = 0
+
+  def close(self):
+    if getattr(self, "_h", None) is not None and self._h:
+      self._lib.qhbm_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def _check(self, rc):
+    if rc != 0:
+      raise EngineError(self._lib.qhbm_last_error(self._h).decode())
+
+  # ---- model -------------------------------------------------------------
+  def set_circuit(self, n_qubits, gates, n_params):
+    """gates: iterable of (kind, q0, q1, param_idx, scalar, offset)."""
+    gates = list(gates)
+    arr = (QhbmGate * max(len(gates), 1))()
+    for i, (kind, q0, q1, pidx, scalar, offset) in enumerate(gates):
+      arr[i] = QhbmGate(int(kind), int(q0), int(q1), int(pidx), float(scalar),
+                        float(offset))
+    self._check(
+        self._lib.qhbm_set_circuit(self._h, int(n_qubits), len(gates), arr,
+                                   int(n_params)))
+    if n_qubits != self.n_qubits:
+      self.n_ops = 0
+    self.n_qubits, self.n_params = int(n_qubits), int(n_params)
+
+  def set_observables(self, ops):
+    """ops: list of ops, each a list of (coeff, x_mask, z_mask), qubit space."""
+    offsets = [0]
+    coeffs, xs, zs = [], [], []
+    for op in ops:
+      for coeff, x, z in op:
+        coeffs.append(coeff)
+        xs.append(x)
+        zs.append(z)
+      offsets.append(len(coeffs))
+    off = np.asarray(offsets, dtype=np.int32)
+    cf = np.asarray(coeffs, dtype=np.float32)
+    xm = np.asarray(xs, dtype=np.uint64)
+    zm = np.asarray(zs, dtype=np.uint64)
+    self._check(
+        self._lib.qhbm_set_observables(self._h, len(ops), off.ctypes.data,
+                                       cf.ctypes.data, xm.ctypes.data,
+                                       zm.ctypes.data))
+    self.n_ops = len(ops)
+
+  def set_option(self, name, value):
+    self._check(self._lib.qhbm_set_option(self._h, name.encode(), int(value)))
+
+  # ---- introspection -------------------------------------------------------
+  def num_passes(self):
+    f, b = ctypes.c_int(), ctypes.c_int()
+    self._check(self._lib.qhbm_num_passes(self._h, ctypes.byref(f),
+                                          ctypes.byref(b)))
+    return f.value, b.value
+
+  def describe_schedule(self):
+    buf = ctypes.create_string_buffer(1 << 16)
+    self._check(self._lib.qhbm_describe_schedule(self._h, buf, len(buf)))
+    return buf.value.decode()
+
+  def workspace_bytes(self, num_states, with_vjp=False):
+    out = ctypes.c_size_t()
+    self._check(
+        self._lib.qhbm_workspace_bytes(self._h, int(num_states), int(with_vjp),
+                                       ctypes.byref(out)))
+    return out.value
+
+  def kernel_time_ms(self, reset=True):
+    f, b = ctypes.c_double(), ctypes.c_double()
+    nf, nb = ctypes.c_int64(), ctypes.c_int64()
+    self._check(
+        self._lib.qhbm_kernel_time_ms(self._h, int(reset), ctypes.byref(f),
+                                      ctypes.byref(nf), ctypes.byref(b),
+                                      ctypes.byref(nb)))
+    return {"fwd_ms": f.value, "fwd_launches": nf.value, "bwd_ms": b.value,
+            "bwd_launches": nb.value}
+
+  # ---- hot path --------------------------------------------------------------
+  def _prep(self, bits, params):
+    if self.device is None:
+      raise EngineError("planning-only engine: no device, no CPU fallback")
+    bits = torch.as_tensor(bits).to(device=self.device, dtype=torch.int8)
+    bits = bits.contiguous()
+    if bits.dim() != 2 or bits.shape[1] != self.n_qubits:
+      raise ValueError(
+          f"bitstrings must have shape [batch, {self.n_qubits}], got "
+          f"{tuple(bits.shape)}")
+    params = torch.as_tensor(params).to(device=self.device,
+                                        dtype=torch.float32).contiguous()
+    if params.numel() != self.n_params:
+      raise ValueError(f"expected {self.n_params} parameters")
+    return bits, params
+
+  def _stream(self):
+    return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+  def expectation(self, bits, params):
+    bits, params = self._prep(bits, params)
+    out = torch.empty((bits.shape[0], self.n_ops), dtype=torch.float32,
+                      device=self.device)
+    with torch.cuda.device(self.device):
+      self._check(
+          self._lib.qhbm_expectation(self._h, bits.data_ptr(), bits.shape[0],
+                                     params.data_ptr(), out.data_ptr(),
+                                     self._stream()))
+    return out
+
+  def expectation_vjp(self, bits, params, upstream, method=GRAD_ADJOINT):
+    bits, params = self._prep(bits, params)
+    upstream = torch.as_tensor(upstream).to(
+        device=self.device, dtype=torch.float32).contiguous()
+    if tuple(upstream.shape) != (bits.shape[0], self.n_ops):
+      raise ValueError("upstream must have shape [batch, n_ops]")
+    vals = torch.empty((bits.shape[0], self.n_ops), dtype=torch.float32,
+                       device=self.device)
+    grad = torch.zeros((self.n_params,), dtype=torch.float32,
+                       device=self.device)
+    with torch.cuda.device(self.device):
+      self._check(
+          self._lib.qhbm_expectation_vjp(self._h, bits.data_ptr(),
+                                         bits.shape[0], params.data_ptr(),
+                                         upstream.data_ptr(), vals.data_ptr(),
+                                         grad.data_ptr(), int(method),
+                                         self._stream()))
+    return vals, grad
+
+  def expectation_jacobian(self, bits, params):
+    bits, params = self._prep(bits, params)
+    vals = torch.empty((bits.shape[0], self.n_ops), dtype=torch.float32,
+                       device=self.device)
+    jac = torch.zeros((bits.shape[0], self.n_ops, self.n_params),
+                      dtype=torch.float32, device=self.device)
+    with torch.cuda.device(self.device):
+      self._check(
+          self._lib.qhbm_expectation_jacobian(self._h, bits.data_ptr(),
+                                              bits.shape[0], params.data_ptr(),
+                                              vals.data_ptr(), jac.data_ptr(),
+                                              self._stream()))
+    return vals, jac

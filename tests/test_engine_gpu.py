@@ -1,0 +1,251 @@
+"""Parity of the HIP engine (through the C ABI) against the numpy oracle.
+
+GPU only.  Tolerances: the engine computes in fp32 (complex64 statevectors);
+the oracle in complex128.  Bars (SURVEY.md 8c / BASELINE.md):
+  expectations  |d| <= 1e-5 * sum|c_k|  (n <= 12),  5e-5 * sum|c_k| deeper/larger
+  gradients     |d| <= 1e-4 * max(1, ||grad||_inf)
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qhbm_oracle as O
+from qhbmlib_amd import _engine as E
+
+pytestmark = pytest.mark.gpu
+
+
+def _op_norm(ops):
+  return np.array([sum(abs(c) for c, _, _ in op) for op in ops])
+
+
+def _engine(n, gates, n_params, ops, **options):
+  eng = E.Engine(0)
+  for k, v in options.items():
+    eng.set_option(k, v)
+  eng.set_circuit(n, gates, n_params)
+  eng.set_observables(ops)
+  return eng
+
+
+def _random_bits(rng, count, n):
+  return rng.integers(0, 2, size=(count, n)).astype(np.int8)
+
+
+def random_circuit(rng, n, n_gates, n_params, kinds=None):
+  """Random flat circuit over every gate kind (the TFQ-serialisable set)."""
+  kinds = kinds or list(range(12))
+  gates = []
+  for _ in range(n_gates):
+    kind = int(rng.choice(kinds))
+    q0 = int(rng.integers(n))
+    q1 = -1
+    if O.gate_num_qubits(kind) == 2:
+      q1 = int(rng.integers(n - 1))
+      if q1 >= q0:
+        q1 += 1
+    if rng.random() < 0.8:
+      gates.append((kind, q0, q1, int(rng.integers(n_params)),
+                    float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-0.5, 0.5))))
+    else:
+      gates.append((kind, q0, q1, -1, 0.0, float(rng.uniform(-1, 1))))
+  return gates
+
+
+def check_values(eng, n, gates, params, bits, ops, rel=1e-5):
+  got = eng.expectation(bits, params).cpu().numpy()
+  want = O.expectation(n, gates, params, bits, ops)
+  tol = rel * np.maximum(_op_norm(ops), 1.0)
+  assert got.shape == want.shape
+  err = np.abs(got - want)
+  assert (err <= tol[None, :]).all(), f"max err {err.max()} tol {tol}"
+  return got, want
+
+
+def check_jacobian(eng, n, gates, params, bits, ops, rel=1e-4):
+  vals, jac = eng.expectation_jacobian(bits, params)
+  want_vals, want_jac = O.expectation_jacobian(n, gates, params, bits, ops)
+  scale = max(1.0, np.abs(want_jac).max())
+  np.testing.assert_allclose(jac.cpu().numpy(), want_jac, atol=rel * scale, rtol=0)
+  np.testing.assert_allclose(vals.cpu().numpy(), want_vals,
+                             atol=1e-5 * max(1.0, _op_norm(ops).max()), rtol=0)
+  return want_jac
+
+
+# ---- BASELINE.json config 1: 4-qubit TFIM, depth-2 HEA, 32 samples -----------
+def test_c1_tfim_hea_all_paths():
+  n, layers = 4, 2
+  rng = np.random.default_rng(0)
+  gates, names = O.hea_gates(n, layers, "c1")
+  params = rng.uniform(-1, 1, len(names))
+  ops = [O.tfim_ring_op(n)]
+  bits = _random_bits(rng, 32, n)
+  eng = _engine(n, gates, len(names), ops)
+  check_values(eng, n, gates, params, bits, ops)
+  want_jac = check_jacobian(eng, n, gates, params, bits, ops)
+  up = rng.normal(size=(32, 1))
+  want_grad = np.einsum("bt,btp->p", up, want_jac)
+  for method in (E.GRAD_ADJOINT, E.GRAD_PARAMETER_SHIFT):
+    vals, grad = eng.expectation_vjp(bits, params, up, method)
+    scale = max(1.0, np.abs(want_grad).max())
+    np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=1e-4 * scale, rtol=0)
+    np.testing.assert_allclose(vals.cpu().numpy(),
+                               O.expectation(n, gates, params, bits, ops), atol=1e-5 * 8)
+
+
+# ---- reference KAT through the engine: X**p (qnn_test.py:83-180) --------------
+def test_x_pow_kat():
+  n, p = 3, 0.37
+  gates = [(O.GATE_XPOW, q, -1, 0, 1.0, 0.0) for q in range(n)]
+  bits = O.all_bitstrings(n)
+  sin, cos = math.sin(math.pi * p), math.cos(math.pi * p)
+  for pauli, val, grad in (
+      ("X", lambda s: 0.0, lambda s: 0.0),
+      ("Y", lambda s: -((-1.0)**s) * sin, lambda s: -((-1.0)**s) * math.pi * cos),
+      ("Z", lambda s: ((-1.0)**s) * cos, lambda s: -((-1.0)**s) * math.pi * sin)):
+    ops = [[O.pauli_term(1.0, [(q, pauli)])] for q in range(n)]
+    eng = _engine(n, gates, 1, ops)
+    vals, jac = eng.expectation_jacobian(bits, [p])
+    np.testing.assert_allclose(vals.cpu().numpy(),
+                               [[val(s) for s in row] for row in bits], atol=1e-6)
+    np.testing.assert_allclose(jac.cpu().numpy()[:, :, 0],
+                               [[grad(s) for s in row] for row in bits], atol=2e-5)
+
+
+# ---- every gate kind, single tile ---------------------------------------------
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_all_gate_kinds_small(seed):
+  n, n_params = 5, 6
+  rng = np.random.default_rng(seed)
+  gates = random_circuit(rng, n, 40, n_params)
+  params = rng.uniform(-1, 1, n_params)
+  ops = [O.random_pauli_op(n, 6, seed + 10, p_identity=0.4), O.tfim_ring_op(n),
+         O.xxz_chain_op(n)] + O.kobe_shards(n, 2)[:4]
+  bits = O.all_bitstrings(n)
+  eng = _engine(n, gates, n_params, ops)
+  check_values(eng, n, gates, params, bits, ops)
+  check_jacobian(eng, n, gates, params, bits, ops, rel=2e-4)
+
+
+# ---- multi-tile scheduling at oracle-checkable sizes ---------------------------
+@pytest.mark.parametrize("n,tile,adj_tile", [(12, 10, 10), (13, 11, 10), (14, 12, 11), (15, 13, 12),
+                                             (15, 10, 10), (14, 14, 13)])
+def test_hea_multi_tile(n, tile, adj_tile):
+  rng = np.random.default_rng(n * 100 + tile)
+  gates, names = O.hea_gates(n, 3, "mt")
+  params = rng.uniform(-1, 1, len(names))
+  ops = [O.xxz_chain_op(n), O.tfim_ring_op(n)]
+  bits = _random_bits(rng, 3, n)
+  eng = _engine(n, gates, len(names), ops, tile_qubits=tile, adjoint_tile_qubits=adj_tile)
+  f, b = eng.num_passes()
+  if n > tile:
+    assert f > 1 and b > 1
+  check_values(eng, n, gates, params, bits, ops, rel=2e-5)
+  up = rng.normal(size=(3, 2))
+  want_vals, want_jac = O.expectation_jacobian(n, gates, params, bits, ops)
+  want_grad = np.einsum("bt,btp->p", up, want_jac)
+  _, grad = eng.expectation_vjp(bits, params, up)
+  np.testing.assert_allclose(grad.cpu().numpy(), want_grad,
+                             atol=2e-4 * max(1.0, np.abs(want_grad).max()), rtol=0)
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_all_gate_kinds_multi_tile(seed):
+  n, n_params = 12, 8
+  rng = np.random.default_rng(seed)
+  gates = random_circuit(rng, n, 60, n_params)
+  params = rng.uniform(-1, 1, n_params)
+  ops = [O.random_pauli_op(n, 12, seed, p_identity=0.7), O.xxz_chain_op(n)]
+  bits = _random_bits(rng, 2, n)
+  eng = _engine(n, gates, n_params, ops, tile_qubits=10, adjoint_tile_qubits=10)
+  check_values(eng, n, gates, params, bits, ops, rel=2e-5)
+  check_jacobian(eng, n, gates, params, bits, ops, rel=3e-4)
+
+
+# ---- BASELINE.json config 2 shape: 12 qubits, depth-8 HEA, TFIM ----------------
+def test_c2_shape_values_and_grad():
+  n, layers = 12, 8
+  rng = np.random.default_rng(12)
+  gates, names = O.hea_gates(n, layers, "c2")
+  params = rng.uniform(-1, 1, len(names))
+  ops = [O.tfim_ring_op(n)]
+  bits = _random_bits(rng, 4, n)
+  eng = _engine(n, gates, len(names), ops)
+  check_values(eng, n, gates, params, bits, ops)
+  up = rng.normal(size=(4, 1))
+  _, want_jac = O.expectation_jacobian(n, gates, params, bits, ops)
+  want_grad = np.einsum("bt,btp->p", up, want_jac)
+  _, grad = eng.expectation_vjp(bits, params, up)
+  np.testing.assert_allclose(grad.cpu().numpy(), want_grad,
+                             atol=1e-4 * max(1.0, np.abs(want_grad).max()), rtol=0)
+
+
+# ---- modular-Hamiltonian branch (qnn.py:69-72,120-127): U + V^dagger, Z shards --
+@pytest.mark.parametrize("order", [1, 2])
+def test_modular_hamiltonian_shards(order):
+  n = 6
+  rng = np.random.default_rng(order)
+  u_gates, u_names = O.hea_gates(n, 2, "u")
+  v_gates, v_names = O.hea_gates(n, 2, "v")
+  p_u = len(u_names)
+  v_shift = [(k, q0, q1, p + p_u, s, o) for (k, q0, q1, p, s, o) in v_gates]
+  total = u_gates + O.inverse_gates(v_shift)
+  params = rng.uniform(-1, 1, p_u + len(v_names))
+  shards = O.bernoulli_shards(n) if order == 1 else O.kobe_shards(n, 2)
+  bits = O.all_bitstrings(n)
+  eng = _engine(n, total, len(params), shards)
+  check_values(eng, n, total, params, bits, shards)
+  check_jacobian(eng, n, total, params, bits, shards)
+
+
+# ---- edge cases ------------------------------------------------------------------
+def test_empty_batch_and_duplicates_and_empty_circuit():
+  n = 4
+  ops = [O.tfim_ring_op(n)]
+  gates, names = O.hea_gates(n, 1, "e")
+  params = np.linspace(-0.5, 0.5, len(names))
+  eng = _engine(n, gates, len(names), ops)
+  out = eng.expectation(np.zeros((0, n), np.int8), params)
+  assert tuple(out.shape) == (0, 1)
+  bits = np.array([[1, 0, 1, 1]] * 5 + [[0, 0, 0, 0]], np.int8)
+  got = eng.expectation(bits, params).cpu().numpy()
+  np.testing.assert_allclose(got, O.expectation(n, gates, params, bits, ops), atol=1e-5)
+  assert np.all(got[:5] == got[0])
+  # no gates at all: <x| H |x>
+  eng2 = _engine(n, [], 0, ops)
+  got = eng2.expectation(bits, []).cpu().numpy()
+  np.testing.assert_allclose(got, O.expectation(n, [], [], bits, ops), atol=1e-6)
+
+
+def test_errors_are_loud():
+  eng = E.Engine(0)
+  with pytest.raises(E.EngineError):
+    eng.set_circuit(3, [(99, 0, -1, -1, 0.0, 0.0)], 0)
+  with pytest.raises(E.EngineError):
+    eng.set_circuit(3, [(O.GATE_XPOW, 5, -1, -1, 0.0, 0.0)], 0)
+  eng.set_circuit(3, [(O.GATE_XPOW, 0, -1, 0, 1.0, 0.0)], 1)
+  with pytest.raises(E.EngineError):
+    eng.expectation(np.zeros((1, 3), np.int8), [0.1])  # no observables yet
+  with pytest.raises(E.EngineError):
+    eng.set_observables([[(1.0, 1 << 3, 0)]])  # qubit 3 does not exist
+  with pytest.raises(ValueError):
+    eng.set_observables([[(1.0, 1, 0)]])
+    eng.expectation(np.zeros((1, 4), np.int8), [0.1])
+
+
+def test_chunked_execution_matches():
+  n = 11
+  rng = np.random.default_rng(4)
+  gates, names = O.hea_gates(n, 2, "ch")
+  params = rng.uniform(-1, 1, len(names))
+  ops = [O.xxz_chain_op(n)]
+  bits = _random_bits(rng, 7, n)
+  eng = _engine(n, gates, len(names), ops, tile_qubits=10, adjoint_tile_qubits=10, chunk_states=3)
+  check_values(eng, n, gates, params, bits, ops, rel=2e-5)
+  up = rng.normal(size=(7, 1))
+  _, want_jac = O.expectation_jacobian(n, gates, params, bits, ops)
+  _, grad = eng.expectation_vjp(bits, params, up)
+  want = np.einsum("bt,btp->p", up, want_jac)
+  np.testing.assert_allclose(grad.cpu().numpy(), want, atol=2e-4 * max(1, np.abs(want).max()), rtol=0)
