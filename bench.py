@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Benchmark of the expectation hot path (BASELINE.json metric).
+
+One "step" = one VQT step's engine work over one batch of synthetic input:
+values [U, 1] of the target Hamiltonian AND the adjoint vector-Jacobian
+product (the [P] gradient of the VQT loss w.r.t. the circuit parameters), for
+U EBM bitstrings already resident in HBM.  With --gpus N the batch is sharded
+over N ranks (one process per GPU, weak scaling: --states-per-gpu is fixed)
+and each step ends with the exchange the path really has: an RCCL all-reduce
+of the [P] gradient and an all-gather of the per-state expectations.
+
+  value = (states over all ranks) x (Pauli terms) / step time      [evals/s]
+
+Workload (config.workload): BASELINE.json configs[2] -- 20-qubit XXZ chain,
+depth-16 hardware-efficient ansatz, 4096 samples sharded over 8 GPUs, i.e.
+512 states per GPU; it fits one GPU, so the same per-GPU shard is the N=1
+workload.  Synthetic inputs: phi ~ U[-1,1] seeded, distinct
+seeded bitstrings (U = B exactly).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "qhbm-library_amd")):
+  if _p not in sys.path:
+    sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def hea_gates(n, layers, name="b"):
+  """tests/test_util.py:25-67 of the reference; parameters in sorted-symbol
+  order (circuit.py:201-204).  Kept here so the product bench does not import
+  the oracle for its workload."""
+  from qhbmlib_amd import _engine as E
+  names = []
+  for layer in range(layers):
+    for q in range(n):
+      names += [f"sx_{name}_{layer}_{q}", f"sz_{name}_{layer}_{q}"]
+    for k in range(len(range(0, n - 1, 2))):
+      names.append(f"sc_{name}_{layer}_{2 * k}")
+    for k in range(len(range(1, n - 1, 2))):
+      names.append(f"sc_{name}_{layer}_{2 * k + 1}")
+  order = {s: i for i, s in enumerate(sorted(names))}
+  gates = []
+  for layer in range(layers):
+    for q in range(n):
+      gates.append((E.GATE_XPOW, q, -1, order[f"sx_{name}_{layer}_{q}"], 1.0, 0.0))
+      gates.append((E.GATE_ZPOW, q, -1, order[f"sz_{name}_{layer}_{q}"], 1.0, 0.0))
+    for k, q0 in enumerate(range(0, n - 1, 2)):
+      gates.append((E.GATE_CZPOW, q0, q0 + 1, order[f"sc_{name}_{layer}_{2 * k}"], 1.0, 0.0))
+    for k, q0 in enumerate(range(1, n - 1, 2)):
+      gates.append((E.GATE_CZPOW, q0, q0 + 1, order[f"sc_{name}_{layer}_{2 * k + 1}"], 1.0, 0.0))
+  return gates, len(names)
+
+
+def xxz_op(n, delta=0.5):
+  terms = []
+  for i in range(n - 1):
+    m = (1 << i) | (1 << (i + 1))
+    terms.append((1.0, m, 0))      # X X
+    terms.append((1.0, m, m))      # Y Y
+    terms.append((delta, 0, m))    # Z Z
+  return terms
+
+
+def tfim_op(n, bias=1.0):
+  terms = [(-bias, 1 << i, 0) for i in range(n)]
+  terms += [(-1.0, 0, (1 << i) | (1 << ((i + 1) % n))) for i in range(n)]
+  return terms
+
+
+def distinct_bitstrings(n, count, seed):
+  rng = np.random.default_rng(seed)
+  if n <= 40:
+    vals = rng.choice(1 << n, size=count, replace=False) if (1 << n) >= count else rng.integers(0, 1 << n, size=count)
+  else:
+    vals = rng.integers(0, 1 << 40, size=count)
+  bits = ((vals[:, None] >> np.arange(n - 1, -1, -1)[None, :]) & 1).astype(np.int8)
+  return bits
+
+
+def cpu_baseline(n, gates, n_params, op, params, sample_states, mode):
+  """The oracle's C restatement (oracle/qhbm_cpu.c) timed on this host's cores on
+  a bounded sample of the same workload -- a reported baseline, never the product."""
+  from oracle import qhbm_cpu as C
+  if not os.path.exists(C.LIB_PATH):
+    return None
+  cores = min(C.max_threads(), os.cpu_count() or 1)
+  states = max(1, min(sample_states, cores))
+  bits = distinct_bitstrings(n, states, 999)
+  up = np.full((states, 1), 1.0 / states, np.float32)
+  t0 = time.perf_counter()
+  if mode == "forward":
+    C.expectation(n, gates, params, bits, [op], n_threads=cores)
+  else:
+    C.expectation_vjp(n, gates, params, bits, [op], up, n_threads=cores)
+  dt = time.perf_counter() - t0
+  return {
+      "value": states * len(op) / dt, "unit": "evals/s", "cores": int(min(cores, states)),
+      "kind": "port",
+      "sample": f"{states} states of the same workload ({mode} step), one state per thread, "
+                f"{dt:.2f} s wall",
+  }
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=5)
+  ap.add_argument("--warmup", type=int, default=2)
+  ap.add_argument("--qubits", type=int, default=20)
+  ap.add_argument("--layers", type=int, default=16)
+  ap.add_argument("--states-per-gpu", type=int, default=512)
+  ap.add_argument("--hamiltonian", choices=["xxz", "tfim"], default="xxz")
+  ap.add_argument("--mode", choices=["vqt", "forward"], default="vqt")
+  ap.add_argument("--tile-qubits", type=int, default=0)
+  ap.add_argument("--adjoint-tile-qubits", type=int, default=0)
+  ap.add_argument("--cpu-sample-states", type=int, default=256)
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  args = ap.parse_args()
+
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  if world != args.gpus and world > 1:
+    args.gpus = world
+  if not torch.cuda.is_available():
+    raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+  torch.cuda.set_device(local_rank)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+
+  from qhbmlib_amd import _engine as E  # pylint: disable=import-outside-toplevel
+
+  n, layers, spg = args.qubits, args.layers, args.states_per_gpu
+  gates, n_params = hea_gates(n, layers)
+  op = xxz_op(n) if args.hamiltonian == "xxz" else tfim_op(n)
+  rng = np.random.default_rng(1234)
+  params_np = rng.uniform(-1, 1, n_params).astype(np.float32)
+  all_bits = distinct_bitstrings(n, spg * world, 4321)
+  bits = torch.from_numpy(all_bits[rank * spg:(rank + 1) * spg]).cuda()
+  params = torch.from_numpy(params_np).cuda()
+  total_states = spg * world
+  upstream = torch.full((spg, 1), 1.0 / total_states, device="cuda")
+
+  eng = E.Engine(local_rank)
+  if args.tile_qubits:
+    eng.set_option("tile_qubits", args.tile_qubits)
+  if args.adjoint_tile_qubits:
+    eng.set_option("adjoint_tile_qubits", args.adjoint_tile_qubits)
+  eng.set_circuit(n, gates, n_params)
+  eng.set_observables([op])
+  eng.set_option("profile_events", 1)
+  fwd_passes, bwd_passes = eng.num_passes()
+  gathered = [torch.empty((spg, 1), device="cuda") for _ in range(world)] if world > 1 else None
+
+  def step():
+    if args.mode == "forward":
+      vals = eng.expectation(bits, params)
+      grad = None
+    else:
+      vals, grad = eng.expectation_vjp(bits, params, upstream)
+    if world > 1:
+      if grad is not None:
+        dist.all_reduce(grad)
+      dist.all_gather(gathered, vals)
+    return vals, grad
+
+  for _ in range(args.warmup):
+    step()
+  torch.cuda.synchronize()
+  eng.kernel_time_ms(reset=True)
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    vals, grad = step()
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+  kt = eng.kernel_time_ms(reset=True)
+
+  if rank == 0:
+    n_terms = len(op)
+    evals_per_step = total_states * n_terms
+    ms_per_step = dt / args.steps * 1e3
+    # ---- roofline of the dominant kernel (algorithmic bytes) ----
+    n_gate = len(gates)
+    amp = float(1 << n)
+    fwd_alg = spg * (16.0 * n_gate + 8.0 * n_terms + 8.0) * amp  # per step, this rank
+    bwd_alg = spg * 48.0 * n_gate * amp
+    use_bwd = args.mode == "vqt" and kt["bwd_ms"] >= kt["fwd_ms"]
+    if use_bwd:
+      launches, ms, alg, name = kt["bwd_launches"], kt["bwd_ms"], bwd_alg, "pass_adj_kernel"
+    else:
+      launches, ms, alg, name = kt["fwd_launches"], kt["fwd_ms"], fwd_alg, "pass_fwd_kernel"
+    per_step_launches = max(1, launches // max(1, args.steps))
+    avg_ms = ms / max(1, launches)
+    achieved = (alg / per_step_launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # physical HBM traffic of one launch if every tile is read and written once
+    io_bytes = spg * amp * 8.0 * 2.0 * (2.0 if use_bwd else 1.0)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+      try:
+        with open(tpath) as f:
+          traffic = json.load(f).get(name, {}).get("hbm_bytes_per_launch")
+      except Exception:  # pylint: disable=broad-except
+        traffic = None
+    line = {
+        "metric": "circuit-expectation evals/sec (samples×Pauli terms) at n qubits; VQT step time",
+        "value": evals_per_step / (dt / args.steps),
+        "unit": "evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"BASELINE configs[2] shard: {n}-qubit "
+                         f"{'XXZ(delta=0.5) open chain' if args.hamiltonian == 'xxz' else 'TFIM ring'}, "
+                         f"HEA depth {layers} ({n_params} params), {spg} states/GPU, "
+                         f"{'VQT step = values + adjoint VJP' if args.mode == 'vqt' else 'forward values only'}"),
+            "n_qubits": n, "layers": layers, "states_per_gpu": spg, "pauli_terms": n_terms,
+            "mode": args.mode, "parallelism": f"batch-sharded x{world}",
+            "forward_passes": fwd_passes, "adjoint_passes": bwd_passes,
+        },
+        "vqt_step_ms": ms_per_step if args.mode == "vqt" else None,
+        "kernel_ms_per_step": {"forward": kt["fwd_ms"] / args.steps, "adjoint": kt["bwd_ms"] / args.steps},
+        "roofline": {
+            "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "avg_launch_ms": avg_ms, "launches_per_step": per_step_launches,
+            "algorithmic_bytes_per_launch": alg / per_step_launches,
+            "tile_io_bytes_per_launch": io_bytes,
+            "tile_io_GBps": io_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+        },
+    }
+    if not args.no_cpu_baseline:
+      try:
+        line["cpu_baseline"] = cpu_baseline(n, gates, n_params, op, params_np, args.cpu_sample_states, args.mode)
+      except Exception as exc:  # pylint: disable=broad-except
+        line["cpu_baseline"] = {"error": str(exc)}
+    print(json.dumps(line))
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

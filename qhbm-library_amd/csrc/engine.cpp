@@ -68,7 +68,7 @@ struct qhbm_engine {
   Model model;
   bool have_circuit = false;
   // options
-  int opt_tile = 0, opt_adj_tile = 0, opt_profile = 0;
+  int opt_tile = 0, opt_adj_tile = 0, opt_profile = 0, opt_round = 0;
   int64_t opt_chunk = 0;
   int64_t opt_budget_mb = 16384;
   // plans
@@ -133,8 +133,8 @@ int build_plans(qhbm_engine* h) {
   if (!h->have_circuit) return fail(h, "qhbm_set_circuit has not been called");
   if (h->model.n_ops > kMaxOps) return fail(h, "too many observables (max 1024)");
   std::string err;
-  if (!build_plan(h->model, h->opt_tile, false, &h->fwd.plan, &err)) return fail(h, "forward plan: " + err);
-  if (!build_plan(h->model, h->opt_adj_tile, true, &h->adj.plan, &err)) return fail(h, "adjoint plan: " + err);
+  if (!build_plan(h->model, h->opt_tile, h->opt_round, false, &h->fwd.plan, &err)) return fail(h, "forward plan: " + err);
+  if (!build_plan(h->model, h->opt_adj_tile, 0, true, &h->adj.plan, &err)) return fail(h, "adjoint plan: " + err);
   h->fwd.uploaded = h->adj.uploaded = false;
   h->plans_valid = true;
   return 0;
@@ -210,7 +210,7 @@ int run_forward_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_
     a.flags = p.flags & PASS_INIT_BASIS;
     if (!p.is_measure_only && (!p.completes_circuit || keep_state || measure_only_after)) a.flags |= PASS_STORE;
     hipEvent_t* ev = timer_begin(h, 0, stream);
-    HIPCHK(launch_pass_fwd(d.plan.K, a, cs, h->psi.p, d_bits, h->model.n, d.prog.p, d.tables.p, d.coef.p,
+    HIPCHK(launch_pass_fwd(d.plan.K, d.plan.R, a, cs, h->psi.p, d_bits, h->model.n, d.prog.p, d.tables.p, d.coef.p,
                            d.angles.p, d_out, s0, stream));
     timer_end(ev, stream);
   }
@@ -251,7 +251,7 @@ int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_pa
   HIPCHK(h->state_grad.reserve(size_t(U) * std::max<uint32_t>(n_slots, 1)));
   HIPCHK(hipMemsetAsync(h->state_grad.p, 0, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), stream));
   uint32_t cs = chunk_states(h, U);
-  if (h->opt_chunk <= 0) cs = std::max<uint32_t>(1, cs / 2);  // two buffers per state
+  if (h->opt_chunk <= 0) cs = uint32_t(std::min<size_t>(size_t(U), std::max<size_t>(1, (size_t(h->opt_budget_mb) << 20) / (2 * state_bytes(h)))));  // two buffers per state
   if (int rc = ensure_state_buffers(h, cs, true)) return rc;
   const uint32_t n_eff = uint32_t(f.plan.n_eff);
   for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += cs) {
@@ -327,7 +327,7 @@ int qhbm_set_circuit(qhbm_engine* h, int n_qubits, int n_gates, const qhbm_gate*
   Model no_obs = m;
   no_obs.terms.clear();
   no_obs.n_ops = 0;
-  if (!build_plan(no_obs, h->opt_tile, false, &probe, &err)) return fail(h, err);
+  if (!build_plan(no_obs, h->opt_tile, h->opt_round, false, &probe, &err)) return fail(h, err);
   h->model = std::move(m);
   h->have_circuit = true;
   h->plans_valid = false;
@@ -369,6 +369,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   if (!h || !name) return 1;
   const std::string k(name);
   if (k == "tile_qubits") { h->opt_tile = int(value); h->plans_valid = false; }
+  else if (k == "round_qubits") { h->opt_round = int(value); h->plans_valid = false; }
   else if (k == "adjoint_tile_qubits") { h->opt_adj_tile = int(value); h->plans_valid = false; }
   else if (k == "chunk_states") h->opt_chunk = value;
   else if (k == "workspace_budget_mb") h->opt_budget_mb = std::max<int64_t>(1, value);

@@ -18,7 +18,7 @@ struct DevTerm {  // one Pauli term, amplitude-index bit space
 size_t fwd_lds_bytes(int K);
 size_t adj_lds_bytes(int K);
 
-hipError_t launch_pass_fwd(int K, const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
+hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
                            int n_user, const uint32_t* prog, const uint32_t* tables, const float* coef,
                            const double* angles, float* out, uint32_t state0, hipStream_t stream);
 hipError_t launch_pass_adj(int K, const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,

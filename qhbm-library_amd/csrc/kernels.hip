@@ -41,51 +41,36 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 template <int N> struct IC { static constexpr int value = N; };
 
-template <int R, typename F>
-__device__ __forceinline__ void dispatch_rb(uint32_t rb, F&& f) {
-  switch (rb) {
-    case 0: f(IC<0>{}); break;
-    case 1: f(IC<1>{}); break;
-    case 2: f(IC<2>{}); break;
-    case 3: f(IC<3>{}); break;
-    default:
-      if constexpr (R > 4) f(IC<4>{});
-      break;
-  }
+// Waves per SIMD the register allocator must leave room for: as many workgroups per CU
+// as the LDS footprint admits (160 KiB per CU), capped at 4 waves per SIMD.
+constexpr int wg_per_cu(int lds_bytes) { return (160 * 1024) / lds_bytes < 1 ? 1 : (160 * 1024) / lds_bytes; }
+constexpr int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+constexpr int fwd_min_waves(int K, int R) {
+  return clampi(wg_per_cu((8 << K) + 8192) * (1 << (K - R)) / 256, 1, 4);
+}
+constexpr int adj_min_waves(int K) {
+  return clampi(wg_per_cu((16 << K) + 12288) * (1 << (K - 4)) / 256, 1, 4);
 }
 
-// (rbh > rbl) pairs
-template <int R, typename F>
-__device__ __forceinline__ void dispatch_rb2(uint32_t rbh, uint32_t rbl, F&& f) {
-  const uint32_t key = rbh * 8 + rbl;
-  switch (key) {
-    case 1 * 8 + 0: f(IC<1>{}, IC<0>{}); break;
-    case 2 * 8 + 0: f(IC<2>{}, IC<0>{}); break;
-    case 2 * 8 + 1: f(IC<2>{}, IC<1>{}); break;
-    case 3 * 8 + 0: f(IC<3>{}, IC<0>{}); break;
-    case 3 * 8 + 1: f(IC<3>{}, IC<1>{}); break;
-    case 3 * 8 + 2: f(IC<3>{}, IC<2>{}); break;
-    default:
-      if constexpr (R > 4) {
-        switch (key) {
-          case 4 * 8 + 0: f(IC<4>{}, IC<0>{}); break;
-          case 4 * 8 + 1: f(IC<4>{}, IC<1>{}); break;
-          case 4 * 8 + 2: f(IC<4>{}, IC<2>{}); break;
-          case 4 * 8 + 3: f(IC<4>{}, IC<3>{}); break;
-          default: break;
-        }
-      }
-      break;
+// Static dispatch on a wave-uniform register-bit index (scalar branch).
+#define QHBM_DISPATCH_RB(R_, rb_, CALL_)                \
+  switch (rb_) {                                        \
+    case 0: { constexpr int RB = 0; CALL_; } break;     \
+    case 1: { constexpr int RB = 1; CALL_; } break;     \
+    case 2: { constexpr int RB = 2; CALL_; } break;     \
+    case 3: { constexpr int RB = 3; CALL_; } break;     \
+    default:                                            \
+      if constexpr ((R_) > 4) { constexpr int RB = (R_) > 4 ? 4 : 0; CALL_; } \
+      break;                                            \
   }
-}
 
 // ---- in-register gate kernels --------------------------------------------------
 // c*I - i*s*X  on register bit RB
 template <int R, int RB>
 __device__ __forceinline__ void apply_x(float (&ar)[1 << R], float (&ai)[1 << R], float c, float s) {
 #pragma unroll
-  for (int m = 0; m < (1 << R); ++m) {
-    if (m & (1 << RB)) continue;
+  for (int p = 0; p < (1 << (R - 1)); ++p) {
+    const int m = ((p >> RB) << (RB + 1)) | (p & ((1 << RB) - 1));
     const int m1 = m | (1 << RB);
     const float r0 = ar[m], i0 = ai[m], r1 = ar[m1], i1 = ai[m1];
     ar[m] = fmaf(s, i1, c * r0);
@@ -99,8 +84,8 @@ __device__ __forceinline__ void apply_x(float (&ar)[1 << R], float (&ai)[1 << R]
 template <int R, int RB>
 __device__ __forceinline__ void apply_y(float (&ar)[1 << R], float (&ai)[1 << R], float c, float s) {
 #pragma unroll
-  for (int m = 0; m < (1 << R); ++m) {
-    if (m & (1 << RB)) continue;
+  for (int p = 0; p < (1 << (R - 1)); ++p) {
+    const int m = ((p >> RB) << (RB + 1)) | (p & ((1 << RB) - 1));
     const int m1 = m | (1 << RB);
     const float r0 = ar[m], i0 = ai[m], r1 = ar[m1], i1 = ai[m1];
     ar[m] = fmaf(-s, r1, c * r0);
@@ -114,39 +99,14 @@ __device__ __forceinline__ void apply_y(float (&ar)[1 << R], float (&ai)[1 << R]
 template <int R, int RB>
 __device__ __forceinline__ void apply_mat1(float (&ar)[1 << R], float (&ai)[1 << R], const float* u) {
 #pragma unroll
-  for (int m = 0; m < (1 << R); ++m) {
-    if (m & (1 << RB)) continue;
+  for (int p = 0; p < (1 << (R - 1)); ++p) {
+    const int m = ((p >> RB) << (RB + 1)) | (p & ((1 << RB) - 1));
     const int m1 = m | (1 << RB);
     const float r0 = ar[m], i0 = ai[m], r1 = ar[m1], i1 = ai[m1];
     ar[m] = u[0] * r0 - u[1] * i0 + u[2] * r1 - u[3] * i1;
     ai[m] = u[0] * i0 + u[1] * r0 + u[2] * i1 + u[3] * r1;
     ar[m1] = u[4] * r0 - u[5] * i0 + u[6] * r1 - u[7] * i1;
     ai[m1] = u[4] * i0 + u[5] * r0 + u[6] * i1 + u[7] * r1;
-  }
-}
-
-// general 4x4 on (RBH = matrix-index high bit, RBL = low bit)
-template <int R, int RBH, int RBL>
-__device__ __forceinline__ void apply_mat2(float (&ar)[1 << R], float (&ai)[1 << R], const float* u) {
-#pragma unroll
-  for (int m = 0; m < (1 << R); ++m) {
-    if (m & ((1 << RBH) | (1 << RBL))) continue;
-    const int ix[4] = {m, m | (1 << RBL), m | (1 << RBH), m | (1 << RBH) | (1 << RBL)};
-    float xr[4], xi[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { xr[j] = ar[ix[j]]; xi[j] = ai[ix[j]]; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float sr = 0.f, si = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float ur = u[(i * 4 + j) * 2], ui = u[(i * 4 + j) * 2 + 1];
-        sr += ur * xr[j] - ui * xi[j];
-        si += ur * xi[j] + ui * xr[j];
-      }
-      ar[ix[i]] = sr;
-      ai[ix[i]] = si;
-    }
   }
 }
 
@@ -169,8 +129,8 @@ __device__ __forceinline__ float im_lam_y_psi(const float (&pr)[1 << R], const f
                                               const float (&lr)[1 << R], const float (&li)[1 << R]) {
   float acc = 0.f;
 #pragma unroll
-  for (int m = 0; m < (1 << R); ++m) {
-    if (m & (1 << RB)) continue;
+  for (int p = 0; p < (1 << (R - 1)); ++p) {
+    const int m = ((p >> RB) << (RB + 1)) | (p & ((1 << RB) - 1));
     const int m1 = m | (1 << RB);
     // conj(l0)*(-i p1) + conj(l1)*(i p0); Im(conj(l)*(-i p)) = -Re(conj(l) p), Im(conj(l)*(i p)) = Re(conj(l) p)
     acc += -(lr[m] * pr[m1] + li[m] * pi[m1]) + (lr[m1] * pr[m] + li[m1] * pi[m]);
@@ -184,8 +144,8 @@ __device__ __forceinline__ float im_lam_g1_psi(const float (&pr)[1 << R], const 
                                                const float* g) {
   float acc = 0.f;
 #pragma unroll
-  for (int m = 0; m < (1 << R); ++m) {
-    if (m & (1 << RB)) continue;
+  for (int p = 0; p < (1 << (R - 1)); ++p) {
+    const int m = ((p >> RB) << (RB + 1)) | (p & ((1 << RB) - 1));
     const int ix[2] = {m, m | (1 << RB)};
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -201,30 +161,6 @@ __device__ __forceinline__ float im_lam_g1_psi(const float (&pr)[1 << R], const 
   }
   return acc;
 }
-template <int R, int RBH, int RBL>
-__device__ __forceinline__ float im_lam_g2_psi(const float (&pr)[1 << R], const float (&pi)[1 << R],
-                                               const float (&lr)[1 << R], const float (&li)[1 << R],
-                                               const float* g) {
-  float acc = 0.f;
-#pragma unroll
-  for (int m = 0; m < (1 << R); ++m) {
-    if (m & ((1 << RBH) | (1 << RBL))) continue;
-    const int ix[4] = {m, m | (1 << RBL), m | (1 << RBH), m | (1 << RBH) | (1 << RBL)};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float sr = 0.f, si = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float gr = g[(i * 4 + j) * 2], gi = g[(i * 4 + j) * 2 + 1];
-        sr += gr * pr[ix[j]] - gi * pi[ix[j]];
-        si += gr * pi[ix[j]] + gi * pr[ix[j]];
-      }
-      acc += lr[ix[i]] * si - li[ix[i]] * sr;
-    }
-  }
-  return acc;
-}
-
 // ---- shared pieces of the pass kernels ----------------------------------------
 struct TileCtx {
   uint32_t tile_base;  // nonlocal bits of this tile, in index space
@@ -262,34 +198,90 @@ __device__ __forceinline__ void store_tile(const float2* __restrict__ tile, floa
   }
 }
 
-// Round geometry: D[m] (uniform, swizzled register part) and T (thread part).
+// Round geometry.  Thread `tid` owns the 2^R amplitudes whose local index has
+// tid's bits deposited on the non-register positions; register value m adds
+// the bits of m on the register positions.  In swizzled slot space both parts
+// combine by XOR, so the 2^R slots are visited in Gray-code order with one
+// v_xor per access: slot(gray(i)) = slot(gray(i-1)) ^ DB[ctz(i)].
 template <int K, int R>
-__device__ __forceinline__ void round_geometry(uint32_t regmask, int tid, uint32_t (&D)[1 << R],
+__device__ __forceinline__ void round_geometry(uint32_t regmask, int tid, uint32_t (&DB)[R],
                                                uint32_t* T) {
-  uint32_t rp[R];
   uint32_t mk = regmask;
 #pragma unroll
   for (int j = 0; j < R; ++j) {
-    rp[j] = __builtin_ctz(mk);
+    DB[j] = swz(mk & (0u - mk));  // lowest set bit, swizzled
     mk &= mk - 1;
   }
-  D[0] = 0;
-#pragma unroll
-  for (int m = 1; m < (1 << R); ++m) {
-    const int j = __builtin_ctz(m);
-    D[m] = D[m & (m - 1)] | (1u << rp[j]);
-  }
-#pragma unroll
-  for (int m = 0; m < (1 << R); ++m) D[m] = swz(D[m]);
   uint32_t freem = ~regmask & ((1u << K) - 1u);
   uint32_t tl = 0;
 #pragma unroll
   for (int j = 0; j < K - R; ++j) {
-    const uint32_t pos = __builtin_ctz(freem);
+    const uint32_t low = freem & (0u - freem);
     freem &= freem - 1;
-    tl |= ((uint32_t(tid) >> j) & 1u) << pos;
+    tl |= ((uint32_t(tid) >> j) & 1u) ? low : 0u;
   }
   *T = swz(tl);
+}
+
+template <int R>
+__device__ __forceinline__ void round_load(const float2* __restrict__ tile, uint32_t T,
+                                           const uint32_t (&DB)[R], float (&ar)[1 << R],
+                                           float (&ai)[1 << R]) {
+  uint32_t addr = T;
+#pragma unroll
+  for (int i = 0; i < (1 << R); ++i) {
+    if (i) addr ^= DB[__builtin_ctz(i)];
+    const float2 v = tile[addr];
+    ar[i ^ (i >> 1)] = v.x;
+    ai[i ^ (i >> 1)] = v.y;
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void round_store(float2* __restrict__ tile, uint32_t T,
+                                            const uint32_t (&DB)[R], const float (&ar)[1 << R],
+                                            const float (&ai)[1 << R]) {
+  uint32_t addr = T;
+#pragma unroll
+  for (int i = 0; i < (1 << R); ++i) {
+    if (i) addr ^= DB[__builtin_ctz(i)];
+    tile[addr] = make_float2(ar[i ^ (i >> 1)], ai[i ^ (i >> 1)]);
+  }
+}
+
+// Dense two-qubit gate applied directly on the LDS tile (not on the hot path of the
+// hardware-efficient ansatz; keeps the register rounds free of 4x4 code).
+// pos0/pos1 = local bit of the first/second qubit; matrix index = (b_q0 << 1) | b_q1.
+template <int K, int NT>
+__device__ __forceinline__ void quad_indices(uint32_t q, uint32_t pos0, uint32_t pos1, uint32_t (&ix)[4]) {
+  const uint32_t pa = pos0 < pos1 ? pos0 : pos1, pb = pos0 < pos1 ? pos1 : pos0;
+  uint32_t l = ((q >> pa) << (pa + 1)) | (q & ((1u << pa) - 1u));
+  l = ((l >> pb) << (pb + 1)) | (l & ((1u << pb) - 1u));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ix[j] = swz(l | (uint32_t(j >> 1) << pos0) | (uint32_t(j & 1) << pos1));
+}
+
+__device__ __forceinline__ void mat4_apply(const float* __restrict__ u, const float2 (&x)[4], float2 (&y)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float sr = 0.f, si = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float ur = u[(i * 4 + j) * 2], ui = u[(i * 4 + j) * 2 + 1];
+      sr += ur * x[j].x - ui * x[j].y;
+      si += ur * x[j].y + ui * x[j].x;
+    }
+    y[i] = make_float2(sr, si);
+  }
+}
+
+// exp(i*pi*x): the angle is accumulated and range-reduced to [-1, 1] in double, the
+// sine/cosine are then evaluated in fp32 (table entries are fp32 anyway).
+__device__ __forceinline__ float2 phase_of(double x) {
+  const float r = float(x - 2.0 * rint(0.5 * x));
+  float sn, cs;
+  sincospif(r, &sn, &cs);
+  return make_float2(cs, sn);
 }
 
 // Diagonal phase tables for one OP_DIAG.  sgn = +1 forward, -1 adjoint (conj).
@@ -302,30 +294,27 @@ __device__ __forceinline__ void build_diag_tables(const uint32_t* __restrict__ t
                                                   float4* cross, int tid) {
   constexpr int NLO = 1 << kLoBits;
   constexpr int NHI = 1 << (K - kLoBits);
-  for (int e = tid; e < NLO + NHI; e += NT) {
-    const bool is_lo = e < NLO;
-    const uint32_t l = is_lo ? uint32_t(e) : (uint32_t(e - NLO) << kLoBits);
-    const uint32_t* tp = is_lo ? terms : terms + n_lo * kDiagTermWords;
-    const uint32_t cnt = is_lo ? n_lo : n_hi;
+  auto entry = [&](uint32_t l, const uint32_t* __restrict__ tp, uint32_t cnt) {
     double ang = 0.0;
     for (uint32_t k = 0; k < cnt; ++k) {
-      const uint32_t w0 = tp[k * kDiagTermWords], nm = tp[k * kDiagTermWords + 1];
+      const uint32_t w0 = uni(tp[k * kDiagTermWords]), nm = uni(tp[k * kDiagTermWords + 1]);
       const uint32_t lm = w0 & 0x7fffffffu;
-      const double a = angles[tp[k * kDiagTermWords + 2]];
+      const double a = angles[uni(tp[k * kDiagTermWords + 2])];
       bool on;
       if (w0 >> 31) on = (__popc(l & lm) + __popc(t.tile_base & nm)) & 1;
       else on = ((l & lm) == lm) && ((t.tile_base & nm) == nm);
       ang += on ? a : 0.0;
     }
-    double sn, cs;
-    sincospi(sgn * ang, &sn, &cs);
-    (is_lo ? e_lo[e] : e_hi[e - NLO]) = make_float2(float(cs), float(sn));
-  }
+    return phase_of(sgn * ang);
+  };
+  for (int e = tid; e < NLO; e += NT) e_lo[e] = entry(uint32_t(e), terms, n_lo);
+  for (int e = tid; e < NHI; e += NT)
+    e_hi[e] = entry(uint32_t(e) << kLoBits, terms + n_lo * kDiagTermWords, n_hi);
   const uint32_t* cp = terms + (n_lo + n_hi) * kDiagTermWords;
   for (uint32_t k = tid; k < n_cross; k += NT) {
     const uint32_t w0 = cp[k * kDiagTermWords], nm = cp[k * kDiagTermWords + 1];
-    double sn, cs;
-    sincospi(sgn * angles[cp[k * kDiagTermWords + 2]], &sn, &cs);
+    const float2 ph = phase_of(sgn * angles[cp[k * kDiagTermWords + 2]]);
+    const float cs = ph.x, sn = ph.y;
     uint32_t flag;
     if (w0 >> 31) flag = __popc(t.tile_base & nm) & 1;   // parity contributed by nonlocal bits
     else flag = ((t.tile_base & nm) == nm) ? 1u : 0u;       // AND term active on this tile
@@ -361,7 +350,7 @@ __device__ __forceinline__ uint32_t basis_index(const int8_t* __restrict__ row, 
 // Forward pass kernel
 // ================================================================================
 template <int K, int R>
-__global__ __launch_bounds__(1 << (K - R)) void pass_fwd_kernel(
+__global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_kernel(
     PassArgs a, float2* __restrict__ psi, const int8_t* __restrict__ bits, int n_user,
     const uint32_t* __restrict__ prog_base, const uint32_t* __restrict__ tables,
     const float* __restrict__ coef, const double* __restrict__ angles, float* __restrict__ out,
@@ -418,38 +407,44 @@ __global__ __launch_bounds__(1 << (K - R)) void pass_fwd_kernel(
     if (opc == OP_ROUND) {
       const uint32_t n_micro = w0 >> 8;
       const uint32_t regmask = uni(prog[pc + 1]);
-      uint32_t D[NR], T;
-      round_geometry<K, R>(regmask, tid, D, &T);
+      uint32_t DB[R], T;
+      round_geometry<K, R>(regmask, tid, DB, &T);
       float ar[NR], ai[NR];
-#pragma unroll
-      for (int m = 0; m < NR; ++m) {
-        const float2 v = tile[T ^ D[m]];
-        ar[m] = v.x;
-        ai[m] = v.y;
-      }
+      round_load<R>(tile, T, DB, ar, ai);
       const uint32_t* mp = prog + pc + 2;
       for (uint32_t i = 0; i < n_micro; ++i, mp += kMicroWords) {
         const uint32_t mw = uni(mp[0]);
         const float* cf = coef + uni(mp[1]);
-        const uint32_t mop = mw & 0xffu, rb0 = (mw >> 8) & 15u, rb1 = (mw >> 12) & 15u;
+        const uint32_t mop = mw & 0xffu, rb0 = (mw >> 8) & 15u;
         if (mop == MOP_X) {
           const float c = cf[0], s = cf[1];
-          dispatch_rb<R>(rb0, [&](auto rb) { apply_x<R, decltype(rb)::value>(ar, ai, c, s); });
+          QHBM_DISPATCH_RB(R, rb0, (apply_x<R, RB>(ar, ai, c, s)));
         } else if (mop == MOP_Y) {
           const float c = cf[0], s = cf[1];
-          dispatch_rb<R>(rb0, [&](auto rb) { apply_y<R, decltype(rb)::value>(ar, ai, c, s); });
-        } else if (mop == MOP_MAT1) {
-          dispatch_rb<R>(rb0, [&](auto rb) { apply_mat1<R, decltype(rb)::value>(ar, ai, cf); });
+          QHBM_DISPATCH_RB(R, rb0, (apply_y<R, RB>(ar, ai, c, s)));
         } else {
-          dispatch_rb2<R>(rb0, rb1, [&](auto rh, auto rl) {
-            apply_mat2<R, decltype(rh)::value, decltype(rl)::value>(ar, ai, cf);
-          });
+          QHBM_DISPATCH_RB(R, rb0, (apply_mat1<R, RB>(ar, ai, cf)));
         }
       }
-#pragma unroll
-      for (int m = 0; m < NR; ++m) tile[T ^ D[m]] = make_float2(ar[m], ai[m]);
+      round_store<R>(tile, T, DB, ar, ai);
       __syncthreads();
       pc += 2 + n_micro * kMicroWords;
+    } else if (opc == OP_GATE2) {
+      const uint32_t pw = uni(prog[pc + 1]);
+      const uint32_t pos0 = pw & 0xffu, pos1 = (pw >> 8) & 0xffu;
+      const float* cf = coef + uni(prog[pc + 2]);
+      for (uint32_t q = tid; q < (1u << (K - 2)); q += NT) {
+        uint32_t ix[4];
+        quad_indices<K, NT>(q, pos0, pos1, ix);
+        float2 x[4], y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = tile[ix[j]];
+        mat4_apply(cf, x, y);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[ix[j]] = y[j];
+      }
+      __syncthreads();
+      pc += kGate2Words;
     } else if (opc == OP_DIAG) {
       const uint32_t cw = uni(prog[pc + 1]);
       const uint32_t n_lo = cw & 1023u, n_hi = (cw >> 10) & 1023u, n_cross = cw >> 20;
@@ -535,7 +530,7 @@ __global__ __launch_bounds__(1 << (K - R)) void pass_fwd_kernel(
 // AFTER the gate and A = sum_k e_k P_k, then both are multiplied by U^dagger.
 // ================================================================================
 template <int K>
-__global__ __launch_bounds__(1 << (K - 4)) void pass_adj_kernel(
+__global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kernel(
     PassArgs a, float2* __restrict__ psi, float2* __restrict__ lam,
     const uint32_t* __restrict__ prog_base, const uint32_t* __restrict__ tables,
     const float* __restrict__ coef, const double* __restrict__ angles,
@@ -586,60 +581,64 @@ __global__ __launch_bounds__(1 << (K - 4)) void pass_adj_kernel(
     if (opc == OP_ROUND) {
       const uint32_t n_micro = w0 >> 8;
       const uint32_t regmask = uni(prog[pc + 1]);
-      uint32_t D[NR], T;
-      round_geometry<K, R>(regmask, tid, D, &T);
+      uint32_t DB[R], T;
+      round_geometry<K, R>(regmask, tid, DB, &T);
       float pr[NR], pi[NR], lr[NR], li[NR];
-#pragma unroll
-      for (int m = 0; m < NR; ++m) {
-        const float2 v = tp[T ^ D[m]];
-        const float2 w = tl[T ^ D[m]];
-        pr[m] = v.x; pi[m] = v.y; lr[m] = w.x; li[m] = w.y;
-      }
+      round_load<R>(tp, T, DB, pr, pi);
+      round_load<R>(tl, T, DB, lr, li);
       const uint32_t* mp = prog + pc + 2;
       for (uint32_t i = 0; i < n_micro; ++i, mp += kMicroWords) {
         const uint32_t mw = uni(mp[0]);
         const float* cf = coef + uni(mp[1]);
         const uint32_t slot = uni(mp[2]);
-        const uint32_t mop = mw & 0xffu, rb0 = (mw >> 8) & 15u, rb1 = (mw >> 12) & 15u;
+        const uint32_t mop = mw & 0xffu, rb0 = (mw >> 8) & 15u;
+        const bool want = slot != 0xffffffffu;
+        float g = 0.f;
         if (mop == MOP_X) {
           const float c = cf[0], s = -cf[1];  // U^dagger = c*I + i*s*X
-          dispatch_rb<R>(rb0, [&](auto rb) {
-            constexpr int RB = decltype(rb)::value;
-            if (slot != 0xffffffffu) add_slot(slot, kPi * im_lam_x_psi<R, RB>(pr, pi, lr, li));
-            apply_x<R, RB>(pr, pi, c, s);
-            apply_x<R, RB>(lr, li, c, s);
-          });
+          QHBM_DISPATCH_RB(R, rb0, (g = want ? kPi * im_lam_x_psi<R, RB>(pr, pi, lr, li) : 0.f,
+                                   apply_x<R, RB>(pr, pi, c, s), apply_x<R, RB>(lr, li, c, s)));
         } else if (mop == MOP_Y) {
           const float c = cf[0], s = -cf[1];
-          dispatch_rb<R>(rb0, [&](auto rb) {
-            constexpr int RB = decltype(rb)::value;
-            if (slot != 0xffffffffu) add_slot(slot, kPi * im_lam_y_psi<R, RB>(pr, pi, lr, li));
-            apply_y<R, RB>(pr, pi, c, s);
-            apply_y<R, RB>(lr, li, c, s);
-          });
-        } else if (mop == MOP_MAT1) {
-          dispatch_rb<R>(rb0, [&](auto rb) {
-            constexpr int RB = decltype(rb)::value;
-            if (slot != 0xffffffffu) add_slot(slot, im_lam_g1_psi<R, RB>(pr, pi, lr, li, cf + 8));
-            apply_mat1<R, RB>(pr, pi, cf);
-            apply_mat1<R, RB>(lr, li, cf);
-          });
+          QHBM_DISPATCH_RB(R, rb0, (g = want ? kPi * im_lam_y_psi<R, RB>(pr, pi, lr, li) : 0.f,
+                                   apply_y<R, RB>(pr, pi, c, s), apply_y<R, RB>(lr, li, c, s)));
         } else {
-          dispatch_rb2<R>(rb0, rb1, [&](auto rh, auto rl) {
-            constexpr int RH = decltype(rh)::value, RL = decltype(rl)::value;
-            if (slot != 0xffffffffu) add_slot(slot, im_lam_g2_psi<R, RH, RL>(pr, pi, lr, li, cf + 32));
-            apply_mat2<R, RH, RL>(pr, pi, cf);
-            apply_mat2<R, RH, RL>(lr, li, cf);
-          });
+          QHBM_DISPATCH_RB(R, rb0, (g = want ? im_lam_g1_psi<R, RB>(pr, pi, lr, li, cf + 8) : 0.f,
+                                   apply_mat1<R, RB>(pr, pi, cf), apply_mat1<R, RB>(lr, li, cf)));
         }
+        if (want) add_slot(slot, g);
       }
-#pragma unroll
-      for (int m = 0; m < NR; ++m) {
-        tp[T ^ D[m]] = make_float2(pr[m], pi[m]);
-        tl[T ^ D[m]] = make_float2(lr[m], li[m]);
-      }
+      round_store<R>(tp, T, DB, pr, pi);
+      round_store<R>(tl, T, DB, lr, li);
       __syncthreads();
       pc += 2 + n_micro * kMicroWords;
+    } else if (opc == OP_GATE2) {
+      const uint32_t pw = uni(prog[pc + 1]);
+      const uint32_t pos0 = pw & 0xffu, pos1 = (pw >> 8) & 0xffu;
+      const float* cf = coef + uni(prog[pc + 2]);  // U^dagger (32 floats) then generator (32 floats)
+      const uint32_t slot = uni(prog[pc + 3]);
+      float gacc = 0.f;
+      for (uint32_t q = tid; q < (1u << (K - 2)); q += NT) {
+        uint32_t ix[4];
+        quad_indices<K, NT>(q, pos0, pos1, ix);
+        float2 x[4], l[4], y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[j] = tp[ix[j]]; l[j] = tl[ix[j]]; }
+        if (slot != 0xffffffffu) {
+          mat4_apply(cf + 32, x, y);  // G psi
+#pragma unroll
+          for (int j = 0; j < 4; ++j) gacc += l[j].x * y[j].y - l[j].y * y[j].x;  // Im(conj(lam) * G psi)
+        }
+        mat4_apply(cf, x, y);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tp[ix[j]] = y[j];
+        mat4_apply(cf, l, y);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tl[ix[j]] = y[j];
+      }
+      if (slot != 0xffffffffu) add_slot(slot, gacc);
+      __syncthreads();
+      pc += kGate2Words;
     } else {  // OP_DIAG
       const uint32_t cw = uni(prog[pc + 1]);
       const uint32_t n_lo = cw & 1023u, n_hi = (cw >> 10) & 1023u, n_cross = cw >> 20;
@@ -919,17 +918,22 @@ static hipError_t launch_fwd_t(const PassArgs& a, uint32_t n_states, float2* psi
   return hipGetLastError();
 }
 
-hipError_t launch_pass_fwd(int K, const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
+hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
                            int n_user, const uint32_t* prog, const uint32_t* tables, const float* coef,
                            const double* angles, float* out, uint32_t state0, hipStream_t stream) {
-  switch (K) {
-    case 10: return launch_fwd_t<10, 4>(a, n_states, psi, bits, n_user, prog, tables, coef, angles, out, state0, stream);
-    case 11: return launch_fwd_t<11, 4>(a, n_states, psi, bits, n_user, prog, tables, coef, angles, out, state0, stream);
-    case 12: return launch_fwd_t<12, 4>(a, n_states, psi, bits, n_user, prog, tables, coef, angles, out, state0, stream);
-    case 13: return launch_fwd_t<13, 5>(a, n_states, psi, bits, n_user, prog, tables, coef, angles, out, state0, stream);
-    case 14: return launch_fwd_t<14, 5>(a, n_states, psi, bits, n_user, prog, tables, coef, angles, out, state0, stream);
-    default: return hipErrorInvalidValue;
-  }
+#define QHBM_FWD_CASE(K_, R_)                                                                          \
+  if (K == K_ && R == R_)                                                                              \
+    return launch_fwd_t<K_, R_>(a, n_states, psi, bits, n_user, prog, tables, coef, angles, out, state0, stream);
+  QHBM_FWD_CASE(10, 4)
+  QHBM_FWD_CASE(11, 4)
+  QHBM_FWD_CASE(12, 4)
+  QHBM_FWD_CASE(12, 5)
+  QHBM_FWD_CASE(13, 4)
+  QHBM_FWD_CASE(13, 5)
+  QHBM_FWD_CASE(14, 4)
+  QHBM_FWD_CASE(14, 5)
+#undef QHBM_FWD_CASE
+  return hipErrorInvalidValue;
 }
 
 template <int K>

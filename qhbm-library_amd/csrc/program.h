@@ -40,11 +40,13 @@ enum : uint32_t {
 // ---- opcodes (low 8 bits of an instruction's first word) --------------------
 enum : uint32_t {
   OP_END = 0,
-  OP_ROUND = 1,    // [op | n_micro<<8] [regmask] then n_micro x {[mop|rb0<<8|rb1<<12|kind<<16] [coef_off] [slot]}
+  OP_ROUND = 1,    // [op | n_micro<<8] [regmask] then n_micro x {[mop|rb0<<8|kind<<16] [coef_off] [slot]}
   OP_DIAG = 2,     // [op] [n_lo | n_hi<<10 | n_cross<<20] then terms x {[lmask|par<<31] [nmask] [angle_idx] [slot]}
-  OP_MEASURE = 3,  // [op | n_groups<<8] then groups x {[xl] [n_terms] terms x {[zl] [zn] [coef bits] [op_idx | ny<<24]}}
+  OP_MEASURE = 3,
+  OP_GATE2 = 4,    // [op | kind<<8] [pos_q0 | pos_q1<<8 (local bits)] [coef_off] [slot]  // [op | n_groups<<8] then groups x {[xl] [n_terms] terms x {[zl] [zn] [coef bits] [op_idx | ny<<24]}}
 };
 constexpr int kMicroWords = 3;
+constexpr int kGate2Words = 4;
 constexpr int kDiagTermWords = 4;
 constexpr int kMeasTermWords = 4;
 
@@ -53,7 +55,7 @@ enum : uint32_t {
   MOP_X = 1,     // c*I - i*s*X on register bit rb0   (coef: c, s)
   MOP_Y = 2,     // c*I - i*s*Y                         (coef: c, s)
   MOP_MAT1 = 3,  // general 2x2 on rb0                  (coef: 8 floats, row-major re,im)
-  MOP_MAT2 = 4,  // general 4x4 on (rb0 = high index bit, rb1 = low index bit) (coef: 32 floats)
+  MOP_MAT2 = 4,  // coefficient-job tag of a dense 4x4 (32 floats); executed by OP_GATE2 on LDS
 };
 
 // Lowered operation kinds produced by the host (one per circuit gate).

@@ -140,7 +140,7 @@ class Builder {
           if (emitted[i]) continue;
           const LoweredOp& op = ops[absorbed[i]];
           if (op.bits & blocked) { blocked |= op.bits; continue; }
-          if (op.type == LOW_DIAG) { blocked |= op.bits; continue; }
+          if (op.type != LOW_MAT1) { blocked |= op.bits; continue; }
           const uint32_t lb = to_local(*p, op.bits);
           if (popc(reg | lb) <= R_) { reg |= lb; in_round.push_back(i); }
           else blocked |= op.bits;
@@ -157,6 +157,17 @@ class Builder {
           --left;
         }
         ++p->n_rounds;
+      }
+      // ---- dense two-qubit gates that are ready (applied directly on LDS) ---------
+      {
+        uint32_t blocked2 = 0;
+        for (size_t i = 0; i < absorbed.size(); ++i) {
+          if (emitted[i]) continue;
+          const LoweredOp& op = ops[absorbed[i]];
+          if (op.bits & blocked2) { blocked2 |= op.bits; continue; }
+          if (op.type == LOW_MAT2) { emit_gate2(p, op); emitted[i] = 1; --left; }
+          else blocked2 |= op.bits;
+        }
       }
       // ---- one diagonal op with every ready diagonal term -----------------------
       std::vector<size_t> diag;
@@ -199,29 +210,43 @@ class Builder {
     job.offset = G.offset;
     job.out_off = plan_->n_coef_floats;
     job.dagger = adjoint_ ? 1 : 0;
-    uint32_t mop, rb0, rb1 = 0;
+    uint32_t mop;
     int nfloat;
-    if (op.type == LOW_MAT1) {
-      rb0 = rank(op.b0);
-      if (op.kind == QHBM_GATE_XPOW) { mop = MOP_X; nfloat = 2; }
-      else if (op.kind == QHBM_GATE_YPOW) { mop = MOP_Y; nfloat = 2; }
-      else { mop = MOP_MAT1; nfloat = adjoint_ ? 16 : 8; }
-    } else {
-      mop = MOP_MAT2;
-      nfloat = adjoint_ ? 64 : 32;
-      const uint32_t r0 = rank(op.b0), r1 = rank(op.b1);
-      // the kernel wants rb0 (matrix-index high bit) > rb1
-      if (r0 > r1) { rb0 = r0; rb1 = r1; job.swap = 0; }
-      else { rb0 = r1; rb1 = r0; job.swap = 1; }
-    }
+    const uint32_t rb0 = rank(op.b0);
+    if (op.kind == QHBM_GATE_XPOW) { mop = MOP_X; nfloat = 2; }
+    else if (op.kind == QHBM_GATE_YPOW) { mop = MOP_Y; nfloat = 2; }
+    else { mop = MOP_MAT1; nfloat = adjoint_ ? 16 : 8; }
     job.mop = mop;
     plan_->n_coef_floats += nfloat;
     plan_->jobs.push_back(job);
     const int slot = new_slot(p, op);
-    p->prog.push_back(mop | (rb0 << 8) | (rb1 << 12) | (uint32_t(op.kind) << 16));
+    p->prog.push_back(mop | (rb0 << 8) | (uint32_t(op.kind) << 16));
     p->prog.push_back(uint32_t(job.out_off));
     p->prog.push_back(uint32_t(slot));
     ++p->n_mat_ops;
+  }
+
+  void emit_gate2(Pass* p, const LoweredOp& op) {
+    const Gate& G = m_.gates[op.gate];
+    CoefJob job{};
+    job.op_kind = op.kind;
+    job.mop = MOP_MAT2;
+    job.gate = op.gate;
+    job.param_idx = G.param_idx;
+    job.scalar = G.scalar;
+    job.offset = G.offset;
+    job.out_off = plan_->n_coef_floats;
+    job.dagger = adjoint_ ? 1 : 0;
+    plan_->n_coef_floats += adjoint_ ? 64 : 32;
+    plan_->jobs.push_back(job);
+    auto local_bit = [&](int gbit) { return uint32_t(__builtin_ctz(to_local(*p, 1u << gbit))); };
+    const int slot = new_slot(p, op);
+    p->prog.push_back(OP_GATE2 | (uint32_t(op.kind) << 8));
+    p->prog.push_back(local_bit(op.b0) | (local_bit(op.b1) << 8));
+    p->prog.push_back(uint32_t(job.out_off));
+    p->prog.push_back(uint32_t(slot));
+    ++p->n_mat_ops;
+    ++p->n_rounds;
   }
 
   void emit_diag(Pass* p, const std::vector<LoweredOp>& ops, const std::vector<int>& absorbed,
@@ -297,7 +322,7 @@ class Builder {
 
 }  // namespace
 
-bool build_plan(const Model& m, int tile_bits, bool adjoint, Plan* plan, std::string* err) {
+bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Plan* plan, std::string* err) {
   *plan = Plan();
   if (m.n < 1 || m.n > kMaxQubits - 1) { *err = "n_qubits must be in [1, 31]"; return false; }
   const int n_eff = std::max(m.n, kMinTileBits);
@@ -312,7 +337,14 @@ bool build_plan(const Model& m, int tile_bits, bool adjoint, Plan* plan, std::st
     }
     K = std::min(n_eff, tile_bits);
   }
-  const int R = adjoint ? 4 : round_bits_for(K);
+  int R = adjoint ? 4 : round_bits_for(K);
+  if (!adjoint && round_bits != 0) {
+    if ((round_bits != 4 && round_bits != 5) || (round_bits == 5 && K < 12)) {
+      *err = "round_qubits must be 4 or 5 (5 needs tile_qubits >= 12)";
+      return false;
+    }
+    R = round_bits;
+  }
   plan->n = m.n;
   plan->n_eff = n_eff;
   plan->K = K;

@@ -90,7 +90,7 @@ inline int threads_for(int K) { return 1 << (K - round_bits_for(K)); }
 // Builds the forward plan (circuit passes + measurement) or, with adjoint =
 // true, the backward plan over (psi, lambda) tile pairs.  `tile_bits` = 0
 // selects automatically.  Returns false and fills `err` on failure.
-bool build_plan(const Model& m, int tile_bits, bool adjoint, Plan* out,
+bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Plan* out,
                 std::string* err);
 
 std::string describe_plan(const Plan& p);
