@@ -51,7 +51,6 @@ struct DevicePlan {
   DevBuf<uint32_t> prog, tables;
   DevBuf<CoefJob> jobs;
   DevBuf<float> coef;
-  DevBuf<double> angles;
   bool uploaded = false;
 };
 
@@ -148,7 +147,6 @@ int upload_plan(qhbm_engine* h, DevicePlan* d) {
   HIPCHK(d->tables.upload(tables));
   HIPCHK(d->jobs.upload(d->plan.jobs));
   HIPCHK(d->coef.reserve(size_t(d->plan.n_coef_floats) + 64));
-  HIPCHK(d->angles.reserve(size_t(d->plan.n_angles) + 1));
   d->uploaded = true;
   return 0;
 }
@@ -211,7 +209,7 @@ int run_forward_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_
     if (!p.is_measure_only && (!p.completes_circuit || keep_state || measure_only_after)) a.flags |= PASS_STORE;
     hipEvent_t* ev = timer_begin(h, 0, stream);
     HIPCHK(launch_pass_fwd(d.plan.K, d.plan.R, a, cs, h->psi.p, d_bits, h->model.n, d.prog.p, d.tables.p, d.coef.p,
-                           d.angles.p, d_out, s0, stream));
+                           d_out, s0, stream));
     timer_end(ev, stream);
   }
   return 0;
@@ -227,7 +225,7 @@ int ensure_state_buffers(qhbm_engine* h, uint32_t cs, bool with_lam) {
 int forward(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, float* d_out,
             int shift_gate, double shift, hipStream_t stream) {
   DevicePlan& d = h->fwd;
-  HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, d.angles.p, shift_gate,
+  HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, shift_gate,
                            shift, stream));
   if (h->model.n_ops) HIPCHK(hipMemsetAsync(d_out, 0, size_t(U) * h->model.n_ops * sizeof(float), stream));
   const uint32_t cs = chunk_states(h, U);
@@ -245,8 +243,8 @@ int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_pa
   DevicePlan& f = h->fwd;
   DevicePlan& b = h->adj;
   const uint32_t n_slots = uint32_t(b.plan.slot_gate.size());
-  HIPCHK(launch_prep_coefs(f.jobs.p, int(f.plan.jobs.size()), d_params, f.coef.p, f.angles.p, -1, 0.0, stream));
-  HIPCHK(launch_prep_coefs(b.jobs.p, int(b.plan.jobs.size()), d_params, b.coef.p, b.angles.p, -1, 0.0, stream));
+  HIPCHK(launch_prep_coefs(f.jobs.p, int(f.plan.jobs.size()), d_params, f.coef.p, -1, 0.0, stream));
+  HIPCHK(launch_prep_coefs(b.jobs.p, int(b.plan.jobs.size()), d_params, b.coef.p, -1, 0.0, stream));
   HIPCHK(hipMemsetAsync(d_out_vals, 0, size_t(U) * h->model.n_ops * sizeof(float), stream));
   HIPCHK(h->state_grad.reserve(size_t(U) * std::max<uint32_t>(n_slots, 1)));
   HIPCHK(hipMemsetAsync(h->state_grad.p, 0, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), stream));
@@ -262,7 +260,7 @@ int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_pa
     for (size_t i = 0; i < b.plan.passes.size(); ++i) {
       hipEvent_t* ev = timer_begin(h, 1, stream);
       HIPCHK(launch_pass_adj(b.plan.K, b.args[i], c, h->psi.p, h->lam.p, b.prog.p, b.tables.p, b.coef.p,
-                             b.angles.p, h->state_grad.p, n_slots, s0, stream));
+                             h->state_grad.p, n_slots, s0, stream));
       timer_end(ev, stream);
     }
   }

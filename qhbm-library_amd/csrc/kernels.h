@@ -20,16 +20,16 @@ size_t adj_lds_bytes(int K);
 
 hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
                            int n_user, const uint32_t* prog, const uint32_t* tables, const float* coef,
-                           const double* angles, float* out, uint32_t state0, hipStream_t stream);
+                           float* out, uint32_t state0, hipStream_t stream);
 hipError_t launch_pass_adj(int K, const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
                            const uint32_t* prog, const uint32_t* tables, const float* coef,
-                           const double* angles, float* state_grad, uint32_t n_slots_total,
+                           float* state_grad, uint32_t n_slots_total,
                            uint32_t state0, hipStream_t stream);
 hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
                                    const DevTerm* terms, uint32_t n_terms, const float* upstream,
                                    uint32_t n_ops, uint32_t state0, hipStream_t stream);
 hipError_t launch_prep_coefs(const CoefJob* jobs, int n_jobs, const float* params, float* coef,
-                             double* angles, int shift_gate, double shift, hipStream_t stream);
+                             int shift_gate, double shift, hipStream_t stream);
 hipError_t launch_reduce_grad(const float* state_grad, uint32_t U, uint32_t n_slots,
                               const int* param_slot_begin, const int* param_slots,
                               const float* slot_factor, float* grad, int n_params, int accumulate,

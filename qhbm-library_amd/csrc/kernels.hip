@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "../../include/qhbm_engine.h"
 #include "kernels.h"
 #include "program.h"
@@ -39,128 +41,225 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-template <int N> struct IC { static constexpr int value = N; };
-
 // Waves per SIMD the register allocator must leave room for: as many workgroups per CU
 // as the LDS footprint admits (160 KiB per CU), capped at 4 waves per SIMD.
 constexpr int wg_per_cu(int lds_bytes) { return (160 * 1024) / lds_bytes < 1 ? 1 : (160 * 1024) / lds_bytes; }
 constexpr int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 constexpr int fwd_min_waves(int K, int R) {
-  return clampi(wg_per_cu((8 << K) + 8192) * (1 << (K - R)) / 256, 1, 4);
+  return clampi(wg_per_cu((8 << K) + 4096) * (1 << (K - R)) / 256, 1, 4);
 }
 constexpr int adj_min_waves(int K) {
-  return clampi(wg_per_cu((16 << K) + 12288) * (1 << (K - 4)) / 256, 1, 4);
+  return clampi(wg_per_cu((16 << K) + 8192) * (1 << (K - 4)) / 256, 1, 4);
 }
 
-// Static dispatch on a wave-uniform register-bit index (scalar branch).
-#define QHBM_DISPATCH_RB(R_, rb_, CALL_)                \
-  switch (rb_) {                                        \
-    case 0: { constexpr int RB = 0; CALL_; } break;     \
-    case 1: { constexpr int RB = 1; CALL_; } break;     \
-    case 2: { constexpr int RB = 2; CALL_; } break;     \
-    case 3: { constexpr int RB = 3; CALL_; } break;     \
-    default:                                            \
-      if constexpr ((R_) > 4) { constexpr int RB = (R_) > 4 ? 4 : 0; CALL_; } \
-      break;                                            \
+// Static iteration over register bits / register-bit pairs WITHOUT lambdas (a lambda
+// capturing the register arrays by reference pins them to scratch memory).
+#define QHBM_FOR_RB(R_, ...)                              \
+  {                                                       \
+    { constexpr int J = 0; __VA_ARGS__ }                  \
+    { constexpr int J = 1; __VA_ARGS__ }                  \
+    { constexpr int J = 2; __VA_ARGS__ }                  \
+    { constexpr int J = 3; __VA_ARGS__ }                  \
+    if constexpr ((R_) > 4) { constexpr int J = (R_) > 4 ? 4 : 0; __VA_ARGS__ } \
   }
+#define QHBM_PAIR(JA_, JB_, ...) { constexpr int JA = JA_; constexpr int JB = JB_; __VA_ARGS__ }
+#define QHBM_FOR_PAIR(R_, ...)                            \
+  {                                                       \
+    QHBM_PAIR(0, 1, __VA_ARGS__) QHBM_PAIR(0, 2, __VA_ARGS__) QHBM_PAIR(1, 2, __VA_ARGS__) \
+    QHBM_PAIR(0, 3, __VA_ARGS__) QHBM_PAIR(1, 3, __VA_ARGS__) QHBM_PAIR(2, 3, __VA_ARGS__) \
+    if constexpr ((R_) > 4) {                             \
+      QHBM_PAIR(0, ((R_) > 4 ? 4 : 1), __VA_ARGS__) QHBM_PAIR(1, ((R_) > 4 ? 4 : 2), __VA_ARGS__) \
+      QHBM_PAIR(2, ((R_) > 4 ? 4 : 3), __VA_ARGS__) QHBM_PAIR(((R_) > 4 ? 3 : 0), ((R_) > 4 ? 4 : 1), __VA_ARGS__) \
+    }                                                     \
+  }
+
+// register index with a zero inserted at bit RB
+template <int RB> constexpr int ins0(int p) { return ((p >> RB) << (RB + 1)) | (p & ((1 << RB) - 1)); }
 
 // ---- in-register gate kernels --------------------------------------------------
+// One amplitude = one 64-bit VGPR pair (re, im).  The hot updates are in-place
+// VOP3P packed-fp32 sequences: op_sel picks which half of a source feeds the
+// low/high result, neg_lo/neg_hi flip a sign, so a complex multiply-add is one
+// v_pk_mul + one v_pk_fma and nothing is ever re-packed.  cs = (c, s) is a
+// wave-uniform SGPR pair, or a VGPR pair for thread-predicated phases.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#define QHBM_X_PAIR(CONSTRAINT)                                                                   \
+  v2f t0;                                                                                         \
+  asm("v_pk_mul_f32 %[t0], %[a0], %[cs] op_sel_hi:[1,0]\n\t"                                      \
+      "v_pk_fma_f32 %[t0], %[a1], %[cs], %[t0] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t" \
+      "v_pk_mul_f32 %[a1], %[a1], %[cs] op_sel_hi:[1,0]\n\t"                                      \
+      "v_pk_fma_f32 %[a1], %[a0], %[cs], %[a1] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t" \
+      "v_mov_b64 %[a0], %[t0]"                                                                    \
+      : [a0] "+v"(a0), [a1] "+v"(a1), [t0] "=&v"(t0)                                              \
+      : [cs] CONSTRAINT(cs));
+
+// (a0, a1) <- (c a0 - i s a1, c a1 - i s a0):  a0' = c a0 + s (a1.im, -a1.re)
+__device__ __forceinline__ void x_pair(v2f& a0, v2f& a1, v2f cs) { QHBM_X_PAIR("s") }
+
+// (a0, a1) <- (c a0 - s a1, s a0 + c a1)
+__device__ __forceinline__ void y_pair(v2f& a0, v2f& a1, v2f cs) {
+  v2f t0;
+  asm("v_pk_mul_f32 %[t0], %[a0], %[cs] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %[t0], %[a1], %[cs], %[t0] op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+      "v_pk_mul_f32 %[a1], %[a1], %[cs] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %[a1], %[a0], %[cs], %[a1] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_mov_b64 %[a0], %[t0]"
+      : [a0] "+v"(a0), [a1] "+v"(a1), [t0] "=&v"(t0)
+      : [cs] "s"(cs));
+}
+
+// a <- (c + i s) a = c a + s (-a.im, a.re)
+__device__ __forceinline__ void phase_s(v2f& a, v2f cs) {
+  v2f t;
+  asm("v_pk_mul_f32 %[t], %[a], %[cs] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %[a], %[a], %[cs], %[t] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+      : [a] "+v"(a), [t] "=&v"(t)
+      : [cs] "s"(cs));
+}
+__device__ __forceinline__ void phase_v(v2f& a, v2f cs) {
+  v2f t;
+  asm("v_pk_mul_f32 %[t], %[a], %[cs] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %[a], %[a], %[cs], %[t] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+      : [a] "+v"(a), [t] "=&v"(t)
+      : [cs] "v"(cs));
+}
+
+__device__ __forceinline__ v2f load_cs(const float* __restrict__ cf) {
+  return *reinterpret_cast<const v2f*>(cf);
+}
+__device__ __forceinline__ v2f conj_cs(v2f cs) { return v2f{cs.x, -cs.y}; }
+
+// All loops over the register file are integer_sequence folds: every index is a
+// constant when the IR is generated, so the array is scalarised into independent
+// VGPR pairs (a run-time loop index, even in a fully unrolled loop, makes the
+// compiler keep the file as ONE 1024-bit tuple and copy it on every update).
+template <int N> using iseq = std::make_integer_sequence<int, N>;
+
+template <int R, int RB, int... P>
+__device__ __forceinline__ void apply_x_(v2f (&a)[1 << R], v2f cs, std::integer_sequence<int, P...>) {
+  (x_pair(a[ins0<RB>(P)], a[ins0<RB>(P) | (1 << RB)], cs), ...);
+}
 // c*I - i*s*X  on register bit RB
 template <int R, int RB>
-__device__ __forceinline__ void apply_x(float (&ar)[1 << R], float (&ai)[1 << R], float c, float s) {
-#pragma unroll
-  for (int p = 0; p < (1 << (R - 1)); ++p) {
-    const int m = ((p >> RB) << (RB + 1)) | (p & ((1 << RB) - 1));
-    const int m1 = m | (1 << RB);
-    const float r0 = ar[m], i0 = ai[m], r1 = ar[m1], i1 = ai[m1];
-    ar[m] = fmaf(s, i1, c * r0);
-    ai[m] = fmaf(-s, r1, c * i0);
-    ar[m1] = fmaf(s, i0, c * r1);
-    ai[m1] = fmaf(-s, r0, c * i1);
-  }
-}
+__device__ __forceinline__ void apply_x(v2f (&a)[1 << R], v2f cs) { apply_x_<R, RB>(a, cs, iseq<(1 << (R - 1))>{}); }
 
+template <int R, int RB, int... P>
+__device__ __forceinline__ void apply_y_(v2f (&a)[1 << R], v2f cs, std::integer_sequence<int, P...>) {
+  (y_pair(a[ins0<RB>(P)], a[ins0<RB>(P) | (1 << RB)], cs), ...);
+}
 // c*I - i*s*Y = [[c, -s], [s, c]]
 template <int R, int RB>
-__device__ __forceinline__ void apply_y(float (&ar)[1 << R], float (&ai)[1 << R], float c, float s) {
-#pragma unroll
-  for (int p = 0; p < (1 << (R - 1)); ++p) {
-    const int m = ((p >> RB) << (RB + 1)) | (p & ((1 << RB) - 1));
-    const int m1 = m | (1 << RB);
-    const float r0 = ar[m], i0 = ai[m], r1 = ar[m1], i1 = ai[m1];
-    ar[m] = fmaf(-s, r1, c * r0);
-    ai[m] = fmaf(-s, i1, c * i0);
-    ar[m1] = fmaf(s, r0, c * r1);
-    ai[m1] = fmaf(s, i0, c * i1);
-  }
-}
+__device__ __forceinline__ void apply_y(v2f (&a)[1 << R], v2f cs) { apply_y_<R, RB>(a, cs, iseq<(1 << (R - 1))>{}); }
 
-// general 2x2, u = row-major {re, im} x 4 (wave-uniform)
+// dense 2x2 in place: u00..u11 are wave-uniform complex numbers (SGPR pairs).
+// n0 = u00 a0 + u01 a1, n1 = u10 a0 + u11 a1;  u*a = u.re * a + u.im * (-a.im, a.re)
+__device__ __forceinline__ void mat1_pair(v2f& a0, v2f& a1, v2f u00, v2f u01, v2f u10, v2f u11) {
+  v2f t0, t1;
+  asm("v_pk_mul_f32 %[t0], %[a0], %[u00] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %[t0], %[a0], %[u00], %[t0] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[t0], %[a1], %[u01], %[t0] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[t0], %[a1], %[u01], %[t0] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+      "v_pk_mul_f32 %[t1], %[a0], %[u10] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %[t1], %[a0], %[u10], %[t1] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[t1], %[a1], %[u11], %[t1] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[t1], %[a1], %[u11], %[t1] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+      "v_mov_b64 %[a0], %[t0]\n\t"
+      "v_mov_b64 %[a1], %[t1]"
+      : [a0] "+v"(a0), [a1] "+v"(a1), [t0] "=&v"(t0), [t1] "=&v"(t1)
+      : [u00] "s"(u00), [u01] "s"(u01), [u10] "s"(u10), [u11] "s"(u11));
+}
+template <int R, int RB, int... P>
+__device__ __forceinline__ void apply_mat1_(v2f (&a)[1 << R], const float* u, std::integer_sequence<int, P...>) {
+  const v2f u00 = load_cs(u), u01 = load_cs(u + 2), u10 = load_cs(u + 4), u11 = load_cs(u + 6);
+  (mat1_pair(a[ins0<RB>(P)], a[ins0<RB>(P) | (1 << RB)], u00, u01, u10, u11), ...);
+}
+// dense 2x2 (rare path), u = row-major {re, im} x 4 (wave-uniform)
 template <int R, int RB>
-__device__ __forceinline__ void apply_mat1(float (&ar)[1 << R], float (&ai)[1 << R], const float* u) {
-#pragma unroll
-  for (int p = 0; p < (1 << (R - 1)); ++p) {
-    const int m = ((p >> RB) << (RB + 1)) | (p & ((1 << RB) - 1));
-    const int m1 = m | (1 << RB);
-    const float r0 = ar[m], i0 = ai[m], r1 = ar[m1], i1 = ai[m1];
-    ar[m] = u[0] * r0 - u[1] * i0 + u[2] * r1 - u[3] * i1;
-    ai[m] = u[0] * i0 + u[1] * r0 + u[2] * i1 + u[3] * r1;
-    ar[m1] = u[4] * r0 - u[5] * i0 + u[6] * r1 - u[7] * i1;
-    ai[m1] = u[4] * i0 + u[5] * r0 + u[6] * i1 + u[7] * r1;
-  }
+__device__ __forceinline__ void apply_mat1(v2f (&a)[1 << R], const float* u) { apply_mat1_<R, RB>(a, u, iseq<(1 << (R - 1))>{}); }
+
+template <int R, int RB, int... P>
+__device__ __forceinline__ void apply_ph1_(v2f (&a)[1 << R], v2f cs, std::integer_sequence<int, P...>) {
+  (phase_s(a[ins0<RB>(P) | (1 << RB)], cs), ...);
+}
+// multiply by (c + i s) the amplitudes whose register bit RB is 1 (uniform coefficient)
+template <int R, int RB>
+__device__ __forceinline__ void apply_ph1(v2f (&a)[1 << R], v2f cs) { apply_ph1_<R, RB>(a, cs, iseq<(1 << (R - 1))>{}); }
+
+template <int R, int RB, int... P>
+__device__ __forceinline__ void apply_ph1_v_(v2f (&a)[1 << R], v2f cs, std::integer_sequence<int, P...>) {
+  (phase_v(a[ins0<RB>(P) | (1 << RB)], cs), ...);
+}
+// same with a per-thread coefficient
+template <int R, int RB>
+__device__ __forceinline__ void apply_ph1_v(v2f (&a)[1 << R], v2f cs) { apply_ph1_v_<R, RB>(a, cs, iseq<(1 << (R - 1))>{}); }
+
+template <int RA, int RB> constexpr int ins11(int p) { return ins0<RB>(ins0<RA>(p)) | (1 << RA) | (1 << RB); }
+template <int R, int RA, int RB, int... P>
+__device__ __forceinline__ void apply_ph2_(v2f (&a)[1 << R], v2f cs, std::integer_sequence<int, P...>) {
+  (phase_s(a[ins11<RA, RB>(P)], cs), ...);
+}
+// ... whose register bits RA < RB are both 1
+template <int R, int RA, int RB>
+__device__ __forceinline__ void apply_ph2(v2f (&a)[1 << R], v2f cs) { apply_ph2_<R, RA, RB>(a, cs, iseq<(1 << (R - 2))>{}); }
+
+__device__ __forceinline__ float im_conj(v2f l, v2f p) { return l.x * p.y - l.y * p.x; }  // Im(conj(l) p)
+__device__ __forceinline__ float re_conj(v2f l, v2f p) { return l.x * p.x + l.y * p.y; }  // Re(conj(l) p)
+
+// sum over selected registers of Im(conj(lam) psi)
+template <int R, int RB, int... P>
+__device__ __forceinline__ float sum_w1_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], std::integer_sequence<int, P...>) {
+  return (im_conj(l[ins0<RB>(P) | (1 << RB)], p[ins0<RB>(P) | (1 << RB)]) + ...);
+}
+template <int R, int RB>
+__device__ __forceinline__ float sum_w1(const v2f (&p)[1 << R], const v2f (&l)[1 << R]) {
+  return sum_w1_<R, RB>(p, l, iseq<(1 << (R - 1))>{});
+}
+template <int R, int RA, int RB, int... P>
+__device__ __forceinline__ float sum_w2_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], std::integer_sequence<int, P...>) {
+  return (im_conj(l[ins11<RA, RB>(P)], p[ins11<RA, RB>(P)]) + ...);
+}
+template <int R, int RA, int RB>
+__device__ __forceinline__ float sum_w2(const v2f (&p)[1 << R], const v2f (&l)[1 << R]) {
+  return sum_w2_<R, RA, RB>(p, l, iseq<(1 << (R - 2))>{});
 }
 
 // Im <lam| G |psi> restricted to this thread's registers, for the generators
 // of the fast-path gates.  X: pairs swap.  Y: (Y psi)_0 = -i psi_1, (Y psi)_1 = i psi_0.
-template <int R, int RB>
-__device__ __forceinline__ float im_lam_x_psi(const float (&pr)[1 << R], const float (&pi)[1 << R],
-                                              const float (&lr)[1 << R], const float (&li)[1 << R]) {
-  float acc = 0.f;
-#pragma unroll
-  for (int m = 0; m < (1 << R); ++m) {
-    const int m1 = m ^ (1 << RB);
-    // Im(conj(lam_m) * psi_m1) = lr*pi - li*pr
-    acc += lr[m] * pi[m1] - li[m] * pr[m1];
-  }
-  return acc;
+template <int R, int RB, int... M>
+__device__ __forceinline__ float im_lam_x_psi_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], std::integer_sequence<int, M...>) {
+  return (im_conj(l[M], p[M ^ (1 << RB)]) + ...);
 }
 template <int R, int RB>
-__device__ __forceinline__ float im_lam_y_psi(const float (&pr)[1 << R], const float (&pi)[1 << R],
-                                              const float (&lr)[1 << R], const float (&li)[1 << R]) {
-  float acc = 0.f;
-#pragma unroll
-  for (int p = 0; p < (1 << (R - 1)); ++p) {
-    const int m = ((p >> RB) << (RB + 1)) | (p & ((1 << RB) - 1));
-    const int m1 = m | (1 << RB);
-    // conj(l0)*(-i p1) + conj(l1)*(i p0); Im(conj(l)*(-i p)) = -Re(conj(l) p), Im(conj(l)*(i p)) = Re(conj(l) p)
-    acc += -(lr[m] * pr[m1] + li[m] * pi[m1]) + (lr[m1] * pr[m] + li[m1] * pi[m]);
-  }
-  return acc;
+__device__ __forceinline__ float im_lam_x_psi(const v2f (&p)[1 << R], const v2f (&l)[1 << R]) {
+  return im_lam_x_psi_<R, RB>(p, l, iseq<(1 << R)>{});
 }
-// Im sum_ij conj(lam_i) g_ij psi_j over pairs / quads, g wave-uniform row-major complex
+template <int R, int RB, int... P>
+__device__ __forceinline__ float im_lam_y_psi_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], std::integer_sequence<int, P...>) {
+  // Im(conj(l0)*(-i p1)) = -Re(conj(l0) p1);  Im(conj(l1)*(i p0)) = Re(conj(l1) p0)
+  return ((re_conj(l[ins0<RB>(P) | (1 << RB)], p[ins0<RB>(P)]) - re_conj(l[ins0<RB>(P)], p[ins0<RB>(P) | (1 << RB)])) + ...);
+}
 template <int R, int RB>
-__device__ __forceinline__ float im_lam_g1_psi(const float (&pr)[1 << R], const float (&pi)[1 << R],
-                                               const float (&lr)[1 << R], const float (&li)[1 << R],
-                                               const float* g) {
-  float acc = 0.f;
-#pragma unroll
-  for (int p = 0; p < (1 << (R - 1)); ++p) {
-    const int m = ((p >> RB) << (RB + 1)) | (p & ((1 << RB) - 1));
-    const int ix[2] = {m, m | (1 << RB)};
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float sr = 0.f, si = 0.f;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float gr = g[(i * 2 + j) * 2], gi = g[(i * 2 + j) * 2 + 1];
-        sr += gr * pr[ix[j]] - gi * pi[ix[j]];
-        si += gr * pi[ix[j]] + gi * pr[ix[j]];
-      }
-      acc += lr[ix[i]] * si - li[ix[i]] * sr;
-    }
-  }
-  return acc;
+__device__ __forceinline__ float im_lam_y_psi(const v2f (&p)[1 << R], const v2f (&l)[1 << R]) {
+  return im_lam_y_psi_<R, RB>(p, l, iseq<(1 << (R - 1))>{});
 }
+// Im sum_ij conj(lam_i) g_ij psi_j over one pair, g wave-uniform row-major complex
+__device__ __forceinline__ float g1_pair(v2f p0, v2f p1, v2f l0, v2f l1, const float* g) {
+  const v2f s0 = v2f{g[0] * p0.x - g[1] * p0.y + g[2] * p1.x - g[3] * p1.y,
+                     g[0] * p0.y + g[1] * p0.x + g[2] * p1.y + g[3] * p1.x};
+  const v2f s1 = v2f{g[4] * p0.x - g[5] * p0.y + g[6] * p1.x - g[7] * p1.y,
+                     g[4] * p0.y + g[5] * p0.x + g[6] * p1.y + g[7] * p1.x};
+  return im_conj(l0, s0) + im_conj(l1, s1);
+}
+template <int R, int RB, int... P>
+__device__ __forceinline__ float im_lam_g1_psi_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], const float* g, std::integer_sequence<int, P...>) {
+  return (g1_pair(p[ins0<RB>(P)], p[ins0<RB>(P) | (1 << RB)], l[ins0<RB>(P)], l[ins0<RB>(P) | (1 << RB)], g) + ...);
+}
+template <int R, int RB>
+__device__ __forceinline__ float im_lam_g1_psi(const v2f (&p)[1 << R], const v2f (&l)[1 << R], const float* g) {
+  return im_lam_g1_psi_<R, RB>(p, l, g, iseq<(1 << (R - 1))>{});
+}
+
 // ---- shared pieces of the pass kernels ----------------------------------------
 struct TileCtx {
   uint32_t tile_base;  // nonlocal bits of this tile, in index space
@@ -198,19 +297,37 @@ __device__ __forceinline__ void store_tile(const float2* __restrict__ tile, floa
   }
 }
 
+__device__ __forceinline__ TileCtx make_tile_ctx(const PassArgs& a, const uint32_t* tables, uint32_t tile_id) {
+  TileCtx t;
+  uint32_t tb = 0;
+  for (uint32_t i = 0; i < a.n_nonlocal; ++i) tb |= ((tile_id >> i) & 1u) << a.nonlocal_pos[i];
+  t.tile_base = tb;
+  t.c = a.c;
+  t.cmask = (1u << a.c) - 1u;
+  t.spread = tables + a.spread_off;
+  return t;
+}
+
 // Round geometry.  Thread `tid` owns the 2^R amplitudes whose local index has
-// tid's bits deposited on the non-register positions; register value m adds
+// tid's bits deposited on the non-register positions (TL); register value m adds
 // the bits of m on the register positions.  In swizzled slot space both parts
 // combine by XOR, so the 2^R slots are visited in Gray-code order with one
-// v_xor per access: slot(gray(i)) = slot(gray(i-1)) ^ DB[ctz(i)].
+// v_xor per access: slot(gray(i)) = slot(gray(i-1)) ^ DB[ctz(i)].  Slots are kept
+// as BYTE offsets (x8) so an access needs no further address arithmetic.
 template <int K, int R>
 __device__ __forceinline__ void round_geometry(uint32_t regmask, int tid, uint32_t (&DB)[R],
-                                               uint32_t* T) {
+                                               uint32_t* T, uint32_t* TL) {
   uint32_t mk = regmask;
-#pragma unroll
-  for (int j = 0; j < R; ++j) {
-    DB[j] = swz(mk & (0u - mk));  // lowest set bit, swizzled
+  DB[0] = swz(mk & (0u - mk)) << 3;  // lowest set bit, swizzled, in bytes
+  mk &= mk - 1;
+  DB[1] = swz(mk & (0u - mk)) << 3;
+  mk &= mk - 1;
+  DB[2] = swz(mk & (0u - mk)) << 3;
+  mk &= mk - 1;
+  DB[3] = swz(mk & (0u - mk)) << 3;
+  if constexpr (R > 4) {
     mk &= mk - 1;
+    DB[R > 4 ? 4 : 0] = swz(mk & (0u - mk)) << 3;
   }
   uint32_t freem = ~regmask & ((1u << K) - 1u);
   uint32_t tl = 0;
@@ -220,39 +337,39 @@ __device__ __forceinline__ void round_geometry(uint32_t regmask, int tid, uint32
     freem &= freem - 1;
     tl |= ((uint32_t(tid) >> j) & 1u) ? low : 0u;
   }
-  *T = swz(tl);
+  *TL = tl;
+  *T = swz(tl) << 3;
 }
 
+template <int R, int... I>
+__device__ __forceinline__ void round_load_(const char* __restrict__ base, uint32_t addr,
+                                            const uint32_t (&DB)[R], v2f (&a)[1 << R],
+                                            std::integer_sequence<int, I...>) {
+  ((addr ^= (I ? DB[I ? __builtin_ctz(I) : 0] : 0u),
+    a[I ^ (I >> 1)] = *reinterpret_cast<const v2f*>(base + addr)), ...);
+}
 template <int R>
 __device__ __forceinline__ void round_load(const float2* __restrict__ tile, uint32_t T,
-                                           const uint32_t (&DB)[R], float (&ar)[1 << R],
-                                           float (&ai)[1 << R]) {
-  uint32_t addr = T;
-#pragma unroll
-  for (int i = 0; i < (1 << R); ++i) {
-    if (i) addr ^= DB[__builtin_ctz(i)];
-    const float2 v = tile[addr];
-    ar[i ^ (i >> 1)] = v.x;
-    ai[i ^ (i >> 1)] = v.y;
-  }
+                                           const uint32_t (&DB)[R], v2f (&a)[1 << R]) {
+  round_load_<R>(reinterpret_cast<const char*>(tile), T, DB, a, iseq<(1 << R)>{});
 }
 
+template <int R, int... I>
+__device__ __forceinline__ void round_store_(char* __restrict__ base, uint32_t addr,
+                                             const uint32_t (&DB)[R], const v2f (&a)[1 << R],
+                                             std::integer_sequence<int, I...>) {
+  ((addr ^= (I ? DB[I ? __builtin_ctz(I) : 0] : 0u),
+    *reinterpret_cast<v2f*>(base + addr) = a[I ^ (I >> 1)]), ...);
+}
 template <int R>
 __device__ __forceinline__ void round_store(float2* __restrict__ tile, uint32_t T,
-                                            const uint32_t (&DB)[R], const float (&ar)[1 << R],
-                                            const float (&ai)[1 << R]) {
-  uint32_t addr = T;
-#pragma unroll
-  for (int i = 0; i < (1 << R); ++i) {
-    if (i) addr ^= DB[__builtin_ctz(i)];
-    tile[addr] = make_float2(ar[i ^ (i >> 1)], ai[i ^ (i >> 1)]);
-  }
+                                            const uint32_t (&DB)[R], const v2f (&a)[1 << R]) {
+  round_store_<R>(reinterpret_cast<char*>(tile), T, DB, a, iseq<(1 << R)>{});
 }
 
 // Dense two-qubit gate applied directly on the LDS tile (not on the hot path of the
 // hardware-efficient ansatz; keeps the register rounds free of 4x4 code).
 // pos0/pos1 = local bit of the first/second qubit; matrix index = (b_q0 << 1) | b_q1.
-template <int K, int NT>
 __device__ __forceinline__ void quad_indices(uint32_t q, uint32_t pos0, uint32_t pos1, uint32_t (&ix)[4]) {
   const uint32_t pa = pos0 < pos1 ? pos0 : pos1, pb = pos0 < pos1 ? pos1 : pos0;
   uint32_t l = ((q >> pa) << (pa + 1)) | (q & ((1u << pa) - 1u));
@@ -275,73 +392,118 @@ __device__ __forceinline__ void mat4_apply(const float* __restrict__ u, const fl
   }
 }
 
-// exp(i*pi*x): the angle is accumulated and range-reduced to [-1, 1] in double, the
-// sine/cosine are then evaluated in fp32 (table entries are fp32 anyway).
-__device__ __forceinline__ float2 phase_of(double x) {
-  const float r = float(x - 2.0 * rint(0.5 * x));
-  float sn, cs;
-  sincospif(r, &sn, &cs);
-  return make_float2(cs, sn);
-}
-
-// Diagonal phase tables for one OP_DIAG.  sgn = +1 forward, -1 adjoint (conj).
-// Returns through LDS: e_lo[128], e_hi[2^(K-7)], cross[n_cross] = {cos, sin, lmask|par<<31, active/parity}.
-template <int K, int NT>
-__device__ __forceinline__ void build_diag_tables(const uint32_t* __restrict__ terms, uint32_t n_lo,
-                                                  uint32_t n_hi, uint32_t n_cross,
-                                                  const double* __restrict__ angles, double sgn,
-                                                  const TileCtx& t, float2* e_lo, float2* e_hi,
-                                                  float4* cross, int tid) {
-  constexpr int NLO = 1 << kLoBits;
-  constexpr int NHI = 1 << (K - kLoBits);
-  auto entry = [&](uint32_t l, const uint32_t* __restrict__ tp, uint32_t cnt) {
-    double ang = 0.0;
-    for (uint32_t k = 0; k < cnt; ++k) {
-      const uint32_t w0 = uni(tp[k * kDiagTermWords]), nm = uni(tp[k * kDiagTermWords + 1]);
-      const uint32_t lm = w0 & 0x7fffffffu;
-      const double a = angles[uni(tp[k * kDiagTermWords + 2])];
-      bool on;
-      if (w0 >> 31) on = (__popc(l & lm) + __popc(t.tile_base & nm)) & 1;
-      else on = ((l & lm) == lm) && ((t.tile_base & nm) == nm);
-      ang += on ? a : 0.0;
-    }
-    return phase_of(sgn * ang);
-  };
-  for (int e = tid; e < NLO; e += NT) e_lo[e] = entry(uint32_t(e), terms, n_lo);
-  for (int e = tid; e < NHI; e += NT)
-    e_hi[e] = entry(uint32_t(e) << kLoBits, terms + n_lo * kDiagTermWords, n_hi);
-  const uint32_t* cp = terms + (n_lo + n_hi) * kDiagTermWords;
-  for (uint32_t k = tid; k < n_cross; k += NT) {
-    const uint32_t w0 = cp[k * kDiagTermWords], nm = cp[k * kDiagTermWords + 1];
-    const float2 ph = phase_of(sgn * angles[cp[k * kDiagTermWords + 2]]);
-    const float cs = ph.x, sn = ph.y;
-    uint32_t flag;
-    if (w0 >> 31) flag = __popc(t.tile_base & nm) & 1;   // parity contributed by nonlocal bits
-    else flag = ((t.tile_base & nm) == nm) ? 1u : 0u;       // AND term active on this tile
-    cross[k] = make_float4(float(cs), float(sn), __uint_as_float(w0), __uint_as_float(flag));
-  }
-}
-
-__device__ __forceinline__ float2 diag_phase(uint32_t l, const float2* e_lo, const float2* e_hi,
-                                             const float4* cross, uint32_t n_cross) {
-  const float2 a = e_lo[l & ((1u << kLoBits) - 1u)], b = e_hi[l >> kLoBits];
-  float2 e = make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-  for (uint32_t k = 0; k < n_cross; ++k) {
-    const float4 ct = cross[k];
-    const uint32_t w0 = __float_as_uint(ct.z), flag = __float_as_uint(ct.w);
-    const uint32_t lm = w0 & 0x7fffffffu;
-    bool on;
-    if (w0 >> 31) on = (__popc(l & lm) + flag) & 1;
-    else on = flag && ((l & lm) == lm);
-    if (on) e = make_float2(e.x * ct.x - e.y * ct.y, e.x * ct.y + e.y * ct.x);
-  }
-  return e;
-}
-
 __device__ __forceinline__ uint32_t basis_index(const int8_t* __restrict__ row, int n_user) {
   uint32_t idx = 0;
   for (int q = 0; q < n_user; ++q) idx |= (row[q] ? 1u : 0u) << (n_user - 1 - q);
   return idx;
+}
+
+// Controlled phase: register bit J AND (a thread bit | a tile bit).
+template <int R, int J>
+__device__ __forceinline__ const uint32_t* cph_fwd(const uint32_t* __restrict__ ip,
+                                                   const float* __restrict__ coef, v2f (&a)[1 << R],
+                                                   uint32_t tl, uint32_t tile_base) {
+  const uint32_t pred = uni(ip[0]);
+  const v2f cs = load_cs(coef + uni(ip[1]));
+  const uint32_t pos = pred & 0xffu;
+  // one code path for both predicate kinds (a two-way branch would make the structuriser
+  // copy the register file): the phase degenerates to 1 where the predicate is false.
+  const bool on = (((pred >> 8) ? tile_base : tl) >> pos) & 1u;
+  apply_ph1_v<R, J>(a, v2f{on ? cs.x : 1.f, on ? cs.y : 0.f});
+  return ip + 3;
+}
+
+__device__ __forceinline__ void add_slot(float* sacc, uint32_t slot_base, int tid, uint32_t slot, float v) {
+  v = wave_sum(v);
+  if ((tid & 63) == 0) atomicAdd(&sacc[slot - slot_base], v);
+}
+
+template <int R, int J>
+__device__ __forceinline__ const uint32_t* cph_adj(const uint32_t* __restrict__ ip,
+                                                   const float* __restrict__ coef, v2f (&p)[1 << R],
+                                                   v2f (&l)[1 << R], uint32_t tl, uint32_t tile_base,
+                                                   float* sacc, uint32_t slot_base, int tid) {
+  const uint32_t pred = uni(ip[0]);
+  const v2f cs = conj_cs(load_cs(coef + uni(ip[1])));
+  const uint32_t slot = uni(ip[2]);
+  const uint32_t pos = pred & 0xffu;
+  constexpr float kM2Pi = -2.f * kPi;
+  const bool on = (((pred >> 8) ? tile_base : tl) >> pos) & 1u;
+  if (slot != 0xffffffffu) add_slot(sacc, slot_base, tid, slot, on ? kM2Pi * sum_w1<R, J>(p, l) : 0.f);
+  const v2f c2 = v2f{on ? cs.x : 1.f, on ? cs.y : 0.f};
+  apply_ph1_v<R, J>(p, c2);
+  apply_ph1_v<R, J>(l, c2);
+  return ip + 3;
+}
+
+// Measurement helpers (register file indexed by the high bits of the local index).
+__device__ __forceinline__ v2f meas_w(const float2* __restrict__ tile, uint32_t s, uint32_t xs) {
+  const float2 p = tile[s];
+  const float2 q = tile[s ^ xs];  // psi[l ^ x]
+  return v2f{q.x * p.x + q.y * p.y, q.x * p.y - q.y * p.x};
+}
+template <int R, int NT, int... I>
+__device__ __forceinline__ void meas_load_(const float2* __restrict__ tile, uint32_t tid, uint32_t xs,
+                                           v2f (&w)[1 << R], std::integer_sequence<int, I...>) {
+  ((w[I] = meas_w(tile, swz(uint32_t(I) * NT + tid), xs)), ...);
+}
+template <int R, int NT>
+__device__ __forceinline__ void meas_load(const float2* __restrict__ tile, uint32_t tid, uint32_t xs,
+                                          v2f (&w)[1 << R]) {
+  meas_load_<R, NT>(tile, tid, xs, w, iseq<(1 << R)>{});
+}
+template <int R, int IM, int... I>
+__device__ __forceinline__ float meas_sum_(const v2f (&w)[1 << R], uint32_t zhi, std::integer_sequence<int, I...>) {
+  return (((__builtin_popcount(uint32_t(I) & zhi) & 1) ? -(IM ? w[I].y : w[I].x) : (IM ? w[I].y : w[I].x)) + ...);
+}
+template <int R, int IM>
+__device__ __forceinline__ float meas_sum(const v2f (&w)[1 << R], uint32_t zhi) {
+  return meas_sum_<R, IM>(w, zhi, iseq<(1 << R)>{});
+}
+
+// One forward instance on the register file.  Returns the advanced entry pointer.
+template <int R>
+__device__ __forceinline__ const uint32_t* instance_fwd(const uint32_t* __restrict__ ip,
+                                                        const float* __restrict__ coef, v2f (&a)[1 << R],
+                                                        uint32_t tl, uint32_t tile_base) {
+  const uint32_t h0 = uni(ip[0]), h1 = uni(ip[1]);
+  ip += 2;
+  // One-qubit gates: a separate predicated slot class per kind (X, Y, dense), each a
+  // plain if-then triangle around in-place code -- no merge copies.
+  QHBM_FOR_RB(R,
+    if ((h0 >> J) & 1u) {
+      const v2f cs = load_cs(coef + uni(ip[0]));
+      ip += 2;
+      apply_x<R, J>(a, cs);
+    })
+  QHBM_FOR_RB(R,
+    if ((h1 >> (16 + J)) & 1u) {
+      const v2f cs = load_cs(coef + uni(ip[0]));
+      ip += 2;
+      apply_y<R, J>(a, cs);
+    })
+  QHBM_FOR_RB(R,
+    if ((h1 >> (24 + J)) & 1u) {
+      const float* cf = coef + uni(ip[0]);
+      ip += 2;
+      apply_mat1<R, J>(a, cf);
+    })
+  QHBM_FOR_RB(R,
+    if ((h0 >> (8 + J)) & 1u) {
+      const v2f cs = load_cs(coef + uni(ip[0]));
+      ip += 2;
+      apply_ph1<R, J>(a, cs);
+    })
+  QHBM_FOR_PAIR(R,
+    if ((h0 >> (16 + pair_index(JA, JB))) & 1u) {
+      const v2f cs = load_cs(coef + uni(ip[0]));
+      ip += 2;
+      apply_ph2<R, JA, JB>(a, cs);
+    })
+  QHBM_FOR_RB(R,
+    if ((h1 >> (2 * J)) & 1u) ip = cph_fwd<R, J>(ip, coef, a, tl, tile_base);
+    if ((h1 >> (2 * J + 1)) & 1u) ip = cph_fwd<R, J>(ip, coef, a, tl, tile_base);)
+  return ip;
 }
 
 }  // namespace
@@ -353,30 +515,17 @@ template <int K, int R>
 __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_kernel(
     PassArgs a, float2* __restrict__ psi, const int8_t* __restrict__ bits, int n_user,
     const uint32_t* __restrict__ prog_base, const uint32_t* __restrict__ tables,
-    const float* __restrict__ coef, const double* __restrict__ angles, float* __restrict__ out,
-    uint32_t state0) {
+    const float* __restrict__ coef, float* __restrict__ out, uint32_t state0) {
   constexpr int NT = 1 << (K - R);
   constexpr int NR = 1 << R;
-  constexpr int NHI = 1 << (K - kLoBits);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* tile = reinterpret_cast<float2*>(smem);
-  float2* e_lo = tile + (1 << K);
-  float2* e_hi = e_lo + (1 << kLoBits);
-  float4* cross = reinterpret_cast<float4*>(e_hi + NHI);
-  float* red = reinterpret_cast<float*>(cross + kMaxCrossTerms);
+  float* red = reinterpret_cast<float*>(tile + (1 << K));
 
   const int tid = threadIdx.x;
   const uint32_t tile_id = blockIdx.x & ((1u << a.n_nonlocal) - 1u);
   const uint32_t s_local = blockIdx.x >> a.n_nonlocal;
-  TileCtx t;
-  {
-    uint32_t tb = 0;
-    for (uint32_t i = 0; i < a.n_nonlocal; ++i) tb |= ((tile_id >> i) & 1u) << a.nonlocal_pos[i];
-    t.tile_base = tb;
-    t.c = a.c;
-    t.cmask = (1u << a.c) - 1u;
-    t.spread = tables + a.spread_off;
-  }
+  const TileCtx t = make_tile_ctx(a, tables, tile_id);
   float2* st = psi + (size_t(s_local) << a.n);
 
   if (a.flags & PASS_INIT_BASIS) {
@@ -405,37 +554,24 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
     const uint32_t opc = w0 & 0xffu;
     if (opc == OP_END) break;
     if (opc == OP_ROUND) {
-      const uint32_t n_micro = w0 >> 8;
+      const uint32_t n_inst = w0 >> 8;
       const uint32_t regmask = uni(prog[pc + 1]);
-      uint32_t DB[R], T;
-      round_geometry<K, R>(regmask, tid, DB, &T);
-      float ar[NR], ai[NR];
-      round_load<R>(tile, T, DB, ar, ai);
-      const uint32_t* mp = prog + pc + 2;
-      for (uint32_t i = 0; i < n_micro; ++i, mp += kMicroWords) {
-        const uint32_t mw = uni(mp[0]);
-        const float* cf = coef + uni(mp[1]);
-        const uint32_t mop = mw & 0xffu, rb0 = (mw >> 8) & 15u;
-        if (mop == MOP_X) {
-          const float c = cf[0], s = cf[1];
-          QHBM_DISPATCH_RB(R, rb0, (apply_x<R, RB>(ar, ai, c, s)));
-        } else if (mop == MOP_Y) {
-          const float c = cf[0], s = cf[1];
-          QHBM_DISPATCH_RB(R, rb0, (apply_y<R, RB>(ar, ai, c, s)));
-        } else {
-          QHBM_DISPATCH_RB(R, rb0, (apply_mat1<R, RB>(ar, ai, cf)));
-        }
-      }
-      round_store<R>(tile, T, DB, ar, ai);
+      uint32_t DB[R], T, TL;
+      round_geometry<K, R>(regmask, tid, DB, &T, &TL);
+      v2f amp[NR];
+      round_load<R>(tile, T, DB, amp);
+      const uint32_t* ip = prog + pc + 2;
+      for (uint32_t i = 0; i < n_inst; ++i) ip = instance_fwd<R>(ip, coef, amp, TL, t.tile_base);
+      round_store<R>(tile, T, DB, amp);
       __syncthreads();
-      pc += 2 + n_micro * kMicroWords;
+      pc = uint32_t(ip - prog);
     } else if (opc == OP_GATE2) {
       const uint32_t pw = uni(prog[pc + 1]);
       const uint32_t pos0 = pw & 0xffu, pos1 = (pw >> 8) & 0xffu;
       const float* cf = coef + uni(prog[pc + 2]);
       for (uint32_t q = tid; q < (1u << (K - 2)); q += NT) {
         uint32_t ix[4];
-        quad_indices<K, NT>(q, pos0, pos1, ix);
+        quad_indices(q, pos0, pos1, ix);
         float2 x[4], y[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) x[j] = tile[ix[j]];
@@ -445,71 +581,42 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
       }
       __syncthreads();
       pc += kGate2Words;
-    } else if (opc == OP_DIAG) {
-      const uint32_t cw = uni(prog[pc + 1]);
-      const uint32_t n_lo = cw & 1023u, n_hi = (cw >> 10) & 1023u, n_cross = cw >> 20;
-      build_diag_tables<K, NT>(prog + pc + 2, n_lo, n_hi, n_cross, angles, 1.0, t, e_lo, e_hi,
-                               cross, tid);
-      __syncthreads();
-#pragma unroll 4
-      for (int i = 0; i < NR; ++i) {
-        const uint32_t l = uint32_t(i) * NT + tid;
-        const float2 e = diag_phase(l, e_lo, e_hi, cross, n_cross);
-        const uint32_t s = swz(l);
-        const float2 v = tile[s];
-        tile[s] = make_float2(v.x * e.x - v.y * e.y, v.x * e.y + v.y * e.x);
-      }
-      __syncthreads();
-      pc += 2 + (n_lo + n_hi + n_cross) * kDiagTermWords;
     } else {  // OP_MEASURE
       const uint32_t n_groups = w0 >> 8;
       pc += 1;
       float acc = 0.f;
       uint32_t cur_op = 0xffffffffu;
-      auto flush = [&]() {
-        if (cur_op != 0xffffffffu) {
-          const float v = wave_sum(acc);
-          if ((tid & 63) == 0) atomicAdd(&red[cur_op], v);
-        }
-        acc = 0.f;
-      };
       for (uint32_t g = 0; g < n_groups; ++g) {
         const uint32_t xl = uni(prog[pc]), n_terms = uni(prog[pc + 1]);
         pc += 2;
-        float wr[NR], wi[NR];
-        const uint32_t xs = swz(xl);
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-          const uint32_t s = swz(uint32_t(i) * NT + tid);
-          const float2 p = tile[s];
-          const float2 q = tile[s ^ xs];  // psi[l ^ x]
-          // w = conj(psi[l^x]) * psi[l]
-          wr[i] = q.x * p.x + q.y * p.y;
-          wi[i] = q.x * p.y - q.y * p.x;
-        }
+        v2f w[NR];  // w = conj(psi[l ^ x]) * psi[l] at l = i*NT + tid
+        meas_load<R, NT>(tile, uint32_t(tid), swz(xl), w);
         for (uint32_t k = 0; k < n_terms; ++k, pc += kMeasTermWords) {
           const uint32_t zl = uni(prog[pc]), zn = uni(prog[pc + 1]);
           const float cf = __uint_as_float(uni(prog[pc + 2]));
           const uint32_t ow = uni(prog[pc + 3]);
           const uint32_t op = ow & 0xffffffu, ny = ow >> 24;
-          if (op != cur_op) { flush(); cur_op = op; }
+          if (op != cur_op) {
+            if (cur_op != 0xffffffffu) {
+              const float v = wave_sum(acc);
+              if ((tid & 63) == 0) atomicAdd(&red[cur_op], v);
+            }
+            acc = 0.f;
+            cur_op = op;
+          }
           // Re( i^ny * (-1)^{popc(l & z)} * w ):  ny=0: wr, 1: -wi, 2: -wr, 3: wi
           float sfac = (ny == 1 || ny == 2) ? -cf : cf;
           if (__popc(t.tile_base & zn) & 1) sfac = -sfac;
           if (__popc(uint32_t(tid) & zl) & 1) sfac = -sfac;
           const uint32_t zhi = zl >> (K - R);  // bits of l above the thread index
-          float sum = 0.f;
-          if (ny & 1) {
-#pragma unroll
-            for (int i = 0; i < NR; ++i) sum += (__builtin_popcount(uint32_t(i) & zhi) & 1) ? -wi[i] : wi[i];
-          } else {
-#pragma unroll
-            for (int i = 0; i < NR; ++i) sum += (__builtin_popcount(uint32_t(i) & zhi) & 1) ? -wr[i] : wr[i];
-          }
+          const float sum = (ny & 1) ? meas_sum<R, 1>(w, zhi) : meas_sum<R, 0>(w, zhi);
           acc = fmaf(sfac, sum, acc);
         }
       }
-      flush();
+      if (cur_op != 0xffffffffu) {
+        const float v = wave_sum(acc);
+        if ((tid & 63) == 0) atomicAdd(&red[cur_op], v);
+      }
       __syncthreads();
     }
   }
@@ -528,38 +635,27 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
 // Adjoint pass kernel: tile pair (psi, lambda); program already in reverse order.
 // For each parametrised gate:  dE/dt = -2*pi * Im <lam| A |psi>  with psi, lam taken
 // AFTER the gate and A = sum_k e_k P_k, then both are multiplied by U^dagger.
+// For a diagonal term with angle t on the index set {bits all 1}:
+//   dE/dt = -2*pi * sum_{selected l} Im(conj(lam_l) psi_l).
 // ================================================================================
 template <int K>
 __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kernel(
     PassArgs a, float2* __restrict__ psi, float2* __restrict__ lam,
     const uint32_t* __restrict__ prog_base, const uint32_t* __restrict__ tables,
-    const float* __restrict__ coef, const double* __restrict__ angles,
-    float* __restrict__ state_grad /*[U, n_slots_total]*/, uint32_t n_slots_total,
-    uint32_t state0) {
+    const float* __restrict__ coef, float* __restrict__ state_grad /*[U, n_slots_total]*/,
+    uint32_t n_slots_total, uint32_t state0) {
   constexpr int R = 4;
   constexpr int NT = 1 << (K - R);
   constexpr int NR = 1 << R;
-  constexpr int NHI = 1 << (K - kLoBits);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* tp = reinterpret_cast<float2*>(smem);
   float2* tl = tp + (1 << K);
-  float2* e_lo = tl + (1 << K);
-  float2* e_hi = e_lo + (1 << kLoBits);
-  float4* cross = reinterpret_cast<float4*>(e_hi + NHI);
-  float* sacc = reinterpret_cast<float*>(cross + kMaxCrossTerms);  // [kMaxSlotsPerPass]
+  float* sacc = reinterpret_cast<float*>(tl + (1 << K));  // [kMaxSlotsPerPass]
 
   const int tid = threadIdx.x;
   const uint32_t tile_id = blockIdx.x & ((1u << a.n_nonlocal) - 1u);
   const uint32_t s_local = blockIdx.x >> a.n_nonlocal;
-  TileCtx t;
-  {
-    uint32_t tb = 0;
-    for (uint32_t i = 0; i < a.n_nonlocal; ++i) tb |= ((tile_id >> i) & 1u) << a.nonlocal_pos[i];
-    t.tile_base = tb;
-    t.c = a.c;
-    t.cmask = (1u << a.c) - 1u;
-    t.spread = tables + a.spread_off;
-  }
+  const TileCtx t = make_tile_ctx(a, tables, tile_id);
   float2* sp = psi + (size_t(s_local) << a.n);
   float2* sl = lam + (size_t(s_local) << a.n);
   load_tile<K, NT>(tp, sp, t, tid);
@@ -567,10 +663,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
   for (uint32_t i = tid; i < a.n_slots; i += NT) sacc[i] = 0.f;
   __syncthreads();
 
-  auto add_slot = [&](uint32_t slot, float v) {
-    v = wave_sum(v);
-    if ((tid & 63) == 0) atomicAdd(&sacc[slot - a.slot_base], v);
-  };
+  constexpr float kM2Pi = -2.f * kPi;
 
   const uint32_t* prog = prog_base + a.prog_off;
   uint32_t pc = 0;
@@ -579,40 +672,77 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
     const uint32_t opc = w0 & 0xffu;
     if (opc == OP_END) break;
     if (opc == OP_ROUND) {
-      const uint32_t n_micro = w0 >> 8;
+      const uint32_t n_inst = w0 >> 8;
       const uint32_t regmask = uni(prog[pc + 1]);
-      uint32_t DB[R], T;
-      round_geometry<K, R>(regmask, tid, DB, &T);
-      float pr[NR], pi[NR], lr[NR], li[NR];
-      round_load<R>(tp, T, DB, pr, pi);
-      round_load<R>(tl, T, DB, lr, li);
-      const uint32_t* mp = prog + pc + 2;
-      for (uint32_t i = 0; i < n_micro; ++i, mp += kMicroWords) {
-        const uint32_t mw = uni(mp[0]);
-        const float* cf = coef + uni(mp[1]);
-        const uint32_t slot = uni(mp[2]);
-        const uint32_t mop = mw & 0xffu, rb0 = (mw >> 8) & 15u;
-        const bool want = slot != 0xffffffffu;
-        float g = 0.f;
-        if (mop == MOP_X) {
-          const float c = cf[0], s = -cf[1];  // U^dagger = c*I + i*s*X
-          QHBM_DISPATCH_RB(R, rb0, (g = want ? kPi * im_lam_x_psi<R, RB>(pr, pi, lr, li) : 0.f,
-                                   apply_x<R, RB>(pr, pi, c, s), apply_x<R, RB>(lr, li, c, s)));
-        } else if (mop == MOP_Y) {
-          const float c = cf[0], s = -cf[1];
-          QHBM_DISPATCH_RB(R, rb0, (g = want ? kPi * im_lam_y_psi<R, RB>(pr, pi, lr, li) : 0.f,
-                                   apply_y<R, RB>(pr, pi, c, s), apply_y<R, RB>(lr, li, c, s)));
-        } else {
-          QHBM_DISPATCH_RB(R, rb0, (g = want ? im_lam_g1_psi<R, RB>(pr, pi, lr, li, cf + 8) : 0.f,
-                                   apply_mat1<R, RB>(pr, pi, cf), apply_mat1<R, RB>(lr, li, cf)));
-        }
-        if (want) add_slot(slot, g);
+      uint32_t DB[R], T, TL;
+      round_geometry<K, R>(regmask, tid, DB, &T, &TL);
+      v2f p[NR], l[NR];
+      round_load<R>(tp, T, DB, p);
+      round_load<R>(tl, T, DB, l);
+      const uint32_t* ip = prog + pc + 2;
+      for (uint32_t inst = 0; inst < n_inst; ++inst) {
+        const uint32_t h0 = uni(ip[0]), h1 = uni(ip[1]);
+        ip += 2;
+        // ---- CPH ----
+        QHBM_FOR_RB(R,
+          if ((h1 >> (2 * J)) & 1u)
+            ip = cph_adj<R, J>(ip, coef, p, l, TL, t.tile_base, sacc, a.slot_base, tid);
+          if ((h1 >> (2 * J + 1)) & 1u)
+            ip = cph_adj<R, J>(ip, coef, p, l, TL, t.tile_base, sacc, a.slot_base, tid);)
+        // ---- PH2 ----
+        QHBM_FOR_PAIR(R,
+          if ((h0 >> (16 + pair_index(JA, JB))) & 1u) {
+            const v2f cs = conj_cs(load_cs(coef + uni(ip[0])));
+            const uint32_t slot = uni(ip[1]);
+            ip += 2;
+            if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kM2Pi * sum_w2<R, JA, JB>(p, l));
+            apply_ph2<R, JA, JB>(p, cs);
+            apply_ph2<R, JA, JB>(l, cs);
+          })
+        // ---- PH1 ----
+        QHBM_FOR_RB(R,
+          if ((h0 >> (8 + J)) & 1u) {
+            const v2f cs = conj_cs(load_cs(coef + uni(ip[0])));
+            const uint32_t slot = uni(ip[1]);
+            ip += 2;
+            if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kM2Pi * sum_w1<R, J>(p, l));
+            apply_ph1<R, J>(p, cs);
+            apply_ph1<R, J>(l, cs);
+          })
+        // ---- one-qubit gates (X, Y, dense slot classes) ----
+        QHBM_FOR_RB(R,
+          if ((h0 >> J) & 1u) {
+            const v2f cs = conj_cs(load_cs(coef + uni(ip[0])));  // U^dagger = c*I + i*s*X
+            const uint32_t slot = uni(ip[1]);
+            ip += 2;
+            if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kPi * im_lam_x_psi<R, J>(p, l));
+            apply_x<R, J>(p, cs);
+            apply_x<R, J>(l, cs);
+          })
+        QHBM_FOR_RB(R,
+          if ((h1 >> (16 + J)) & 1u) {
+            const v2f cs = conj_cs(load_cs(coef + uni(ip[0])));
+            const uint32_t slot = uni(ip[1]);
+            ip += 2;
+            if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kPi * im_lam_y_psi<R, J>(p, l));
+            apply_y<R, J>(p, cs);
+            apply_y<R, J>(l, cs);
+          })
+        QHBM_FOR_RB(R,
+          if ((h1 >> (24 + J)) & 1u) {
+            const float* cf = coef + uni(ip[0]);
+            const uint32_t slot = uni(ip[1]);
+            ip += 2;
+            if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, im_lam_g1_psi<R, J>(p, l, cf + 8));
+            apply_mat1<R, J>(p, cf);
+            apply_mat1<R, J>(l, cf);
+          })
       }
-      round_store<R>(tp, T, DB, pr, pi);
-      round_store<R>(tl, T, DB, lr, li);
+      round_store<R>(tp, T, DB, p);
+      round_store<R>(tl, T, DB, l);
       __syncthreads();
-      pc += 2 + n_micro * kMicroWords;
-    } else if (opc == OP_GATE2) {
+      pc = uint32_t(ip - prog);
+    } else {  // OP_GATE2
       const uint32_t pw = uni(prog[pc + 1]);
       const uint32_t pos0 = pw & 0xffu, pos1 = (pw >> 8) & 0xffu;
       const float* cf = coef + uni(prog[pc + 2]);  // U^dagger (32 floats) then generator (32 floats)
@@ -620,7 +750,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
       float gacc = 0.f;
       for (uint32_t q = tid; q < (1u << (K - 2)); q += NT) {
         uint32_t ix[4];
-        quad_indices<K, NT>(q, pos0, pos1, ix);
+        quad_indices(q, pos0, pos1, ix);
         float2 x[4], l[4], y[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { x[j] = tp[ix[j]]; l[j] = tl[ix[j]]; }
@@ -636,59 +766,9 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
 #pragma unroll
         for (int j = 0; j < 4; ++j) tl[ix[j]] = y[j];
       }
-      if (slot != 0xffffffffu) add_slot(slot, gacc);
+      if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, gacc);
       __syncthreads();
       pc += kGate2Words;
-    } else {  // OP_DIAG
-      const uint32_t cw = uni(prog[pc + 1]);
-      const uint32_t n_lo = cw & 1023u, n_hi = (cw >> 10) & 1023u, n_cross = cw >> 20;
-      const uint32_t n_terms = n_lo + n_hi + n_cross;
-      const uint32_t* terms = prog + pc + 2;
-      build_diag_tables<K, NT>(terms, n_lo, n_hi, n_cross, angles, -1.0, t, e_lo, e_hi, cross, tid);
-      // w_i = Im(conj(lam) psi) at l = i*NT + tid (invariant under the diagonal itself)
-      float w[NR];
-      float wtot = 0.f;
-#pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        const uint32_t s = swz(uint32_t(i) * NT + tid);
-        const float2 p = tp[s], q = tl[s];
-        w[i] = q.x * p.y - q.y * p.x;
-        wtot += w[i];
-      }
-      for (uint32_t k = 0; k < n_terms; ++k) {
-        const uint32_t tw = uni(terms[k * kDiagTermWords]), nm = uni(terms[k * kDiagTermWords + 1]);
-        const uint32_t slot = uni(terms[k * kDiagTermWords + 3]);
-        if (slot == 0xffffffffu) continue;
-        const uint32_t lm = tw & 0x7fffffffu;
-        const uint32_t lm_t = lm & (NT - 1u), lm_h = lm >> (K - R);
-        float v;
-        if (tw >> 31) {  // parity term: sum_l w(l) * parity(idx & mask)
-          float asum = 0.f;
-#pragma unroll
-          for (int i = 0; i < NR; ++i) asum += (__builtin_popcount(uint32_t(i) & lm_h) & 1) ? w[i] : 0.f;
-          const bool pt = (__popc(uint32_t(tid) & lm_t) + __popc(t.tile_base & nm)) & 1;
-          v = pt ? (wtot - asum) : asum;
-        } else {  // AND term
-          float asum = 0.f;
-#pragma unroll
-          for (int i = 0; i < NR; ++i) asum += ((uint32_t(i) & lm_h) == lm_h) ? w[i] : 0.f;
-          const bool on = ((uint32_t(tid) & lm_t) == lm_t) && ((t.tile_base & nm) == nm);
-          v = on ? asum : 0.f;
-        }
-        add_slot(slot, -2.f * kPi * v);
-      }
-      __syncthreads();
-#pragma unroll 4
-      for (int i = 0; i < NR; ++i) {
-        const uint32_t l = uint32_t(i) * NT + tid;
-        const float2 e = diag_phase(l, e_lo, e_hi, cross, n_cross);
-        const uint32_t s = swz(l);
-        const float2 v = tp[s], u = tl[s];
-        tp[s] = make_float2(v.x * e.x - v.y * e.y, v.x * e.y + v.y * e.x);
-        tl[s] = make_float2(u.x * e.x - u.y * e.y, u.x * e.y + u.y * e.x);
-      }
-      __syncthreads();
-      pc += 2 + n_terms * kDiagTermWords;
     }
   }
   __syncthreads();
@@ -756,15 +836,21 @@ __device__ void involution2(int kind, int (&perm)[4], Cplx (&ph)[4]) {
 
 __global__ void prep_coefs_kernel(const CoefJob* __restrict__ jobs, int n_jobs,
                                   const float* __restrict__ params, float* __restrict__ coef,
-                                  double* __restrict__ angles, int shift_gate, double shift) {
+                                  int shift_gate, double shift) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_jobs) return;
   const CoefJob jb = jobs[j];
   double t = double(jb.offset);
   if (jb.param_idx >= 0) t += double(jb.scalar) * double(params[jb.param_idx]);
   if (jb.gate == shift_gate) t += shift;
-  if (jb.mop == 0) { angles[jb.out_off] = t; return; }
   float* o = coef + jb.out_off;
+  if (jb.mop == MOP_PHASE) {  // diagonal term exp(i*pi*mult*t) on its index set
+    double sn, cs;
+    sincospi(double(jb.mult) * t, &sn, &cs);
+    o[0] = float(cs);
+    o[1] = float(sn);
+    return;
+  }
   double sh, ch;  // sin, cos of pi*t/2
   sincospi(0.5 * t, &sh, &ch);
   if (jb.mop == MOP_X || jb.mop == MOP_Y) {
@@ -890,19 +976,13 @@ __global__ __launch_bounds__(256) void shift_accumulate_kernel(
 // ================================================================================
 // Host-side launchers
 // ================================================================================
-size_t fwd_lds_bytes(int K) {
-  return (size_t(1) << K) * 8 + (size_t(1) << kLoBits) * 8 + (size_t(1) << (K - kLoBits)) * 8 +
-         size_t(kMaxCrossTerms) * 16 + size_t(kMaxOps) * 4;
-}
-size_t adj_lds_bytes(int K) {
-  return (size_t(2) << K) * 8 + (size_t(1) << kLoBits) * 8 + (size_t(1) << (K - kLoBits)) * 8 +
-         size_t(kMaxCrossTerms) * 16 + size_t(kMaxSlotsPerPass) * 4;
-}
+size_t fwd_lds_bytes(int K) { return (size_t(1) << K) * 8 + size_t(kMaxOps) * 4; }
+size_t adj_lds_bytes(int K) { return (size_t(2) << K) * 8 + size_t(kMaxSlotsPerPass) * 4; }
 
 template <int K, int R>
 static hipError_t launch_fwd_t(const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
                                int n_user, const uint32_t* prog, const uint32_t* tables,
-                               const float* coef, const double* angles, float* out, uint32_t state0,
+                               const float* coef, float* out, uint32_t state0,
                                hipStream_t stream) {
   const size_t lds = fwd_lds_bytes(K);
   static bool attr_done = false;
@@ -914,16 +994,16 @@ static hipError_t launch_fwd_t(const PassArgs& a, uint32_t n_states, float2* psi
   }
   const uint32_t grid = n_states << a.n_nonlocal;
   hipLaunchKernelGGL((pass_fwd_kernel<K, R>), dim3(grid), dim3(1 << (K - R)), lds, stream, a, psi, bits,
-                     n_user, prog, tables, coef, angles, out, state0);
+                     n_user, prog, tables, coef, out, state0);
   return hipGetLastError();
 }
 
 hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
                            int n_user, const uint32_t* prog, const uint32_t* tables, const float* coef,
-                           const double* angles, float* out, uint32_t state0, hipStream_t stream) {
+                           float* out, uint32_t state0, hipStream_t stream) {
 #define QHBM_FWD_CASE(K_, R_)                                                                          \
   if (K == K_ && R == R_)                                                                              \
-    return launch_fwd_t<K_, R_>(a, n_states, psi, bits, n_user, prog, tables, coef, angles, out, state0, stream);
+    return launch_fwd_t<K_, R_>(a, n_states, psi, bits, n_user, prog, tables, coef, out, state0, stream);
   QHBM_FWD_CASE(10, 4)
   QHBM_FWD_CASE(11, 4)
   QHBM_FWD_CASE(12, 4)
@@ -939,7 +1019,7 @@ hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, f
 template <int K>
 static hipError_t launch_adj_t(const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
                                const uint32_t* prog, const uint32_t* tables, const float* coef,
-                               const double* angles, float* state_grad, uint32_t n_slots_total,
+                               float* state_grad, uint32_t n_slots_total,
                                uint32_t state0, hipStream_t stream) {
   const size_t lds = adj_lds_bytes(K);
   static bool attr_done = false;
@@ -951,19 +1031,19 @@ static hipError_t launch_adj_t(const PassArgs& a, uint32_t n_states, float2* psi
   }
   const uint32_t grid = n_states << a.n_nonlocal;
   hipLaunchKernelGGL((pass_adj_kernel<K>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, lam, prog,
-                     tables, coef, angles, state_grad, n_slots_total, state0);
+                     tables, coef, state_grad, n_slots_total, state0);
   return hipGetLastError();
 }
 
 hipError_t launch_pass_adj(int K, const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
                            const uint32_t* prog, const uint32_t* tables, const float* coef,
-                           const double* angles, float* state_grad, uint32_t n_slots_total,
+                           float* state_grad, uint32_t n_slots_total,
                            uint32_t state0, hipStream_t stream) {
   switch (K) {
-    case 10: return launch_adj_t<10>(a, n_states, psi, lam, prog, tables, coef, angles, state_grad, n_slots_total, state0, stream);
-    case 11: return launch_adj_t<11>(a, n_states, psi, lam, prog, tables, coef, angles, state_grad, n_slots_total, state0, stream);
-    case 12: return launch_adj_t<12>(a, n_states, psi, lam, prog, tables, coef, angles, state_grad, n_slots_total, state0, stream);
-    case 13: return launch_adj_t<13>(a, n_states, psi, lam, prog, tables, coef, angles, state_grad, n_slots_total, state0, stream);
+    case 10: return launch_adj_t<10>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream);
+    case 11: return launch_adj_t<11>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream);
+    case 12: return launch_adj_t<12>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream);
+    case 13: return launch_adj_t<13>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream);
     default: return hipErrorInvalidValue;
   }
 }
@@ -978,10 +1058,10 @@ hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, u
 }
 
 hipError_t launch_prep_coefs(const CoefJob* jobs, int n_jobs, const float* params, float* coef,
-                             double* angles, int shift_gate, double shift, hipStream_t stream) {
+                             int shift_gate, double shift, hipStream_t stream) {
   if (n_jobs == 0) return hipSuccess;
   hipLaunchKernelGGL(prep_coefs_kernel, dim3((n_jobs + 127) / 128), dim3(128), 0, stream, jobs, n_jobs,
-                     params, coef, angles, shift_gate, shift);
+                     params, coef, shift_gate, shift);
   return hipGetLastError();
 }
 

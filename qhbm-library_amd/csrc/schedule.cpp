@@ -1,12 +1,19 @@
 // schedule.cpp -- circuit lowering and LDS-tile pass scheduling (host, no HIP).
 //
-// Scheduling model.  Every gate touches a few amplitude-index bits.  A pass
-// keeps K "local" bits resident in LDS, so it can apply any non-diagonal gate
-// whose bits are all local, and ANY diagonal gate (a diagonal gate never moves
-// data: non-local bits are constants of the tile).  Gates on disjoint bits
-// commute, so a pass greedily absorbs every gate whose per-bit predecessors
-// have been absorbed -- for nearest-neighbour ansaetze this eats a whole
-// light-cone of the circuit in one HBM round trip, not one layer.
+// Scheduling model.  Every gate touches a few amplitude-index bits.
+//   * A PASS keeps K "local" bits resident in LDS.  It can apply any
+//     non-diagonal gate whose bits are all local, and any diagonal term that
+//     has at least one local bit (non-local bits are constants of the tile).
+//     Gates on disjoint bits commute, so a pass greedily absorbs every gate
+//     whose per-bit predecessors have been absorbed -- for nearest-neighbour
+//     ansaetze this eats a whole light-cone of the circuit in one HBM round
+//     trip, not one layer.
+//   * Inside a pass, a ROUND keeps R of the K local bits in registers (2^R
+//     amplitudes per thread) and again absorbs a light-cone: every one-qubit
+//     gate on a register bit and every diagonal term with a register bit whose
+//     predecessors are done.  The micro-ops of a round are packed into fixed
+//     template INSTANCES (program.h) so the kernel body is straight-line code
+//     with predicated in-place slots.
 #include "schedule.h"
 
 #include <algorithm>
@@ -21,21 +28,15 @@ namespace {
 
 inline int popc(uint32_t x) { return __builtin_popcount(x); }
 
-bool lower(const Model& m, int n_eff, std::vector<LoweredOp>* ops, int* n_angles,
-           std::string* err) {
-  (void)n_eff;
+bool lower(const Model& m, std::vector<LoweredOp>* ops, std::string* err) {
   ops->clear();
-  *n_angles = 0;
   for (size_t g = 0; g < m.gates.size(); ++g) {
     const Gate& G = m.gates[g];
-    LoweredOp op;
-    op.kind = G.kind;
-    op.gate = static_cast<int>(g);
-    const bool two = G.kind >= QHBM_GATE_CZPOW && G.kind < QHBM_GATE_KIND_COUNT;
     if (G.kind < 0 || G.kind >= QHBM_GATE_KIND_COUNT) {
       *err = "gate " + std::to_string(g) + ": unknown kind " + std::to_string(G.kind);
       return false;
     }
+    const bool two = G.kind >= QHBM_GATE_CZPOW;
     if (G.q0 < 0 || G.q0 >= m.n || (two && (G.q1 < 0 || G.q1 >= m.n || G.q1 == G.q0))) {
       *err = "gate " + std::to_string(g) + ": qubit out of range";
       return false;
@@ -44,21 +45,42 @@ bool lower(const Model& m, int n_eff, std::vector<LoweredOp>* ops, int* n_angles
       *err = "gate " + std::to_string(g) + ": param_idx out of range";
       return false;
     }
+    LoweredOp op;
+    op.kind = G.kind;
+    op.gate = static_cast<int>(g);
     op.b0 = m.n - 1 - G.q0;
     op.b1 = two ? m.n - 1 - G.q1 : -1;
     op.bits = (1u << op.b0) | (two ? (1u << op.b1) : 0u);
     switch (G.kind) {
-      case QHBM_GATE_I: op.type = LOW_SKIP; break;
-      case QHBM_GATE_ZPOW:
-      case QHBM_GATE_CZPOW: op.type = LOW_DIAG; op.par = false; break;
-      case QHBM_GATE_ZZPOW: op.type = LOW_DIAG; op.par = true; break;
+      case QHBM_GATE_I: break;
+      case QHBM_GATE_ZPOW:   // diag(1, e^{i pi t})
+      case QHBM_GATE_CZPOW:  // diag(1, 1, 1, e^{i pi t})
+        op.type = LOW_DIAG;
+        ops->push_back(op);
+        break;
+      case QHBM_GATE_ZZPOW: {
+        // e^{i pi t [b0 xor b1]} = e^{i pi t b0} e^{i pi t b1} e^{-2 i pi t b0 b1}
+        LoweredOp a = op, b = op, c = op;
+        a.type = b.type = c.type = LOW_DIAG;
+        a.bits = 1u << op.b0; a.b1 = -1;
+        b.bits = 1u << op.b1; b.b0 = op.b1; b.b1 = -1;
+        c.mult = -2.f;
+        ops->push_back(a);
+        ops->push_back(b);
+        ops->push_back(c);
+        break;
+      }
       case QHBM_GATE_XPOW:
       case QHBM_GATE_YPOW:
-      case QHBM_GATE_HPOW: op.type = LOW_MAT1; break;
-      default: op.type = LOW_MAT2; break;
+      case QHBM_GATE_HPOW:
+        op.type = LOW_MAT1;
+        ops->push_back(op);
+        break;
+      default:
+        op.type = LOW_MAT2;
+        ops->push_back(op);
+        break;
     }
-    if (op.type == LOW_DIAG) op.angle_idx = (*n_angles)++;
-    if (op.type != LOW_SKIP) ops->push_back(op);
   }
   return true;
 }
@@ -74,8 +96,11 @@ std::vector<int> absorb(const std::vector<LoweredOp>& ops, const std::vector<int
   for (int oi : order) {
     if (done[oi]) continue;
     const LoweredOp& op = ops[oi];
-    if (op.bits & blocked) { blocked |= op.bits; }
-    else if (op.type == LOW_DIAG || (op.bits & ~S) == 0) {
+    bool ok = false;
+    if (!(op.bits & blocked)) {
+      ok = op.type == LOW_DIAG ? (op.bits & S) != 0 : (op.bits & ~S) == 0;
+    }
+    if (ok) {
       out.push_back(oi);
       if (op.type != LOW_DIAG) ++*n_mat;
     } else {
@@ -89,6 +114,18 @@ std::vector<int> absorb(const std::vector<LoweredOp>& ops, const std::vector<int
 struct MeasGroup {
   uint32_t x;
   std::vector<int> terms;  // indices into Model::terms
+};
+
+struct Entry {
+  uint32_t w0 = 0;  // MAT: mop; CPH: pred
+  uint32_t coef_off = 0;
+  uint32_t slot = 0xffffffffu;
+};
+
+struct Instance {
+  uint32_t mat_mask = 0, ph1_mask = 0, ph2_mask = 0, cph_mask = 0;
+  uint32_t diag_touch = 0;  // register bits touched by a diagonal entry
+  Entry mat[5], ph1[5], ph2[10], cph[10];
 };
 
 class Builder {
@@ -126,63 +163,51 @@ class Builder {
     return s;
   }
 
-  // Packs the absorbed ops into rounds / diagonal ops and appends the words.
-  void emit_ops(Pass* p, const std::vector<LoweredOp>& ops, const std::vector<int>& absorbed) {
+  // Packs the absorbed ops of a pass into rounds / dense two-qubit ops.
+  bool emit_ops(Pass* p, const std::vector<LoweredOp>& ops, const std::vector<int>& absorbed,
+                std::string* err) {
     std::vector<char> emitted(absorbed.size(), 0);
     size_t left = absorbed.size();
     const uint32_t S = local_set_mask(*p);
     while (left) {
-      // ---- gate rounds until no gate is ready --------------------------------
-      for (;;) {
-        uint32_t blocked = 0, reg = 0;
-        std::vector<size_t> in_round;
-        for (size_t i = 0; i < absorbed.size(); ++i) {
-          if (emitted[i]) continue;
-          const LoweredOp& op = ops[absorbed[i]];
-          if (op.bits & blocked) { blocked |= op.bits; continue; }
-          if (op.type != LOW_MAT1) { blocked |= op.bits; continue; }
-          const uint32_t lb = to_local(*p, op.bits);
-          if (popc(reg | lb) <= R_) { reg |= lb; in_round.push_back(i); }
-          else blocked |= op.bits;
-        }
-        if (in_round.empty()) break;
-        // pad the register mask to exactly R bits, highest free local bits first
-        for (int i = K_ - 1; i >= 0 && popc(reg) < R_; --i) if (!(reg >> i & 1)) reg |= 1u << i;
-        p->prog.push_back(OP_ROUND | (uint32_t(in_round.size()) << 8));
-        p->prog.push_back(reg);
-        for (size_t i : in_round) {
-          const LoweredOp& op = ops[absorbed[i]];
-          emit_micro(p, op, reg);
-          emitted[i] = 1;
-          --left;
-        }
-        ++p->n_rounds;
-      }
-      // ---- dense two-qubit gates that are ready (applied directly on LDS) ---------
-      {
-        uint32_t blocked2 = 0;
-        for (size_t i = 0; i < absorbed.size(); ++i) {
-          if (emitted[i]) continue;
-          const LoweredOp& op = ops[absorbed[i]];
-          if (op.bits & blocked2) { blocked2 |= op.bits; continue; }
-          if (op.type == LOW_MAT2) { emit_gate2(p, op); emitted[i] = 1; --left; }
-          else blocked2 |= op.bits;
-        }
-      }
-      // ---- one diagonal op with every ready diagonal term -----------------------
-      std::vector<size_t> diag;
-      uint32_t blocked = 0;
+      const size_t before = left;
+      // ---- one round: light-cone over up to R register bits -------------------
+      uint32_t reg = 0, blocked = 0;
+      std::vector<size_t> seq;
       for (size_t i = 0; i < absorbed.size(); ++i) {
         if (emitted[i]) continue;
         const LoweredOp& op = ops[absorbed[i]];
         if (op.bits & blocked) { blocked |= op.bits; continue; }
-        if (op.type == LOW_DIAG) diag.push_back(i); else blocked |= op.bits;
+        if (op.type == LOW_MAT1) {
+          const uint32_t lb = to_local(*p, op.bits);
+          if ((reg & lb) || popc(reg) < R_) { reg |= lb; seq.push_back(i); }
+          else blocked |= op.bits;
+        } else if (op.type == LOW_DIAG) {
+          const uint32_t ll = to_local(*p, op.bits & S);
+          if (ll & reg) seq.push_back(i);
+          else if (popc(reg) < R_) { reg |= ll & (0u - ll); seq.push_back(i); }
+          else blocked |= op.bits;
+        } else {
+          blocked |= op.bits;
+        }
       }
-      if (!diag.empty()) {
-        emit_diag(p, ops, absorbed, diag, S);
-        for (size_t i : diag) { emitted[i] = 1; --left; }
+      if (!seq.empty()) {
+        for (int i = K_ - 1; i >= 0 && popc(reg) < R_; --i) if (!(reg >> i & 1)) reg |= 1u << i;
+        emit_round(p, ops, absorbed, seq, reg, S);
+        for (size_t i : seq) { emitted[i] = 1; --left; }
       }
+      // ---- dense two-qubit gates that are ready (applied directly on LDS) ---------
+      uint32_t blocked2 = 0;
+      for (size_t i = 0; i < absorbed.size(); ++i) {
+        if (emitted[i]) continue;
+        const LoweredOp& op = ops[absorbed[i]];
+        if (op.bits & blocked2) { blocked2 |= op.bits; continue; }
+        if (op.type == LOW_MAT2) { emit_gate2(p, op); emitted[i] = 1; --left; }
+        else blocked2 |= op.bits;
+      }
+      if (left == before) { *err = "internal: round packing made no progress"; return false; }
     }
+    return true;
   }
 
   int new_slot(Pass* p, const LoweredOp& op) {
@@ -191,17 +216,13 @@ class Builder {
     if (G.param_idx < 0) return -1;
     const int slot = static_cast<int>(plan_->slot_gate.size());
     plan_->slot_gate.push_back(op.gate);
-    plan_->slot_factor.push_back(G.scalar);
+    plan_->slot_factor.push_back(G.scalar * (op.type == LOW_DIAG ? op.mult : 1.f));
     ++p->n_slots;
     return slot;
   }
 
-  void emit_micro(Pass* p, const LoweredOp& op, uint32_t reg) {
+  CoefJob base_job(const LoweredOp& op) {
     const Gate& G = m_.gates[op.gate];
-    auto rank = [&](int gbit) {
-      uint32_t lb = to_local(*p, 1u << gbit);
-      return popc(reg & (lb - 1));
-    };
     CoefJob job{};
     job.op_kind = op.kind;
     job.gate = op.gate;
@@ -210,33 +231,113 @@ class Builder {
     job.offset = G.offset;
     job.out_off = plan_->n_coef_floats;
     job.dagger = adjoint_ ? 1 : 0;
-    uint32_t mop;
-    int nfloat;
-    const uint32_t rb0 = rank(op.b0);
-    if (op.kind == QHBM_GATE_XPOW) { mop = MOP_X; nfloat = 2; }
-    else if (op.kind == QHBM_GATE_YPOW) { mop = MOP_Y; nfloat = 2; }
-    else { mop = MOP_MAT1; nfloat = adjoint_ ? 16 : 8; }
-    job.mop = mop;
-    plan_->n_coef_floats += nfloat;
-    plan_->jobs.push_back(job);
-    const int slot = new_slot(p, op);
-    p->prog.push_back(mop | (rb0 << 8) | (uint32_t(op.kind) << 16));
-    p->prog.push_back(uint32_t(job.out_off));
-    p->prog.push_back(uint32_t(slot));
-    ++p->n_mat_ops;
+    job.mult = 1.f;
+    return job;
+  }
+
+  void emit_round(Pass* p, const std::vector<LoweredOp>& ops, const std::vector<int>& absorbed,
+                  const std::vector<size_t>& seq, uint32_t reg, uint32_t S) {
+    auto rank_of = [&](uint32_t local_bit_mask) { return popc(reg & (local_bit_mask - 1)); };
+    std::vector<Instance> insts(1);
+    for (size_t i : seq) {
+      const LoweredOp& op = ops[absorbed[i]];
+      Entry e;
+      e.slot = uint32_t(new_slot(p, op));
+      CoefJob job = base_job(op);
+      e.coef_off = uint32_t(job.out_off);
+      if (op.type == LOW_MAT1) {
+        const int j = rank_of(to_local(*p, op.bits));
+        int nfloat;
+        if (op.kind == QHBM_GATE_XPOW) { job.mop = MOP_X; nfloat = 2; }
+        else if (op.kind == QHBM_GATE_YPOW) { job.mop = MOP_Y; nfloat = 2; }
+        else { job.mop = MOP_MAT1; nfloat = adjoint_ ? 16 : 8; }
+        plan_->n_coef_floats += nfloat;
+        e.w0 = uint32_t(job.mop);
+        Instance* in = &insts.back();
+        const bool conflict = adjoint_ ? bool(in->mat_mask >> j & 1)
+                                       : bool((in->mat_mask >> j & 1) || (in->diag_touch >> j & 1));
+        if (conflict) { insts.emplace_back(); in = &insts.back(); }
+        in->mat_mask |= 1u << j;
+        in->mat[j] = e;
+        ++p->n_mat_ops;
+      } else {  // diagonal term
+        job.mop = MOP_PHASE;
+        job.mult = op.mult;
+        plan_->n_coef_floats += 2;
+        const uint32_t ll = to_local(*p, op.bits & S);
+        const uint32_t in_reg = ll & reg;
+        const uint32_t other_local = ll & ~reg;
+        const uint32_t other_nonlocal = op.bits & ~S;
+        const int j = rank_of(in_reg & (0u - in_reg));
+        int kind;  // 1 PH1, 2 PH2, 3 CPH
+        int j2 = -1;
+        if (popc(in_reg) == 2) { kind = 2; j2 = rank_of(in_reg & (in_reg - 1)); }
+        else if (other_local) { kind = 3; e.w0 = uint32_t(__builtin_ctz(other_local)); }
+        else if (other_nonlocal) { kind = 3; e.w0 = uint32_t(__builtin_ctz(other_nonlocal)) | (1u << 8); }
+        else kind = 1;
+        const uint32_t touch = (1u << j) | (j2 >= 0 ? (1u << j2) : 0u);
+        auto fits = [&](const Instance& in) {
+          if (adjoint_ && (in.mat_mask & touch)) return false;  // MAT executes after diagonals there
+          if (kind == 1) return !(in.ph1_mask >> j & 1);
+          if (kind == 2) return !(in.ph2_mask >> pair_index(j, j2) & 1);
+          return ((in.cph_mask >> (2 * j)) & 3u) != 3u;
+        };
+        if (!fits(insts.back())) insts.emplace_back();
+        Instance* in = &insts.back();
+        in->diag_touch |= touch;
+        if (kind == 1) { in->ph1_mask |= 1u << j; in->ph1[j] = e; }
+        else if (kind == 2) { const int pi = pair_index(j, j2); in->ph2_mask |= 1u << pi; in->ph2[pi] = e; }
+        else {
+          const int k = ((in->cph_mask >> (2 * j)) & 1u) ? 1 : 0;
+          in->cph_mask |= 1u << (2 * j + k);
+          in->cph[2 * j + k] = e;
+        }
+        ++p->n_diag_terms;
+      }
+      plan_->jobs.push_back(job);
+    }
+    // ---- serialise ----
+    p->prog.push_back(OP_ROUND | (uint32_t(insts.size()) << 8));
+    p->prog.push_back(reg);
+    const int n_pairs = R_ * (R_ - 1) / 2;
+    for (const Instance& in : insts) {
+      uint32_t kmask[3] = {0, 0, 0};  // X, Y, dense
+      for (int j = 0; j < R_; ++j) if (in.mat_mask >> j & 1) {
+        kmask[in.mat[j].w0 == MOP_X ? 0 : (in.mat[j].w0 == MOP_Y ? 1 : 2)] |= 1u << j;
+      }
+      p->prog.push_back(kmask[0] | (in.ph1_mask << 8) | (in.ph2_mask << 16));
+      p->prog.push_back(in.cph_mask | (kmask[1] << 16) | (kmask[2] << 24));
+      auto put_mat = [&]() {
+        for (int k = 0; k < 3; ++k)
+          for (int j = 0; j < R_; ++j) if (kmask[k] >> j & 1) {
+            p->prog.push_back(in.mat[j].coef_off); p->prog.push_back(in.mat[j].slot);
+          }
+      };
+      auto put_ph1 = [&]() {
+        for (int j = 0; j < R_; ++j) if (in.ph1_mask >> j & 1) {
+          p->prog.push_back(in.ph1[j].coef_off); p->prog.push_back(in.ph1[j].slot);
+        }
+      };
+      auto put_ph2 = [&]() {
+        for (int j = 0; j < n_pairs; ++j) if (in.ph2_mask >> j & 1) {
+          p->prog.push_back(in.ph2[j].coef_off); p->prog.push_back(in.ph2[j].slot);
+        }
+      };
+      auto put_cph = [&]() {
+        for (int j = 0; j < 2 * R_; ++j) if (in.cph_mask >> j & 1) {
+          p->prog.push_back(in.cph[j].w0); p->prog.push_back(in.cph[j].coef_off); p->prog.push_back(in.cph[j].slot);
+        }
+      };
+      if (adjoint_) { put_cph(); put_ph2(); put_ph1(); put_mat(); }
+      else { put_mat(); put_ph1(); put_ph2(); put_cph(); }
+    }
+    ++p->n_rounds;
+    p->n_instances += int(insts.size());
   }
 
   void emit_gate2(Pass* p, const LoweredOp& op) {
-    const Gate& G = m_.gates[op.gate];
-    CoefJob job{};
-    job.op_kind = op.kind;
+    CoefJob job = base_job(op);
     job.mop = MOP_MAT2;
-    job.gate = op.gate;
-    job.param_idx = G.param_idx;
-    job.scalar = G.scalar;
-    job.offset = G.offset;
-    job.out_off = plan_->n_coef_floats;
-    job.dagger = adjoint_ ? 1 : 0;
     plan_->n_coef_floats += adjoint_ ? 64 : 32;
     plan_->jobs.push_back(job);
     auto local_bit = [&](int gbit) { return uint32_t(__builtin_ctz(to_local(*p, 1u << gbit))); };
@@ -247,48 +348,6 @@ class Builder {
     p->prog.push_back(uint32_t(slot));
     ++p->n_mat_ops;
     ++p->n_rounds;
-  }
-
-  void emit_diag(Pass* p, const std::vector<LoweredOp>& ops, const std::vector<int>& absorbed,
-                 const std::vector<size_t>& diag, uint32_t S) {
-    const uint32_t lo_mask = (1u << std::min(kLoBits, K_)) - 1;
-    std::vector<uint32_t> cls[3];  // lo, hi(+const), cross
-    for (size_t i : diag) {
-      const LoweredOp& op = ops[absorbed[i]];
-      const uint32_t lm = to_local(*p, op.bits & S);
-      const uint32_t nm = op.bits & ~S;
-      int k;
-      if (lm == 0 || (lm & lo_mask) == 0) k = 1;
-      else if ((lm & ~lo_mask) == 0) k = 0;
-      else k = 2;
-      const int slot = new_slot(p, op);
-      cls[k].push_back(lm | (op.par ? 0x80000000u : 0u));
-      cls[k].push_back(nm);
-      cls[k].push_back(uint32_t(op.angle_idx));
-      cls[k].push_back(uint32_t(slot));
-      ++p->n_diag_terms;
-    }
-    // at most kMaxCrossTerms cross terms per OP_DIAG (LDS table); overflow goes to
-    // follow-up OP_DIAGs whose lo/hi tables are identically one.
-    const size_t n_cross = cls[2].size() / kDiagTermWords;
-    size_t done_cross = 0;
-    bool first = true;
-    do {
-      const size_t take = std::min(n_cross - done_cross, size_t(kMaxCrossTerms));
-      const uint32_t n_lo = first ? uint32_t(cls[0].size() / kDiagTermWords) : 0u;
-      const uint32_t n_hi = first ? uint32_t(cls[1].size() / kDiagTermWords) : 0u;
-      p->prog.push_back(OP_DIAG);
-      p->prog.push_back(n_lo | n_hi << 10 | uint32_t(take) << 20);
-      if (first) {
-        p->prog.insert(p->prog.end(), cls[0].begin(), cls[0].end());
-        p->prog.insert(p->prog.end(), cls[1].begin(), cls[1].end());
-      }
-      p->prog.insert(p->prog.end(), cls[2].begin() + done_cross * kDiagTermWords,
-                     cls[2].begin() + (done_cross + take) * kDiagTermWords);
-      done_cross += take;
-      first = false;
-      ++p->n_diag_ops;
-    } while (done_cross < n_cross);
   }
 
   void emit_measure(Pass* p, const std::vector<MeasGroup>& groups, const std::vector<int>& which) {
@@ -337,7 +396,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     }
     K = std::min(n_eff, tile_bits);
   }
-  int R = adjoint ? 4 : round_bits_for(K);
+  int R = 4;
   if (!adjoint && round_bits != 0) {
     if ((round_bits != 4 && round_bits != 5) || (round_bits == 5 && K < 12)) {
       *err = "round_qubits must be 4 or 5 (5 needs tile_qubits >= 12)";
@@ -352,20 +411,11 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   plan->adjoint = adjoint;
 
   std::vector<LoweredOp> ops;
-  if (!lower(m, n_eff, &ops, &plan->n_angles, err)) return false;
-  // diagonal-angle jobs (shared by every pass that evaluates the term)
-  for (const LoweredOp& op : ops) {
-    if (op.type != LOW_DIAG) continue;
-    const Gate& G = m.gates[op.gate];
-    CoefJob j{};
-    j.op_kind = op.kind; j.mop = 0; j.gate = op.gate; j.param_idx = G.param_idx;
-    j.scalar = G.scalar; j.offset = G.offset; j.out_off = op.angle_idx;
-    plan->jobs.push_back(j);
-  }
+  if (!lower(m, &ops, err)) return false;
   std::vector<int> order(ops.size());
   for (size_t i = 0; i < ops.size(); ++i) order[i] = adjoint ? int(ops.size() - 1 - i) : int(i);
 
-  const uint32_t all_bits = n_eff >= 32 ? 0xFFFFFFFFu : ((1u << n_eff) - 1);
+  const uint32_t all_bits = (1u << n_eff) - 1;
   const int c_min = std::min(K, 4);
   Builder b(m, K, R, n_eff, adjoint, plan);
   std::vector<char> done(ops.size(), 0);
@@ -380,17 +430,19 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
       const uint32_t low = (1u << c_min) - 1;
       const int h = K - c_min;
       for (int p = c_min; p + h <= n_eff; ++p) cands.push_back(low | (((1u << h) - 1) << p));
-      // demand-driven: bits of the earliest ready non-diagonal ops
-      uint32_t S = low, blocked = 0;
-      for (int oi : order) {
-        if (done[oi]) continue;
-        const LoweredOp& op = ops[oi];
-        if (op.bits & blocked) { blocked |= op.bits; continue; }
-        if (op.type == LOW_DIAG) continue;
-        if (popc(S | op.bits) <= K) S |= op.bits; else blocked |= op.bits;
+      // demand-driven: bits of the earliest ready ops (non-diagonal first)
+      for (int with_diag = 0; with_diag < 2; ++with_diag) {
+        uint32_t S = low, blocked = 0;
+        for (int oi : order) {
+          if (done[oi]) continue;
+          const LoweredOp& op = ops[oi];
+          if (op.bits & blocked) { blocked |= op.bits; continue; }
+          if (op.type == LOW_DIAG && !with_diag) continue;
+          if (popc(S | op.bits) <= K) S |= op.bits; else blocked |= op.bits;
+        }
+        for (int bit = n_eff - 1; bit >= 0 && popc(S) < K; --bit) if (!(S >> bit & 1)) S |= 1u << bit;
+        cands.push_back(S);
       }
-      for (int bit = n_eff - 1; bit >= 0 && popc(S) < K; --bit) if (!(S >> bit & 1)) S |= 1u << bit;
-      cands.push_back(S);
     }
     uint32_t best_S = 0;
     int best_mat = -1;
@@ -414,7 +466,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     }
     Pass p = b.begin_pass(best_S);
     p.slot_base = int(plan->slot_gate.size());
-    b.emit_ops(&p, ops, best_list);
+    if (!b.emit_ops(&p, ops, best_list, err)) return false;
     for (int oi : best_list) { done[oi] = 1; ++n_done; }
     plan->passes.push_back(std::move(p));
   }
@@ -456,7 +508,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   };
   take(&plan->passes.back());
   while (g_left) {
-    // measurement-only pass: local set = low bits + the x-bits of as many groups as fit
+    // measurement-only pass: the x-bits of as many groups as fit, then low bits
     uint32_t S = 1u;  // bit 0 is always local (amplitudes move in 16-byte pairs)
     for (size_t gi = 0; gi < groups.size(); ++gi) {
       if (gdone[gi]) continue;
@@ -481,13 +533,13 @@ std::string describe_plan(const Plan& p) {
   std::ostringstream os;
   os << (p.adjoint ? "adjoint" : "forward") << " plan: n=" << p.n << " n_eff=" << p.n_eff
      << " tile_bits=" << p.K << " round_bits=" << p.R << " passes=" << p.passes.size()
-     << " coef_floats=" << p.n_coef_floats << " angles=" << p.n_angles << "\n";
+     << " coef_floats=" << p.n_coef_floats << "\n";
   for (size_t i = 0; i < p.passes.size(); ++i) {
     const Pass& q = p.passes[i];
     os << "  pass " << i << ": c=" << q.c << " local=[";
     for (size_t k = 0; k < q.local_pos.size(); ++k) os << (k ? "," : "") << q.local_pos[k];
-    os << "] mat_ops=" << q.n_mat_ops << " rounds=" << q.n_rounds << " diag_ops=" << q.n_diag_ops
-       << " diag_terms=" << q.n_diag_terms << " meas_groups=" << q.n_meas_groups
+    os << "] mat_ops=" << q.n_mat_ops << " diag_terms=" << q.n_diag_terms << " rounds=" << q.n_rounds
+       << " instances=" << q.n_instances << " meas_groups=" << q.n_meas_groups
        << " meas_terms=" << q.n_meas_terms << " slots=" << q.n_slots
        << (q.is_measure_only ? " [measure-only]" : "") << " words=" << q.prog.size() << "\n";
   }

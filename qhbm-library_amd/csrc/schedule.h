@@ -32,20 +32,20 @@ struct LoweredOp {
   int gate = -1;        // index into the circuit
   uint32_t bits = 0;    // index bits touched
   int b0 = -1, b1 = -1; // index bit of q0 / q1
-  bool par = false;     // LOW_DIAG: parity term (ZZPOW) instead of AND term
-  int angle_idx = -1;   // LOW_DIAG: index into the angle buffer
+  float mult = 1.f;     // LOW_DIAG: phase = exp(i*pi*mult*t) where all `bits` are 1
 };
 
 // One entry of the per-call coefficient preparation.
 struct CoefJob {
   int32_t op_kind;    // qhbm_gate_kind
-  int32_t mop;        // MOP_X / MOP_Y / MOP_MAT1 / MOP_MAT2 / 0 = diagonal angle
+  int32_t mop;        // MOP_X / MOP_Y / MOP_MAT1 / MOP_MAT2 / MOP_PHASE
   int32_t gate;       // circuit gate (for exponent and parameter-shift)
   int32_t param_idx;
   float scalar, offset;
-  int32_t out_off;    // float offset in the coefficient buffer (or angle index)
+  int32_t out_off;    // float offset in the coefficient buffer
   int32_t swap;       // MAT2: matrix index bits swapped
   int32_t dagger;     // write U^dagger (adjoint plan), followed by the generator
+  float mult;         // MOP_PHASE: multiplier of the exponent
 };
 
 struct Pass {
@@ -58,7 +58,7 @@ struct Pass {
   bool is_measure_only = false;
   bool completes_circuit = false;
   // statistics (DESIGN.md / bench roofline accounting)
-  int n_mat_ops = 0, n_diag_terms = 0, n_rounds = 0, n_diag_ops = 0;
+  int n_mat_ops = 0, n_diag_terms = 0, n_rounds = 0, n_instances = 0;
   int n_meas_groups = 0, n_meas_terms = 0;
   int slot_base = 0, n_slots = 0;
 };
@@ -69,7 +69,6 @@ struct Plan {
   std::vector<Pass> passes;
   std::vector<CoefJob> jobs;
   int n_coef_floats = 0;
-  int n_angles = 0;
   // adjoint: gradient slot -> (gate, chain-rule factor to the exponent)
   std::vector<int> slot_gate;
   std::vector<float> slot_factor;
