@@ -35,10 +35,22 @@ __device__ __forceinline__ uint32_t swz(uint32_t l) { return l ^ ((l >> 5) & 31u
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Sum over the 64 lanes of a wave (the result is wave-uniform).  Rows of 16 lanes are
+// reduced with DPP (no LDS traffic, no waitcnt); the four row sums are combined
+// through readlane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_step(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
+  return v + __int_as_float(t);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = dpp_step<0xB1>(v);   // quad_perm:[1,0,3,2]
+  v = dpp_step<0x4E>(v);   // quad_perm:[2,3,0,1]
+  v = dpp_step<0x141>(v);  // row_half_mirror
+  v = dpp_step<0x140>(v);  // row_mirror  -> every lane holds its 16-lane row sum
+  const int iv = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16)) +
+         __int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48));
 }
 
 // Waves per SIMD the register allocator must leave room for: as many workgroups per CU

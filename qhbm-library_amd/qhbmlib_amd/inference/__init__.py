@@ -1,0 +1,10 @@
+"""Inference (reference: qhbmlib/inference/__init__.py:32-47)."""
+from qhbmlib_amd.inference.ebm import (AnalyticEnergyInference, BernoulliEnergyInference,
+                                       EnergyInference, EnergyInferenceBase)
+from qhbmlib_amd.inference.qhbm import QHBM
+from qhbmlib_amd.inference.qmhl_loss import qmhl
+from qhbmlib_amd.inference.qnn import AnalyticQuantumInference, QuantumInference
+from qhbmlib_amd.inference.vqt_loss import vqt
+
+__all__ = ["AnalyticEnergyInference", "AnalyticQuantumInference", "BernoulliEnergyInference",
+           "EnergyInference", "EnergyInferenceBase", "QHBM", "QuantumInference", "qmhl", "vqt"]

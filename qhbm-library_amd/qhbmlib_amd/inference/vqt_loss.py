@@ -1,0 +1,21 @@
+"""VQT loss (reference: qhbmlib/inference/vqt_loss.py)."""
+import torch
+
+from qhbmlib_amd.inference import qhbm  # noqa: F401
+
+
+def vqt(input_qhbm: "qhbm.QHBM", target_hamiltonian, beta):
+  """beta <H> - S(rho) as a differentiable sample average (vqt_loss.py:25-55).
+  `target_hamiltonian` is `[pauli_sum]` (one operator) or a Hamiltonian."""
+  beta = torch.as_tensor(beta, dtype=torch.float32)
+
+  def f_vqt(bitstrings):
+    h_expectations = torch.squeeze(
+        input_qhbm.q_inference.expectation(bitstrings, target_hamiltonian), 1)
+    beta_h_expectations = beta.to(h_expectations.device) * h_expectations
+    energies = input_qhbm.e_inference.energy(bitstrings).detach()
+    return beta_h_expectations - energies.to(h_expectations.device)
+
+  average_expectation = input_qhbm.e_inference.expectation(f_vqt)
+  current_partition = input_qhbm.e_inference.log_partition().detach()
+  return average_expectation - current_partition.to(average_expectation.device)

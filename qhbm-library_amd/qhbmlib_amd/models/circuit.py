@@ -1,0 +1,138 @@
+"""Quantum circuit models (reference: qhbmlib/models/circuit.py)."""
+from typing import Callable, List, Sequence, Union
+
+import torch
+
+from qhbmlib_amd import ir
+from qhbmlib_amd.models import circuit_utils
+
+
+class QuantumCircuit(torch.nn.Module):
+  """A parameterized circuit plus the trainable map to its symbol values
+  (circuit.py:27-178).
+
+  `pqc` is an `ir.Circuit` (the reference holds a serialized TFQ proto);
+  `value_layers_inputs[i]` (a Parameter or list of Parameters) is fed through
+  `value_layers[i]` (callables) and the results are concatenated into
+  `symbol_values`, aligned with `symbol_names`.
+  """
+
+  def __init__(self, pqc: ir.Circuit, qubits: Sequence[ir.GridQubit],
+               symbol_names: Sequence[str],
+               value_layers_inputs: List[Union[torch.nn.Parameter, List[torch.nn.Parameter]]],
+               value_layers: List[List[Callable]], name: Union[None, str] = None,
+               tfq_compat_bit_order: bool = False):
+    super().__init__()
+    self.name = name or "quantum_circuit"
+    self._pqc = pqc
+    self._qubits = sorted(qubits)  # circuit.py:54
+    self._symbol_names = list(symbol_names)
+    self._value_layers = value_layers
+    self._value_layers_inputs = value_layers_inputs
+    flat = []
+    for inputs in value_layers_inputs:
+      flat.extend(inputs if isinstance(inputs, (list, tuple)) else [inputs])
+    self._params = torch.nn.ParameterList(flat)
+    for layers in value_layers:
+      for k, layer in enumerate(layers):
+        if isinstance(layer, torch.nn.Module):
+          self.add_module(f"value_layer_{id(layer)}_{k}", layer)
+    self._bit_symbol_names = circuit_utils.bit_symbol_names(self._qubits)
+    # the reference maps bitstring column j to the j-th
+    # lexicographically sorted injector symbol.  Default here: column j <-> sorted
+    # qubit j (the evident intent); tfq_compat_bit_order=True reproduces the
+    # reference's permutation for n >= 11.
+    self.tfq_compat_bit_order = tfq_compat_bit_order
+
+  @property
+  def qubits(self):
+    return self._qubits
+
+  @property
+  def symbol_names(self):
+    return self._symbol_names
+
+  @property
+  def value_layers_inputs(self):
+    return self._value_layers_inputs
+
+  @property
+  def value_layers(self):
+    return self._value_layers
+
+  @property
+  def trainable_variables(self):
+    return [p for p in self._params if p.requires_grad]
+
+  @property
+  def symbol_values(self):
+    """1-D tensor, `symbol_values[i]` is the value of `symbol_names[i]` (circuit.py:93-107)."""
+    intermediate = []
+    for inputs, layers in zip(self.value_layers_inputs, self.value_layers):
+      x = inputs
+      for layer in layers:
+        x = layer(x)
+      intermediate.append(x.reshape(-1))
+    if not intermediate:
+      return torch.zeros((0,), dtype=torch.float32)
+    return torch.cat(intermediate, 0)
+
+  @property
+  def pqc(self):
+    return self._pqc
+
+  def build(self, input_shape):
+    del input_shape
+
+  def bit_column_to_qubit(self):
+    """perm[j] = index (into self.qubits) of the qubit driven by bitstring column j."""
+    n = len(self.qubits)
+    return circuit_utils.tfq_bit_permutation(n) if self.tfq_compat_bit_order else list(range(n))
+
+  def forward(self, inputs):
+    """Bitstrings prepended as initial states (circuit.py:129-136).  Returns the
+    (bitstrings, circuit) pair the engine consumes instead of [U] protos."""
+    return inputs, self
+
+  def __add__(self, other: "QuantumCircuit"):
+    """self.pqc followed by other.pqc; shares the variables (circuit.py:138-162)."""
+    if not isinstance(other, QuantumCircuit):
+      raise TypeError
+    if set(self.symbol_names) & set(other.symbol_names):
+      raise ValueError("Circuits to be summed must not have symbols in common.")
+    new_qubits = list(set(self.qubits + other.qubits))
+    return QuantumCircuit(
+        self.pqc + other.pqc, new_qubits, self.symbol_names + other.symbol_names,
+        self.value_layers_inputs + other.value_layers_inputs,
+        self.value_layers + other.value_layers, self.name + "_" + other.name,
+        self.tfq_compat_bit_order or other.tfq_compat_bit_order)
+
+  def __pow__(self, exponent):
+    """Inverse circuit on the SAME variables (circuit.py:164-178)."""
+    if exponent == -1:
+      new_pqc = self.pqc**-1
+      return QuantumCircuit(new_pqc, self.qubits, self.symbol_names, self.value_layers_inputs,
+                            self.value_layers, self.name + "_inverse", self.tfq_compat_bit_order)
+    raise ValueError("Only the inverse (exponent == -1) is supported.")
+
+
+def _random_uniform(minval, maxval, seed=None):
+  def init(shape):
+    gen = torch.Generator().manual_seed(seed) if seed is not None else None
+    return torch.empty(shape).uniform_(minval, maxval, generator=gen)
+  return init
+
+
+class DirectQuantumCircuit(QuantumCircuit):
+  """QuantumCircuit with a direct map from variables to circuit parameters
+  (circuit.py:181-208).  The variable layout is sorted(symbol names) --
+  lexicographic."""
+
+  def __init__(self, pqc: ir.Circuit, initializer=None, name: Union[None, str] = None,
+               tfq_compat_bit_order: bool = False):
+    raw_symbol_names = sorted(pqc.symbols())
+    initializer = initializer or _random_uniform(0.0, 2.0)
+    values = [torch.nn.Parameter(
+        torch.as_tensor(initializer([len(raw_symbol_names)]), dtype=torch.float32).clone())]
+    super().__init__(pqc, pqc.all_qubits(), raw_symbol_names, values, [[]], name,
+                     tfq_compat_bit_order)

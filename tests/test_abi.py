@@ -1,0 +1,100 @@
+"""The C-ABI shared library: loads on a CPU-only box, exports every symbol the
+header declares, keeps the enum values the oracle and host use, and its
+planning side (scheduler) works without a device.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import qhbm_oracle as O
+from qhbmlib_amd import _engine as E
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "qhbm_engine.h")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(E.LIB_PATH),
+                                reason="engine library not built (run __graft_entry__.build())")
+
+
+def _header_text():
+  with open(HEADER) as f:
+    return f.read()
+
+
+def test_every_declared_symbol_is_exported():
+  text = re.sub(r"/\*.*?\*/", "", _header_text(), flags=re.S)
+  declared = set(re.findall(r"\b(qhbm_[a-z_]+)\s*\(", text))
+  assert declared == set(E.ABI_SYMBOLS)
+  lib = ctypes.CDLL(E.LIB_PATH)
+  for sym in declared:
+    assert hasattr(lib, sym), sym
+  assert lib.qhbm_abi_version() == 1
+
+
+def test_gate_kind_enum_matches_host_and_oracle():
+  text = _header_text()
+  for name, value in re.findall(r"QHBM_GATE_([A-Z]+)\s*=\s*(\d+)", text):
+    if name == "KIND_COUNT":
+      continue
+    assert getattr(E, f"GATE_{name}") == int(value)
+    assert getattr(O, f"GATE_{name}") == int(value)
+  assert ctypes.sizeof(E.QhbmGate) == 24
+
+
+def _planner(n, layers, op, **opts):
+  eng = E.Engine(device=None)
+  for k, v in opts.items():
+    eng.set_option(k, v)
+  gates, names = O.hea_gates(n, layers)
+  eng.set_circuit(n, gates, len(names))
+  eng.set_observables([op])
+  return eng
+
+
+def test_planning_without_device_and_loud_compute_failure():
+  eng = _planner(4, 2, O.tfim_ring_op(4))
+  assert eng.num_passes() == (1, 1)
+  assert "forward plan" in eng.describe_schedule()
+  with pytest.raises(E.EngineError, match="no CPU fallback|no device"):
+    eng.expectation(np.zeros((1, 4), np.int8), np.zeros(22, np.float32))
+
+
+@pytest.mark.parametrize("n,layers,max_fwd", [(12, 8, 1), (20, 16, 12), (24, 16, 16), (28, 32, 40)])
+def test_baseline_configs_schedule(n, layers, max_fwd):
+  """Light-cone scheduling: far fewer HBM passes than gates (944 gates at n=20)."""
+  op = O.xxz_chain_op(n) if n == 20 else O.tfim_ring_op(n)
+  eng = _planner(n, layers, op)
+  fwd, bwd = eng.num_passes()
+  assert 1 <= fwd <= max_fwd
+  assert 1 <= bwd <= 2 * max_fwd
+  assert eng.workspace_bytes(8) >= 8 * 8 * 2**n or n > 24
+
+
+def test_schedule_options_and_errors():
+  eng = _planner(14, 2, O.xxz_chain_op(14), tile_qubits=10, adjoint_tile_qubits=10)
+  fwd, bwd = eng.num_passes()
+  assert fwd > 1 and bwd > 1
+  with pytest.raises(E.EngineError):
+    E.Engine(device=None).set_option("no_such_option", 1)
+  bad = E.Engine(device=None)
+  with pytest.raises(E.EngineError):
+    bad.set_circuit(3, [(O.GATE_CZPOW, 0, 0, -1, 0.0, 1.0)], 0)  # q1 == q0
+  with pytest.raises(E.EngineError):
+    bad.set_circuit(40, [], 0)
+  bad.set_circuit(3, [], 0)
+  with pytest.raises(E.EngineError):
+    bad.set_observables([[(1.0, 8, 0)]])
+  # every gate kind schedules
+  rng = np.random.default_rng(0)
+  gates = []
+  for kind in range(12):
+    q0 = int(rng.integers(12))
+    q1 = (q0 + 1 + int(rng.integers(11))) % 12 if O.gate_num_qubits(kind) == 2 else -1
+    gates.append((kind, q0, q1, kind % 3, 0.5, 0.1))
+  eng = E.Engine(device=None)
+  eng.set_option("tile_qubits", 10)
+  eng.set_circuit(12, gates, 3)
+  eng.set_observables([O.tfim_ring_op(12)])
+  assert eng.num_passes()[0] >= 1

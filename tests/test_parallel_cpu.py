@@ -1,0 +1,77 @@
+"""N > 1 path on CPU: world_size-2 gloo process group, the single-device call is
+played by the oracle (tests may use it as the checker / stand-in; the product never does)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import qhbm_oracle as O
+from qhbmlib_amd import parallel
+
+
+def test_partition():
+  assert parallel.partition(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+  assert parallel.partition(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+  assert parallel.partition(0, 2) == [(0, 0), (0, 0)]
+  assert parallel.partition(4096, 8) == [(512 * r, 512 * (r + 1)) for r in range(8)]
+
+
+def _problem():
+  n = 4
+  gates, names = O.hea_gates(n, 2, "p")
+  rng = np.random.default_rng(3)
+  params = rng.uniform(-1, 1, len(names))
+  bits = rng.integers(0, 2, size=(7, n)).astype(np.int8)
+  ops = [O.tfim_ring_op(n), O.xxz_chain_op(n)]
+  up = rng.normal(size=(7, 2))
+  return n, gates, params, bits, ops, up
+
+
+def _oracle_local(n, gates, ops):
+  def local(bits, params, upstream):
+    b = bits.numpy()
+    if b.shape[0] == 0:
+      return torch.zeros((0, len(ops))), torch.zeros(len(params))
+    vals, jac = O.expectation_jacobian(n, gates, params.numpy(), b, ops)
+    grad = np.einsum("bt,btp->p", upstream.numpy(), jac)
+    return torch.from_numpy(vals).float(), torch.from_numpy(grad).float()
+  return local
+
+
+def _worker(rank, world, port, out):
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  n, gates, params, bits, ops, up = _problem()
+  sharded = parallel.ShardedExpectation(_oracle_local(n, gates, ops))
+  vals, grad = sharded.expectation_vjp(torch.from_numpy(bits), torch.from_numpy(params),
+                                       torch.from_numpy(up))
+  out[rank] = (vals.numpy(), grad.numpy())
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_sharded_matches_single_process_world2():
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  mgr = mp.Manager()
+  out = mgr.dict()
+  mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+  n, gates, params, bits, ops, up = _problem()
+  want_vals, want_jac = O.expectation_jacobian(n, gates, params, bits, ops)
+  want_grad = np.einsum("bt,btp->p", up, want_jac)
+  for rank in range(2):
+    vals, grad = out[rank]
+    np.testing.assert_allclose(vals, want_vals, atol=1e-6)
+    np.testing.assert_allclose(grad, want_grad, atol=1e-5)
+
+
+def test_unsharded_passthrough():
+  n, gates, params, bits, ops, up = _problem()
+  sharded = parallel.ShardedExpectation(_oracle_local(n, gates, ops))
+  vals, _ = sharded.expectation_vjp(torch.from_numpy(bits), torch.from_numpy(params), torch.from_numpy(up))
+  np.testing.assert_allclose(vals.numpy(), O.expectation(n, gates, params, bits, ops), atol=1e-6)
