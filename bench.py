@@ -123,7 +123,7 @@ def main():
   ap.add_argument("--mode", choices=["vqt", "forward"], default="vqt")
   ap.add_argument("--tile-qubits", type=int, default=0)
   ap.add_argument("--adjoint-tile-qubits", type=int, default=0)
-  ap.add_argument("--cpu-sample-states", type=int, default=256)
+  ap.add_argument("--cpu-sample-states", type=int, default=64)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   args = ap.parse_args()
 
@@ -217,12 +217,16 @@ def main():
     achieved = (alg / per_step_launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # physical HBM traffic of one launch if every tile is read and written once
     io_bytes = spg * amp * 8.0 * 2.0 * (2.0 if use_bwd else 1.0)
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
+    # passes of this same command; scripts/profile_bench.sh + scripts/summarize_profile.py).
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
       try:
         with open(tpath) as f:
-          traffic = json.load(f).get(name, {}).get("hbm_bytes_per_launch")
+          tj = json.load(f)
+        if tj.get("states_per_gpu") == spg and tj.get("n_qubits") == n and args.hamiltonian == "xxz":
+          traffic = tj.get(name, {}).get("hbm_bytes_per_launch")
       except Exception:  # pylint: disable=broad-except
         traffic = None
     line = {
