@@ -146,7 +146,11 @@ int upload_plan(qhbm_engine* h, DevicePlan* d) {
   HIPCHK(d->prog.upload(prog));
   HIPCHK(d->tables.upload(tables));
   HIPCHK(d->jobs.upload(d->plan.jobs));
-  HIPCHK(d->coef.reserve(size_t(d->plan.n_coef_floats) + 64));
+  {
+    std::vector<float> init(d->plan.coef_init.size() + 64, 0.f);
+    std::memcpy(init.data(), d->plan.coef_init.data(), d->plan.coef_init.size() * sizeof(uint32_t));
+    HIPCHK(d->coef.upload(init));
+  }
   d->uploaded = true;
   return 0;
 }

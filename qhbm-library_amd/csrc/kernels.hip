@@ -182,13 +182,15 @@ __device__ __forceinline__ void mat1_pair(v2f& a0, v2f& a1, v2f u00, v2f u01, v2
       : [u00] "s"(u00), [u01] "s"(u01), [u10] "s"(u10), [u11] "s"(u11));
 }
 template <int R, int RB, int... P>
-__device__ __forceinline__ void apply_mat1_(v2f (&a)[1 << R], const float* u, std::integer_sequence<int, P...>) {
-  const v2f u00 = load_cs(u), u01 = load_cs(u + 2), u10 = load_cs(u + 4), u11 = load_cs(u + 6);
+__device__ __forceinline__ void apply_mat1_(v2f (&a)[1 << R], v2f u00, v2f u01, v2f u10, v2f u11,
+                                            std::integer_sequence<int, P...>) {
   (mat1_pair(a[ins0<RB>(P)], a[ins0<RB>(P) | (1 << RB)], u00, u01, u10, u11), ...);
 }
-// dense 2x2 (rare path), u = row-major {re, im} x 4 (wave-uniform)
+// dense 2x2 (rare path), u = row-major wave-uniform complex entries
 template <int R, int RB>
-__device__ __forceinline__ void apply_mat1(v2f (&a)[1 << R], const float* u) { apply_mat1_<R, RB>(a, u, iseq<(1 << (R - 1))>{}); }
+__device__ __forceinline__ void apply_mat1(v2f (&a)[1 << R], v2f u00, v2f u01, v2f u10, v2f u11) {
+  apply_mat1_<R, RB>(a, u00, u01, u10, u11, iseq<(1 << (R - 1))>{});
+}
 
 template <int R, int RB, int... P>
 __device__ __forceinline__ void apply_ph1_(v2f (&a)[1 << R], v2f cs, std::integer_sequence<int, P...>) {
@@ -256,19 +258,19 @@ __device__ __forceinline__ float im_lam_y_psi(const v2f (&p)[1 << R], const v2f 
   return im_lam_y_psi_<R, RB>(p, l, iseq<(1 << (R - 1))>{});
 }
 // Im sum_ij conj(lam_i) g_ij psi_j over one pair, g wave-uniform row-major complex
-__device__ __forceinline__ float g1_pair(v2f p0, v2f p1, v2f l0, v2f l1, const float* g) {
-  const v2f s0 = v2f{g[0] * p0.x - g[1] * p0.y + g[2] * p1.x - g[3] * p1.y,
-                     g[0] * p0.y + g[1] * p0.x + g[2] * p1.y + g[3] * p1.x};
-  const v2f s1 = v2f{g[4] * p0.x - g[5] * p0.y + g[6] * p1.x - g[7] * p1.y,
-                     g[4] * p0.y + g[5] * p0.x + g[6] * p1.y + g[7] * p1.x};
+struct Gen2 { v2f g00, g01, g10, g11; };
+__device__ __forceinline__ v2f cmul(v2f g, v2f p) { return v2f{g.x * p.x - g.y * p.y, g.x * p.y + g.y * p.x}; }
+__device__ __forceinline__ float g1_pair(v2f p0, v2f p1, v2f l0, v2f l1, const Gen2& g) {
+  const v2f s0 = cmul(g.g00, p0) + cmul(g.g01, p1);
+  const v2f s1 = cmul(g.g10, p0) + cmul(g.g11, p1);
   return im_conj(l0, s0) + im_conj(l1, s1);
 }
 template <int R, int RB, int... P>
-__device__ __forceinline__ float im_lam_g1_psi_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], const float* g, std::integer_sequence<int, P...>) {
+__device__ __forceinline__ float im_lam_g1_psi_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], const Gen2& g, std::integer_sequence<int, P...>) {
   return (g1_pair(p[ins0<RB>(P)], p[ins0<RB>(P) | (1 << RB)], l[ins0<RB>(P)], l[ins0<RB>(P) | (1 << RB)], g) + ...);
 }
 template <int R, int RB>
-__device__ __forceinline__ float im_lam_g1_psi(const v2f (&p)[1 << R], const v2f (&l)[1 << R], const float* g) {
+__device__ __forceinline__ float im_lam_g1_psi(const v2f (&p)[1 << R], const v2f (&l)[1 << R], const Gen2& g) {
   return im_lam_g1_psi_<R, RB>(p, l, g, iseq<(1 << (R - 1))>{});
 }
 
@@ -410,19 +412,21 @@ __device__ __forceinline__ uint32_t basis_index(const int8_t* __restrict__ row, 
   return idx;
 }
 
-// Controlled phase: register bit J AND (a thread bit | a tile bit).
-template <int R, int J>
-__device__ __forceinline__ const uint32_t* cph_fwd(const uint32_t* __restrict__ ip,
-                                                   const float* __restrict__ coef, v2f (&a)[1 << R],
-                                                   uint32_t tl, uint32_t tile_base) {
-  const uint32_t pred = uni(ip[0]);
-  const v2f cs = load_cs(coef + uni(ip[1]));
-  const uint32_t pos = pred & 0xffu;
-  // one code path for both predicate kinds (a two-way branch would make the structuriser
-  // copy the register file): the phase degenerates to 1 where the predicate is false.
-  const bool on = (((pred >> 8) ? tile_base : tl) >> pos) & 1u;
-  apply_ph1_v<R, J>(a, v2f{on ? cs.x : 1.f, on ? cs.y : 0.f});
-  return ip + 3;
+// ---- fixed-layout instance records (program.h RecordLayout) -------------------------------
+// rv[i] holds words 64*i .. 64*i+63 of the record, one word per lane.
+template <int W, int NV>
+__device__ __forceinline__ uint32_t rec_word(const uint32_t (&rv)[NV]) {
+  return uint32_t(__builtin_amdgcn_readlane(int(rv[W / 64]), W % 64));
+}
+template <int W, int NV>
+__device__ __forceinline__ v2f rec_cs(const uint32_t (&rv)[NV]) {
+  return v2f{__uint_as_float(rec_word<W>(rv)), __uint_as_float(rec_word<W + 1>(rv))};
+}
+template <int NV>
+__device__ __forceinline__ void rec_load(const uint32_t* __restrict__ recs, uint32_t off, int lane,
+                                         uint32_t (&rv)[NV]) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) rv[i] = recs[off + 64u * i + uint32_t(lane)];
 }
 
 __device__ __forceinline__ void add_slot(float* sacc, uint32_t slot_base, int tid, uint32_t slot, float v) {
@@ -430,22 +434,60 @@ __device__ __forceinline__ void add_slot(float* sacc, uint32_t slot_base, int ti
   if ((tid & 63) == 0) atomicAdd(&sacc[slot - slot_base], v);
 }
 
+// Controlled phase: register bit J AND (a thread bit | a tile bit).  One code path for both
+// predicate kinds (a two-way branch would make the structuriser copy the register file): the
+// phase degenerates to 1 where the predicate is false.
 template <int R, int J>
-__device__ __forceinline__ const uint32_t* cph_adj(const uint32_t* __restrict__ ip,
-                                                   const float* __restrict__ coef, v2f (&p)[1 << R],
-                                                   v2f (&l)[1 << R], uint32_t tl, uint32_t tile_base,
-                                                   float* sacc, uint32_t slot_base, int tid) {
-  const uint32_t pred = uni(ip[0]);
-  const v2f cs = conj_cs(load_cs(coef + uni(ip[1])));
-  const uint32_t slot = uni(ip[2]);
-  const uint32_t pos = pred & 0xffu;
+__device__ __forceinline__ void cph_fwd(v2f (&a)[1 << R], v2f cs, uint32_t pred, uint32_t tl,
+                                        uint32_t tile_base) {
+  const bool on = (((pred >> 8) ? tile_base : tl) >> (pred & 0xffu)) & 1u;
+  apply_ph1_v<R, J>(a, v2f{on ? cs.x : 1.f, on ? cs.y : 0.f});
+}
+
+template <int R, int J>
+__device__ __forceinline__ void cph_adj(v2f (&p)[1 << R], v2f (&l)[1 << R], v2f cs, uint32_t pred,
+                                        uint32_t slot, uint32_t tl, uint32_t tile_base, float* sacc,
+                                        uint32_t slot_base, int tid) {
   constexpr float kM2Pi = -2.f * kPi;
-  const bool on = (((pred >> 8) ? tile_base : tl) >> pos) & 1u;
+  const bool on = (((pred >> 8) ? tile_base : tl) >> (pred & 0xffu)) & 1u;
   if (slot != 0xffffffffu) add_slot(sacc, slot_base, tid, slot, on ? kM2Pi * sum_w1<R, J>(p, l) : 0.f);
-  const v2f c2 = v2f{on ? cs.x : 1.f, on ? cs.y : 0.f};
+  const v2f c2 = v2f{on ? cs.x : 1.f, on ? -cs.y : 0.f};
   apply_ph1_v<R, J>(p, c2);
   apply_ph1_v<R, J>(l, c2);
-  return ip + 3;
+}
+
+// One forward instance on the register file.
+template <int R, int NV>
+__device__ __forceinline__ void instance_fwd(const uint32_t (&rv)[NV], const uint32_t* __restrict__ recs,
+                                             uint32_t rec_off, int lane, v2f (&a)[1 << R], uint32_t tl,
+                                             uint32_t tile_base) {
+  constexpr RecordLayout L(R, false);
+  const uint32_t h0 = rec_word<0>(rv), h1 = rec_word<1>(rv);
+  // One-qubit gates: a separate predicated slot class per kind (X, Y, dense), each a plain
+  // if-then triangle around in-place code -- no merge copies.
+  QHBM_FOR_RB(R, if ((h0 >> J) & 1u) apply_x<R, J>(a, rec_cs<L.x(J)>(rv));)
+  if ((h1 >> 16) & 0xffu) {
+    QHBM_FOR_RB(R, if ((h1 >> (16 + J)) & 1u) apply_y<R, J>(a, rec_cs<L.y(J)>(rv));)
+  }
+  if (h1 >> 24) {  // dense 2x2 gates (rare): their coefficients sit in the record's second part
+    uint32_t dv[1];
+    rec_load<1>(recs, rec_off + 64u * L.base_vecs(), lane, dv);
+    QHBM_FOR_RB(R,
+      if ((h1 >> (24 + J)) & 1u)
+        apply_mat1<R, J>(a, rec_cs<8 * J>(dv), rec_cs<8 * J + 2>(dv), rec_cs<8 * J + 4>(dv), rec_cs<8 * J + 6>(dv));)
+  }
+  QHBM_FOR_RB(R, if ((h0 >> (8 + J)) & 1u) apply_ph1<R, J>(a, rec_cs<L.ph1(J)>(rv));)
+  if (h0 >> 16) {
+    QHBM_FOR_PAIR(R,
+      if ((h0 >> (16 + pair_index(JA, JB))) & 1u) apply_ph2<R, JA, JB>(a, rec_cs<L.ph2(pair_index(JA, JB))>(rv));)
+  }
+  if (h1 & 0xffffu) {
+    QHBM_FOR_RB(R,
+      if ((h1 >> (2 * J)) & 1u)
+        cph_fwd<R, J>(a, rec_cs<L.cph(2 * J)>(rv), rec_word<L.pred(2 * J)>(rv), tl, tile_base);
+      if ((h1 >> (2 * J + 1)) & 1u)
+        cph_fwd<R, J>(a, rec_cs<L.cph(2 * J + 1)>(rv), rec_word<L.pred(2 * J + 1)>(rv), tl, tile_base);)
+  }
 }
 
 // Measurement helpers (register file indexed by the high bits of the local index).
@@ -535,6 +577,8 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
   float* red = reinterpret_cast<float*>(tile + (1 << K));
 
   const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const uint32_t* recs = reinterpret_cast<const uint32_t*>(coef);
   const uint32_t tile_id = blockIdx.x & ((1u << a.n_nonlocal) - 1u);
   const uint32_t s_local = blockIdx.x >> a.n_nonlocal;
   const TileCtx t = make_tile_ctx(a, tables, tile_id);
@@ -568,15 +612,25 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
     if (opc == OP_ROUND) {
       const uint32_t n_inst = w0 >> 8;
       const uint32_t regmask = uni(prog[pc + 1]);
+      uint32_t rec_off = uni(prog[pc + 2]);
+      constexpr RecordLayout L(R, false);
+      constexpr int NV = L.base_vecs();
+      uint32_t cur[NV], nxt[NV];
+      rec_load<NV>(recs, rec_off, lane, cur);
       uint32_t DB[R], T, TL;
       round_geometry<K, R>(regmask, tid, DB, &T, &TL);
       v2f amp[NR];
       round_load<R>(tile, T, DB, amp);
-      const uint32_t* ip = prog + pc + 2;
-      for (uint32_t i = 0; i < n_inst; ++i) ip = instance_fwd<R>(ip, coef, amp, TL, t.tile_base);
+      for (uint32_t i = 0; i < n_inst; ++i) {
+        rec_load<NV>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
+        instance_fwd<R, NV>(cur, recs, rec_off, lane, amp, TL, t.tile_base);
+        rec_off += L.words();
+#pragma unroll
+        for (int v = 0; v < NV; ++v) cur[v] = nxt[v];
+      }
       round_store<R>(tile, T, DB, amp);
       __syncthreads();
-      pc = uint32_t(ip - prog);
+      pc += 3;
     } else if (opc == OP_GATE2) {
       const uint32_t pw = uni(prog[pc + 1]);
       const uint32_t pos0 = pw & 0xffu, pos1 = (pw >> 8) & 0xffu;
@@ -665,6 +719,8 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
   float* sacc = reinterpret_cast<float*>(tl + (1 << K));  // [kMaxSlotsPerPass]
 
   const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const uint32_t* recs = reinterpret_cast<const uint32_t*>(coef);
   const uint32_t tile_id = blockIdx.x & ((1u << a.n_nonlocal) - 1u);
   const uint32_t s_local = blockIdx.x >> a.n_nonlocal;
   const TileCtx t = make_tile_ctx(a, tables, tile_id);
@@ -686,37 +742,48 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
     if (opc == OP_ROUND) {
       const uint32_t n_inst = w0 >> 8;
       const uint32_t regmask = uni(prog[pc + 1]);
+      uint32_t rec_off = uni(prog[pc + 2]);
+      constexpr RecordLayout L(R, true);
+      constexpr int NB = L.base_vecs();
+      uint32_t cur[NB], nxt[NB], sv[1], svn[1];
+      rec_load<NB>(recs, rec_off, lane, cur);
+      rec_load<1>(recs, rec_off + L.slot0(), lane, sv);
       uint32_t DB[R], T, TL;
       round_geometry<K, R>(regmask, tid, DB, &T, &TL);
       v2f p[NR], l[NR];
       round_load<R>(tp, T, DB, p);
       round_load<R>(tl, T, DB, l);
-      const uint32_t* ip = prog + pc + 2;
+      constexpr int S0 = L.slot0();
       for (uint32_t inst = 0; inst < n_inst; ++inst) {
-        const uint32_t h0 = uni(ip[0]), h1 = uni(ip[1]);
-        ip += 2;
+        rec_load<NB>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
+        rec_load<1>(recs, rec_off + L.words() + L.slot0(), lane, svn);
+        const uint32_t h0 = rec_word<0>(cur), h1 = rec_word<1>(cur);
         // ---- CPH ----
-        QHBM_FOR_RB(R,
-          if ((h1 >> (2 * J)) & 1u)
-            ip = cph_adj<R, J>(ip, coef, p, l, TL, t.tile_base, sacc, a.slot_base, tid);
-          if ((h1 >> (2 * J + 1)) & 1u)
-            ip = cph_adj<R, J>(ip, coef, p, l, TL, t.tile_base, sacc, a.slot_base, tid);)
+        if (h1 & 0xffffu) {
+          QHBM_FOR_RB(R,
+            if ((h1 >> (2 * J)) & 1u)
+              cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J)>(cur), rec_word<L.pred(2 * J)>(cur),
+                            rec_word<L.slot_cph(2 * J) - S0>(sv), TL, t.tile_base, sacc, a.slot_base, tid);
+            if ((h1 >> (2 * J + 1)) & 1u)
+              cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J + 1)>(cur), rec_word<L.pred(2 * J + 1)>(cur),
+                            rec_word<L.slot_cph(2 * J + 1) - S0>(sv), TL, t.tile_base, sacc, a.slot_base, tid);)
+        }
         // ---- PH2 ----
-        QHBM_FOR_PAIR(R,
-          if ((h0 >> (16 + pair_index(JA, JB))) & 1u) {
-            const v2f cs = conj_cs(load_cs(coef + uni(ip[0])));
-            const uint32_t slot = uni(ip[1]);
-            ip += 2;
-            if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kM2Pi * sum_w2<R, JA, JB>(p, l));
-            apply_ph2<R, JA, JB>(p, cs);
-            apply_ph2<R, JA, JB>(l, cs);
-          })
+        if (h0 >> 16) {
+          QHBM_FOR_PAIR(R,
+            if ((h0 >> (16 + pair_index(JA, JB))) & 1u) {
+              const v2f cs = conj_cs(rec_cs<L.ph2(pair_index(JA, JB))>(cur));
+              const uint32_t slot = rec_word<L.slot_ph2(pair_index(JA, JB)) - S0>(sv);
+              if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kM2Pi * sum_w2<R, JA, JB>(p, l));
+              apply_ph2<R, JA, JB>(p, cs);
+              apply_ph2<R, JA, JB>(l, cs);
+            })
+        }
         // ---- PH1 ----
         QHBM_FOR_RB(R,
           if ((h0 >> (8 + J)) & 1u) {
-            const v2f cs = conj_cs(load_cs(coef + uni(ip[0])));
-            const uint32_t slot = uni(ip[1]);
-            ip += 2;
+            const v2f cs = conj_cs(rec_cs<L.ph1(J)>(cur));
+            const uint32_t slot = rec_word<L.slot_ph1(J) - S0>(sv);
             if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kM2Pi * sum_w1<R, J>(p, l));
             apply_ph1<R, J>(p, cs);
             apply_ph1<R, J>(l, cs);
@@ -724,36 +791,43 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
         // ---- one-qubit gates (X, Y, dense slot classes) ----
         QHBM_FOR_RB(R,
           if ((h0 >> J) & 1u) {
-            const v2f cs = conj_cs(load_cs(coef + uni(ip[0])));  // U^dagger = c*I + i*s*X
-            const uint32_t slot = uni(ip[1]);
-            ip += 2;
+            const v2f cs = conj_cs(rec_cs<L.x(J)>(cur));  // U^dagger = c*I + i*s*X
+            const uint32_t slot = rec_word<L.slot_x(J) - S0>(sv);
             if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kPi * im_lam_x_psi<R, J>(p, l));
             apply_x<R, J>(p, cs);
             apply_x<R, J>(l, cs);
           })
-        QHBM_FOR_RB(R,
-          if ((h1 >> (16 + J)) & 1u) {
-            const v2f cs = conj_cs(load_cs(coef + uni(ip[0])));
-            const uint32_t slot = uni(ip[1]);
-            ip += 2;
-            if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kPi * im_lam_y_psi<R, J>(p, l));
-            apply_y<R, J>(p, cs);
-            apply_y<R, J>(l, cs);
-          })
-        QHBM_FOR_RB(R,
-          if ((h1 >> (24 + J)) & 1u) {
-            const float* cf = coef + uni(ip[0]);
-            const uint32_t slot = uni(ip[1]);
-            ip += 2;
-            if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, im_lam_g1_psi<R, J>(p, l, cf + 8));
-            apply_mat1<R, J>(p, cf);
-            apply_mat1<R, J>(l, cf);
-          })
+        if ((h1 >> 16) & 0xffu) {
+          QHBM_FOR_RB(R,
+            if ((h1 >> (16 + J)) & 1u) {
+              const v2f cs = conj_cs(rec_cs<L.y(J)>(cur));
+              const uint32_t slot = rec_word<L.slot_y(J) - S0>(sv);
+              if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kPi * im_lam_y_psi<R, J>(p, l));
+              apply_y<R, J>(p, cs);
+              apply_y<R, J>(l, cs);
+            })
+        }
+        if (h1 >> 24) {  // dense: U^dagger (8 floats) then generator (8 floats) per register bit
+          uint32_t dv[1];
+          rec_load<1>(recs, rec_off + 64u * NB, lane, dv);
+          QHBM_FOR_RB(R,
+            if ((h1 >> (24 + J)) & 1u) {
+              const uint32_t slot = rec_word<L.slot_dense(J) - S0>(sv);
+              const Gen2 g{rec_cs<16 * J + 8>(dv), rec_cs<16 * J + 10>(dv), rec_cs<16 * J + 12>(dv), rec_cs<16 * J + 14>(dv)};
+              if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, im_lam_g1_psi<R, J>(p, l, g));
+              apply_mat1<R, J>(p, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
+              apply_mat1<R, J>(l, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
+            })
+        }
+        rec_off += L.words();
+#pragma unroll
+        for (int v = 0; v < NB; ++v) cur[v] = nxt[v];
+        sv[0] = svn[0];
       }
       round_store<R>(tp, T, DB, p);
       round_store<R>(tl, T, DB, l);
       __syncthreads();
-      pc = uint32_t(ip - prog);
+      pc += 3;
     } else {  // OP_GATE2
       const uint32_t pw = uni(prog[pc + 1]);
       const uint32_t pos0 = pw & 0xffu, pos1 = (pw >> 8) & 0xffu;

@@ -43,13 +43,8 @@ enum : uint32_t {
 // ---- opcodes (low 8 bits of an instruction's first word) --------------------
 enum : uint32_t {
   OP_END = 0,
-  // [op | n_inst<<8] [regmask] then n_inst instances:
-  //   [x_mask | ph1_mask<<8 | ph2_mask<<16] [cph_mask | y_mask<<16 | dense_mask<<24]
-  //   then one entry per set bit, in execution order (forward: X, Y, DENSE, PH1, PH2, CPH;
-  //   adjoint: CPH, PH2, PH1, X, Y, DENSE -- the host lays entries out in that order):
-  //     X/Y/DENSE/PH1/PH2: [coef_off] [slot]
-  //     CPH: [pred] [coef_off] [slot]     pred = pos | kind<<8; kind 0 = local thread bit,
-  //                                       kind 1 = tile (non-local) index bit
+  // [op | n_inst<<8] [regmask] [first_record]: n_inst consecutive fixed-layout RECORDS in the
+  // coefficient buffer (see RecordLayout) drive the round.
   OP_ROUND = 1,
   OP_MEASURE = 3,  // [op | n_groups<<8] then groups x {[xl] [n_terms] terms x {[zl] [zn] [coef bits] [op_idx | ny<<24]}}
   OP_GATE2 = 4,    // [op | kind<<8] [pos_q0 | pos_q1<<8 (local bits)] [coef_off] [slot]
@@ -67,6 +62,44 @@ enum : uint32_t {
 };
 
 constexpr int pair_index(int lo, int hi) { return hi * (hi - 1) / 2 + lo; }  // lo < hi
+
+// One INSTANCE = one fixed-layout record of 32-bit words in the coefficient buffer, so that a
+// wave fetches it with one coalesced load per 64 words (lane i <- word i, prefetched one
+// instance ahead) and picks fields with v_readlane at compile-time lane indices -- no
+// per-entry pointer chasing.  Static words (masks, predicates, gradient slots) are written once
+// at upload; the coefficient words are rewritten by prep_coefs_kernel on every call.
+//   word 0   x_mask | ph1_mask<<8 | ph2_mask<<16          word 1   cph_mask | y_mask<<16 | dense_mask<<24
+//   X[R]{c,s}  PH1[R]{c,s}  PH2[NP]{c,s}  CPH[2R]{c,s}  CPHPRED[2R]  Y[R]{c,s}      (NP = R(R-1)/2)
+//   CPHPRED = pos | kind<<8; kind 0 = local thread bit, kind 1 = tile (non-local) index bit
+// then, 64-word aligned: dense 2x2 blocks DENSE[R] (8 floats; adjoint: U^dagger then generator,
+// 16 floats) and, adjoint only, SLOT[6R+NP] = gradient slot per entry in the order
+// X, Y, DENSE, PH1, PH2, CPH.
+struct RecordLayout {
+  int R, NP;
+  bool adjoint;
+  constexpr RecordLayout(int r, bool adj) : R(r), NP(r * (r - 1) / 2), adjoint(adj) {}
+  constexpr int x(int j) const { return 2 + 2 * j; }
+  constexpr int ph1(int j) const { return 2 + 2 * R + 2 * j; }
+  constexpr int ph2(int pi) const { return 2 + 4 * R + 2 * pi; }
+  constexpr int cph(int k) const { return 2 + 4 * R + 2 * NP + 2 * k; }
+  constexpr int pred(int k) const { return 2 + 8 * R + 2 * NP + k; }
+  constexpr int y(int j) const { return 2 + 10 * R + 2 * NP + 2 * j; }
+  constexpr int base_words() const { return 2 + 12 * R + 2 * NP; }              // 62 (R=4), 82 (R=5)
+  constexpr int base_vecs() const { return (base_words() + 63) / 64; }
+  constexpr int dense_words() const { return adjoint ? 16 : 8; }
+  constexpr int dense(int j) const { return 64 * base_vecs() + dense_words() * j; }
+  constexpr int dense_vecs() const { return (R * dense_words() + 63) / 64; }
+  constexpr int slot0() const { return 64 * (base_vecs() + dense_vecs()); }
+  // slot order: X[R] Y[R] DENSE[R] PH1[R] PH2[NP] CPH[2R]
+  constexpr int slot_x(int j) const { return slot0() + j; }
+  constexpr int slot_y(int j) const { return slot0() + R + j; }
+  constexpr int slot_dense(int j) const { return slot0() + 2 * R + j; }
+  constexpr int slot_ph1(int j) const { return slot0() + 3 * R + j; }
+  constexpr int slot_ph2(int pi) const { return slot0() + 4 * R + pi; }
+  constexpr int slot_cph(int k) const { return slot0() + 4 * R + NP + k; }
+  constexpr int vecs() const { return base_vecs() + dense_vecs() + (adjoint ? 1 : 0); }
+  constexpr int words() const { return 64 * vecs(); }
+};
 
 // Lowered operation kinds produced by the host.
 enum LoweredType : int { LOW_SKIP = 0, LOW_DIAG = 1, LOW_MAT1 = 2, LOW_MAT2 = 3 };

@@ -229,108 +229,110 @@ class Builder {
     job.param_idx = G.param_idx;
     job.scalar = G.scalar;
     job.offset = G.offset;
-    job.out_off = plan_->n_coef_floats;
+    job.out_off = 0;
     job.dagger = adjoint_ ? 1 : 0;
     job.mult = 1.f;
     return job;
   }
 
+  uint32_t alloc_coef(int words, int align) {
+    size_t base = (plan_->coef_init.size() + size_t(align) - 1) / size_t(align) * size_t(align);
+    plan_->coef_init.resize(base + size_t(words), 0u);
+    plan_->n_coef_floats = int(plan_->coef_init.size());
+    return uint32_t(base);
+  }
+
   void emit_round(Pass* p, const std::vector<LoweredOp>& ops, const std::vector<int>& absorbed,
                   const std::vector<size_t>& seq, uint32_t reg, uint32_t S) {
     auto rank_of = [&](uint32_t local_bit_mask) { return popc(reg & (local_bit_mask - 1)); };
+    struct Placed { int inst; int kind; int j, j2, k; uint32_t pred; const LoweredOp* op; };
+    // kind: 0 X, 1 Y, 2 dense, 3 PH1, 4 PH2, 5 CPH
     std::vector<Instance> insts(1);
+    std::vector<Placed> placed;
     for (size_t i : seq) {
       const LoweredOp& op = ops[absorbed[i]];
-      Entry e;
-      e.slot = uint32_t(new_slot(p, op));
-      CoefJob job = base_job(op);
-      e.coef_off = uint32_t(job.out_off);
+      Placed pl{};
+      pl.op = &op;
       if (op.type == LOW_MAT1) {
         const int j = rank_of(to_local(*p, op.bits));
-        int nfloat;
-        if (op.kind == QHBM_GATE_XPOW) { job.mop = MOP_X; nfloat = 2; }
-        else if (op.kind == QHBM_GATE_YPOW) { job.mop = MOP_Y; nfloat = 2; }
-        else { job.mop = MOP_MAT1; nfloat = adjoint_ ? 16 : 8; }
-        plan_->n_coef_floats += nfloat;
-        e.w0 = uint32_t(job.mop);
         Instance* in = &insts.back();
         const bool conflict = adjoint_ ? bool(in->mat_mask >> j & 1)
                                        : bool((in->mat_mask >> j & 1) || (in->diag_touch >> j & 1));
         if (conflict) { insts.emplace_back(); in = &insts.back(); }
         in->mat_mask |= 1u << j;
-        in->mat[j] = e;
+        pl.kind = op.kind == QHBM_GATE_XPOW ? 0 : (op.kind == QHBM_GATE_YPOW ? 1 : 2);
+        in->mat[j].w0 = uint32_t(pl.kind);
+        pl.j = j;
         ++p->n_mat_ops;
       } else {  // diagonal term
-        job.mop = MOP_PHASE;
-        job.mult = op.mult;
-        plan_->n_coef_floats += 2;
         const uint32_t ll = to_local(*p, op.bits & S);
         const uint32_t in_reg = ll & reg;
         const uint32_t other_local = ll & ~reg;
         const uint32_t other_nonlocal = op.bits & ~S;
         const int j = rank_of(in_reg & (0u - in_reg));
-        int kind;  // 1 PH1, 2 PH2, 3 CPH
         int j2 = -1;
-        if (popc(in_reg) == 2) { kind = 2; j2 = rank_of(in_reg & (in_reg - 1)); }
-        else if (other_local) { kind = 3; e.w0 = uint32_t(__builtin_ctz(other_local)); }
-        else if (other_nonlocal) { kind = 3; e.w0 = uint32_t(__builtin_ctz(other_nonlocal)) | (1u << 8); }
-        else kind = 1;
+        if (popc(in_reg) == 2) { pl.kind = 4; j2 = rank_of(in_reg & (in_reg - 1)); }
+        else if (other_local) { pl.kind = 5; pl.pred = uint32_t(__builtin_ctz(other_local)); }
+        else if (other_nonlocal) { pl.kind = 5; pl.pred = uint32_t(__builtin_ctz(other_nonlocal)) | (1u << 8); }
+        else pl.kind = 3;
         const uint32_t touch = (1u << j) | (j2 >= 0 ? (1u << j2) : 0u);
         auto fits = [&](const Instance& in) {
           if (adjoint_ && (in.mat_mask & touch)) return false;  // MAT executes after diagonals there
-          if (kind == 1) return !(in.ph1_mask >> j & 1);
-          if (kind == 2) return !(in.ph2_mask >> pair_index(j, j2) & 1);
+          if (pl.kind == 3) return !(in.ph1_mask >> j & 1);
+          if (pl.kind == 4) return !(in.ph2_mask >> pair_index(j, j2) & 1);
           return ((in.cph_mask >> (2 * j)) & 3u) != 3u;
         };
         if (!fits(insts.back())) insts.emplace_back();
         Instance* in = &insts.back();
         in->diag_touch |= touch;
-        if (kind == 1) { in->ph1_mask |= 1u << j; in->ph1[j] = e; }
-        else if (kind == 2) { const int pi = pair_index(j, j2); in->ph2_mask |= 1u << pi; in->ph2[pi] = e; }
+        pl.j = j;
+        pl.j2 = j2;
+        if (pl.kind == 3) in->ph1_mask |= 1u << j;
+        else if (pl.kind == 4) in->ph2_mask |= 1u << pair_index(j, j2);
         else {
-          const int k = ((in->cph_mask >> (2 * j)) & 1u) ? 1 : 0;
-          in->cph_mask |= 1u << (2 * j + k);
-          in->cph[2 * j + k] = e;
+          pl.k = 2 * j + (((in->cph_mask >> (2 * j)) & 1u) ? 1 : 0);
+          in->cph_mask |= 1u << pl.k;
         }
         ++p->n_diag_terms;
       }
-      plan_->jobs.push_back(job);
+      pl.inst = int(insts.size()) - 1;
+      placed.push_back(pl);
     }
-    // ---- serialise ----
+    // ---- fixed-layout records (program.h RecordLayout), consecutive in the coefficient buffer
+    const RecordLayout L(R_, adjoint_);
+    const uint32_t first = alloc_coef(L.words() * int(insts.size()), 64);
+    for (size_t ii = 0; ii < insts.size(); ++ii) {
+      const Instance& in = insts[ii];
+      uint32_t kmask[3] = {0, 0, 0};
+      for (int j = 0; j < R_; ++j) if (in.mat_mask >> j & 1) kmask[in.mat[j].w0] |= 1u << j;
+      uint32_t* rec = &plan_->coef_init[first + ii * size_t(L.words())];
+      rec[0] = kmask[0] | (in.ph1_mask << 8) | (in.ph2_mask << 16);
+      rec[1] = in.cph_mask | (kmask[1] << 16) | (kmask[2] << 24);
+      if (adjoint_) for (int k = 0; k < 6 * R_ + L.NP; ++k) rec[L.slot0() + k] = 0xffffffffu;
+    }
+    for (const Placed& pl : placed) {
+      const LoweredOp& op = *pl.op;
+      const uint32_t rb = first + uint32_t(pl.inst) * uint32_t(L.words());
+      uint32_t* rec = &plan_->coef_init[rb];
+      CoefJob job = base_job(op);
+      int lane = 0, slot_lane = 0;
+      switch (pl.kind) {
+        case 0: job.mop = MOP_X; lane = L.x(pl.j); slot_lane = L.slot_x(pl.j); break;
+        case 1: job.mop = MOP_Y; lane = L.y(pl.j); slot_lane = L.slot_y(pl.j); break;
+        case 2: job.mop = MOP_MAT1; lane = L.dense(pl.j); slot_lane = L.slot_dense(pl.j); break;
+        case 3: job.mop = MOP_PHASE; lane = L.ph1(pl.j); slot_lane = L.slot_ph1(pl.j); break;
+        case 4: job.mop = MOP_PHASE; lane = L.ph2(pair_index(pl.j, pl.j2)); slot_lane = L.slot_ph2(pair_index(pl.j, pl.j2)); break;
+        default: job.mop = MOP_PHASE; lane = L.cph(pl.k); slot_lane = L.slot_cph(pl.k); rec[L.pred(pl.k)] = pl.pred; break;
+      }
+      if (job.mop == MOP_PHASE) job.mult = op.mult;
+      job.out_off = int32_t(rb) + lane;
+      plan_->jobs.push_back(job);
+      const int slot = new_slot(p, op);
+      if (adjoint_) rec[slot_lane] = uint32_t(slot);
+    }
     p->prog.push_back(OP_ROUND | (uint32_t(insts.size()) << 8));
     p->prog.push_back(reg);
-    const int n_pairs = R_ * (R_ - 1) / 2;
-    for (const Instance& in : insts) {
-      uint32_t kmask[3] = {0, 0, 0};  // X, Y, dense
-      for (int j = 0; j < R_; ++j) if (in.mat_mask >> j & 1) {
-        kmask[in.mat[j].w0 == MOP_X ? 0 : (in.mat[j].w0 == MOP_Y ? 1 : 2)] |= 1u << j;
-      }
-      p->prog.push_back(kmask[0] | (in.ph1_mask << 8) | (in.ph2_mask << 16));
-      p->prog.push_back(in.cph_mask | (kmask[1] << 16) | (kmask[2] << 24));
-      auto put_mat = [&]() {
-        for (int k = 0; k < 3; ++k)
-          for (int j = 0; j < R_; ++j) if (kmask[k] >> j & 1) {
-            p->prog.push_back(in.mat[j].coef_off); p->prog.push_back(in.mat[j].slot);
-          }
-      };
-      auto put_ph1 = [&]() {
-        for (int j = 0; j < R_; ++j) if (in.ph1_mask >> j & 1) {
-          p->prog.push_back(in.ph1[j].coef_off); p->prog.push_back(in.ph1[j].slot);
-        }
-      };
-      auto put_ph2 = [&]() {
-        for (int j = 0; j < n_pairs; ++j) if (in.ph2_mask >> j & 1) {
-          p->prog.push_back(in.ph2[j].coef_off); p->prog.push_back(in.ph2[j].slot);
-        }
-      };
-      auto put_cph = [&]() {
-        for (int j = 0; j < 2 * R_; ++j) if (in.cph_mask >> j & 1) {
-          p->prog.push_back(in.cph[j].w0); p->prog.push_back(in.cph[j].coef_off); p->prog.push_back(in.cph[j].slot);
-        }
-      };
-      if (adjoint_) { put_cph(); put_ph2(); put_ph1(); put_mat(); }
-      else { put_mat(); put_ph1(); put_ph2(); put_cph(); }
-    }
+    p->prog.push_back(first);
     ++p->n_rounds;
     p->n_instances += int(insts.size());
   }
@@ -338,7 +340,7 @@ class Builder {
   void emit_gate2(Pass* p, const LoweredOp& op) {
     CoefJob job = base_job(op);
     job.mop = MOP_MAT2;
-    plan_->n_coef_floats += adjoint_ ? 64 : 32;
+    job.out_off = int32_t(alloc_coef(adjoint_ ? 64 : 32, 4));
     plan_->jobs.push_back(job);
     auto local_bit = [&](int gbit) { return uint32_t(__builtin_ctz(to_local(*p, 1u << gbit))); };
     const int slot = new_slot(p, op);
@@ -471,6 +473,11 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     plan->passes.push_back(std::move(p));
   }
 
+  {  // the kernels prefetch one record past the last one of a round
+    const RecordLayout L(R, adjoint);
+    plan->coef_init.resize(plan->coef_init.size() + size_t(L.words()) + 64, 0u);
+    plan->n_coef_floats = int(plan->coef_init.size());
+  }
   if (adjoint) {
     for (Pass& p : plan->passes) {
       p.flags = PASS_ADJOINT | PASS_STORE;

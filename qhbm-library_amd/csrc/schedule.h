@@ -69,6 +69,7 @@ struct Plan {
   std::vector<Pass> passes;
   std::vector<CoefJob> jobs;
   int n_coef_floats = 0;
+  std::vector<uint32_t> coef_init;  // static words of the coefficient buffer (records)
   // adjoint: gradient slot -> (gate, chain-rule factor to the exponent)
   std::vector<int> slot_gate;
   std::vector<float> slot_factor;
