@@ -48,7 +48,7 @@ struct DevBuf {
 struct DevicePlan {
   Plan plan;
   std::vector<PassArgs> args;
-  DevBuf<uint32_t> prog, tables;
+  DevBuf<uint32_t> prog, tables, rec_offsets;
   DevBuf<CoefJob> jobs;
   DevBuf<float> coef;
   bool uploaded = false;
@@ -68,6 +68,7 @@ struct qhbm_engine {
   bool have_circuit = false;
   // options
   int opt_tile = 0, opt_adj_tile = 0, opt_profile = 0, opt_round = 0;
+  int opt_full_fwd = 60, opt_full_adj = 60, opt_force_general = 0;
   int64_t opt_chunk = 0;
   int64_t opt_budget_mb = 16384;
   // plans
@@ -132,8 +133,8 @@ int build_plans(qhbm_engine* h) {
   if (!h->have_circuit) return fail(h, "qhbm_set_circuit has not been called");
   if (h->model.n_ops > kMaxOps) return fail(h, "too many observables (max 1024)");
   std::string err;
-  if (!build_plan(h->model, h->opt_tile, h->opt_round, false, &h->fwd.plan, &err)) return fail(h, "forward plan: " + err);
-  if (!build_plan(h->model, h->opt_adj_tile, 0, true, &h->adj.plan, &err)) return fail(h, "adjoint plan: " + err);
+  if (!build_plan(h->model, h->opt_tile, h->opt_round, false, &h->fwd.plan, &err, h->opt_full_fwd)) return fail(h, "forward plan: " + err);
+  if (!build_plan(h->model, h->opt_adj_tile, 0, true, &h->adj.plan, &err, h->opt_full_adj)) return fail(h, "adjoint plan: " + err);
   h->fwd.uploaded = h->adj.uploaded = false;
   h->plans_valid = true;
   return 0;
@@ -146,6 +147,7 @@ int upload_plan(qhbm_engine* h, DevicePlan* d) {
   HIPCHK(d->prog.upload(prog));
   HIPCHK(d->tables.upload(tables));
   HIPCHK(d->jobs.upload(d->plan.jobs));
+  HIPCHK(d->rec_offsets.upload(d->plan.record_offsets));
   {
     std::vector<float> init(d->plan.coef_init.size() + 64, 0.f);
     std::memcpy(init.data(), d->plan.coef_init.data(), d->plan.coef_init.size() * sizeof(uint32_t));
@@ -209,7 +211,8 @@ int run_forward_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_
   for (size_t i = 0; i < np; ++i) {
     const Pass& p = d.plan.passes[i];
     PassArgs a = d.args[i];
-    a.flags = p.flags & PASS_INIT_BASIS;
+    a.flags = p.flags & (PASS_INIT_BASIS | PASS_GENERAL);
+    if (h->opt_force_general) a.flags |= PASS_GENERAL;
     if (!p.is_measure_only && (!p.completes_circuit || keep_state || measure_only_after)) a.flags |= PASS_STORE;
     hipEvent_t* ev = timer_begin(h, 0, stream);
     HIPCHK(launch_pass_fwd(d.plan.K, d.plan.R, a, cs, h->psi.p, d_bits, h->model.n, d.prog.p, d.tables.p, d.coef.p,
@@ -231,6 +234,7 @@ int forward(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, 
   DevicePlan& d = h->fwd;
   HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, shift_gate,
                            shift, stream));
+  HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), stream));
   if (h->model.n_ops) HIPCHK(hipMemsetAsync(d_out, 0, size_t(U) * h->model.n_ops * sizeof(float), stream));
   const uint32_t cs = chunk_states(h, U);
   if (int rc = ensure_state_buffers(h, cs, false)) return rc;
@@ -248,7 +252,9 @@ int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_pa
   DevicePlan& b = h->adj;
   const uint32_t n_slots = uint32_t(b.plan.slot_gate.size());
   HIPCHK(launch_prep_coefs(f.jobs.p, int(f.plan.jobs.size()), d_params, f.coef.p, -1, 0.0, stream));
+  HIPCHK(launch_combine_diag(f.coef.p, f.rec_offsets.p, int(f.plan.record_offsets.size()), stream));
   HIPCHK(launch_prep_coefs(b.jobs.p, int(b.plan.jobs.size()), d_params, b.coef.p, -1, 0.0, stream));
+  HIPCHK(launch_combine_diag(b.coef.p, b.rec_offsets.p, int(b.plan.record_offsets.size()), stream));
   HIPCHK(hipMemsetAsync(d_out_vals, 0, size_t(U) * h->model.n_ops * sizeof(float), stream));
   HIPCHK(h->state_grad.reserve(size_t(U) * std::max<uint32_t>(n_slots, 1)));
   HIPCHK(hipMemsetAsync(h->state_grad.p, 0, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), stream));
@@ -263,7 +269,9 @@ int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_pa
                                    d_upstream, uint32_t(h->model.n_ops), s0, stream));
     for (size_t i = 0; i < b.plan.passes.size(); ++i) {
       hipEvent_t* ev = timer_begin(h, 1, stream);
-      HIPCHK(launch_pass_adj(b.plan.K, b.args[i], c, h->psi.p, h->lam.p, b.prog.p, b.tables.p, b.coef.p,
+      PassArgs ba = b.args[i];
+      if (h->opt_force_general) ba.flags |= PASS_GENERAL;
+      HIPCHK(launch_pass_adj(b.plan.K, ba, c, h->psi.p, h->lam.p, b.prog.p, b.tables.p, b.coef.p,
                              h->state_grad.p, n_slots, s0, stream));
       timer_end(ev, stream);
     }
@@ -372,6 +380,9 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   const std::string k(name);
   if (k == "tile_qubits") { h->opt_tile = int(value); h->plans_valid = false; }
   else if (k == "round_qubits") { h->opt_round = int(value); h->plans_valid = false; }
+  else if (k == "force_general_kernels") h->opt_force_general = int(value);
+  else if (k == "full_diag_threshold") { h->opt_full_fwd = int(value); h->plans_valid = false; }
+  else if (k == "adjoint_full_diag_threshold") { h->opt_full_adj = int(value); h->plans_valid = false; }
   else if (k == "adjoint_tile_qubits") { h->opt_adj_tile = int(value); h->plans_valid = false; }
   else if (k == "chunk_states") h->opt_chunk = value;
   else if (k == "workspace_budget_mb") h->opt_budget_mb = std::max<int64_t>(1, value);

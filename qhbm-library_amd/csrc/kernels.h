@@ -30,6 +30,7 @@ hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, u
                                    uint32_t n_ops, uint32_t state0, hipStream_t stream);
 hipError_t launch_prep_coefs(const CoefJob* jobs, int n_jobs, const float* params, float* coef,
                              int shift_gate, double shift, hipStream_t stream);
+hipError_t launch_combine_diag(float* coef, const uint32_t* rec_offsets, int n_records, hipStream_t stream);
 hipError_t launch_reduce_grad(const float* state_grad, uint32_t U, uint32_t n_slots,
                               const int* param_slot_begin, const int* param_slots,
                               const float* slot_factor, float* grad, int n_params, int accumulate,

@@ -429,9 +429,35 @@ __device__ __forceinline__ void rec_load(const uint32_t* __restrict__ recs, uint
   for (int i = 0; i < NV; ++i) rv[i] = recs[off + 64u * i + uint32_t(lane)];
 }
 
+// Gradient partial of one slot: wave sum (DPP rows + readlane), one LDS atomic per wave.
 __device__ __forceinline__ void add_slot(float* sacc, uint32_t slot_base, int tid, uint32_t slot, float v) {
   v = wave_sum(v);
   if ((tid & 63) == 0) atomicAdd(&sacc[slot - slot_base], v);
+}
+
+// FULL diagonal table: amplitude with register value m (1..15) times FULL[m-1].
+template <int NV, int... M>
+__device__ __forceinline__ void apply_full_(v2f (&a)[16], const uint32_t (&rv)[NV], bool conj,
+                                            std::integer_sequence<int, M...>) {
+  constexpr RecordLayout L(4, false);
+  (phase_s(a[M + 1], conj ? conj_cs(rec_cs<L.full(M + 1)>(rv)) : rec_cs<L.full(M + 1)>(rv)), ...);
+}
+template <int NV>
+__device__ __forceinline__ void apply_full(v2f (&a)[16], const uint32_t (&rv)[NV], bool conj) {
+  apply_full_<NV>(a, rv, conj, iseq<15>{});
+}
+template <int... M>
+__device__ __forceinline__ void w_all_(float (&w)[16], const v2f (&p)[16], const v2f (&l)[16],
+                                       std::integer_sequence<int, M...>) {
+  ((w[M] = im_conj(l[M], p[M])), ...);
+}
+template <int RB, int... P>
+__device__ __forceinline__ float wsum1_(const float (&w)[16], std::integer_sequence<int, P...>) {
+  return (w[ins0<RB>(P) | (1 << RB)] + ...);
+}
+template <int RA, int RB, int... P>
+__device__ __forceinline__ float wsum2_(const float (&w)[16], std::integer_sequence<int, P...>) {
+  return (w[ins11<RA, RB>(P)] + ...);
 }
 
 // Controlled phase: register bit J AND (a thread bit | a tile bit).  One code path for both
@@ -457,7 +483,7 @@ __device__ __forceinline__ void cph_adj(v2f (&p)[1 << R], v2f (&l)[1 << R], v2f 
 }
 
 // One forward instance on the register file.
-template <int R, int NV>
+template <int R, int NV, bool GEN>
 __device__ __forceinline__ void instance_fwd(const uint32_t (&rv)[NV], const uint32_t* __restrict__ recs,
                                              uint32_t rec_off, int lane, v2f (&a)[1 << R], uint32_t tl,
                                              uint32_t tile_base) {
@@ -466,22 +492,26 @@ __device__ __forceinline__ void instance_fwd(const uint32_t (&rv)[NV], const uin
   // One-qubit gates: a separate predicated slot class per kind (X, Y, dense), each a plain
   // if-then triangle around in-place code -- no merge copies.
   QHBM_FOR_RB(R, if ((h0 >> J) & 1u) apply_x<R, J>(a, rec_cs<L.x(J)>(rv));)
-  if ((h1 >> 16) & 0xffu) {
+  if constexpr (GEN) {
+  if ((h1 >> 16) & 0xfu) {
     QHBM_FOR_RB(R, if ((h1 >> (16 + J)) & 1u) apply_y<R, J>(a, rec_cs<L.y(J)>(rv));)
   }
-  if (h1 >> 24) {  // dense 2x2 gates (rare): their coefficients sit in the record's second part
+  if ((h1 >> 24) & 0xfu) {  // dense 2x2 gates (rare): their coefficients sit in the record's third part
     uint32_t dv[1];
-    rec_load<1>(recs, rec_off + 64u * L.base_vecs(), lane, dv);
+    rec_load<1>(recs, rec_off + 128u, lane, dv);
     QHBM_FOR_RB(R,
       if ((h1 >> (24 + J)) & 1u)
         apply_mat1<R, J>(a, rec_cs<8 * J>(dv), rec_cs<8 * J + 2>(dv), rec_cs<8 * J + 4>(dv), rec_cs<8 * J + 6>(dv));)
   }
+  }
+  // (a FULL instance has its PH1 / PH2 masks zeroed in word 0: independent triangles, no else)
+  if (h1 & kFullDiagFlag) apply_full<NV>(a, rv, false);
   QHBM_FOR_RB(R, if ((h0 >> (8 + J)) & 1u) apply_ph1<R, J>(a, rec_cs<L.ph1(J)>(rv));)
-  if (h0 >> 16) {
+  if ((h0 >> 16) & 0x3fu) {
     QHBM_FOR_PAIR(R,
       if ((h0 >> (16 + pair_index(JA, JB))) & 1u) apply_ph2<R, JA, JB>(a, rec_cs<L.ph2(pair_index(JA, JB))>(rv));)
   }
-  if (h1 & 0xffffu) {
+  if (h1 & 0xffu) {
     QHBM_FOR_RB(R,
       if ((h1 >> (2 * J)) & 1u)
         cph_fwd<R, J>(a, rec_cs<L.cph(2 * J)>(rv), rec_word<L.pred(2 * J)>(rv), tl, tile_base);
@@ -565,7 +595,7 @@ __device__ __forceinline__ const uint32_t* instance_fwd(const uint32_t* __restri
 // ================================================================================
 // Forward pass kernel
 // ================================================================================
-template <int K, int R>
+template <int K, int R, bool GEN>
 __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_kernel(
     PassArgs a, float2* __restrict__ psi, const int8_t* __restrict__ bits, int n_user,
     const uint32_t* __restrict__ prog_base, const uint32_t* __restrict__ tables,
@@ -614,7 +644,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
       const uint32_t regmask = uni(prog[pc + 1]);
       uint32_t rec_off = uni(prog[pc + 2]);
       constexpr RecordLayout L(R, false);
-      constexpr int NV = L.base_vecs();
+      constexpr int NV = 1;
       uint32_t cur[NV], nxt[NV];
       rec_load<NV>(recs, rec_off, lane, cur);
       uint32_t DB[R], T, TL;
@@ -623,7 +653,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
       round_load<R>(tile, T, DB, amp);
       for (uint32_t i = 0; i < n_inst; ++i) {
         rec_load<NV>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
-        instance_fwd<R, NV>(cur, recs, rec_off, lane, amp, TL, t.tile_base);
+        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);
         rec_off += L.words();
 #pragma unroll
         for (int v = 0; v < NV; ++v) cur[v] = nxt[v];
@@ -632,20 +662,22 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
       __syncthreads();
       pc += 3;
     } else if (opc == OP_GATE2) {
-      const uint32_t pw = uni(prog[pc + 1]);
-      const uint32_t pos0 = pw & 0xffu, pos1 = (pw >> 8) & 0xffu;
-      const float* cf = coef + uni(prog[pc + 2]);
-      for (uint32_t q = tid; q < (1u << (K - 2)); q += NT) {
-        uint32_t ix[4];
-        quad_indices(q, pos0, pos1, ix);
-        float2 x[4], y[4];
+      if constexpr (GEN) {
+        const uint32_t pw = uni(prog[pc + 1]);
+        const uint32_t pos0 = pw & 0xffu, pos1 = (pw >> 8) & 0xffu;
+        const float* cf = coef + uni(prog[pc + 2]);
+        for (uint32_t q = tid; q < (1u << (K - 2)); q += NT) {
+          uint32_t ix[4];
+          quad_indices(q, pos0, pos1, ix);
+          float2 x[4], y[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = tile[ix[j]];
-        mat4_apply(cf, x, y);
+          for (int j = 0; j < 4; ++j) x[j] = tile[ix[j]];
+          mat4_apply(cf, x, y);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tile[ix[j]] = y[j];
+          for (int j = 0; j < 4; ++j) tile[ix[j]] = y[j];
+        }
+        __syncthreads();
       }
-      __syncthreads();
       pc += kGate2Words;
     } else {  // OP_MEASURE
       const uint32_t n_groups = w0 >> 8;
@@ -704,7 +736,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
 // For a diagonal term with angle t on the index set {bits all 1}:
 //   dE/dt = -2*pi * sum_{selected l} Im(conj(lam_l) psi_l).
 // ================================================================================
-template <int K>
+template <int K, bool GEN>
 __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kernel(
     PassArgs a, float2* __restrict__ psi, float2* __restrict__ lam,
     const uint32_t* __restrict__ prog_base, const uint32_t* __restrict__ tables,
@@ -744,7 +776,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
       const uint32_t regmask = uni(prog[pc + 1]);
       uint32_t rec_off = uni(prog[pc + 2]);
       constexpr RecordLayout L(R, true);
-      constexpr int NB = L.base_vecs();
+      constexpr int NB = 1;
       uint32_t cur[NB], nxt[NB], sv[1], svn[1];
       rec_load<NB>(recs, rec_off, lane, cur);
       rec_load<1>(recs, rec_off + L.slot0(), lane, sv);
@@ -759,7 +791,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
         rec_load<1>(recs, rec_off + L.words() + L.slot0(), lane, svn);
         const uint32_t h0 = rec_word<0>(cur), h1 = rec_word<1>(cur);
         // ---- CPH ----
-        if (h1 & 0xffffu) {
+        if (h1 & 0xffu) {
           QHBM_FOR_RB(R,
             if ((h1 >> (2 * J)) & 1u)
               cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J)>(cur), rec_word<L.pred(2 * J)>(cur),
@@ -768,8 +800,27 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
               cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J + 1)>(cur), rec_word<L.pred(2 * J + 1)>(cur),
                             rec_word<L.slot_cph(2 * J + 1) - S0>(sv), TL, t.tile_base, sacc, a.slot_base, tid);)
         }
+        if (h1 & kFullDiagFlag) {
+          // ---- all PH1/PH2 terms at once: w = Im(conj(lam) psi) per register value, per-term
+          // gradients are sums of w over the term's index set, then ONE conj-table multiply ----
+          float w[NR];
+          w_all_(w, p, l, iseq<NR>{});
+          QHBM_FOR_PAIR(R,
+            if ((h0 >> (24 + pair_index(JA, JB))) & 1u) {
+              const uint32_t slot = rec_word<L.slot_ph2(pair_index(JA, JB)) - S0>(sv);
+              if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kM2Pi * wsum2_<JA, JB>(w, iseq<4>{}));
+            })
+          QHBM_FOR_RB(R,
+            if ((h0 >> (4 + J)) & 1u) {
+              const uint32_t slot = rec_word<L.slot_ph1(J) - S0>(sv);
+              if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kM2Pi * wsum1_<J>(w, iseq<8>{}));
+            })
+          apply_full<NB>(p, cur, true);
+          apply_full<NB>(l, cur, true);
+        }
+        {
         // ---- PH2 ----
-        if (h0 >> 16) {
+        if ((h0 >> 16) & 0x3fu) {
           QHBM_FOR_PAIR(R,
             if ((h0 >> (16 + pair_index(JA, JB))) & 1u) {
               const v2f cs = conj_cs(rec_cs<L.ph2(pair_index(JA, JB))>(cur));
@@ -788,6 +839,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
             apply_ph1<R, J>(p, cs);
             apply_ph1<R, J>(l, cs);
           })
+        }
         // ---- one-qubit gates (X, Y, dense slot classes) ----
         QHBM_FOR_RB(R,
           if ((h0 >> J) & 1u) {
@@ -797,7 +849,8 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
             apply_x<R, J>(p, cs);
             apply_x<R, J>(l, cs);
           })
-        if ((h1 >> 16) & 0xffu) {
+        if constexpr (GEN) {
+        if ((h1 >> 16) & 0xfu) {
           QHBM_FOR_RB(R,
             if ((h1 >> (16 + J)) & 1u) {
               const v2f cs = conj_cs(rec_cs<L.y(J)>(cur));
@@ -807,9 +860,9 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
               apply_y<R, J>(l, cs);
             })
         }
-        if (h1 >> 24) {  // dense: U^dagger (8 floats) then generator (8 floats) per register bit
+        if ((h1 >> 24) & 0xfu) {  // dense: U^dagger (8 floats) then generator (8 floats) per register bit
           uint32_t dv[1];
-          rec_load<1>(recs, rec_off + 64u * NB, lane, dv);
+          rec_load<1>(recs, rec_off + 128u, lane, dv);
           QHBM_FOR_RB(R,
             if ((h1 >> (24 + J)) & 1u) {
               const uint32_t slot = rec_word<L.slot_dense(J) - S0>(sv);
@@ -818,6 +871,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
               apply_mat1<R, J>(p, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
               apply_mat1<R, J>(l, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
             })
+        }
         }
         rec_off += L.words();
 #pragma unroll
@@ -829,6 +883,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
       __syncthreads();
       pc += 3;
     } else {  // OP_GATE2
+      if constexpr (GEN) {
       const uint32_t pw = uni(prog[pc + 1]);
       const uint32_t pos0 = pw & 0xffu, pos1 = (pw >> 8) & 0xffu;
       const float* cf = coef + uni(prog[pc + 2]);  // U^dagger (32 floats) then generator (32 floats)
@@ -854,6 +909,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
       }
       if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, gacc);
       __syncthreads();
+      }
       pc += kGate2Words;
     }
   }
@@ -1001,6 +1057,33 @@ __global__ void prep_coefs_kernel(const CoefJob* __restrict__ jobs, int n_jobs,
     }
 }
 
+// FULL[m-1] = product of the instance's PH1 / PH2 phases contained in register value m
+// (program.h RecordLayout).  One block per record, run after prep_coefs_kernel.
+__global__ void combine_diag_kernel(float* __restrict__ coef, const uint32_t* __restrict__ rec_offsets,
+                                    int n_records) {
+  const int r = blockIdx.x;
+  const int m = threadIdx.x;
+  if (r >= n_records || m == 0 || m > 15) return;
+  constexpr RecordLayout L(4, false);
+  float* rec = coef + rec_offsets[r];
+  const uint32_t h0 = __float_as_uint(rec[0]), h1 = __float_as_uint(rec[1]);
+  if (!(h1 & kFullDiagFlag)) return;
+  double cr = 1.0, ci = 0.0;
+  auto mul = [&](int w) {
+    const double a = rec[w], b = rec[w + 1];
+    const double nr = cr * a - ci * b, ni = cr * b + ci * a;
+    cr = nr;
+    ci = ni;
+  };
+  for (int j = 0; j < 4; ++j)
+    if (((m >> j) & 1) && ((h0 >> (4 + j)) & 1u)) mul(L.in_ph1(j));
+  for (int jb = 1; jb < 4; ++jb)
+    for (int ja = 0; ja < jb; ++ja)
+      if (((m >> ja) & 1) && ((m >> jb) & 1) && ((h0 >> (24 + pair_index(ja, jb))) & 1u)) mul(L.in_ph2(pair_index(ja, jb)));
+  rec[L.full(m)] = float(cr);
+  rec[L.full(m) + 1] = float(ci);
+}
+
 // grad[p] = sum_s sum_slot(p) factor * state_grad[s, slot]   (fixed order: deterministic
 // given state_grad).  One block per parameter.
 __global__ __launch_bounds__(256) void reduce_grad_kernel(
@@ -1065,7 +1148,7 @@ __global__ __launch_bounds__(256) void shift_accumulate_kernel(
 size_t fwd_lds_bytes(int K) { return (size_t(1) << K) * 8 + size_t(kMaxOps) * 4; }
 size_t adj_lds_bytes(int K) { return (size_t(2) << K) * 8 + size_t(kMaxSlotsPerPass) * 4; }
 
-template <int K, int R>
+template <int K, int R, bool GEN>
 static hipError_t launch_fwd_t(const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
                                int n_user, const uint32_t* prog, const uint32_t* tables,
                                const float* coef, float* out, uint32_t state0,
@@ -1073,13 +1156,13 @@ static hipError_t launch_fwd_t(const PassArgs& a, uint32_t n_states, float2* psi
   const size_t lds = fwd_lds_bytes(K);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_fwd_kernel<K, R>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_fwd_kernel<K, R, GEN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const uint32_t grid = n_states << a.n_nonlocal;
-  hipLaunchKernelGGL((pass_fwd_kernel<K, R>), dim3(grid), dim3(1 << (K - R)), lds, stream, a, psi, bits,
+  hipLaunchKernelGGL((pass_fwd_kernel<K, R, GEN>), dim3(grid), dim3(1 << (K - R)), lds, stream, a, psi, bits,
                      n_user, prog, tables, coef, out, state0);
   return hipGetLastError();
 }
@@ -1089,20 +1172,19 @@ hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, f
                            float* out, uint32_t state0, hipStream_t stream) {
 #define QHBM_FWD_CASE(K_, R_)                                                                          \
   if (K == K_ && R == R_)                                                                              \
-    return launch_fwd_t<K_, R_>(a, n_states, psi, bits, n_user, prog, tables, coef, out, state0, stream);
+    return (a.flags & PASS_GENERAL)                                                                    \
+               ? launch_fwd_t<K_, R_, true>(a, n_states, psi, bits, n_user, prog, tables, coef, out, state0, stream)   \
+               : launch_fwd_t<K_, R_, false>(a, n_states, psi, bits, n_user, prog, tables, coef, out, state0, stream);
   QHBM_FWD_CASE(10, 4)
   QHBM_FWD_CASE(11, 4)
   QHBM_FWD_CASE(12, 4)
-  QHBM_FWD_CASE(12, 5)
   QHBM_FWD_CASE(13, 4)
-  QHBM_FWD_CASE(13, 5)
   QHBM_FWD_CASE(14, 4)
-  QHBM_FWD_CASE(14, 5)
 #undef QHBM_FWD_CASE
   return hipErrorInvalidValue;
 }
 
-template <int K>
+template <int K, bool GEN>
 static hipError_t launch_adj_t(const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
                                const uint32_t* prog, const uint32_t* tables, const float* coef,
                                float* state_grad, uint32_t n_slots_total,
@@ -1110,13 +1192,13 @@ static hipError_t launch_adj_t(const PassArgs& a, uint32_t n_states, float2* psi
   const size_t lds = adj_lds_bytes(K);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_adj_kernel<K>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_adj_kernel<K, GEN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const uint32_t grid = n_states << a.n_nonlocal;
-  hipLaunchKernelGGL((pass_adj_kernel<K>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, lam, prog,
+  hipLaunchKernelGGL((pass_adj_kernel<K, GEN>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, lam, prog,
                      tables, coef, state_grad, n_slots_total, state0);
   return hipGetLastError();
 }
@@ -1126,10 +1208,14 @@ hipError_t launch_pass_adj(int K, const PassArgs& a, uint32_t n_states, float2* 
                            float* state_grad, uint32_t n_slots_total,
                            uint32_t state0, hipStream_t stream) {
   switch (K) {
-    case 10: return launch_adj_t<10>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream);
-    case 11: return launch_adj_t<11>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream);
-    case 12: return launch_adj_t<12>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream);
-    case 13: return launch_adj_t<13>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream);
+    case 10: return (a.flags & PASS_GENERAL) ? launch_adj_t<10, true>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream)
+                                            : launch_adj_t<10, false>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream);
+    case 11: return (a.flags & PASS_GENERAL) ? launch_adj_t<11, true>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream)
+                                            : launch_adj_t<11, false>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream);
+    case 12: return (a.flags & PASS_GENERAL) ? launch_adj_t<12, true>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream)
+                                            : launch_adj_t<12, false>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream);
+    case 13: return (a.flags & PASS_GENERAL) ? launch_adj_t<13, true>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream)
+                                            : launch_adj_t<13, false>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream);
     default: return hipErrorInvalidValue;
   }
 }
@@ -1148,6 +1234,12 @@ hipError_t launch_prep_coefs(const CoefJob* jobs, int n_jobs, const float* param
   if (n_jobs == 0) return hipSuccess;
   hipLaunchKernelGGL(prep_coefs_kernel, dim3((n_jobs + 127) / 128), dim3(128), 0, stream, jobs, n_jobs,
                      params, coef, shift_gate, shift);
+  return hipGetLastError();
+}
+
+hipError_t launch_combine_diag(float* coef, const uint32_t* rec_offsets, int n_records, hipStream_t stream) {
+  if (n_records == 0) return hipSuccess;
+  hipLaunchKernelGGL(combine_diag_kernel, dim3(n_records), dim3(16), 0, stream, coef, rec_offsets, n_records);
   return hipGetLastError();
 }
 

@@ -38,6 +38,7 @@ enum : uint32_t {
   PASS_INIT_BASIS = 1u << 0,  // tile := |bits> instead of loading it
   PASS_STORE = 1u << 1,       // write the tile back at the end
   PASS_ADJOINT = 1u << 2,     // tile pair (psi, lambda), program is a backward program
+  PASS_GENERAL = 1u << 3,     // the program uses Y / dense 2x2 / dense two-qubit ops (rare-path kernel variant)
 };
 
 // ---- opcodes (low 8 bits of an instruction's first word) --------------------
@@ -67,39 +68,50 @@ constexpr int pair_index(int lo, int hi) { return hi * (hi - 1) / 2 + lo; }  // 
 // wave fetches it with one coalesced load per 64 words (lane i <- word i, prefetched one
 // instance ahead) and picks fields with v_readlane at compile-time lane indices -- no
 // per-entry pointer chasing.  Static words (masks, predicates, gradient slots) are written once
-// at upload; the coefficient words are rewritten by prep_coefs_kernel on every call.
-//   word 0   x_mask | ph1_mask<<8 | ph2_mask<<16          word 1   cph_mask | y_mask<<16 | dense_mask<<24
-//   X[R]{c,s}  PH1[R]{c,s}  PH2[NP]{c,s}  CPH[2R]{c,s}  CPHPRED[2R]  Y[R]{c,s}      (NP = R(R-1)/2)
-//   CPHPRED = pos | kind<<8; kind 0 = local thread bit, kind 1 = tile (non-local) index bit
-// then, 64-word aligned: dense 2x2 blocks DENSE[R] (8 floats; adjoint: U^dagger then generator,
-// 16 floats) and, adjoint only, SLOT[6R+NP] = gradient slot per entry in the order
-// X, Y, DENSE, PH1, PH2, CPH.
+// at upload; coefficient words are rewritten on every call by prep_coefs_kernel (one (cos, sin)
+// or matrix per gate) and combine_diag_kernel (the FULL table).  Rounds hold R = 4 register bits.
+//   vec 0:  [0] x_mask | fph1<<4 | ph1_mask<<8 | ph2_mask<<16 | fph2<<24
+//           [1] cph_mask | y_mask<<16 | dense_mask<<24 | FULL<<31
+//           X[4]{c,s}  CPH[8]{c,s}  CPHPRED[8]  then EITHER  PH1[4]{c,s} PH2[6]{c,s} Y[4]{c,s}
+//                                               OR (FULL)  FULL[15]{c,s}
+//           CPHPRED = pos | kind<<8; kind 0 = local thread bit, kind 1 = tile (non-local) index bit
+//           FULL[m-1] = product of the instance's PH1/PH2 phases whose bits are all set in the
+//           register value m: the whole diagonal on the register bits is then ONE complex
+//           multiply per amplitude.  A FULL instance keeps its term masks in fph1/fph2 and has
+//           ph1_mask = ph2_mask = 0, so table and per-term slots are independent triangles.
+//   vec 1:  (FULL only) the per-term phases PH1[4] PH2[6] that combine_diag_kernel multiplies
+//   vec 2:  DENSE[4] 2x2 blocks (8 floats; adjoint: U^dagger then generator, 16 floats)
+//   vec 3:  (adjoint) SLOT[30] = gradient slot per entry, order X Y DENSE PH1 PH2 CPH
+// Everything a round touches per instance sits in vec 0 (one coalesced 256-byte load per wave).
+constexpr int kRoundBits = 4;
 struct RecordLayout {
   int R, NP;
   bool adjoint;
   constexpr RecordLayout(int r, bool adj) : R(r), NP(r * (r - 1) / 2), adjoint(adj) {}
   constexpr int x(int j) const { return 2 + 2 * j; }
-  constexpr int ph1(int j) const { return 2 + 2 * R + 2 * j; }
-  constexpr int ph2(int pi) const { return 2 + 4 * R + 2 * pi; }
-  constexpr int cph(int k) const { return 2 + 4 * R + 2 * NP + 2 * k; }
-  constexpr int pred(int k) const { return 2 + 8 * R + 2 * NP + k; }
-  constexpr int y(int j) const { return 2 + 10 * R + 2 * NP + 2 * j; }
-  constexpr int base_words() const { return 2 + 12 * R + 2 * NP; }              // 62 (R=4), 82 (R=5)
-  constexpr int base_vecs() const { return (base_words() + 63) / 64; }
+  constexpr int cph(int k) const { return 10 + 2 * k; }
+  constexpr int pred(int k) const { return 26 + k; }
+  constexpr int full(int m) const { return 34 + 2 * (m - 1); }  // m = 1..15
+  constexpr int ph1(int j) const { return 34 + 2 * j; }
+  constexpr int ph2(int pi) const { return 42 + 2 * pi; }
+  constexpr int y(int j) const { return 54 + 2 * j; }
+  constexpr int in_ph1(int j) const { return 64 + 2 * j; }    // FULL: combine inputs
+  constexpr int in_ph2(int pi) const { return 72 + 2 * pi; }
   constexpr int dense_words() const { return adjoint ? 16 : 8; }
-  constexpr int dense(int j) const { return 64 * base_vecs() + dense_words() * j; }
-  constexpr int dense_vecs() const { return (R * dense_words() + 63) / 64; }
-  constexpr int slot0() const { return 64 * (base_vecs() + dense_vecs()); }
-  // slot order: X[R] Y[R] DENSE[R] PH1[R] PH2[NP] CPH[2R]
+  constexpr int dense(int j) const { return 128 + dense_words() * j; }
+  constexpr int slot0() const { return 192; }
   constexpr int slot_x(int j) const { return slot0() + j; }
   constexpr int slot_y(int j) const { return slot0() + R + j; }
   constexpr int slot_dense(int j) const { return slot0() + 2 * R + j; }
   constexpr int slot_ph1(int j) const { return slot0() + 3 * R + j; }
   constexpr int slot_ph2(int pi) const { return slot0() + 4 * R + pi; }
   constexpr int slot_cph(int k) const { return slot0() + 4 * R + NP + k; }
-  constexpr int vecs() const { return base_vecs() + dense_vecs() + (adjoint ? 1 : 0); }
+  // 3 / 5 vectors: an odd count keeps the 256-byte record vectors that every wave of the chip
+  // streams at the same time spread over all L2 channels (a 1 KiB stride hits every 4th).
+  constexpr int vecs() const { return adjoint ? 5 : 3; }
   constexpr int words() const { return 64 * vecs(); }
 };
+constexpr uint32_t kFullDiagFlag = 1u << 31;
 
 // Lowered operation kinds produced by the host.
 enum LoweredType : int { LOW_SKIP = 0, LOW_DIAG = 1, LOW_MAT1 = 2, LOW_MAT2 = 3 };

@@ -261,6 +261,7 @@ class Builder {
         if (conflict) { insts.emplace_back(); in = &insts.back(); }
         in->mat_mask |= 1u << j;
         pl.kind = op.kind == QHBM_GATE_XPOW ? 0 : (op.kind == QHBM_GATE_YPOW ? 1 : 2);
+        if (pl.kind != 0) p->flags |= PASS_GENERAL;
         in->mat[j].w0 = uint32_t(pl.kind);
         pl.j = j;
         ++p->n_mat_ops;
@@ -308,6 +309,13 @@ class Builder {
       uint32_t* rec = &plan_->coef_init[first + ii * size_t(L.words())];
       rec[0] = kmask[0] | (in.ph1_mask << 8) | (in.ph2_mask << 16);
       rec[1] = in.cph_mask | (kmask[1] << 16) | (kmask[2] << 24);
+      // one table multiply per amplitude (15 x 4 issue slots) beats per-term phases
+      // (18 per PH1, 10 per PH2) once the instance holds enough of them
+      if (kmask[1] == 0 && 18 * popc(in.ph1_mask) + 10 * popc(in.ph2_mask) > plan_->full_threshold) {
+        rec[0] = kmask[0] | (in.ph1_mask << 4) | (in.ph2_mask << 24);
+        rec[1] |= kFullDiagFlag;
+      }
+      plan_->record_offsets.push_back(uint32_t(first + ii * size_t(L.words())));
       if (adjoint_) for (int k = 0; k < 6 * R_ + L.NP; ++k) rec[L.slot0() + k] = 0xffffffffu;
     }
     for (const Placed& pl : placed) {
@@ -320,8 +328,16 @@ class Builder {
         case 0: job.mop = MOP_X; lane = L.x(pl.j); slot_lane = L.slot_x(pl.j); break;
         case 1: job.mop = MOP_Y; lane = L.y(pl.j); slot_lane = L.slot_y(pl.j); break;
         case 2: job.mop = MOP_MAT1; lane = L.dense(pl.j); slot_lane = L.slot_dense(pl.j); break;
-        case 3: job.mop = MOP_PHASE; lane = L.ph1(pl.j); slot_lane = L.slot_ph1(pl.j); break;
-        case 4: job.mop = MOP_PHASE; lane = L.ph2(pair_index(pl.j, pl.j2)); slot_lane = L.slot_ph2(pair_index(pl.j, pl.j2)); break;
+        case 3:
+          job.mop = MOP_PHASE;
+          lane = (rec[1] & kFullDiagFlag) ? L.in_ph1(pl.j) : L.ph1(pl.j);
+          slot_lane = L.slot_ph1(pl.j);
+          break;
+        case 4:
+          job.mop = MOP_PHASE;
+          lane = (rec[1] & kFullDiagFlag) ? L.in_ph2(pair_index(pl.j, pl.j2)) : L.ph2(pair_index(pl.j, pl.j2));
+          slot_lane = L.slot_ph2(pair_index(pl.j, pl.j2));
+          break;
         default: job.mop = MOP_PHASE; lane = L.cph(pl.k); slot_lane = L.slot_cph(pl.k); rec[L.pred(pl.k)] = pl.pred; break;
       }
       if (job.mop == MOP_PHASE) job.mult = op.mult;
@@ -344,6 +360,7 @@ class Builder {
     plan_->jobs.push_back(job);
     auto local_bit = [&](int gbit) { return uint32_t(__builtin_ctz(to_local(*p, 1u << gbit))); };
     const int slot = new_slot(p, op);
+    p->flags |= PASS_GENERAL;
     p->prog.push_back(OP_GATE2 | (uint32_t(op.kind) << 8));
     p->prog.push_back(local_bit(op.b0) | (local_bit(op.b1) << 8));
     p->prog.push_back(uint32_t(job.out_off));
@@ -383,8 +400,10 @@ class Builder {
 
 }  // namespace
 
-bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Plan* plan, std::string* err) {
+bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Plan* plan, std::string* err,
+                int full_threshold) {
   *plan = Plan();
+  plan->full_threshold = full_threshold;
   if (m.n < 1 || m.n > kMaxQubits - 1) { *err = "n_qubits must be in [1, 31]"; return false; }
   const int n_eff = std::max(m.n, kMinTileBits);
   const int k_cap = adjoint ? kMaxTileBits - 1 : kMaxTileBits;
@@ -398,13 +417,10 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     }
     K = std::min(n_eff, tile_bits);
   }
-  int R = 4;
-  if (!adjoint && round_bits != 0) {
-    if ((round_bits != 4 && round_bits != 5) || (round_bits == 5 && K < 12)) {
-      *err = "round_qubits must be 4 or 5 (5 needs tile_qubits >= 12)";
-      return false;
-    }
-    R = round_bits;
+  const int R = kRoundBits;
+  if (round_bits != 0 && round_bits != kRoundBits) {
+    *err = "round_qubits must be 4";
+    return false;
   }
   plan->n = m.n;
   plan->n_eff = n_eff;
@@ -480,7 +496,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   }
   if (adjoint) {
     for (Pass& p : plan->passes) {
-      p.flags = PASS_ADJOINT | PASS_STORE;
+      p.flags |= PASS_ADJOINT | PASS_STORE;
       p.prog.push_back(OP_END);
     }
     if (!plan->passes.empty()) plan->passes.back().flags &= ~PASS_STORE;

@@ -70,6 +70,8 @@ struct Plan {
   std::vector<CoefJob> jobs;
   int n_coef_floats = 0;
   std::vector<uint32_t> coef_init;  // static words of the coefficient buffer (records)
+  std::vector<uint32_t> record_offsets;  // word offset of every instance record
+  int full_threshold = 60;  // per-term cost above which an instance uses the FULL diagonal table
   // adjoint: gradient slot -> (gate, chain-rule factor to the exponent)
   std::vector<int> slot_gate;
   std::vector<float> slot_factor;
@@ -84,14 +86,12 @@ struct Model {
 };
 
 // Tile geometry for a given tile size.
-inline int round_bits_for(int K) { return K >= 13 ? 5 : 4; }
-inline int threads_for(int K) { return 1 << (K - round_bits_for(K)); }
 
 // Builds the forward plan (circuit passes + measurement) or, with adjoint =
 // true, the backward plan over (psi, lambda) tile pairs.  `tile_bits` = 0
 // selects automatically.  Returns false and fills `err` on failure.
 bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Plan* out,
-                std::string* err);
+                std::string* err, int full_threshold = 60);
 
 std::string describe_plan(const Plan& p);
 

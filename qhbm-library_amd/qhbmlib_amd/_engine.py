@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libqhbm_engine.so")
+LIB_PATH = os.environ.get("QHBM_ENGINE_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libqhbm_engine.so")
 
 # Gate kinds: values of enum qhbm_gate_kind.
 GATE_I = 0

@@ -131,7 +131,7 @@ def test_tile_geometries_agree_at_n20():
   bits = bench.distinct_bitstrings(n, states, 11)
   up = np.full((states, 1), 0.25, np.float32)
   ref_vals = ref_grad = None
-  for tile, rnd, adj in ((13, 4, 12), (12, 4, 11), (14, 5, 13), (13, 5, 10)):
+  for tile, rnd, adj in ((13, 4, 12), (12, 4, 11), (14, 4, 13), (11, 4, 10)):
     eng = _engine(n, gates, n_params, [bench.xxz_op(n)], tile_qubits=tile, round_qubits=rnd,
                   adjoint_tile_qubits=adj)
     vals, grad = eng.expectation_vjp(bits, params, up)
