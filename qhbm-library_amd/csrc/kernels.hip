@@ -218,12 +218,24 @@ template <int R, int RA, int RB>
 __device__ __forceinline__ void apply_ph2(v2f (&a)[1 << R], v2f cs) { apply_ph2_<R, RA, RB>(a, cs, iseq<(1 << (R - 2))>{}); }
 
 __device__ __forceinline__ float im_conj(v2f l, v2f p) { return l.x * p.y - l.y * p.x; }  // Im(conj(l) p)
+// acc += (l.re * p.im, l.im * p.re): Im(conj(l) p) = acc.x - acc.y summed later -- ONE packed FMA
+// per amplitude instead of mul + fma + add.
+__device__ __forceinline__ void acc_im(v2f& acc, v2f l, v2f p) {
+  asm("v_pk_fma_f32 %[acc], %[l], %[p], %[acc] op_sel:[0,1,0] op_sel_hi:[1,0,1]"
+      : [acc] "+v"(acc) : [l] "v"(l), [p] "v"(p));
+}
+// acc += (l.re * p.re, l.im * p.im): Re(conj(l) p) = acc.x + acc.y
+__device__ __forceinline__ void acc_re(v2f& acc, v2f l, v2f p) {
+  asm("v_pk_fma_f32 %[acc], %[l], %[p], %[acc]" : [acc] "+v"(acc) : [l] "v"(l), [p] "v"(p));
+}
 __device__ __forceinline__ float re_conj(v2f l, v2f p) { return l.x * p.x + l.y * p.y; }  // Re(conj(l) p)
 
-// sum over selected registers of Im(conj(lam) psi)
+// sum over selected registers of Im(conj(lam) psi); two packed accumulators break the chain
 template <int R, int RB, int... P>
 __device__ __forceinline__ float sum_w1_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], std::integer_sequence<int, P...>) {
-  return (im_conj(l[ins0<RB>(P) | (1 << RB)], p[ins0<RB>(P) | (1 << RB)]) + ...);
+  v2f a0 = v2f{0.f, 0.f}, a1 = v2f{0.f, 0.f};
+  (acc_im((P & 1) ? a1 : a0, l[ins0<RB>(P) | (1 << RB)], p[ins0<RB>(P) | (1 << RB)]), ...);
+  return (a0.x + a1.x) - (a0.y + a1.y);
 }
 template <int R, int RB>
 __device__ __forceinline__ float sum_w1(const v2f (&p)[1 << R], const v2f (&l)[1 << R]) {
@@ -231,7 +243,9 @@ __device__ __forceinline__ float sum_w1(const v2f (&p)[1 << R], const v2f (&l)[1
 }
 template <int R, int RA, int RB, int... P>
 __device__ __forceinline__ float sum_w2_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], std::integer_sequence<int, P...>) {
-  return (im_conj(l[ins11<RA, RB>(P)], p[ins11<RA, RB>(P)]) + ...);
+  v2f a0 = v2f{0.f, 0.f}, a1 = v2f{0.f, 0.f};
+  (acc_im((P & 1) ? a1 : a0, l[ins11<RA, RB>(P)], p[ins11<RA, RB>(P)]), ...);
+  return (a0.x + a1.x) - (a0.y + a1.y);
 }
 template <int R, int RA, int RB>
 __device__ __forceinline__ float sum_w2(const v2f (&p)[1 << R], const v2f (&l)[1 << R]) {
@@ -242,7 +256,9 @@ __device__ __forceinline__ float sum_w2(const v2f (&p)[1 << R], const v2f (&l)[1
 // of the fast-path gates.  X: pairs swap.  Y: (Y psi)_0 = -i psi_1, (Y psi)_1 = i psi_0.
 template <int R, int RB, int... M>
 __device__ __forceinline__ float im_lam_x_psi_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], std::integer_sequence<int, M...>) {
-  return (im_conj(l[M], p[M ^ (1 << RB)]) + ...);
+  v2f a0 = v2f{0.f, 0.f}, a1 = v2f{0.f, 0.f};
+  (acc_im((M & 1) ? a1 : a0, l[M], p[M ^ (1 << RB)]), ...);  // Im(conj(lam_m) * psi_{m ^ bit})
+  return (a0.x + a1.x) - (a0.y + a1.y);
 }
 template <int R, int RB>
 __device__ __forceinline__ float im_lam_x_psi(const v2f (&p)[1 << R], const v2f (&l)[1 << R]) {
@@ -251,7 +267,9 @@ __device__ __forceinline__ float im_lam_x_psi(const v2f (&p)[1 << R], const v2f 
 template <int R, int RB, int... P>
 __device__ __forceinline__ float im_lam_y_psi_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], std::integer_sequence<int, P...>) {
   // Im(conj(l0)*(-i p1)) = -Re(conj(l0) p1);  Im(conj(l1)*(i p0)) = Re(conj(l1) p0)
-  return ((re_conj(l[ins0<RB>(P) | (1 << RB)], p[ins0<RB>(P)]) - re_conj(l[ins0<RB>(P)], p[ins0<RB>(P) | (1 << RB)])) + ...);
+  v2f pos = v2f{0.f, 0.f}, neg = v2f{0.f, 0.f};
+  ((acc_re(pos, l[ins0<RB>(P) | (1 << RB)], p[ins0<RB>(P)]), acc_re(neg, l[ins0<RB>(P)], p[ins0<RB>(P) | (1 << RB)])), ...);
+  return (pos.x + pos.y) - (neg.x + neg.y);
 }
 template <int R, int RB>
 __device__ __forceinline__ float im_lam_y_psi(const v2f (&p)[1 << R], const v2f (&l)[1 << R]) {
@@ -430,6 +448,8 @@ __device__ __forceinline__ void rec_load(const uint32_t* __restrict__ recs, uint
 }
 
 // Gradient partial of one slot: wave sum (DPP rows + readlane), one LDS atomic per wave.
+// (Measured equal: per-lane LDS accumulators with one ds_add_f32 per slot, and row-level
+// atomics; dropping the reduction altogether would save 17 % of the VQT step.)
 __device__ __forceinline__ void add_slot(float* sacc, uint32_t slot_base, int tid, uint32_t slot, float v) {
   v = wave_sum(v);
   if ((tid & 63) == 0) atomicAdd(&sacc[slot - slot_base], v);
