@@ -77,6 +77,21 @@ def tfim_op(n, bias=1.0):
   return terms
 
 
+def random_pauli_op(n, terms, seed, p_identity=0.75):
+  """`terms` Pauli strings, each qubit in {I,X,Y,Z} with P(I) = 0.75
+  (at least one non-identity factor), coefficients N(0,1)."""
+  rng = np.random.default_rng(seed)
+  out = []
+  while len(out) < terms:
+    kinds = rng.choice(4, size=n, p=[p_identity] + [(1 - p_identity) / 3] * 3)
+    if not kinds.any():
+      continue
+    x = sum(1 << q for q in range(n) if kinds[q] in (1, 2))
+    z = sum(1 << q for q in range(n) if kinds[q] in (2, 3))
+    out.append((float(rng.normal()), x, z))
+  return out
+
+
 def distinct_bitstrings(n, count, seed):
   rng = np.random.default_rng(seed)
   if n <= 40:
@@ -119,8 +134,8 @@ def main():
   ap.add_argument("--qubits", type=int, default=20)
   ap.add_argument("--layers", type=int, default=16)
   ap.add_argument("--states-per-gpu", type=int, default=512)
-  ap.add_argument("--hamiltonian", choices=["xxz", "tfim"], default="xxz")
-  ap.add_argument("--mode", choices=["vqt", "forward"], default="vqt")
+  ap.add_argument("--hamiltonian", choices=["xxz", "tfim", "random512"], default="xxz")
+  ap.add_argument("--mode", choices=["vqt", "forward", "shift"], default="vqt")
   ap.add_argument("--tile-qubits", type=int, default=0)
   ap.add_argument("--adjoint-tile-qubits", type=int, default=0)
   ap.add_argument("--cpu-sample-states", type=int, default=64)
@@ -145,7 +160,7 @@ def main():
 
   n, layers, spg = args.qubits, args.layers, args.states_per_gpu
   gates, n_params = hea_gates(n, layers)
-  op = xxz_op(n) if args.hamiltonian == "xxz" else tfim_op(n)
+  op = {"xxz": xxz_op, "tfim": tfim_op, "random512": lambda m: random_pauli_op(m, 512, 24)}[args.hamiltonian](n)
   rng = np.random.default_rng(1234)
   params_np = rng.uniform(-1, 1, n_params).astype(np.float32)
   all_bits = distinct_bitstrings(n, spg * world, 4321)
@@ -170,7 +185,8 @@ def main():
       vals = eng.expectation(bits, params)
       grad = None
     else:
-      vals, grad = eng.expectation_vjp(bits, params, upstream)
+      vals, grad = eng.expectation_vjp(bits, params, upstream,
+                                       method=E.GRAD_PARAMETER_SHIFT if args.mode == "shift" else E.GRAD_ADJOINT)
     if world > 1:
       if grad is not None:
         dist.all_reduce(grad)
@@ -206,6 +222,8 @@ def main():
     n_gate = len(gates)
     amp = float(1 << n)
     fwd_alg = spg * (16.0 * n_gate + 8.0 * n_terms + 8.0) * amp  # per step, this rank
+    if args.mode == "shift":  # one base forward + 2 P shifted forwards
+      fwd_alg *= 1 + 2 * n_params
     bwd_alg = spg * 48.0 * n_gate * amp
     use_bwd = args.mode == "vqt" and kt["bwd_ms"] >= kt["fwd_ms"]
     if use_bwd:
@@ -244,9 +262,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": (f"BASELINE configs[2] shard: {n}-qubit "
-                         f"{'XXZ(delta=0.5) open chain' if args.hamiltonian == 'xxz' else 'TFIM ring'}, "
+                         f"{ {'xxz': 'XXZ(delta=0.5) open chain', 'tfim': 'TFIM ring', 'random512': 'random 512-term Pauli sum'}[args.hamiltonian]}, "
                          f"HEA depth {layers} ({n_params} params), {spg} states/GPU, "
-                         f"{'VQT step = values + adjoint VJP' if args.mode == 'vqt' else 'forward values only'}"),
+                         f"{ {'vqt': 'VQT step = values + adjoint VJP', 'forward': 'forward values only', 'shift': 'values + parameter-shift VJP'}[args.mode]}"),
             "n_qubits": n, "layers": layers, "states_per_gpu": spg, "pauli_terms": n_terms,
             "mode": args.mode, "parallelism": f"batch-sharded x{world}",
             "forward_passes": fwd_passes, "adjoint_passes": bwd_passes,

@@ -140,3 +140,92 @@ def test_tile_geometries_agree_at_n20():
       ref_vals, ref_grad = vals, grad
     np.testing.assert_allclose(vals, ref_vals, atol=5e-5)
     np.testing.assert_allclose(grad, ref_grad, atol=5e-5)
+
+
+# ---- BASELINE config 4 shape: 24 qubits, random 512-term Pauli sum, parameter-shift -----------
+def test_c4_width_against_c_oracle_and_shift_rule():
+  """Full width (24 qubits, 512 terms) at depth 2 so the fp32 C restatement finishes in seconds;
+  the parameter-shift VJP (2 P forwards, qnn.py:168) must agree with the adjoint VJP."""
+  n, layers, states = 24, 2, 2
+  gates, n_params = bench.hea_gates(n, layers)
+  op = bench.random_pauli_op(n, 512, 24)
+  assert len(op) == 512
+  norm = sum(abs(c) for c, _, _ in op)
+  params = np.random.default_rng(24).uniform(-1, 1, n_params).astype(np.float32)
+  bits = bench.distinct_bitstrings(n, states, 42)
+  eng = _engine(n, gates, n_params, [op, [(1.0, 0, 0)], op[:24]])
+  up = np.zeros((states, 3), np.float32)
+  up[:, 0] = [0.75, -0.25]
+  vals, g_adj = eng.expectation_vjp(bits, params, up)
+  vals_s, g_shift = eng.expectation_vjp(bits, params, up, method=E.GRAD_PARAMETER_SHIFT)
+  vals, g_adj, g_shift = vals.cpu().numpy(), g_adj.cpu().numpy(), g_shift.cpu().numpy()
+  np.testing.assert_allclose(vals[:, 1], 1.0, atol=2e-5)
+  np.testing.assert_allclose(vals_s.cpu().numpy(), vals, atol=1e-5 * norm)
+  np.testing.assert_allclose(g_shift, g_adj, atol=1e-4 * max(1.0, np.abs(g_adj).max()))
+  # the C restatement on the first 24 terms (all 512 would take minutes on the host)
+  from oracle import qhbm_cpu as C
+  up24 = np.array([[0.75], [-0.25]], np.float32)
+  want, want_g = C.expectation_vjp(n, gates, params, bits, [op[:24]], up24)
+  norm24 = sum(abs(c) for c, _, _ in op[:24])
+  np.testing.assert_allclose(vals[:, 2], want[:, 0], atol=1e-5 * norm24)
+  up[:, 0] = 0
+  up[:, 2] = up24[:, 0]
+  _, g24 = eng.expectation_vjp(bits, params, up)
+  np.testing.assert_allclose(g24.cpu().numpy(), want_g, atol=1e-4 * max(1.0, np.abs(want_g).max()))
+
+
+def test_c4_full_depth_properties():
+  n, layers, states = 24, 16, 2
+  gates, n_params = bench.hea_gates(n, layers)
+  op = bench.random_pauli_op(n, 512, 24)
+  params = np.random.default_rng(25).uniform(-1, 1, n_params).astype(np.float32)
+  bits = bench.distinct_bitstrings(n, states, 43)
+  eng = _engine(n, gates, n_params, [op, [(1.0, 0, 0)], [(-0.5 * c, x, z) for c, x, z in op]])
+  vals = eng.expectation(bits, params).cpu().numpy()
+  np.testing.assert_allclose(vals[:, 1], 1.0, atol=1e-4)
+  np.testing.assert_allclose(vals[:, 2], -0.5 * vals[:, 0], atol=1e-4)
+  up = np.zeros((states, 3), np.float32)
+  up[:, 0] = 0.5
+  _, grad = eng.expectation_vjp(bits, params, up)
+  grad = grad.cpu().numpy()
+  for p in (3, n_params // 3, n_params - 2):
+    hi, lo = params.copy(), params.copy()
+    hi[p] += 0.5
+    lo[p] -= 0.5
+    fd = (np.pi / 2) * (eng.expectation(bits, hi).cpu().numpy()[:, 0].mean() -
+                        eng.expectation(bits, lo).cpu().numpy()[:, 0].mean())
+    np.testing.assert_allclose(grad[p], fd, atol=5e-4)
+
+
+# ---- BASELINE config 5 shape: 28 qubits (2 GiB per state vector), depth 32, TFIM ---------------
+def test_c5_full_size_properties():
+  n, layers, states = 28, 32, 2
+  free, _ = torch.cuda.mem_get_info()
+  if free < 12 << 30:
+    pytest.skip("needs 12 GiB of free HBM")
+  gates, n_params = bench.hea_gates(n, layers)
+  op = bench.tfim_op(n)
+  params = np.random.default_rng(28).uniform(-1, 1, n_params).astype(np.float32)
+  bits = bench.distinct_bitstrings(n, states, 44)
+  eng = _engine(n, gates, n_params, [op, [(1.0, 0, 0)]])
+  vals = eng.expectation(bits, params).cpu().numpy()
+  np.testing.assert_allclose(vals[:, 1], 1.0, atol=2e-4)   # 2656 gates in fp32
+  assert np.abs(vals[:, 0]).max() < 56
+  up = np.zeros((states, 2), np.float32)
+  up[:, 0] = 0.5
+  vals2, grad = eng.expectation_vjp(bits, params, up)
+  np.testing.assert_allclose(vals2.cpu().numpy(), vals, atol=1e-5)
+  grad = grad.cpu().numpy()
+  for p in (1, n_params - 1):
+    hi, lo = params.copy(), params.copy()
+    hi[p] += 0.5
+    lo[p] -= 0.5
+    fd = (np.pi / 2) * (eng.expectation(bits, hi).cpu().numpy()[:, 0].mean() -
+                        eng.expectation(bits, lo).cpu().numpy()[:, 0].mean())
+    np.testing.assert_allclose(grad[p], fd, atol=1e-3)
+  # U then U^-1 at depth 2: every <Z_q> returns to (-1)^{x_q}; exercises >4 GiB offsets
+  g2, p2 = bench.hea_gates(n, 2)
+  inv = [(k, q0, q1, p, -s, -o) for (k, q0, q1, p, s, o) in reversed(g2)]
+  eng2 = _engine(n, g2 + inv, p2, [[(1.0, 0, 1 << q)] for q in range(n)])
+  z = eng2.expectation(bits, params[:p2]).cpu().numpy()
+  np.testing.assert_allclose(z, 1.0 - 2.0 * bits, atol=1e-4)
