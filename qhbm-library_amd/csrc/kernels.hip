@@ -448,11 +448,40 @@ __device__ __forceinline__ void rec_load(const uint32_t* __restrict__ recs, uint
 }
 
 // Gradient partial of one slot: wave sum (DPP rows + readlane), one LDS atomic per wave.
-// (Measured equal: per-lane LDS accumulators with one ds_add_f32 per slot, and row-level
-// atomics; dropping the reduction altogether would save 17 % of the VQT step.)
 __device__ __forceinline__ void add_slot(float* sacc, uint32_t slot_base, int tid, uint32_t slot, float v) {
   v = wave_sum(v);
   if ((tid & 63) == 0) atomicAdd(&sacc[slot - slot_base], v);
+}
+
+// Gradient partials of the four slots of record slot group G, reduced over the wave TOGETHER:
+// two select+quad_perm butterflies leave lane l with the quad sum of g[l & 3]; row_ror 4 / 8 sum
+// the four quads of a row; permlane16/32 swaps (gfx950) sum the four rows.  Lanes 4G..4G+3 --
+// the lanes whose slot-vector word `sv` IS the slot of g[l & 3] -- then issue one ds_add_f32.
+// 23 instructions for four slots; one slot at a time (wave_sum + readlanes + single-lane atomic)
+// was 45 each and cost 17 % of the VQT step.
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float rows_sum(float u) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u), __float_as_uint(u), false, false);
+  u = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int G>
+__device__ __forceinline__ void add_slots4(float* sacc, uint32_t slot_base, int lane, uint32_t sv, float scale,
+                                           float g0, float g1, float g2, float g3) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2;
+  t0 += dpp_get<0xB1>(b0 ? g0 : g1);  // quad_perm:[1,0,3,2]
+  t1 += dpp_get<0xB1>(b0 ? g2 : g3);
+  float u = b1 ? t1 : t0;
+  u += dpp_get<0x4E>(b1 ? t0 : t1);   // quad_perm:[2,3,0,1]
+  u += dpp_get<0x124>(u);             // row_ror:4
+  u += dpp_get<0x128>(u);             // row_ror:8
+  u = rows_sum(u);
+  if ((lane >> 2) == G && sv != 0xffffffffu) atomicAdd(&sacc[sv - slot_base], scale * u);
 }
 
 // FULL diagonal table: amplitude with register value m (1..15) times FULL[m-1].
@@ -491,15 +520,14 @@ __device__ __forceinline__ void cph_fwd(v2f (&a)[1 << R], v2f cs, uint32_t pred,
 }
 
 template <int R, int J>
-__device__ __forceinline__ void cph_adj(v2f (&p)[1 << R], v2f (&l)[1 << R], v2f cs, uint32_t pred,
-                                        uint32_t slot, uint32_t tl, uint32_t tile_base, float* sacc,
-                                        uint32_t slot_base, int tid) {
-  constexpr float kM2Pi = -2.f * kPi;
+__device__ __forceinline__ float cph_adj(v2f (&p)[1 << R], v2f (&l)[1 << R], v2f cs, uint32_t pred,
+                                         uint32_t tl, uint32_t tile_base) {
   const bool on = (((pred >> 8) ? tile_base : tl) >> (pred & 0xffu)) & 1u;
-  if (slot != 0xffffffffu) add_slot(sacc, slot_base, tid, slot, on ? kM2Pi * sum_w1<R, J>(p, l) : 0.f);
+  const float g = on ? sum_w1<R, J>(p, l) : 0.f;
   const v2f c2 = v2f{on ? cs.x : 1.f, on ? -cs.y : 0.f};
   apply_ph1_v<R, J>(p, c2);
   apply_ph1_v<R, J>(l, c2);
+  return g;
 }
 
 // One forward instance on the register file.
@@ -810,87 +838,101 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
         rec_load<NB>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
         rec_load<1>(recs, rec_off + L.words() + L.slot0(), lane, svn);
         const uint32_t h0 = rec_word<0>(cur), h1 = rec_word<1>(cur);
-        // ---- CPH ----
+        // ---- CPH (slot groups 6, 7) ----
         if (h1 & 0xffu) {
+          float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           QHBM_FOR_RB(R,
             if ((h1 >> (2 * J)) & 1u)
-              cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J)>(cur), rec_word<L.pred(2 * J)>(cur),
-                            rec_word<L.slot_cph(2 * J) - S0>(sv), TL, t.tile_base, sacc, a.slot_base, tid);
+              g[2 * J] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J)>(cur), rec_word<L.pred(2 * J)>(cur), TL, t.tile_base);
             if ((h1 >> (2 * J + 1)) & 1u)
-              cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J + 1)>(cur), rec_word<L.pred(2 * J + 1)>(cur),
-                            rec_word<L.slot_cph(2 * J + 1) - S0>(sv), TL, t.tile_base, sacc, a.slot_base, tid);)
+              g[2 * J + 1] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J + 1)>(cur), rec_word<L.pred(2 * J + 1)>(cur), TL,
+                                          t.tile_base);)
+          if (h1 & 0x0fu) add_slots4<L.group_cph()>(sacc, a.slot_base, lane, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
+          if (h1 & 0xf0u) add_slots4<L.group_cph() + 1>(sacc, a.slot_base, lane, sv[0], kM2Pi, g[4], g[5], g[6], g[7]);
         }
         if (h1 & kFullDiagFlag) {
           // ---- all PH1/PH2 terms at once: w = Im(conj(lam) psi) per register value, per-term
           // gradients are sums of w over the term's index set, then ONE conj-table multiply ----
           float w[NR];
           w_all_(w, p, l, iseq<NR>{});
-          QHBM_FOR_PAIR(R,
-            if ((h0 >> (24 + pair_index(JA, JB))) & 1u) {
-              const uint32_t slot = rec_word<L.slot_ph2(pair_index(JA, JB)) - S0>(sv);
-              if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kM2Pi * wsum2_<JA, JB>(w, iseq<4>{}));
-            })
-          QHBM_FOR_RB(R,
-            if ((h0 >> (4 + J)) & 1u) {
-              const uint32_t slot = rec_word<L.slot_ph1(J) - S0>(sv);
-              if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kM2Pi * wsum1_<J>(w, iseq<8>{}));
-            })
+          if ((h0 >> 24) & 0x3fu) {
+            float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            QHBM_FOR_PAIR(R,
+              if ((h0 >> (24 + pair_index(JA, JB))) & 1u) g[pair_index(JA, JB)] = wsum2_<JA, JB>(w, iseq<4>{});)
+            if ((h0 >> 24) & 0x0fu) add_slots4<L.group_ph2()>(sacc, a.slot_base, lane, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
+            if ((h0 >> 24) & 0x30u) add_slots4<L.group_ph2() + 1>(sacc, a.slot_base, lane, sv[0], kM2Pi, g[4], g[5], 0.f, 0.f);
+          }
+          if ((h0 >> 4) & 0xfu) {
+            float g[4] = {0.f, 0.f, 0.f, 0.f};
+            QHBM_FOR_RB(R, if ((h0 >> (4 + J)) & 1u) g[J] = wsum1_<J>(w, iseq<8>{});)
+            add_slots4<L.group_ph1()>(sacc, a.slot_base, lane, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
+          }
           apply_full<NB>(p, cur, true);
           apply_full<NB>(l, cur, true);
         }
         {
-        // ---- PH2 ----
+        // ---- PH2 (slot groups 4, 5) ----
         if ((h0 >> 16) & 0x3fu) {
+          float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           QHBM_FOR_PAIR(R,
             if ((h0 >> (16 + pair_index(JA, JB))) & 1u) {
               const v2f cs = conj_cs(rec_cs<L.ph2(pair_index(JA, JB))>(cur));
-              const uint32_t slot = rec_word<L.slot_ph2(pair_index(JA, JB)) - S0>(sv);
-              if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kM2Pi * sum_w2<R, JA, JB>(p, l));
+              g[pair_index(JA, JB)] = sum_w2<R, JA, JB>(p, l);
               apply_ph2<R, JA, JB>(p, cs);
               apply_ph2<R, JA, JB>(l, cs);
             })
+          if ((h0 >> 16) & 0x0fu) add_slots4<L.group_ph2()>(sacc, a.slot_base, lane, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
+          if ((h0 >> 16) & 0x30u) add_slots4<L.group_ph2() + 1>(sacc, a.slot_base, lane, sv[0], kM2Pi, g[4], g[5], 0.f, 0.f);
         }
-        // ---- PH1 ----
-        QHBM_FOR_RB(R,
-          if ((h0 >> (8 + J)) & 1u) {
-            const v2f cs = conj_cs(rec_cs<L.ph1(J)>(cur));
-            const uint32_t slot = rec_word<L.slot_ph1(J) - S0>(sv);
-            if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kM2Pi * sum_w1<R, J>(p, l));
-            apply_ph1<R, J>(p, cs);
-            apply_ph1<R, J>(l, cs);
-          })
+        // ---- PH1 (slot group 3) ----
+        if ((h0 >> 8) & 0xfu) {
+          float g[4] = {0.f, 0.f, 0.f, 0.f};
+          QHBM_FOR_RB(R,
+            if ((h0 >> (8 + J)) & 1u) {
+              const v2f cs = conj_cs(rec_cs<L.ph1(J)>(cur));
+              g[J] = sum_w1<R, J>(p, l);
+              apply_ph1<R, J>(p, cs);
+              apply_ph1<R, J>(l, cs);
+            })
+          add_slots4<L.group_ph1()>(sacc, a.slot_base, lane, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
         }
-        // ---- one-qubit gates (X, Y, dense slot classes) ----
-        QHBM_FOR_RB(R,
-          if ((h0 >> J) & 1u) {
-            const v2f cs = conj_cs(rec_cs<L.x(J)>(cur));  // U^dagger = c*I + i*s*X
-            const uint32_t slot = rec_word<L.slot_x(J) - S0>(sv);
-            if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kPi * im_lam_x_psi<R, J>(p, l));
-            apply_x<R, J>(p, cs);
-            apply_x<R, J>(l, cs);
-          })
+        }
+        // ---- one-qubit gates (X, Y, dense slot classes: groups 0, 1, 2) ----
+        if (h0 & 0xfu) {
+          float g[4] = {0.f, 0.f, 0.f, 0.f};
+          QHBM_FOR_RB(R,
+            if ((h0 >> J) & 1u) {
+              const v2f cs = conj_cs(rec_cs<L.x(J)>(cur));  // U^dagger = c*I + i*s*X
+              if (rec_word<L.slot_x(J) - S0>(sv) != 0xffffffffu) g[J] = im_lam_x_psi<R, J>(p, l);
+              apply_x<R, J>(p, cs);
+              apply_x<R, J>(l, cs);
+            })
+          add_slots4<L.group_x()>(sacc, a.slot_base, lane, sv[0], kPi, g[0], g[1], g[2], g[3]);
+        }
         if constexpr (GEN) {
         if ((h1 >> 16) & 0xfu) {
+          float g[4] = {0.f, 0.f, 0.f, 0.f};
           QHBM_FOR_RB(R,
             if ((h1 >> (16 + J)) & 1u) {
               const v2f cs = conj_cs(rec_cs<L.y(J)>(cur));
-              const uint32_t slot = rec_word<L.slot_y(J) - S0>(sv);
-              if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, kPi * im_lam_y_psi<R, J>(p, l));
+              if (rec_word<L.slot_y(J) - S0>(sv) != 0xffffffffu) g[J] = im_lam_y_psi<R, J>(p, l);
               apply_y<R, J>(p, cs);
               apply_y<R, J>(l, cs);
             })
+          add_slots4<L.group_y()>(sacc, a.slot_base, lane, sv[0], kPi, g[0], g[1], g[2], g[3]);
         }
         if ((h1 >> 24) & 0xfu) {  // dense: U^dagger (8 floats) then generator (8 floats) per register bit
           uint32_t dv[1];
           rec_load<1>(recs, rec_off + 128u, lane, dv);
+          float g[4] = {0.f, 0.f, 0.f, 0.f};
           QHBM_FOR_RB(R,
             if ((h1 >> (24 + J)) & 1u) {
-              const uint32_t slot = rec_word<L.slot_dense(J) - S0>(sv);
-              const Gen2 g{rec_cs<16 * J + 8>(dv), rec_cs<16 * J + 10>(dv), rec_cs<16 * J + 12>(dv), rec_cs<16 * J + 14>(dv)};
-              if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, im_lam_g1_psi<R, J>(p, l, g));
+              const Gen2 gen{rec_cs<16 * J + 8>(dv), rec_cs<16 * J + 10>(dv), rec_cs<16 * J + 12>(dv), rec_cs<16 * J + 14>(dv)};
+              if (rec_word<L.slot_dense(J) - S0>(sv) != 0xffffffffu) g[J] = im_lam_g1_psi<R, J>(p, l, gen);
               apply_mat1<R, J>(p, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
               apply_mat1<R, J>(l, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
             })
+          add_slots4<L.group_dense()>(sacc, a.slot_base, lane, sv[0], 1.f, g[0], g[1], g[2], g[3]);
         }
         }
         rec_off += L.words();

@@ -81,7 +81,7 @@ constexpr int pair_index(int lo, int hi) { return hi * (hi - 1) / 2 + lo; }  // 
 //           ph1_mask = ph2_mask = 0, so table and per-term slots are independent triangles.
 //   vec 1:  (FULL only) the per-term phases PH1[4] PH2[6] that combine_diag_kernel multiplies
 //   vec 2:  DENSE[4] 2x2 blocks (8 floats; adjoint: U^dagger then generator, 16 floats)
-//   vec 3:  (adjoint) SLOT[30] = gradient slot per entry, order X Y DENSE PH1 PH2 CPH
+//   vec 3:  (adjoint) SLOT[32] = gradient slot per entry in groups of four lanes: X Y DENSE PH1 PH2[6+2 pad] CPH[8]
 // Everything a round touches per instance sits in vec 0 (one coalesced 256-byte load per wave).
 constexpr int kRoundBits = 4;
 struct RecordLayout {
@@ -105,7 +105,16 @@ struct RecordLayout {
   constexpr int slot_dense(int j) const { return slot0() + 2 * R + j; }
   constexpr int slot_ph1(int j) const { return slot0() + 3 * R + j; }
   constexpr int slot_ph2(int pi) const { return slot0() + 4 * R + pi; }
-  constexpr int slot_cph(int k) const { return slot0() + 4 * R + NP + k; }
+  constexpr int slot_cph(int k) const { return slot0() + 4 * R + 8 + k; }
+  // Slot groups: lanes 4G..4G+3 of the slot vector hold the slots the adjoint kernel reduces
+  // together (R = 4: X, Y, dense, PH1, PH2[0..3], PH2[4..5], CPH[0..3], CPH[4..7]).
+  constexpr int group_x() const { return 0; }
+  constexpr int group_y() const { return R / 4; }
+  constexpr int group_dense() const { return 2 * R / 4; }
+  constexpr int group_ph1() const { return 3 * R / 4; }
+  constexpr int group_ph2() const { return 4 * R / 4; }
+  constexpr int group_cph() const { return 4 * R / 4 + 2; }
+  constexpr int n_slot_lanes() const { return 4 * R + 8 + 2 * R; }
   // 3 / 5 vectors: an odd count keeps the 256-byte record vectors that every wave of the chip
   // streams at the same time spread over all L2 channels (a 1 KiB stride hits every 4th).
   constexpr int vecs() const { return adjoint ? 5 : 3; }

@@ -316,7 +316,7 @@ class Builder {
         rec[1] |= kFullDiagFlag;
       }
       plan_->record_offsets.push_back(uint32_t(first + ii * size_t(L.words())));
-      if (adjoint_) for (int k = 0; k < 6 * R_ + L.NP; ++k) rec[L.slot0() + k] = 0xffffffffu;
+      if (adjoint_) for (int k = 0; k < 64; ++k) rec[L.slot0() + k] = 0xffffffffu;
     }
     for (const Placed& pl : placed) {
       const LoweredOp& op = *pl.op;
