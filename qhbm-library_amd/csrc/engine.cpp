@@ -75,6 +75,8 @@ struct qhbm_engine {
   bool plans_valid = false;
   DevicePlan fwd, adj;
   DevBuf<DevTerm> terms;
+  DevBuf<ObsGroup> obs_groups;
+  uint32_t n_obs_groups = 0;
   DevBuf<float2> psi, lam;
   DevBuf<float> state_grad, slot_factor, vals_tmp, vals_p, vals_m, upstream_tmp;
   DevBuf<int> param_slot_begin, param_slots;
@@ -162,10 +164,19 @@ int upload_model(qhbm_engine* h) {
   if (int rc = upload_plan(h, &h->fwd)) return rc;
   if (int rc = upload_plan(h, &h->adj)) return rc;
   if (!h->terms.p) {
+    // lambda = O psi gathers psi[j ^ x] once per distinct x mask: sort by x, cut into groups
     std::vector<DevTerm> t;
     for (const PauliTerm& pt : h->model.terms)
       t.push_back(DevTerm{pt.coeff, pt.x, pt.z, uint32_t(pt.ny), uint32_t(pt.op)});
+    std::stable_sort(t.begin(), t.end(), [](const DevTerm& a, const DevTerm& b) { return a.x < b.x; });
+    std::vector<ObsGroup> groups;
+    for (size_t k = 0; k < t.size(); ++k) {
+      if (k == 0 || t[k].x != t[k - 1].x || k % kObsTermChunk == 0) groups.push_back(ObsGroup{t[k].x, 0});
+      groups.back().end = uint32_t(k + 1);
+    }
     HIPCHK(h->terms.upload(t));
+    HIPCHK(h->obs_groups.upload(groups));
+    h->n_obs_groups = uint32_t(groups.size());
   }
   // parameter -> slots map for the adjoint reduction
   const Plan& ap = h->adj.plan;
@@ -266,7 +277,7 @@ int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_pa
     const uint32_t c = std::min<uint32_t>(cs, uint32_t(U) - s0);
     if (int rc = run_forward_chunk(h, d_bits, s0, c, d_out_vals, true, stream)) return rc;
     HIPCHK(launch_apply_observable(h->psi.p, h->lam.p, n_eff, c, h->terms.p, uint32_t(h->model.terms.size()),
-                                   d_upstream, uint32_t(h->model.n_ops), s0, stream));
+                                   h->obs_groups.p, h->n_obs_groups, d_upstream, uint32_t(h->model.n_ops), s0, stream));
     for (size_t i = 0; i < b.plan.passes.size(); ++i) {
       hipEvent_t* ev = timer_begin(h, 1, stream);
       PassArgs ba = b.args[i];

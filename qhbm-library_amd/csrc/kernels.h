@@ -15,6 +15,13 @@ struct DevTerm {  // one Pauli term, amplitude-index bit space
   uint32_t op;
 };
 
+// Terms of equal x mask, consecutive in the x-sorted term array: [previous end, end).  A group
+// never straddles a multiple of kObsTermChunk (the kernel stages that many terms in LDS at a time).
+struct ObsGroup {
+  uint32_t x, end;
+};
+constexpr uint32_t kObsTermChunk = 1024;
+
 size_t fwd_lds_bytes(int K);
 size_t adj_lds_bytes(int K);
 
@@ -26,8 +33,9 @@ hipError_t launch_pass_adj(int K, const PassArgs& a, uint32_t n_states, float2* 
                            float* state_grad, uint32_t n_slots_total,
                            uint32_t state0, hipStream_t stream);
 hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
-                                   const DevTerm* terms, uint32_t n_terms, const float* upstream,
-                                   uint32_t n_ops, uint32_t state0, hipStream_t stream);
+                                   const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
+                                   uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
+                                   hipStream_t stream);
 hipError_t launch_prep_coefs(const CoefJob* jobs, int n_jobs, const float* params, float* coef,
                              int shift_gate, double shift, hipStream_t stream);
 hipError_t launch_combine_diag(float* coef, const uint32_t* rec_offsets, int n_records, hipStream_t stream);

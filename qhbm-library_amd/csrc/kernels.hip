@@ -987,31 +987,70 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
 }
 
 // ================================================================================
-// lambda = sum_k upstream[s, op_k] * c_k * P_k psi      (one thread per amplitude)
-// (P psi)[j] = i^ny (-1)^{popc((j^x) & z)} psi[j ^ x]
+// lambda = sum_k upstream[s, op_k] * c_k * P_k psi,   (P psi)[j] = i^ny (-1)^{popc((j^x) & z)} psi[j ^ x]
+// Terms arrive sorted by x mask and cut into GROUPS of equal x: one gather psi[j ^ x] per group
+// serves all of its terms (XXZ: 57 terms, 20 gathers), whose signed weights -- staged once per
+// workgroup in LDS as upstream * coeff * i^ny -- fold into one complex factor per amplitude.
+// Each thread owns kObsAmps amplitudes 256 apart, so a group issues that many independent
+// coalesced loads before any of them is needed.
 // ================================================================================
+constexpr int kObsAmps = 4;
+constexpr uint32_t kObsChunk = kObsTermChunk;  // terms staged in LDS at a time (16 KiB)
 __global__ __launch_bounds__(256) void apply_observable_kernel(
     const float2* __restrict__ psi, float2* __restrict__ lam, uint32_t n, const DevTerm* __restrict__ terms,
-    uint32_t n_terms, const float* __restrict__ upstream, uint32_t n_ops, uint32_t state0) {
+    uint32_t n_terms, const ObsGroup* __restrict__ groups, uint32_t n_groups,
+    const float* __restrict__ upstream, uint32_t n_ops, uint32_t state0) {
+  __shared__ float4 sterm[kObsChunk];
   const uint32_t s_local = blockIdx.y;
-  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t j0 = blockIdx.x * (256u * kObsAmps) + threadIdx.x;
   const float2* ps = psi + (size_t(s_local) << n);
   const float* up = upstream + size_t(state0 + s_local) * n_ops;
-  float ar = 0.f, ai = 0.f;
-  for (uint32_t k = 0; k < n_terms; ++k) {
-    const DevTerm tm = terms[k];
-    const float w = up[tm.op] * tm.coeff;
-    const uint32_t src = j ^ tm.x;
-    const float2 v = ps[src];
-    const float sg = (__popc(src & tm.z) & 1) ? -w : w;
-    switch (tm.ny & 3) {
-      case 0: ar += sg * v.x; ai += sg * v.y; break;
-      case 1: ar -= sg * v.y; ai += sg * v.x; break;
-      case 2: ar -= sg * v.x; ai -= sg * v.y; break;
-      default: ar += sg * v.y; ai -= sg * v.x; break;
+  float ar[kObsAmps], ai[kObsAmps];
+#pragma unroll
+  for (int a = 0; a < kObsAmps; ++a) ar[a] = ai[a] = 0.f;
+  uint32_t g = 0;
+  for (uint32_t k0 = 0; k0 < n_terms; k0 += kObsChunk) {
+    const uint32_t k1 = min(n_terms, k0 + kObsChunk);
+    if (k0) __syncthreads();
+    for (uint32_t k = k0 + threadIdx.x; k < k1; k += 256u) {
+      const DevTerm tm = terms[k];
+      const float w = up[tm.op] * tm.coeff;
+      const float m = (tm.ny & 2u) ? -w : w;
+      sterm[k - k0] = make_float4(__uint_as_float(tm.z), (tm.ny & 1u) ? 0.f : m, (tm.ny & 1u) ? m : 0.f, 0.f);
+    }
+    __syncthreads();
+    uint32_t k = k0;
+    for (; g < n_groups; ++g) {
+      const ObsGroup gr = groups[g];  // wave-uniform
+      if (gr.end > k1) break;
+      uint32_t src[kObsAmps];
+      float2 v[kObsAmps];
+      float cr[kObsAmps], ci[kObsAmps];
+#pragma unroll
+      for (int a = 0; a < kObsAmps; ++a) {
+        src[a] = (j0 + 256u * a) ^ gr.x;
+        v[a] = ps[src[a]];
+        cr[a] = ci[a] = 0.f;
+      }
+      for (; k < gr.end; ++k) {
+        const float4 t = sterm[k - k0];
+        const uint32_t z = __float_as_uint(t.x);
+#pragma unroll
+        for (int a = 0; a < kObsAmps; ++a) {
+          const uint32_t sgn = uint32_t(__popc(src[a] & z)) << 31;
+          cr[a] += __uint_as_float(__float_as_uint(t.y) ^ sgn);
+          ci[a] += __uint_as_float(__float_as_uint(t.z) ^ sgn);
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < kObsAmps; ++a) {
+        ar[a] += cr[a] * v[a].x - ci[a] * v[a].y;
+        ai[a] += cr[a] * v[a].y + ci[a] * v[a].x;
+      }
     }
   }
-  lam[(size_t(s_local) << n) + j] = make_float2(ar, ai);
+#pragma unroll
+  for (int a = 0; a < kObsAmps; ++a) lam[(size_t(s_local) << n) + j0 + 256u * a] = make_float2(ar[a], ai[a]);
 }
 
 // ================================================================================
@@ -1283,11 +1322,12 @@ hipError_t launch_pass_adj(int K, const PassArgs& a, uint32_t n_states, float2* 
 }
 
 hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
-                                   const DevTerm* terms, uint32_t n_terms, const float* upstream,
-                                   uint32_t n_ops, uint32_t state0, hipStream_t stream) {
-  const uint32_t blocks = (1u << n) / 256u;
+                                   const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
+                                   uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
+                                   hipStream_t stream) {
+  const uint32_t blocks = (1u << n) / (256u * kObsAmps);
   hipLaunchKernelGGL(apply_observable_kernel, dim3(blocks, n_states), dim3(256), 0, stream, psi, lam, n,
-                     terms, n_terms, upstream, n_ops, state0);
+                     terms, n_terms, groups, n_groups, upstream, n_ops, state0);
   return hipGetLastError();
 }
 
