@@ -96,28 +96,28 @@ template <int RB> constexpr int ins0(int p) { return ((p >> RB) << (RB + 1)) | (
 // wave-uniform SGPR pair, or a VGPR pair for thread-predicated phases.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// (a0, a1) <- (c a0 - i s a1, c a1 - i s a0).  -i s (x + i y) = (s y, -s x): both rotated
+// products go to temporaries first, then each amplitude is updated in place -- four packed
+// ops, no register copy.
 #define QHBM_X_PAIR(CONSTRAINT)                                                                   \
-  v2f t0;                                                                                         \
-  asm("v_pk_mul_f32 %[t0], %[a0], %[cs] op_sel_hi:[1,0]\n\t"                                      \
-      "v_pk_fma_f32 %[t0], %[a1], %[cs], %[t0] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t" \
-      "v_pk_mul_f32 %[a1], %[a1], %[cs] op_sel_hi:[1,0]\n\t"                                      \
-      "v_pk_fma_f32 %[a1], %[a0], %[cs], %[a1] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t" \
-      "v_mov_b64 %[a0], %[t0]"                                                                    \
-      : [a0] "+v"(a0), [a1] "+v"(a1), [t0] "=&v"(t0)                                              \
+  v2f t0, t1;                                                                                     \
+  asm("v_pk_mul_f32 %[t0], %[a0], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"            \
+      "v_pk_mul_f32 %[t1], %[a1], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"            \
+      "v_pk_fma_f32 %[a0], %[a0], %[cs], %[t1] op_sel_hi:[1,0,1]\n\t"                             \
+      "v_pk_fma_f32 %[a1], %[a1], %[cs], %[t0] op_sel_hi:[1,0,1]"                                  \
+      : [a0] "+v"(a0), [a1] "+v"(a1), [t0] "=&v"(t0), [t1] "=&v"(t1)                              \
       : [cs] CONSTRAINT(cs));
 
-// (a0, a1) <- (c a0 - i s a1, c a1 - i s a0):  a0' = c a0 + s (a1.im, -a1.re)
 __device__ __forceinline__ void x_pair(v2f& a0, v2f& a1, v2f cs) { QHBM_X_PAIR("s") }
 
 // (a0, a1) <- (c a0 - s a1, s a0 + c a1)
 __device__ __forceinline__ void y_pair(v2f& a0, v2f& a1, v2f cs) {
-  v2f t0;
-  asm("v_pk_mul_f32 %[t0], %[a0], %[cs] op_sel_hi:[1,0]\n\t"
-      "v_pk_fma_f32 %[t0], %[a1], %[cs], %[t0] op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-      "v_pk_mul_f32 %[a1], %[a1], %[cs] op_sel_hi:[1,0]\n\t"
-      "v_pk_fma_f32 %[a1], %[a0], %[cs], %[a1] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-      "v_mov_b64 %[a0], %[t0]"
-      : [a0] "+v"(a0), [a1] "+v"(a1), [t0] "=&v"(t0)
+  v2f t0, t1;
+  asm("v_pk_mul_f32 %[t0], %[a0], %[cs] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %[t1], %[a1], %[cs] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %[a0], %[a0], %[cs], %[t1] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[a1], %[a1], %[cs], %[t0] op_sel_hi:[1,0,1]"
+      : [a0] "+v"(a0), [a1] "+v"(a1), [t0] "=&v"(t0), [t1] "=&v"(t1)
       : [cs] "s"(cs));
 }
 
