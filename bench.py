@@ -140,6 +140,8 @@ def main():
   ap.add_argument("--adjoint-tile-qubits", type=int, default=0)
   ap.add_argument("--cpu-sample-states", type=int, default=64)
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--verify", action="store_true",
+                  help="rank 0 re-evaluates the whole batch alone and compares with the sharded result")
   args = ap.parse_args()
 
   rank = int(os.environ.get("RANK", "0"))
@@ -149,12 +151,34 @@ def main():
     args.gpus = world
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+  # Test hooks (tests/test_bench_gpu.py runs two ranks on ONE GPU): QHBM_BENCH_SHARE_DEVICE=1 puts
+  # every rank on cuda:0 and QHBM_BENCH_BACKEND=gloo carries the collectives through the host.
+  if os.environ.get("QHBM_BENCH_SHARE_DEVICE") == "1":
+    local_rank = 0
+  backend = os.environ.get("QHBM_BENCH_BACKEND", "nccl")
   torch.cuda.set_device(local_rank)
   dist = None
   if world > 1:
     import torch.distributed as dist  # pylint: disable=import-outside-toplevel
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+
+  def all_reduce_sum(t):
+    if backend == "gloo":
+      c = t.cpu()
+      dist.all_reduce(c)
+      t.copy_(c)
+    else:
+      dist.all_reduce(t)
+
+  def all_gather(outs, t):
+    if backend == "gloo":
+      couts = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+      dist.all_gather(couts, t.cpu())
+      for o, c in zip(outs, couts):
+        o.copy_(c)
+    else:
+      dist.all_gather(outs, t)
 
   from qhbmlib_amd import _engine as E  # pylint: disable=import-outside-toplevel
 
@@ -189,8 +213,8 @@ def main():
                                        method=E.GRAD_PARAMETER_SHIFT if args.mode == "shift" else E.GRAD_ADJOINT)
     if world > 1:
       if grad is not None:
-        dist.all_reduce(grad)
-      dist.all_gather(gathered, vals)
+        all_reduce_sum(grad)
+      all_gather(gathered, vals)
     return vals, grad
 
   for _ in range(args.warmup):
@@ -209,7 +233,7 @@ def main():
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
   if world > 1:
-    tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
   kt = eng.kernel_time_ms(reset=True)
@@ -280,6 +304,21 @@ def main():
             "tile_io_GBps": io_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
         },
     }
+    if args.verify:
+      # the sharded step against one process evaluating every state (same engine, same inputs)
+      full_bits = torch.from_numpy(all_bits).cuda()
+      full_up = torch.full((total_states, 1), 1.0 / total_states, device="cuda")
+      if args.mode == "forward":
+        ref_vals, ref_grad = eng.expectation(full_bits, params), None
+      else:
+        ref_vals, ref_grad = eng.expectation_vjp(
+            full_bits, params, full_up,
+            method=E.GRAD_PARAMETER_SHIFT if args.mode == "shift" else E.GRAD_ADJOINT)
+      got_vals = torch.cat(gathered) if world > 1 else vals
+      err_v = float((got_vals - ref_vals).abs().max())
+      err_g = float((grad - ref_grad).abs().max()) if ref_grad is not None else 0.0
+      line["verify"] = {"max_err_values": err_v, "max_err_grad": err_g,
+                        "ok": bool(err_v < 1e-4 * len(op) and err_g < 1e-4)}
     if not args.no_cpu_baseline:
       try:
         line["cpu_baseline"] = cpu_baseline(n, gates, n_params, op, params_np, args.cpu_sample_states, args.mode)

@@ -1,0 +1,52 @@
+"""bench.py end to end on the GPU: the single-process line and the N > 1 launch exactly as the
+driver issues it (torch.distributed.run, one process per rank).  The box has one GPU, so the two
+ranks share cuda:0 and the collectives travel over gloo (bench.py's test hooks); the sharding,
+barrier/max timing and aggregation logic is the code the 8-GPU run uses."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--qubits", "12", "--layers", "2", "--states-per-gpu", "16", "--steps", "2", "--warmup", "1",
+         "--hamiltonian", "tfim", "--verify"]
+
+
+def _line(out):
+  lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
+  assert len(lines) == 1, out[-2000:]
+  return json.loads(lines[0])
+
+
+def test_bench_single_process_line():
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--cpu-sample-states", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+  assert out.returncode == 0, out.stderr[-2000:]
+  line = _line(out.stdout)
+  for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+    assert key in line, key
+  assert line["n_gpus"] == 1 and line["steps"] == 2 and line["scaling"] == "weak"
+  assert line["value"] > 0 and line["roofline"]["achieved"] > 0
+  assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+  assert line["verify"]["ok"], line["verify"]
+
+
+def test_bench_two_ranks_as_the_driver_launches_it():
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  env = dict(os.environ, QHBM_BENCH_SHARE_DEVICE="1", QHBM_BENCH_BACKEND="gloo")
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+         "--gpus", "2", "--no-cpu-baseline"] + SMALL
+  out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+  assert out.returncode == 0, out.stderr[-3000:]
+  line = _line(out.stdout)
+  assert line["n_gpus"] == 2
+  assert line["config"]["parallelism"] == "batch-sharded x2"
+  assert line["verify"]["ok"], line["verify"]
