@@ -140,6 +140,16 @@ int qhbm_expectation_jacobian(qhbm_engine* h, const int8_t* d_bits, int U,
                               const float* d_params, float* d_out_vals,
                               float* d_jac, void* stream);
 
+/* Final state vectors C(params)|x_u> (the data behind
+ * qhbmlib/inference/qnn_utils.py:23-33 `unitary` (tfq.layers.Unitary) and
+ * qhbm_utils.py:24-116 `density_matrix` / `fidelity`).
+ *   d_out_states [U, 2^n_qubits] complex64 as interleaved (re, im) floats (device);
+ *   amplitude index = the bitstring read as a big-endian binary number (qubit 0 is
+ *   the most significant bit, as cirq orders `final_state_vector`).
+ * Observables need not be installed. */
+int qhbm_statevector(qhbm_engine* h, const int8_t* d_bits, int U,
+                     const float* d_params, void* d_out_states, void* stream);
+
 /* ---- introspection (tests, bench, DESIGN.md numbers) ------------------- */
 /* Number of HBM passes (kernel launches over the state) the scheduler emits
  * for one forward of the installed circuit + observables. */

@@ -537,3 +537,37 @@ def vqt_loss_and_grads(n, gates, params, samples, target_op, beta, energy_fn,
   dtheta = avg_e_grads * avg_f - avg_prod
   dparams = beta * weighted_average(counts, jac[:, 0, :])
   return float(loss), dtheta, dparams
+
+
+# ---------------------------------------------------------------------------
+# Dense metrics: qnn_utils.py:23-33 unitary, ebm_utils.py:24-36
+# probabilities, qhbm_utils.py:24-116 density_matrix / fidelity.
+# ---------------------------------------------------------------------------
+def unitary(n, gates, params):
+  """Matrix of the circuit: column x is simulate(|x>), indices big-endian."""
+  cols = [simulate(n, gates, params, list(b)).ravel() for b in itertools.product([0, 1], repeat=n)]
+  return np.stack(cols, axis=1)
+
+
+def probabilities(energy_fn, n):
+  """exp(-E(x)) / Z over all bitstrings in itertools.product order (ebm_utils.py:24-36)."""
+  e = np.exp(-energy_fn(all_bitstrings(n)))
+  return e / e.sum()
+
+
+def density_matrix(n, gates, params, energy_fn):
+  """rho = U diag(p) U^dagger (qhbm_utils.py:57-59)."""
+  u = unitary(n, gates, params)
+  return (u * probabilities(energy_fn, n)[None, :]) @ u.conj().T
+
+
+def _sqrtm_psd(m):
+  w, v = np.linalg.eigh((m + m.conj().T) / 2)
+  return (v * np.sqrt(np.clip(w, 0, None))[None, :]) @ v.conj().T
+
+
+def fidelity_direct(rho, sigma):
+  """(tr sqrt(sqrt(rho) sigma sqrt(rho)))^2, the direct formula the reference test compares
+  with (tests/inference/qhbm_utils_test.py:83-88)."""
+  s = _sqrtm_psd(rho)
+  return float(np.real(np.trace(_sqrtm_psd(s @ sigma @ s)))**2)

@@ -78,7 +78,7 @@ struct qhbm_engine {
   DevBuf<ObsGroup> obs_groups;
   uint32_t n_obs_groups = 0;
   DevBuf<float2> psi, lam;
-  DevBuf<float> state_grad, slot_factor, vals_tmp, vals_p, vals_m, upstream_tmp;
+  DevBuf<float> state_grad, slot_factor, vals_tmp, vals_p, vals_m, upstream_tmp, phase_cs;
   DevBuf<int> param_slot_begin, param_slots;
   std::vector<TimedEvent> events;
   std::vector<TimedEvent> free_events;
@@ -418,6 +418,38 @@ int qhbm_expectation(qhbm_engine* h, const int8_t* d_bits, int U, const float* d
   if (int rc = check_call(h, U)) return rc;
   if (U == 0) return 0;
   return forward(h, d_bits, U, d_params, d_out, -1, 0.0, static_cast<hipStream_t>(stream));
+}
+
+int qhbm_statevector(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params,
+                     void* d_out_states, void* stream) {
+  if (!h) return 1;
+  if (int rc = need_device(h)) return rc;
+  if (U < 0) return fail(h, "negative batch size");
+  if (int rc = upload_model(h)) return rc;
+  if (U == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DevicePlan& d = h->fwd;
+  HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, -1, 0.0, s));
+  HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), s));
+  // expectation values of installed observables are a by-product; they land in a scratch buffer
+  const size_t nv = size_t(U) * std::max(h->model.n_ops, 1);
+  HIPCHK(h->vals_tmp.reserve(nv));
+  HIPCHK(hipMemsetAsync(h->vals_tmp.p, 0, nv * sizeof(float), s));
+  const uint32_t cs = chunk_states(h, U);
+  if (int rc = ensure_state_buffers(h, cs, false)) return rc;
+  const size_t row = size_t(8) << h->model.n, pitch = size_t(8) << d.plan.n_eff;
+  for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += cs) {
+    const uint32_t c = std::min<uint32_t>(cs, uint32_t(U) - s0);
+    if (int rc = run_forward_chunk(h, d_bits, s0, c, h->vals_tmp.p, true, s)) return rc;
+    // idle padding qubits (n < 10) are the high index bits and stay |0>: keep the first 2^n amplitudes
+    HIPCHK(hipMemcpy2DAsync(static_cast<char*>(d_out_states) + size_t(s0) * row, row, h->psi.p, pitch, row, c,
+                            hipMemcpyDeviceToDevice, s));
+  }
+  // restore the global phase the X**t / Y**t kernels leave out (cirq's e^{i pi t / 2} per gate)
+  HIPCHK(h->phase_cs.reserve(2));
+  HIPCHK(launch_global_phase(d.jobs.p, int(d.plan.jobs.size()), d_params, h->phase_cs.p, s));
+  HIPCHK(launch_scale_states(static_cast<float2*>(d_out_states), size_t(U) << h->model.n, h->phase_cs.p, s));
+  return 0;
 }
 
 int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params,

@@ -36,6 +36,9 @@ hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, u
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
                                    hipStream_t stream);
+hipError_t launch_global_phase(const CoefJob* jobs, int n_jobs, const float* params, float* out_cs,
+                               hipStream_t stream);
+hipError_t launch_scale_states(float2* st, size_t count, const float* cs, hipStream_t stream);
 hipError_t launch_prep_coefs(const CoefJob* jobs, int n_jobs, const float* params, float* coef,
                              int shift_gate, double shift, hipStream_t stream);
 hipError_t launch_combine_diag(float* coef, const uint32_t* rec_offsets, int n_records, hipStream_t stream);

@@ -1321,6 +1321,58 @@ hipError_t launch_pass_adj(int K, const PassArgs& a, uint32_t n_states, float2* 
   }
 }
 
+// ================================================================================
+// qhbm_statevector only: X**t and Y**t are applied as c*I - i*s*G, i.e. without cirq's global
+// phase e^{i pi t / 2} (expectation values never see it).  The exported state restores the
+// product of those phases so that it equals cirq's final_state_vector, not just its ray.
+// ================================================================================
+__global__ void global_phase_kernel(const CoefJob* __restrict__ jobs, int n_jobs,
+                                    const float* __restrict__ params, float* __restrict__ out_cs) {
+  __shared__ double part[256];
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < n_jobs; j += 256) {
+    const CoefJob jb = jobs[j];
+    if (jb.mop != MOP_X && jb.mop != MOP_Y) continue;
+    double t = double(jb.offset);
+    if (jb.param_idx >= 0) t += double(jb.scalar) * double(params[jb.param_idx]);
+    acc += 0.5 * t;
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (int(threadIdx.x) < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double sn, cs;
+    sincospi(part[0], &sn, &cs);
+    out_cs[0] = float(cs);
+    out_cs[1] = float(sn);
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_states_kernel(float2* __restrict__ st, size_t count,
+                                                           const float* __restrict__ cs) {
+  const float c = cs[0], s = cs[1];
+  for (size_t i = size_t(blockIdx.x) * 256u + threadIdx.x; i < count; i += size_t(gridDim.x) * 256u) {
+    const float2 v = st[i];
+    st[i] = make_float2(c * v.x - s * v.y, c * v.y + s * v.x);
+  }
+}
+
+hipError_t launch_global_phase(const CoefJob* jobs, int n_jobs, const float* params, float* out_cs,
+                               hipStream_t stream) {
+  hipLaunchKernelGGL(global_phase_kernel, dim3(1), dim3(256), 0, stream, jobs, n_jobs, params, out_cs);
+  return hipGetLastError();
+}
+
+hipError_t launch_scale_states(float2* st, size_t count, const float* cs, hipStream_t stream) {
+  if (count == 0) return hipSuccess;
+  const unsigned blocks = unsigned(std::min<size_t>((count + 255) / 256, 65536));
+  hipLaunchKernelGGL(scale_states_kernel, dim3(blocks), dim3(256), 0, stream, st, count, cs);
+  return hipGetLastError();
+}
+
 hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,

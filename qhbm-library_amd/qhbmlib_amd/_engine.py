@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "qhbm_abi_version", "qhbm_create", "qhbm_destroy", "qhbm_last_error",
     "qhbm_set_circuit", "qhbm_set_observables", "qhbm_set_option",
     "qhbm_workspace_bytes", "qhbm_expectation", "qhbm_expectation_vjp",
-    "qhbm_expectation_jacobian", "qhbm_num_passes", "qhbm_describe_schedule",
+    "qhbm_expectation_jacobian", "qhbm_statevector", "qhbm_num_passes", "qhbm_describe_schedule",
     "qhbm_kernel_time_ms",
 )
 
@@ -78,6 +78,7 @@ def load_library():
   lib.qhbm_expectation.argtypes = [vp, vp, i32, vp, vp, vp]
   lib.qhbm_expectation_vjp.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp]
   lib.qhbm_expectation_jacobian.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+  lib.qhbm_statevector.argtypes = [vp, vp, i32, vp, vp, vp]
   lib.qhbm_num_passes.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
   lib.qhbm_describe_schedule.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
   lib.qhbm_kernel_time_ms.argtypes = [
@@ -232,6 +233,18 @@ class Engine:
                                          grad.data_ptr(), int(method),
                                          self._stream()))
     return vals, grad
+
+  def statevector(self, bits, params):
+    """Final states C(params)|x_u>, complex64 [batch, 2^n] (qubit 0 = most significant bit)."""
+    bits, params = self._prep(bits, params)
+    out = torch.empty((bits.shape[0], 1 << self.n_qubits), dtype=torch.complex64,
+                      device=self.device)
+    with torch.cuda.device(self.device):
+      self._check(
+          self._lib.qhbm_statevector(self._h, bits.data_ptr(), bits.shape[0],
+                                     params.data_ptr(), out.data_ptr(),
+                                     self._stream()))
+    return out
 
   def expectation_jacobian(self, bits, params):
     bits, params = self._prep(bits, params)

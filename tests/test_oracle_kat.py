@@ -304,3 +304,27 @@ def test_hea_structure():
     assert len(names) == layers * (3 * n - 1)
     assert len(gates) == len(names)
     assert sorted(g[3] for g in gates) == list(range(len(names)))
+
+
+# ---- tests/inference/qhbm_utils_test.py:28-51 : density matrix of the Bell state --------------
+def test_bell_density_matrix():
+  gates = [(O.GATE_HPOW, 0, -1, -1, 0.0, 1.0),
+           (O.GATE_CNOTPOW, 0, 1, -1, 0.0, 1.0)]
+  thetas = np.array([-10.0, -10.0])  # pins the EBM at |00>
+  dm = O.density_matrix(2, gates, [], lambda b: O.bernoulli_energy(b, thetas))
+  expected = np.array([[0.5, 0, 0, 0.5], [0, 0, 0, 0], [0, 0, 0, 0], [0.5, 0, 0, 0.5]])
+  np.testing.assert_allclose(dm, expected, atol=1e-6)
+
+
+# ---- tests/inference/qhbm_utils_test.py:61-80 : fidelity of a model with itself is 1 ----------
+def test_fidelity_self_is_one():
+  n = 4
+  gates, names = O.hea_gates(n, 3, "f")
+  rng = np.random.default_rng(11)
+  params = rng.uniform(-1, 1, len(names))
+  thetas = rng.uniform(-1, 1, n)
+  dm = O.density_matrix(n, gates, params, lambda b: O.bernoulli_energy(b, thetas))
+  np.testing.assert_allclose(np.trace(dm).real, 1.0, atol=1e-12)
+  np.testing.assert_allclose(O.fidelity_direct(dm, dm), 1.0, rtol=1e-6)
+  u = O.unitary(n, gates, params)
+  np.testing.assert_allclose(u.conj().T @ u, np.eye(2**n), atol=1e-12)
