@@ -383,3 +383,66 @@ PauliSumLike = Union[PauliSum, PauliString]
 
 def as_pauli_sum(op: PauliSumLike) -> PauliSum:
   return op if isinstance(op, PauliSum) else PauliSum.from_pauli_strings(op)
+
+
+# ---------------------------------------------------------------------------
+# exp(-i * coefficient * PauliSum) as a circuit (restatement of tfq.util.exponential, TFQ 0.6.1,
+# used by qhbmlib/models/circuit.py:271-272 to build the QAIA ansatz)
+# ---------------------------------------------------------------------------
+def _strings_commute(a: PauliString, b: PauliString) -> bool:
+  anti = sum(1 for q, p in a.paulis.items() if q in b.paulis and b.paulis[q] != p)
+  return anti % 2 == 0
+
+
+def _exponential_of_string(theta, string: PauliString) -> List[Gate]:
+  """exp(-i theta c P): Clifford basis change to Z...Z (X: H, Y: rx(pi/2)), CNOT ladder onto the
+  last qubit, rz(2 theta c) there, and everything undone."""
+  qubits = sorted(string.paulis)
+  if not qubits:
+    return []  # identity string: a global phase
+  to_z = []
+  for q in qubits:
+    p = string.paulis[q]
+    if p == "X":
+      to_z.append(H(q))
+    elif p == "Y":
+      to_z.append(rx(math.pi / 2)(q))
+  focal = qubits[-1]
+  ladder = [CNOT(q, focal) for q in qubits[:-1]]
+  core = rz(_as_exponent(theta) * (2.0 * string.coefficient))(focal)
+  undo = [g.inverse() for g in reversed(to_z + ladder)]
+  return to_z + ladder + [core] + undo
+
+
+def exponential(operators, coefficients=None) -> Circuit:
+  """Circuit of prod_k exp(-i coefficients[k] operators[k]), operators applied in list order.
+
+  `operators`: PauliStrings or PauliSums whose terms commute with one another (TFQ raises
+  otherwise, so does this); `coefficients`: floats, symbol names or `Symbol`s (default 1.0).
+  Every emitted gate has exponent scalar*symbol + offset, the form the engine's C ABI takes.
+  """
+  operators = list(operators)
+  if coefficients is None:
+    coefficients = [1.0] * len(operators)
+  coefficients = list(coefficients)
+  if len(coefficients) != len(operators):
+    raise ValueError("the number of coefficients must match the number of operators")
+  circuit = Circuit()
+  for coeff, op in zip(coefficients, operators):
+    if isinstance(coeff, str):
+      coeff = Symbol(coeff)
+    if not isinstance(coeff, (int, float, Symbol, Exponent)):
+      raise TypeError("a coefficient must be a real number, a symbol name or a Symbol")
+    if isinstance(op, PauliString):
+      terms = [op]
+    elif isinstance(op, PauliSum):
+      terms = op.terms
+      for i, a in enumerate(terms):
+        for b in terms[i + 1:]:
+          if not _strings_commute(a, b):
+            raise ValueError("the terms of a PauliSum to exponentiate must commute with one another")
+    else:
+      raise TypeError("an operator must be a PauliString or a PauliSum")
+    for term in terms:
+      circuit += _exponential_of_string(coeff, term)
+  return circuit

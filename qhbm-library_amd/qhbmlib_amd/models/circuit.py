@@ -1,4 +1,5 @@
 """Quantum circuit models (reference: qhbmlib/models/circuit.py)."""
+import math
 from typing import Callable, List, Sequence, Union
 
 import torch
@@ -136,3 +137,43 @@ class DirectQuantumCircuit(QuantumCircuit):
         torch.as_tensor(initializer([len(raw_symbol_names)]), dtype=torch.float32).clone())]
     super().__init__(pqc, pqc.all_qubits(), raw_symbol_names, values, [[]], name,
                      tfq_compat_bit_order)
+
+
+class QAIA(QuantumCircuit):
+  """Quantum adiabatic-inspired ansatz defined by a classical energy and a Hamiltonian
+  (circuit.py:211-292): per layer, exp(-i gamma_{l,r} H_r) for every quantum term followed by
+  exp(-i eta_l theta_b Z^b) for every classical term.
+
+  SURVEY.md quirk Q2, kept as the reference has it: symbol NAMES run
+  [gamma_l_*, eta_l_*] per layer (circuit.py:258-273) while symbol VALUES run
+  [eta_l * theta_*, gamma_l_*] per layer (circuit.py:280-286); `tests/models/circuit_test.py:303-342`
+  pins both orders independently.
+  """
+
+  def __init__(self, quantum_h_terms: List[ir.PauliSumLike], classical_h_terms: List[ir.PauliSumLike],
+               num_layers: int, initializer=None, name: Union[None, str] = None):
+    quantum_symbols, classical_symbols = [], []
+    for j in range(num_layers):
+      quantum_symbols.append([f"gamma_{j}_{k}" for k, _ in enumerate(quantum_h_terms)])
+      classical_symbols.append([f"eta_{j}_{k}" for k, _ in enumerate(classical_h_terms)])
+    pqc = ir.Circuit()
+    flat_symbols = []
+    for q_symb, c_symb in zip(quantum_symbols, classical_symbols):
+      pqc += ir.exponential(quantum_h_terms, coefficients=q_symb)
+      pqc += ir.exponential(classical_h_terms, coefficients=c_symb)
+      flat_symbols.extend(q_symb + c_symb)
+    initializer = initializer or _random_uniform(0.0, 2.0 * math.pi)
+    make = lambda shape: torch.nn.Parameter(torch.as_tensor(initializer(shape), dtype=torch.float32).clone())
+    value_layers_inputs = [[
+        make([num_layers]),                        # true etas
+        make([len(classical_h_terms)]),            # thetas
+        make([num_layers, len(quantum_h_terms)]),  # gammas
+    ]]
+
+    def embed_params(inputs):
+      """Ties the QAIA parameters: [eta_l * theta_b ..., gamma_l_r ...] per layer."""
+      etas, thetas, gammas = inputs
+      classical_params = etas.unsqueeze(1) * thetas.unsqueeze(0)
+      return torch.cat([classical_params, gammas], 1).reshape(-1)
+
+    super().__init__(pqc, pqc.all_qubits(), flat_symbols, value_layers_inputs, [[embed_params]], name)

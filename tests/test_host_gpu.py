@@ -246,3 +246,43 @@ def test_qmhl_loss_value_x_rot(num_qubits):
                              rtol=close_rtol, atol=5e-3)
   np.testing.assert_allclose(g_phis.cpu().numpy(), -thetas * (2 * data_probs - 1) * np.cos(alphas) * np.sin(phis),
                              rtol=close_rtol, atol=5e-3)
+
+
+# ---- QAIA ansatz on the engine (circuit.py:211-292, used at baselines/train.py:139-143) ----
+def test_qaia_expectation_and_tied_gradients_vs_oracle():
+  n, num_layers = 4, 2
+  qubits = ir.GridQubit.rect(1, n)
+  classical = [ir.PZ(q) for q in qubits] + [ir.PZ(a) * ir.PZ(b) for a, b in zip(qubits, qubits[1:])]
+  x_terms, zz_xx = ir.PauliSum(), ir.PauliSum()
+  for q in qubits:
+    x_terms += ir.PX(q)
+  for a, b in zip(qubits[::2], qubits[1::2]):
+    zz_xx += ir.PY(a) * ir.PY(b)
+  quantum = [x_terms, zz_xx]
+  qaia = models.QAIA(quantum, classical, num_layers)
+  rng = np.random.default_rng(17)
+  etas, thetas, gammas = qaia.value_layers_inputs[0]
+  _set(etas, rng.uniform(-1, 1, etas.shape))
+  _set(thetas, rng.uniform(-1, 1, thetas.shape))
+  _set(gammas, rng.uniform(-1, 1, gammas.shape))
+  xxz = ir.PauliSum()
+  for a, b in zip(qubits, qubits[1:]):
+    xxz += ir.PX(a) * ir.PX(b) + ir.PY(a) * ir.PY(b) + 0.5 * ir.PZ(a) * ir.PZ(b)
+  ops = [xxz, ir.as_pauli_sum(1.0 * ir.PZ(qubits[1]) * ir.PX(qubits[3]))]
+  all_bits = torch.tensor(list(itertools.product([0, 1], repeat=n)), dtype=torch.int8)
+  qnn = inference.AnalyticQuantumInference(qaia)
+  actual, jacs = _jacobian(lambda: qnn.expectation(all_bits, ops), qaia.trainable_variables)
+  values = qaia.symbol_values.detach().cpu().numpy().astype(np.float64)
+  flat = qaia.pqc.flat_gates(qaia.qubits, qaia.symbol_names)
+  want, want_jac = O.expectation_jacobian(n, flat, values, all_bits.numpy(), [op.masks(qubits) for op in ops])
+  np.testing.assert_allclose(actual.detach().cpu().numpy(), want, atol=2e-5)
+  # chain rule through embed_params: values per layer are [eta_l * theta_b ..., gamma_l_r ...]
+  c, q = len(classical), len(quantum)
+  per_layer = want_jac.reshape(want.shape + (num_layers, c + q))
+  e, t = etas.detach().numpy().astype(np.float64), thetas.detach().numpy().astype(np.float64)
+  want_eta = np.einsum("btlc,c->btl", per_layer[..., :c], t)
+  want_theta = np.einsum("btlc,l->btc", per_layer[..., :c], e)
+  want_gamma = per_layer[..., c:]
+  np.testing.assert_allclose(jacs[0], want_eta, atol=2e-4)
+  np.testing.assert_allclose(jacs[1], want_theta, atol=2e-4)
+  np.testing.assert_allclose(jacs[2], want_gamma, atol=2e-4)

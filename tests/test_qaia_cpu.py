@@ -1,0 +1,113 @@
+"""QAIA ansatz and the exponential-of-Pauli-sums circuit builder, host side.
+
+Reference: qhbmlib/models/circuit.py:211-292, tests/models/circuit_test.py:284-342.  The
+reference's expected circuit is `tfq.util.exponential` itself (un-vendored TFQ 0.6.1); here the
+builder is pinned against the matrix exponential instead, through the numpy oracle.
+"""
+import random
+
+import numpy as np
+import pytest
+import scipy.linalg
+import torch
+
+from oracle import qhbm_oracle as O
+from qhbmlib_amd import ir, models
+
+_P = {"I": np.eye(2, dtype=complex), "X": np.array([[0, 1], [1, 0]], dtype=complex),
+      "Y": np.array([[0, -1j], [1j, 0]]), "Z": np.diag([1.0 + 0j, -1.0])}
+
+
+def _dense(op, qubits):
+  total = np.zeros((2**len(qubits),) * 2, dtype=complex)
+  for term in ir.as_pauli_sum(op).terms:
+    m = np.array([[1.0 + 0j]])
+    for q in qubits:
+      m = np.kron(m, _P[term.paulis.get(q, "I")])
+    total += term.coefficient * m
+  return total
+
+
+def _equal_up_to_phase(u, want, atol=1e-10):
+  k = np.unravel_index(np.argmax(np.abs(want)), want.shape)
+  np.testing.assert_allclose(u * (want[k] / u[k]), want, atol=atol)
+
+
+def test_exponential_of_pauli_strings_is_the_matrix_exponential():
+  qs = ir.GridQubit.rect(1, 3)
+  strings = [0.7 * ir.PX(qs[0]) * ir.PY(qs[1]) * ir.PZ(qs[2]), -1.3 * ir.PY(qs[1]),
+             ir.PZ(qs[0]) * ir.PZ(qs[2]), ir.PX(qs[2]) * ir.PX(qs[0]), ir.PY(qs[0]) * ir.PY(qs[2])]
+  for string in strings:
+    circuit = ir.exponential([string], ["t"])
+    assert circuit.symbols() == {"t"}
+    u = O.unitary(3, circuit.flat_gates(qs, ["t"]), [0.37])
+    _equal_up_to_phase(u, scipy.linalg.expm(-1j * 0.37 * _dense(string, qs)))
+  # numeric coefficient, default coefficient, several operators in order
+  both = ir.exponential([strings[0], strings[1]], [0.25, 0.5])
+  assert both.symbols() == set()
+  want = scipy.linalg.expm(-0.5j * _dense(strings[1], qs)) @ scipy.linalg.expm(-0.25j * _dense(strings[0], qs))
+  _equal_up_to_phase(O.unitary(3, both.flat_gates(qs, []), []), want)
+  one = ir.exponential([strings[2]])
+  _equal_up_to_phase(O.unitary(3, one.flat_gates(qs, []), []), scipy.linalg.expm(-1j * _dense(strings[2], qs)))
+
+
+def test_exponential_of_commuting_sum_and_errors():
+  qs = ir.GridQubit.rect(1, 3)
+  x_terms = ir.PX(qs[0]) + ir.PX(qs[1]) + ir.PX(qs[2])
+  u = O.unitary(3, ir.exponential([x_terms], ["g"]).flat_gates(qs, ["g"]), [-0.81])
+  _equal_up_to_phase(u, scipy.linalg.expm(0.81j * _dense(x_terms, qs)))
+  zz_xx = ir.PZ(qs[0]) * ir.PZ(qs[1]) + ir.PX(qs[0]) * ir.PX(qs[1])   # commute (two anticommuting sites)
+  ir.exponential([zz_xx])
+  with pytest.raises(ValueError, match="commute"):
+    ir.exponential([ir.PX(qs[0]) + ir.PZ(qs[0])])
+  with pytest.raises(ValueError, match="number of coefficients"):
+    ir.exponential([x_terms], ["a", "b"])
+  with pytest.raises(TypeError):
+    ir.exponential([x_terms], [1j])
+  with pytest.raises(TypeError):
+    ir.exponential(["XX"])
+
+
+def test_qaia_init():
+  """tests/models/circuit_test.py:287-342, including the name/value order mismatch (quirk Q2)."""
+  num_qubits = 3
+  expected_qubits = ir.GridQubit.rect(1, num_qubits)
+  classical_h_terms = [ir.PZ(q0) * ir.PZ(q1) for q0, q1 in zip(expected_qubits, expected_qubits[1:])]
+  x_terms, y_terms = ir.PauliSum(), ir.PauliSum()
+  for q in expected_qubits:
+    x_terms += ir.PX(q)
+    y_terms += ir.PY(q)
+  quantum_h_terms = [x_terms, y_terms]
+  num_layers = 2
+  expected_symbol_names = []
+  expected_pqc = ir.Circuit()
+  for p in range(num_layers):
+    for k, q in enumerate(quantum_h_terms):
+      expected_symbol_names.append(f"gamma_{p}_{k}")
+      expected_pqc += ir.exponential([q], [f"gamma_{p}_{k}"])
+    for k, c in enumerate(classical_h_terms):
+      expected_symbol_names.append(f"eta_{p}_{k}")
+      expected_pqc += ir.exponential([c], [f"eta_{p}_{k}"])
+  eta_const, theta_const, gamma_const = (random.uniform(-1, 1) for _ in range(3))
+  expected_symbol_values = []
+  for _ in range(num_layers):
+    expected_symbol_values += ([eta_const * theta_const] * len(classical_h_terms) +
+                               [gamma_const] * len(quantum_h_terms))
+  actual_qnn = models.QAIA(quantum_h_terms, classical_h_terms, num_layers)
+  assert actual_qnn.qubits == expected_qubits
+  assert actual_qnn.symbol_names == expected_symbol_names
+  assert actual_qnn.pqc == expected_pqc
+  etas, thetas, gammas = actual_qnn.value_layers_inputs[0]
+  assert etas.shape == (num_layers,) and thetas.shape == (len(classical_h_terms),)
+  assert gammas.shape == (num_layers, len(quantum_h_terms))
+  assert float(torch.cat([etas, thetas, gammas.reshape(-1)]).detach().min()) >= 0.0  # U[0, 2 pi)
+  assert float(torch.cat([etas, thetas, gammas.reshape(-1)]).detach().max()) <= 2 * np.pi
+  with torch.no_grad():
+    etas.fill_(eta_const)
+    thetas.fill_(theta_const)
+    gammas.fill_(gamma_const)
+  np.testing.assert_allclose(actual_qnn.symbol_values.detach().numpy(), expected_symbol_values, rtol=1e-6)
+  assert len(actual_qnn.trainable_variables) == 3
+  # ties: d symbol_values / d theta_b sums over layers with weight eta_l
+  actual_qnn.symbol_values.sum().backward()
+  np.testing.assert_allclose(thetas.grad.numpy(), [num_layers * eta_const] * len(classical_h_terms), rtol=1e-6)
