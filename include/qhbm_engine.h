@@ -150,6 +150,18 @@ int qhbm_expectation_jacobian(qhbm_engine* h, const int8_t* d_bits, int U,
 int qhbm_statevector(qhbm_engine* h, const int8_t* d_bits, int U,
                      const float* d_params, void* d_out_states, void* stream);
 
+/* Computational-basis samples of the final states (tfq.layers.Sample as used at
+ * qhbmlib/inference/qnn.py:169,177-181,286-291):
+ *   d_out_samples [U, n_shots, n_qubits] int8 (device); shot j of state u is drawn from
+ *   |<x|C(params)|x_u>|^2 with a counter-based generator keyed by (seed, u, j), so a call is
+ *   reproducible and independent of chunking.
+ * shift_gate >= 0 adds `shift` to the exponent of that gate of the installed circuit: one
+ * program of tfq.differentiators.ParameterShift.get_gradient_circuits (qnn.py:192-199);
+ * pass -1, 0.0 for the unshifted circuit. */
+int qhbm_sample(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params,
+                int n_shots, uint64_t seed, int shift_gate, double shift,
+                int8_t* d_out_samples, void* stream);
+
 /* ---- introspection (tests, bench, DESIGN.md numbers) ------------------- */
 /* Number of HBM passes (kernel launches over the state) the scheduler emits
  * for one forward of the installed circuit + observables. */

@@ -79,6 +79,7 @@ struct qhbm_engine {
   uint32_t n_obs_groups = 0;
   DevBuf<float2> psi, lam;
   DevBuf<float> state_grad, slot_factor, vals_tmp, vals_p, vals_m, upstream_tmp, phase_cs;
+  DevBuf<double> block_cum;
   DevBuf<int> param_slot_begin, param_slots;
   std::vector<TimedEvent> events;
   std::vector<TimedEvent> free_events;
@@ -449,6 +450,36 @@ int qhbm_statevector(qhbm_engine* h, const int8_t* d_bits, int U, const float* d
   HIPCHK(h->phase_cs.reserve(2));
   HIPCHK(launch_global_phase(d.jobs.p, int(d.plan.jobs.size()), d_params, h->phase_cs.p, s));
   HIPCHK(launch_scale_states(static_cast<float2*>(d_out_states), size_t(U) << h->model.n, h->phase_cs.p, s));
+  return 0;
+}
+
+int qhbm_sample(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, int n_shots,
+                uint64_t seed, int shift_gate, double shift, int8_t* d_out_samples, void* stream) {
+  if (!h) return 1;
+  if (int rc = need_device(h)) return rc;
+  if (U < 0 || n_shots < 0) return fail(h, "negative batch size or shot count");
+  if (shift_gate >= int(h->model.gates.size())) return fail(h, "shift_gate out of range");
+  if (int rc = upload_model(h)) return rc;
+  if (U == 0 || n_shots == 0) return 0;
+  if (n_shots > 65535 * 64) return fail(h, "too many shots per state in one call");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DevicePlan& d = h->fwd;
+  HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, shift_gate, shift, s));
+  HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), s));
+  const size_t nv = size_t(U) * std::max(h->model.n_ops, 1);
+  HIPCHK(h->vals_tmp.reserve(nv));
+  HIPCHK(hipMemsetAsync(h->vals_tmp.p, 0, nv * sizeof(float), s));
+  const uint32_t cs = std::min<uint32_t>(chunk_states(h, U), 65535u);
+  if (int rc = ensure_state_buffers(h, cs, false)) return rc;
+  const uint32_t n_eff = uint32_t(d.plan.n_eff);
+  HIPCHK(h->block_cum.reserve(size_t(cs) << (n_eff - 10)));
+  for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += cs) {
+    const uint32_t c = std::min<uint32_t>(cs, uint32_t(U) - s0);
+    if (int rc = run_forward_chunk(h, d_bits, s0, c, h->vals_tmp.p, true, s)) return rc;
+    // shots are drawn in slices of <= 65535 (grid.x); the shot index feeds the counter RNG
+    HIPCHK(launch_sample(h->psi.p, n_eff, h->model.n, c, h->block_cum.p, uint32_t(n_shots), seed, s0,
+                         d_out_samples, s));
+  }
   return 0;
 }
 

@@ -36,6 +36,9 @@ hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, u
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
                                    hipStream_t stream);
+// block_cum: n_states * 2^n / 1024 doubles of scratch.
+hipError_t launch_sample(const float2* psi, uint32_t n, int n_user, uint32_t n_states, double* block_cum,
+                         uint32_t n_shots, uint64_t seed, uint32_t state0, int8_t* out, hipStream_t stream);
 hipError_t launch_global_phase(const CoefJob* jobs, int n_jobs, const float* params, float* out_cs,
                                hipStream_t stream);
 hipError_t launch_scale_states(float2* st, size_t count, const float* cs, hipStream_t stream);

@@ -1373,6 +1373,138 @@ hipError_t launch_scale_states(float2* st, size_t count, const float* cs, hipStr
   return hipGetLastError();
 }
 
+// ================================================================================
+// Sampling bitstrings from |psi|^2 (tfq.layers.Sample, qnn.py:169,177-181,286-291).
+//   1. block_prob_kernel: sum of |psi|^2 over each block of 1024 amplitudes (fp64).
+//   2. block_scan_kernel: per state, inclusive prefix sums of the block masses.
+//   3. draw_kernel: one wave per (state, shot): Philox4x32-10 uniform -> binary search over
+//      the block prefix sums -> wave prefix scan inside the block -> amplitude index -> bits.
+// ================================================================================
+constexpr uint32_t kSampleBlock = 1024;
+
+__global__ __launch_bounds__(256) void block_prob_kernel(const float2* __restrict__ psi, uint32_t n,
+                                                         double* __restrict__ block_mass) {
+  __shared__ double part[256];
+  const uint32_t nb = (1u << n) / kSampleBlock;
+  const uint32_t s = blockIdx.y, b = blockIdx.x;
+  const float2* p = psi + (size_t(s) << n) + size_t(b) * kSampleBlock;
+  double acc = 0.0;
+  for (uint32_t i = threadIdx.x; i < kSampleBlock; i += 256u) {
+    const float2 v = p[i];
+    acc += double(v.x) * double(v.x) + double(v.y) * double(v.y);
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (int(threadIdx.x) < k) part[threadIdx.x] += part[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_mass[size_t(s) * nb + b] = part[0];
+}
+
+__global__ __launch_bounds__(256) void block_scan_kernel(double* __restrict__ block_mass, uint32_t nb) {
+  __shared__ double part[256];
+  __shared__ double carry;
+  double* m = block_mass + size_t(blockIdx.x) * nb;
+  if (threadIdx.x == 0) carry = 0.0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nb; base += 256u) {
+    const uint32_t i = base + threadIdx.x;
+    part[threadIdx.x] = i < nb ? m[i] : 0.0;
+    __syncthreads();
+    for (int k = 1; k < 256; k <<= 1) {  // Hillis-Steele inclusive scan
+      const double add = int(threadIdx.x) >= k ? part[threadIdx.x - k] : 0.0;
+      __syncthreads();
+      part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < nb) m[i] = carry + part[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 255) carry += part[255];
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = uint64_t(0xD2511F53u) * c[0], p1 = uint64_t(0xCD9E8D57u) * c[2];
+    const uint32_t n0 = uint32_t(p1 >> 32) ^ c[1] ^ k0, n2 = uint32_t(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = uint32_t(p1);
+    c[3] = uint32_t(p0);
+    c[0] = n0;
+    c[2] = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ __launch_bounds__(64) void draw_kernel(const float2* __restrict__ psi, uint32_t n, int n_user,
+                                                  const double* __restrict__ block_cum, uint32_t n_shots,
+                                                  uint64_t seed, uint32_t state0, int8_t* __restrict__ out) {
+  const uint32_t shot = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
+  const uint32_t nb = (1u << n) / kSampleBlock;
+  const double* cum = block_cum + size_t(s) * nb;
+  uint32_t c[4] = {shot, state0 + s, 0x51b0c6a1u, 0u};
+  philox4x32_10(c, uint32_t(seed), uint32_t(seed >> 32));
+  const double total = cum[nb - 1];
+  const double u = (double(c[0]) * 0x1p-32 + double(c[1]) * 0x1p-64) * total;  // [0, total)
+  uint32_t lo = 0, hi = nb - 1;  // first block whose inclusive prefix exceeds u
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (cum[mid] > u) hi = mid; else lo = mid + 1;
+  }
+  const float r = float(u - (lo ? cum[lo - 1] : 0.0));
+  const float2* p = psi + (size_t(s) << n) + size_t(lo) * kSampleBlock;
+  constexpr int kPer = kSampleBlock / 64;  // 16 consecutive amplitudes per lane
+  float w[kPer];
+  float mine = 0.f;
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) {
+    const float2 v = p[lane * kPer + i];
+    w[i] = v.x * v.x + v.y * v.y;
+    mine += w[i];
+  }
+  float incl = mine;  // inclusive prefix over lanes
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) {
+    const float t = __shfl_up(incl, k);
+    if (int(lane) >= k) incl += t;
+  }
+  const float excl = incl - mine;
+  // the lane whose interval [excl, incl) holds r; rounding may push r past the block mass:
+  // then the last lane with any mass takes it
+  const bool hit = (r >= excl && r < incl) || (lane == 63 && r >= incl);
+  uint64_t ballot = __ballot(hit && mine > 0.f);
+  if (ballot == 0) ballot = __ballot(mine > 0.f);
+  if (ballot == 0) ballot = 1ull;
+  const int owner = (r >= __shfl(incl, 63)) ? 63 - __builtin_clzll(ballot) : __builtin_ctzll(ballot);
+  if (int(lane) == owner) {
+    float acc = excl;
+    int pick = -1, last_nz = 0;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      if (w[i] > 0.f) last_nz = i;
+      acc += w[i];
+      if (pick < 0 && r < acc && w[i] > 0.f) pick = i;
+    }
+    if (pick < 0) pick = last_nz;
+    const uint32_t idx = lo * kSampleBlock + lane * kPer + uint32_t(pick);
+    int8_t* o = out + (size_t(state0 + s) * n_shots + shot) * size_t(n_user);
+    for (int q = 0; q < n_user; ++q) o[q] = int8_t((idx >> (n_user - 1 - q)) & 1u);
+  }
+}
+
+hipError_t launch_sample(const float2* psi, uint32_t n, int n_user, uint32_t n_states, double* block_cum,
+                         uint32_t n_shots, uint64_t seed, uint32_t state0, int8_t* out, hipStream_t stream) {
+  const uint32_t nb = (1u << n) / kSampleBlock;
+  hipLaunchKernelGGL(block_prob_kernel, dim3(nb, n_states), dim3(256), 0, stream, psi, n, block_cum);
+  hipLaunchKernelGGL(block_scan_kernel, dim3(n_states), dim3(256), 0, stream, block_cum, nb);
+  if (n_shots) hipLaunchKernelGGL(draw_kernel, dim3(n_shots, n_states), dim3(64), 0, stream, psi, n, n_user, block_cum,
+                                  n_shots, seed, state0, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,

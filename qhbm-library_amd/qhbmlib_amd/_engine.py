@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "qhbm_abi_version", "qhbm_create", "qhbm_destroy", "qhbm_last_error",
     "qhbm_set_circuit", "qhbm_set_observables", "qhbm_set_option",
     "qhbm_workspace_bytes", "qhbm_expectation", "qhbm_expectation_vjp",
-    "qhbm_expectation_jacobian", "qhbm_statevector", "qhbm_num_passes", "qhbm_describe_schedule",
+    "qhbm_expectation_jacobian", "qhbm_statevector", "qhbm_sample", "qhbm_num_passes", "qhbm_describe_schedule",
     "qhbm_kernel_time_ms",
 )
 
@@ -79,6 +79,7 @@ def load_library():
   lib.qhbm_expectation_vjp.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp]
   lib.qhbm_expectation_jacobian.argtypes = [vp, vp, i32, vp, vp, vp, vp]
   lib.qhbm_statevector.argtypes = [vp, vp, i32, vp, vp, vp]
+  lib.qhbm_sample.argtypes = [vp, vp, i32, vp, i32, ctypes.c_uint64, i32, ctypes.c_double, vp, vp]
   lib.qhbm_num_passes.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
   lib.qhbm_describe_schedule.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
   lib.qhbm_kernel_time_ms.argtypes = [
@@ -244,6 +245,19 @@ class Engine:
           self._lib.qhbm_statevector(self._h, bits.data_ptr(), bits.shape[0],
                                      params.data_ptr(), out.data_ptr(),
                                      self._stream()))
+    return out
+
+  def sample(self, bits, params, n_shots, seed=0, shift_gate=-1, shift=0.0):
+    """int8 [batch, n_shots, n_qubits]: computational-basis samples of C(params)|x_u>;
+    `shift_gate`/`shift` select one parameter-shifted program (see include/qhbm_engine.h)."""
+    bits, params = self._prep(bits, params)
+    out = torch.empty((bits.shape[0], int(n_shots), self.n_qubits), dtype=torch.int8,
+                      device=self.device)
+    with torch.cuda.device(self.device):
+      self._check(
+          self._lib.qhbm_sample(self._h, bits.data_ptr(), bits.shape[0], params.data_ptr(),
+                                int(n_shots), int(seed) & (2**64 - 1), int(shift_gate),
+                                float(shift), out.data_ptr(), self._stream()))
     return out
 
   def expectation_jacobian(self, bits, params):
