@@ -461,7 +461,6 @@ int qhbm_sample(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_para
   if (shift_gate >= int(h->model.gates.size())) return fail(h, "shift_gate out of range");
   if (int rc = upload_model(h)) return rc;
   if (U == 0 || n_shots == 0) return 0;
-  if (n_shots > 65535 * 64) return fail(h, "too many shots per state in one call");
   hipStream_t s = static_cast<hipStream_t>(stream);
   DevicePlan& d = h->fwd;
   HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, shift_gate, shift, s));

@@ -5,10 +5,12 @@ from qhbmlib_amd.inference.ebm_utils import probabilities
 from qhbmlib_amd.inference.qhbm import QHBM
 from qhbmlib_amd.inference.qhbm_utils import density_matrix, fidelity
 from qhbmlib_amd.inference.qmhl_loss import qmhl
-from qhbmlib_amd.inference.qnn import AnalyticQuantumInference, QuantumInference
+from qhbmlib_amd.inference.qnn import (AnalyticQuantumInference, QuantumInference,
+                                       SampledQuantumInference)
 from qhbmlib_amd.inference.qnn_utils import unitary
 from qhbmlib_amd.inference.vqt_loss import vqt
 
 __all__ = ["AnalyticEnergyInference", "AnalyticQuantumInference", "BernoulliEnergyInference",
-           "EnergyInference", "EnergyInferenceBase", "QHBM", "QuantumInference", "density_matrix",
+           "EnergyInference", "EnergyInferenceBase", "QHBM", "QuantumInference",
+           "SampledQuantumInference", "density_matrix",
            "fidelity", "probabilities", "qmhl", "unitary", "vqt"]

@@ -6,6 +6,7 @@ name: where the reference tiles protos and calls `tfq.layers.Expectation`
 symbol values to the HIP engine through the C ABI.  There is no CPU path.
 """
 import abc
+import math
 from typing import List, Sequence, Union
 
 import torch
@@ -122,3 +123,175 @@ class AnalyticQuantumInference(QuantumInference):
     symbol_values = total_circuit.symbol_values.to(torch.float32)
     expectations = _ExpectationFunction.apply(symbol_values, eng, bits, self.gradient_method)
     return post_process(expectations)
+
+
+class _ParameterShiftSurrogate(torch.autograd.Function):
+  """Zero-valued term whose backward is the two-term parameter-shift rule on SAMPLED estimates
+  (tfq.differentiators.ParameterShift as driven at qnn.py:188-226): for every gate occurrence
+  with exponent c*s + o, d/ds = (pi c / 2) [f(o + 1/2) - f(o - 1/2)].  `estimator(g, shift)`
+  returns the no-grad estimate [U, T] with gate g's exponent shifted."""
+
+  @staticmethod
+  def forward(ctx, symbol_values, estimator, gates, shape):
+    ctx.estimator, ctx.gates = estimator, gates
+    ctx.save_for_backward(symbol_values)
+    return torch.zeros(shape, dtype=torch.float32, device=symbol_values.device)
+
+  @staticmethod
+  def backward(ctx, upstream):
+    (symbol_values,) = ctx.saved_tensors
+    grad = torch.zeros_like(symbol_values)
+    for g, (kind, _, _, pidx, scalar, _) in enumerate(ctx.gates):
+      if pidx < 0 or kind == _engine.GATE_I:
+        continue
+      if kind == _engine.GATE_ISWAPPOW:
+        raise _engine.EngineError("the two-term parameter-shift rule does not apply to ISWAPPOW")
+      plus, minus = ctx.estimator(g, 0.5), ctx.estimator(g, -0.5)
+      grad[pidx] += (0.5 * math.pi * scalar) * torch.sum(upstream.to(plus.device) * (plus - minus)).to(grad.device)
+    return grad, None, None, None
+
+
+class SampledQuantumInference(QuantumInference):
+  """Sampling methods for inference on QuantumCircuit objects (qnn.py:142-292): expectation
+  values are averages over `expectation_samples` computational-basis shots drawn by the engine
+  (`qhbm_sample`), derivatives use the parameter-shift rule on sampled estimates."""
+
+  def __init__(self, input_circuit: circuit.QuantumCircuit, expectation_samples: int,
+               name: Union[None, str] = None, device: Union[None, int] = None,
+               initial_seed: Union[None, int] = None):
+    super().__init__(input_circuit, name)
+    self._expectation_samples = int(expectation_samples)
+    self._device = device
+    self._engines = {}
+    self._seed = int(torch.seed() if initial_seed is None else initial_seed) & (2**63 - 1)
+
+  def _next_seed(self):
+    self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & (2**63 - 1)
+    return self._seed
+
+  def _engine_for(self, qubits, flat_gates, n_symbols):
+    key = (len(qubits), tuple(flat_gates), n_symbols)
+    eng = self._engines.get(key)
+    if eng is None:
+      if not torch.cuda.is_available():
+        raise _engine.EngineError(
+            "SampledQuantumInference needs an MI355X: the engine is HIP-only, no CPU fallback")
+      dev = torch.cuda.current_device() if self._device is None else self._device
+      eng = _engine.Engine(dev)
+      eng.set_circuit(len(qubits), flat_gates, n_symbols)
+      self._engines[key] = eng
+    return eng
+
+  @staticmethod
+  def _engine_bits(total_circuit, states):
+    perm = total_circuit.bit_column_to_qubit()
+    bits = states.to(torch.int8)
+    if perm != list(range(len(perm))):
+      permuted = torch.zeros_like(bits)
+      permuted[:, perm] = bits
+      bits = permuted
+    return bits
+
+  def _pauli_estimator(self, total_circuit, bits, values, strings):
+    """estimator(shift_gate, shift) -> [U, len(strings)] sampled <P> of each Pauli string.
+    Strings are grouped by their X/Y pattern; a group shares one rotated circuit
+    (X: H, Y: rx(pi/2), appended after the circuit) and one batch of shots."""
+    qubits = total_circuit.qubits
+    names = total_circuit.symbol_names
+    base = total_circuit.pqc.flat_gates(qubits, names)
+    qindex = {q: i for i, q in enumerate(qubits)}
+    groups = {}
+    for k, st in enumerate(strings):
+      key = tuple(sorted((qindex[q], p) for q, p in st.paulis.items() if p in ("X", "Y")))
+      groups.setdefault(key, []).append(k)
+    plans = []
+    for key, members in groups.items():
+      rot = ir.Circuit([ir.H(qubits[i]) if p == "X" else ir.rx(math.pi / 2)(qubits[i]) for i, p in key])
+      eng = self._engine_for(qubits, base + rot.flat_gates(qubits, names), len(names))
+      masks = torch.zeros((len(members), len(qubits)), dtype=torch.float32)
+      for row, k in enumerate(members):
+        for q in strings[k].paulis:
+          masks[row, qindex[q]] = 1.0
+      plans.append((eng, members, masks))
+
+    def estimator(shift_gate=-1, shift=0.0):
+      out = torch.ones((bits.shape[0], len(strings)), dtype=torch.float32, device=values.device)
+      for eng, members, masks in plans:
+        shots = eng.sample(bits, values, self._expectation_samples, self._next_seed(), shift_gate, shift)
+        ones = torch.matmul(shots.to(torch.float32), masks.to(shots.device).t())  # [U, shots, members]
+        parity = 1.0 - 2.0 * torch.remainder(ones, 2.0)
+        out[:, members] = parity.mean(1).to(out.device)
+      return out
+    return estimator, base
+
+  def _expectation(self, unique_states, total_circuit, observables):
+    """qnn.py:228-264.  Pauli-sum observables and PauliMixin Hamiltonians are estimated term by
+    term; any other Hamiltonian averages `energy(x)` over shots of circuit + hamiltonian.circuit_dagger
+    (`_sampled_expectation`, qnn.py:170-226)."""
+    bits = self._engine_bits(total_circuit, unique_states)
+    symbol_values = total_circuit.symbol_values.to(torch.float32)
+    values = symbol_values.detach()
+    if isinstance(observables, hamiltonian.Hamiltonian) and not isinstance(observables.energy, energy.PauliMixin):
+      qubits, names = total_circuit.qubits, total_circuit.symbol_names
+      base = total_circuit.pqc.flat_gates(qubits, names)
+      eng = self._engine_for(qubits, base, len(names))
+
+      def shots(shift_gate=-1, shift=0.0):
+        return eng.sample(bits, values, self._expectation_samples, self._next_seed(), shift_gate, shift)
+
+      energy_device = next(iter(observables.energy.parameters()), torch.zeros(())).device
+
+      def mean_energy(samples):
+        """[U, 1] shot average of energy(x): the energy is evaluated once per DISTINCT
+        (state, bitstring) pair, found on the GPU, and weighted by its count."""
+        n_states, n_shots, n = samples.shape
+        weights = (1 << torch.arange(n - 1, -1, -1, device=samples.device, dtype=torch.int64))
+        key = (samples.to(torch.int64) * weights).sum(-1) + (
+            torch.arange(n_states, device=samples.device, dtype=torch.int64).unsqueeze(1) << n)
+        uniq, counts = torch.unique(key, return_counts=True)
+        rows = ((uniq.unsqueeze(1) >> torch.arange(n - 1, -1, -1, device=uniq.device)) & 1).to(torch.int8)
+        e = observables.energy(rows.to(energy_device))
+        w = (counts.to(torch.float32) / float(n_shots)).to(e.device)
+        out = torch.zeros(n_states, dtype=e.dtype, device=e.device)
+        return out.index_add(0, (uniq >> n).to(e.device), e * w).unsqueeze(1)
+
+      def estimator(shift_gate, shift):
+        with torch.no_grad():
+          return mean_energy(shots(shift_gate, shift)).to(torch.float32)
+
+      forward_pass = mean_energy(shots())  # differentiable w.r.t. the energy's variables
+      surrogate = _ParameterShiftSurrogate.apply(symbol_values, estimator, base, tuple(forward_pass.shape))
+      return forward_pass + surrogate.to(forward_pass.device)
+
+    if isinstance(observables, hamiltonian.Hamiltonian):
+      ops = [ir.as_pauli_sum(op) for op in observables.operator_shards]
+      post_process = lambda y: observables.energy.operator_expectation(y).unsqueeze(-1)
+    else:
+      ops = [ir.as_pauli_sum(op) for op in observables]
+      post_process = lambda x: x
+    strings, coeffs = [], []
+    for t, op in enumerate(ops):
+      for term in op.terms:
+        strings.append(term)
+        coeffs.append((len(strings) - 1, t, term.coefficient))
+    mix = torch.zeros((len(strings), len(ops)), dtype=torch.float32)
+    for k, t, c in coeffs:
+      mix[k, t] = c
+    estimator, base = self._pauli_estimator(total_circuit, bits, values, strings)
+    with torch.no_grad():
+      estimates = estimator()
+    surrogate = _ParameterShiftSurrogate.apply(symbol_values, estimator, base, tuple(estimates.shape))
+    return post_process(torch.matmul(estimates + surrogate.to(estimates.device), mix.to(estimates.device)))
+
+  def _sample(self, initial_states: torch.Tensor, counts: torch.Tensor):
+    """`ragged[i]` = `counts[i]` bitstrings drawn from circuit|initial_states[i]> (qnn.py:266-292).
+    Shots are i.i.d., so the first counts[i] of max(counts) drawn stand for the reference's
+    shuffled mask."""
+    initial_states = torch.as_tensor(initial_states)
+    counts = [int(c) for c in torch.as_tensor(counts).reshape(-1)]
+    qubits, names = self.circuit.qubits, self.circuit.symbol_names
+    eng = self._engine_for(qubits, self.circuit.pqc.flat_gates(qubits, names), len(names))
+    bits = self._engine_bits(self.circuit, initial_states)
+    values = self.circuit.symbol_values.detach().to(torch.float32)
+    shots = eng.sample(bits, values, max(counts) if counts else 0, self._next_seed())
+    return [shots[i, :c] for i, c in enumerate(counts)]
