@@ -1,6 +1,8 @@
 """Inference (reference: qhbmlib/inference/__init__.py:32-47)."""
+from qhbmlib_amd.inference import ebm  # noqa: F401
 from qhbmlib_amd.inference.ebm import (AnalyticEnergyInference, BernoulliEnergyInference,
-                                       EnergyInference, EnergyInferenceBase)
+                                       EnergyInference, EnergyInferenceBase,
+                                       GibbsWithGradientsInference)
 from qhbmlib_amd.inference.ebm_utils import probabilities
 from qhbmlib_amd.inference.qhbm import QHBM
 from qhbmlib_amd.inference.qhbm_utils import density_matrix, fidelity
@@ -11,6 +13,6 @@ from qhbmlib_amd.inference.qnn_utils import unitary
 from qhbmlib_amd.inference.vqt_loss import vqt
 
 __all__ = ["AnalyticEnergyInference", "AnalyticQuantumInference", "BernoulliEnergyInference",
-           "EnergyInference", "EnergyInferenceBase", "QHBM", "QuantumInference",
+           "EnergyInference", "EnergyInferenceBase", "GibbsWithGradientsInference", "QHBM", "QuantumInference",
            "SampledQuantumInference", "density_matrix",
            "fidelity", "probabilities", "qmhl", "unitary", "vqt"]

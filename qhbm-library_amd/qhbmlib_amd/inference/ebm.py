@@ -230,3 +230,86 @@ class BernoulliEnergyInference(EnergyInference):
   def _sample(self, num_samples: int):
     p = torch.sigmoid(self._logits).expand(num_samples, -1)
     return torch.bernoulli(p, generator=self._rng()).to(torch.int8)
+
+
+class GibbsWithGradientsKernel:
+  """The Gibbs-With-Gradients update rule, Algorithm 1 of arXiv:2102.04509v2 (ebm.py:564-702):
+  a Metropolis-Hastings chain over bitstrings whose index proposal q(i | x) is the softmax of the
+  first-order estimate of the energy change of flipping bit i, d(x) ~ (2x - 1) * dE(x)/dx."""
+
+  def __init__(self, input_energy: energy.BitstringEnergy, generator: Union[None, torch.Generator] = None):
+    self._energy = input_energy
+    self._num_bits = input_energy.num_bits
+    self._parameters = dict(input_energy=input_energy)
+    self._generator = generator
+
+  @property
+  def is_calibrated(self):
+    """True: the chain converges to the distribution of the energy (ebm.py:687-690)."""
+    return True
+
+  def bootstrap_results(self, init_state):
+    del init_state
+    return []
+
+  def _get_index_proposal_probs(self, x):
+    """Equation 6 of the paper with the Taylor estimate of equation 3 (ebm.py:618-650)."""
+    x_float = torch.as_tensor(x).to(torch.float32).detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+      current_energy = self._energy(x_float.unsqueeze(0)).squeeze()
+      (e_grad,) = torch.autograd.grad(current_energy, x_float)
+    f_grad = -1.0 * e_grad  # f(x) = -E(x)
+    approx_energy_diff = -(2.0 * x_float.detach() - 1.0) * f_grad
+    return torch.softmax(approx_energy_diff / 2.0, 0)
+
+  def one_step(self, current_state, previous_kernel_results):
+    """One Metropolis-Hastings step (ebm.py:652-685): returns (next_state, [])."""
+    del previous_kernel_results
+    current_state = torch.as_tensor(current_state).to(torch.int8)
+    with torch.no_grad():
+      probs = self._get_index_proposal_probs(current_state)
+      i = int(torch.multinomial(probs, 1, generator=self._generator))
+      x_prime = current_state.clone()
+      x_prime[i] = 1 - x_prime[i]
+      probs_prime = self._get_index_proposal_probs(x_prime)
+      q_ratio = probs_prime[i] / probs[i]
+      energies = self._energy(torch.stack([x_prime, current_state]))
+      accept_prob = torch.clamp(torch.exp(-energies[0] + energies[1]) * q_ratio, max=1.0)
+      roll = torch.rand((), generator=self._generator)
+      next_state = x_prime if bool(roll <= accept_prob.cpu()) else current_state
+    return next_state, []
+
+
+class GibbsWithGradientsInference(EnergyInference):
+  """Inference with a Gibbs-With-Gradients Markov chain (ebm.py:705-760): the chain state
+  persists between calls; `num_burnin_samples` steps are discarded whenever the energy's
+  variables have changed."""
+
+  def __init__(self, input_energy: energy.BitstringEnergy, num_expectation_samples: int,
+               num_burnin_samples: int, name: Union[None, str] = None,
+               initial_seed: Union[None, int] = None):
+    super().__init__(input_energy, num_expectation_samples, initial_seed, name)
+    # the chain owns its random stream (the base class re-seeds the shared generator per call)
+    self._chain_generator = torch.Generator().manual_seed(self._seed % (2**63))
+    self._kernel = GibbsWithGradientsKernel(input_energy, self._chain_generator)
+    self._chain_state = torch.bernoulli(torch.full((self.energy.num_bits,), 0.5),
+                                        generator=self._chain_generator).to(torch.int8)
+    self.num_burnin_samples = num_burnin_samples
+
+  def _ready_inference(self):
+    state = self._chain_state
+    for _ in range(int(self.num_burnin_samples)):
+      state, _ = self._kernel.one_step(state, [])
+    self._chain_state = state
+
+  def _call(self, inputs):
+    return self.sample(inputs)
+
+  def _sample(self, num_samples: int):
+    out = torch.empty((int(num_samples), self.energy.num_bits), dtype=torch.int8)
+    state = self._chain_state
+    for i in range(int(num_samples)):
+      state, _ = self._kernel.one_step(state, [])
+      out[i] = state
+    self._chain_state = state
+    return out
