@@ -162,6 +162,21 @@ int qhbm_sample(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_para
                 int n_shots, uint64_t seed, int shift_gate, double shift,
                 int8_t* d_out_samples, void* stream);
 
+/* ---- EBM side -------------------------------------------- */
+/* Spin-parity energies of bitstrings on the current HIP device (no engine handle):
+ *   d_energy[i] = sum_k d_thetas[k] * prod_{q in S_k} (1 - 2 x_i[q]),  S_k = set bits of d_masks[k]
+ * over the COLUMNS of d_bits [n_rows, n_bits] int8.  This is BernoulliEnergy / KOBE
+ * (qhbmlib/models/energy.py:123-209: SpinsFromBitstrings -> Parity -> VariableDot,
+ * energy_utils.py:39-110) as one kernel; qhbmlib/inference/ebm.py:458-461 evaluates it over
+ * all 2^n bitstrings after every variable update. */
+int qhbm_parity_energy(const int8_t* d_bits, int64_t n_rows, int n_bits,
+                       const uint64_t* d_masks, const float* d_thetas, int n_terms,
+                       float* d_energy, void* stream);
+/* Its VJP with respect to thetas: d_grad[k] = sum_i d_weights[i] * parity_k(x_i) (overwritten). */
+int qhbm_parity_energy_vjp(const int8_t* d_bits, int64_t n_rows, int n_bits,
+                           const uint64_t* d_masks, int n_terms, const float* d_weights,
+                           float* d_grad, void* stream);
+
 /* ---- introspection (tests, bench, DESIGN.md numbers) ------------------- */
 /* Number of HBM passes (kernel launches over the state) the scheduler emits
  * for one forward of the installed circuit + observables. */

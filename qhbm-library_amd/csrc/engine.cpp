@@ -453,6 +453,27 @@ int qhbm_statevector(qhbm_engine* h, const int8_t* d_bits, int U, const float* d
   return 0;
 }
 
+int qhbm_parity_energy(const int8_t* d_bits, int64_t n_rows, int n_bits, const uint64_t* d_masks,
+                       const float* d_thetas, int n_terms, float* d_energy, void* stream) {
+  if (n_rows < 0 || n_terms < 0) return fail(nullptr, "negative size");
+  if (n_bits < 1 || n_bits > 64) return fail(nullptr, "n_bits must be in [1, 64]");
+  hipError_t e = launch_parity_energy(d_bits, n_rows, n_bits, d_masks, d_thetas, n_terms, d_energy,
+                                      static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(nullptr, std::string("qhbm_parity_energy: ") + hipGetErrorString(e));
+  return 0;
+}
+
+int qhbm_parity_energy_vjp(const int8_t* d_bits, int64_t n_rows, int n_bits, const uint64_t* d_masks,
+                           int n_terms, const float* d_weights, float* d_grad, void* stream) {
+  if (n_rows < 0 || n_terms < 0) return fail(nullptr, "negative size");
+  if (n_bits < 1 || n_bits > 64) return fail(nullptr, "n_bits must be in [1, 64]");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = n_terms ? hipMemsetAsync(d_grad, 0, size_t(n_terms) * sizeof(float), s) : hipSuccess;
+  if (e == hipSuccess) e = launch_parity_energy_vjp(d_bits, n_rows, n_bits, d_masks, n_terms, d_weights, d_grad, s);
+  if (e != hipSuccess) return fail(nullptr, std::string("qhbm_parity_energy_vjp: ") + hipGetErrorString(e));
+  return 0;
+}
+
 int qhbm_sample(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, int n_shots,
                 uint64_t seed, int shift_gate, double shift, int8_t* d_out_samples, void* stream) {
   if (!h) return 1;

@@ -36,6 +36,10 @@ hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, u
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
                                    hipStream_t stream);
+hipError_t launch_parity_energy(const int8_t* bits, int64_t n_rows, int n, const uint64_t* masks,
+                                const float* thetas, int n_terms, float* energy, hipStream_t stream);
+hipError_t launch_parity_energy_vjp(const int8_t* bits, int64_t n_rows, int n, const uint64_t* masks, int n_terms,
+                                    const float* w, float* grad, hipStream_t stream);
 // block_cum: n_states * 2^n / 1024 doubles of scratch.
 hipError_t launch_sample(const float2* psi, uint32_t n, int n_user, uint32_t n_states, double* block_cum,
                          uint32_t n_shots, uint64_t seed, uint32_t state0, int8_t* out, hipStream_t stream);

@@ -1505,6 +1505,89 @@ hipError_t launch_sample(const float2* psi, uint32_t n, int n_user, uint32_t n_s
   return hipGetLastError();
 }
 
+// ================================================================================
+// EBM side: spin-parity energies of bitstrings,
+//   E(x) = sum_k theta_k * prod_{q in S_k} (1 - 2 x_q)
+// BernoulliEnergy / KOBE = SpinsFromBitstrings -> Parity -> VariableDot
+// (qhbmlib/models/energy.py:123-209, energy_utils.py:39-110).  S_k is a bit mask over the
+// columns of the bitstring.  One thread per bitstring; terms are staged in LDS.
+// ================================================================================
+constexpr int kParityChunk = 1024;  // terms staged per LDS fill
+
+__device__ __forceinline__ uint64_t pack_bits(const int8_t* __restrict__ row, int n) {
+  uint64_t x = 0;
+  for (int q = 0; q < n; ++q) x |= uint64_t(row[q] & 1) << q;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void parity_energy_kernel(const int8_t* __restrict__ bits, int64_t n_rows, int n,
+                                                            const uint64_t* __restrict__ masks,
+                                                            const float* __restrict__ thetas, int n_terms,
+                                                            float* __restrict__ energy) {
+  __shared__ uint64_t sm[kParityChunk];
+  __shared__ float st[kParityChunk];
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const uint64_t x = i < n_rows ? pack_bits(bits + i * n, n) : 0ull;
+  float e = 0.f;
+  for (int k0 = 0; k0 < n_terms; k0 += kParityChunk) {
+    const int kn = min(kParityChunk, n_terms - k0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < kn; k += 256) { sm[k] = masks[k0 + k]; st[k] = thetas[k0 + k]; }
+    __syncthreads();
+    for (int k = 0; k < kn; ++k) e += (__popcll(x & sm[k]) & 1) ? -st[k] : st[k];
+  }
+  if (i < n_rows) energy[i] = e;
+}
+
+// grad[k] = sum_i w[i] * parity_k(x_i): the VJP of the energies with respect to theta.
+// A workgroup keeps 256 x 8 bitstrings (and their weights) in registers and walks the terms.
+constexpr int kParityRows = 8;
+__global__ __launch_bounds__(256) void parity_energy_vjp_kernel(const int8_t* __restrict__ bits, int64_t n_rows, int n,
+                                                                const uint64_t* __restrict__ masks, int n_terms,
+                                                                const float* __restrict__ w,
+                                                                float* __restrict__ grad) {
+  uint64_t x[kParityRows];
+  float wt[kParityRows];
+#pragma unroll
+  for (int j = 0; j < kParityRows; ++j) {
+    const int64_t i = (int64_t(blockIdx.x) * kParityRows + j) * 256 + threadIdx.x;
+    x[j] = i < n_rows ? pack_bits(bits + i * n, n) : 0ull;
+    wt[j] = i < n_rows ? w[i] : 0.f;
+  }
+  __shared__ float part[4];
+  for (int k = 0; k < n_terms; ++k) {
+    const uint64_t m = masks[k];
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < kParityRows; ++j) acc += (__popcll(x[j] & m) & 1) ? -wt[j] : wt[j];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float v = part[0] + part[1] + part[2] + part[3];
+      if (v != 0.f) atomicAdd(&grad[k], v);
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_parity_energy(const int8_t* bits, int64_t n_rows, int n, const uint64_t* masks,
+                                const float* thetas, int n_terms, float* energy, hipStream_t stream) {
+  if (n_rows == 0) return hipSuccess;
+  hipLaunchKernelGGL(parity_energy_kernel, dim3(unsigned((n_rows + 255) / 256)), dim3(256), 0, stream, bits, n_rows, n,
+                     masks, thetas, n_terms, energy);
+  return hipGetLastError();
+}
+
+hipError_t launch_parity_energy_vjp(const int8_t* bits, int64_t n_rows, int n, const uint64_t* masks, int n_terms,
+                                    const float* w, float* grad, hipStream_t stream) {
+  if (n_rows == 0 || n_terms == 0) return hipSuccess;
+  const int64_t per_block = 256 * kParityRows;
+  hipLaunchKernelGGL(parity_energy_vjp_kernel, dim3(unsigned((n_rows + per_block - 1) / per_block)), dim3(256), 0,
+                     stream, bits, n_rows, n, masks, n_terms, w, grad);
+  return hipGetLastError();
+}
+
 hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,

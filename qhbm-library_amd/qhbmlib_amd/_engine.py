@@ -34,7 +34,8 @@ ABI_SYMBOLS = (
     "qhbm_abi_version", "qhbm_create", "qhbm_destroy", "qhbm_last_error",
     "qhbm_set_circuit", "qhbm_set_observables", "qhbm_set_option",
     "qhbm_workspace_bytes", "qhbm_expectation", "qhbm_expectation_vjp",
-    "qhbm_expectation_jacobian", "qhbm_statevector", "qhbm_sample", "qhbm_num_passes", "qhbm_describe_schedule",
+    "qhbm_expectation_jacobian", "qhbm_statevector", "qhbm_sample", "qhbm_parity_energy", "qhbm_parity_energy_vjp",
+    "qhbm_num_passes", "qhbm_describe_schedule",
     "qhbm_kernel_time_ms",
 )
 
@@ -80,6 +81,8 @@ def load_library():
   lib.qhbm_expectation_jacobian.argtypes = [vp, vp, i32, vp, vp, vp, vp]
   lib.qhbm_statevector.argtypes = [vp, vp, i32, vp, vp, vp]
   lib.qhbm_sample.argtypes = [vp, vp, i32, vp, i32, ctypes.c_uint64, i32, ctypes.c_double, vp, vp]
+  lib.qhbm_parity_energy.argtypes = [vp, i64, i32, vp, vp, i32, vp, vp]
+  lib.qhbm_parity_energy_vjp.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp]
   lib.qhbm_num_passes.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
   lib.qhbm_describe_schedule.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
   lib.qhbm_kernel_time_ms.argtypes = [
@@ -87,6 +90,51 @@ def load_library():
       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
   _lib = lib
   return lib
+
+
+def _check_global(rc):
+  if rc != 0:
+    raise EngineError(load_library().qhbm_last_error(None).decode())
+
+
+class _ParityEnergyFunction(torch.autograd.Function):
+  """energies[i] = sum_k thetas[k] * parity_k(bits[i]) on the GPU (qhbm_parity_energy); the
+  backward is qhbm_parity_energy_vjp.  `masks` is an int64 CUDA tensor of column masks."""
+
+  @staticmethod
+  def forward(ctx, thetas, bits, masks):
+    lib = load_library()
+    bits = bits.to(torch.int8).contiguous()
+    th = thetas.detach().to(device=bits.device, dtype=torch.float32).contiguous()
+    out = torch.empty((bits.shape[0],), dtype=torch.float32, device=bits.device)
+    with torch.cuda.device(bits.device):
+      _check_global(lib.qhbm_parity_energy(
+          bits.data_ptr(), bits.shape[0], bits.shape[1], masks.data_ptr(), th.data_ptr(),
+          masks.numel(), out.data_ptr(),
+          ctypes.c_void_p(torch.cuda.current_stream(bits.device).cuda_stream)))
+    ctx.bits, ctx.masks = bits, masks
+    ctx.theta_device = thetas.device
+    return out
+
+  @staticmethod
+  def backward(ctx, upstream):
+    lib = load_library()
+    bits, masks = ctx.bits, ctx.masks
+    w = upstream.to(device=bits.device, dtype=torch.float32).contiguous()
+    grad = torch.empty((masks.numel(),), dtype=torch.float32, device=bits.device)
+    with torch.cuda.device(bits.device):
+      _check_global(lib.qhbm_parity_energy_vjp(
+          bits.data_ptr(), bits.shape[0], bits.shape[1], masks.data_ptr(), masks.numel(),
+          w.data_ptr(), grad.data_ptr(),
+          ctypes.c_void_p(torch.cuda.current_stream(bits.device).cuda_stream)))
+    return grad.to(ctx.theta_device), None, None
+
+
+def parity_energy(thetas, bits, masks):
+  """Differentiable (w.r.t. `thetas`) spin-parity energies of CUDA `bits` [N, n]."""
+  if not bits.is_cuda:
+    raise EngineError("parity_energy runs on the GPU: pass CUDA bitstrings (CPU tensors use the torch layers)")
+  return _ParityEnergyFunction.apply(thetas, bits, masks)
 
 
 class Engine:

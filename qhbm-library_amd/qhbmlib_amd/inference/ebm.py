@@ -159,30 +159,50 @@ class EnergyInference(EnergyInferenceBase):
 
 
 class AnalyticEnergyInference(EnergyInference):
-  """Explicit categorical distribution over all bitstrings (ebm.py:418-492)."""
+  """Explicit categorical distribution over all bitstrings (ebm.py:418-492).
+
+  The 2^n bitstrings, their energies and the categorical live on the device of the energy's
+  variables: with the energy on the GPU, `_ready_inference` over 2^20 bitstrings of a KOBE is one
+  `qhbm_parity_energy` launch (the reference re-evaluates a Python loop over the parity terms,
+  `energy_utils.py:106-110`, after every variable update)."""
 
   def __init__(self, input_energy: energy.BitstringEnergy, num_expectation_samples: int,
                initial_seed: Union[None, int] = None, name: Union[None, str] = None):
     super().__init__(input_energy, num_expectation_samples, initial_seed, name)
-    self._all_bitstrings = torch.tensor(
-        list(itertools.product([0, 1], repeat=input_energy.num_bits)), dtype=torch.int8)
+    n = input_energy.num_bits
+    # rows in itertools.product([0, 1], repeat=n) order (ebm.py:445-447)
+    index = torch.arange(2**n, dtype=torch.int64).unsqueeze(1)
+    shifts = torch.arange(n - 1, -1, -1, dtype=torch.int64).unsqueeze(0)
+    self._all_bitstrings = ((index >> shifts) & 1).to(torch.int8)
     self._logits = None
+    self._device_generator = None
+
+  def _device(self):
+    return next(iter(self.energy.parameters()), torch.zeros(())).device
 
   @property
   def all_bitstrings(self):
+    dev = self._device()
+    if self._all_bitstrings.device != dev:
+      self._all_bitstrings = self._all_bitstrings.to(dev)
     return self._all_bitstrings
 
   @property
   def all_energies(self):
     return self.energy(self.all_bitstrings)
 
+  @property
+  def distribution(self):
+    """The categorical over all bitstrings (ebm.py:462-465)."""
+    return torch.distributions.Categorical(logits=self._logits)
+
   def _ready_inference(self):
     with torch.no_grad():
-      self._logits = -self.all_energies.detach().cpu()
+      self._logits = -self.all_energies.detach()
 
   def _call(self, inputs):
     if inputs is None:
-      return torch.distributions.Categorical(logits=self._logits)
+      return self.distribution
     return self.sample(inputs)
 
   def _entropy(self):
@@ -195,7 +215,17 @@ class AnalyticEnergyInference(EnergyInference):
 
   def _sample(self, num_samples: int):
     probs = torch.softmax(self._logits.to(torch.float64), 0)
-    idx = torch.multinomial(probs, num_samples, replacement=True, generator=self._rng())
+    if probs.is_cuda:
+      if self._device_generator is None or self._device_generator.device != probs.device:
+        self._device_generator = torch.Generator(device=probs.device)
+      gen = self._device_generator.manual_seed(self._seed % (2**63))
+    else:
+      gen = self._rng()
+    if probs.numel() <= 2**24:
+      idx = torch.multinomial(probs, num_samples, replacement=True, generator=gen)
+    else:  # torch.multinomial stops at 2^24 categories: inverse-CDF sampling
+      u = torch.rand(num_samples, dtype=torch.float64, device=probs.device, generator=gen)
+      idx = torch.searchsorted(torch.cumsum(probs, 0), u).clamp_(max=probs.numel() - 1)
     return self.all_bitstrings[idx]
 
 

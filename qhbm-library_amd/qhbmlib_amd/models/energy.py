@@ -66,6 +66,32 @@ class PauliMixin(abc.ABC):
       x = layer(x)
     return x
 
+  # ---- GPU path of the spin-parity energies ----------------------------------
+  def _parity_index_sets(self):
+    """Column index sets whose spin products the energy weights, in kernel order."""
+    raise NotImplementedError()
+
+  def _parity_masks(self, device):
+    cache = self.__dict__.setdefault("_mask_cache", {})
+    key = str(device)
+    if key not in cache:
+      masks = [sum(1 << int(c) for c in ix) for ix in self._parity_index_sets()]
+      cache[key] = torch.tensor(masks, dtype=torch.int64, device=device)
+    return cache[key]
+
+  def _gpu_energy(self, inputs):
+    """One HIP kernel instead of SpinsFromBitstrings -> Parity -> VariableDot when the
+    bitstrings are integer CUDA tensors with at most 64 columns (qhbm_parity_energy)."""
+    from qhbmlib_amd import _engine  # pylint: disable=import-outside-toplevel
+    flat = inputs.reshape(-1, inputs.shape[-1])
+    kernel = self.post_process[0].kernel
+    e = _engine.parity_energy(kernel, flat, self._parity_masks(flat.device))
+    return e.reshape(inputs.shape[:-1])
+
+  def _use_gpu_energy(self, inputs):
+    return (torch.is_tensor(inputs) and inputs.is_cuda and not inputs.is_floating_point() and
+            inputs.shape[-1] <= 64 and self.post_process[0].kernel is not None)
+
 
 class BernoulliEnergy(BitstringEnergy, PauliMixin):
   """Tensor product of coin flips, E(b) = sum_i theta_i (1 - 2 b_i) (energy.py:123-167)."""
@@ -89,6 +115,14 @@ class BernoulliEnergy(BitstringEnergy, PauliMixin):
   def operator_shards(self, qubits):
     """energy.py:165-167."""
     return [ir.PauliSum.from_pauli_strings(ir.PZ(q)) for q in qubits]
+
+  def _parity_index_sets(self):
+    return [(i,) for i in range(self.num_bits)]
+
+  def forward(self, inputs):
+    if self._use_gpu_energy(inputs):
+      return self._gpu_energy(inputs)
+    return super().forward(inputs)
 
 
 class KOBE(BitstringEnergy, PauliMixin):
@@ -116,3 +150,11 @@ class KOBE(BitstringEnergy, PauliMixin):
       string = ir.PauliString(*[ir.PZ(qubits[loc]) for loc in self._indices[i]])
       ops.append(ir.PauliSum.from_pauli_strings(string))
     return ops
+
+  def _parity_index_sets(self):
+    return self._indices
+
+  def forward(self, inputs):
+    if self._use_gpu_energy(inputs):
+      return self._gpu_energy(inputs)
+    return super().forward(inputs)
