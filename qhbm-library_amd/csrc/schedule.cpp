@@ -437,6 +437,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   const int c_min = std::min(K, 4);
   Builder b(m, K, R, n_eff, adjoint, plan);
   std::vector<char> done(ops.size(), 0);
+  std::vector<int> op_pass(ops.size(), 0);  // pass that executes each lowered op
   size_t n_done = 0;
 
   while (n_done < ops.size()) {
@@ -485,7 +486,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     Pass p = b.begin_pass(best_S);
     p.slot_base = int(plan->slot_gate.size());
     if (!b.emit_ops(&p, ops, best_list, err)) return false;
-    for (int oi : best_list) { done[oi] = 1; ++n_done; }
+    for (int oi : best_list) { done[oi] = 1; op_pass[oi] = int(plan->passes.size()); ++n_done; }
     plan->passes.push_back(std::move(p));
   }
 
@@ -520,6 +521,37 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   }
   std::vector<char> gdone(groups.size(), 0);
   size_t g_left = groups.size();
+  // A term may be measured as soon as every op that does not commute with it has run: ops on
+  // disjoint bits commute, and so does a diagonal op that meets the term only where the term
+  // is Z.  Each X-mask group goes to the earliest pass after that point whose tile holds its
+  // flipped bits -- usually a pass that exists anyway, so the HEA + nearest-neighbour sums of
+  // the benchmarks need no measurement-only pass (one full read of the state saved).
+  {
+    std::vector<std::vector<int>> early(plan->passes.size());
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+      int ready = 0;
+      for (int ti : groups[gi].terms) {
+        const uint32_t supp = m.terms[size_t(ti)].x | m.terms[size_t(ti)].z;
+        for (size_t oi = 0; oi < ops.size(); ++oi) {
+          if (!(ops[oi].bits & supp)) continue;
+          if (ops[oi].type == LOW_DIAG && !(ops[oi].bits & m.terms[size_t(ti)].x)) continue;
+          ready = std::max(ready, op_pass[oi]);
+        }
+      }
+      for (size_t pi = size_t(ready); pi + 1 < plan->passes.size(); ++pi) {  // the last pass is handled below
+        uint32_t S = 0;
+        for (int bb : plan->passes[pi].local_pos) S |= 1u << bb;
+        if ((groups[gi].x & ~S) == 0) {
+          early[pi].push_back(int(gi));
+          gdone[gi] = 1;
+          --g_left;
+          break;
+        }
+      }
+    }
+    for (size_t pi = 0; pi < early.size(); ++pi)
+      if (!early[pi].empty()) b.emit_measure(&plan->passes[pi], groups, early[pi]);
+  }
   auto take = [&](Pass* p) {
     uint32_t S = 0;
     for (int bb : p->local_pos) S |= 1u << bb;
