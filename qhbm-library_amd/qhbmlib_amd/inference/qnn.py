@@ -75,6 +75,8 @@ class AnalyticQuantumInference(QuantumInference):
   `_engine.GRAD_PARAMETER_SHIFT` to use two shifted forwards per gate occurrence
   instead (the rule of tfq.differentiators.ParameterShift, qnn.py:168)."""
 
+  MAX_OPS_PER_CALL = 1024  # kMaxOps of the engine (csrc/program.h)
+
   def __init__(self, input_circuit: circuit.QuantumCircuit, name: Union[None, str] = None,
                device: Union[None, int] = None, gradient_method: int = _engine.GRAD_ADJOINT):
     super().__init__(input_circuit, name)
@@ -113,7 +115,6 @@ class AnalyticQuantumInference(QuantumInference):
       ops = list(observables)
       post_process = lambda x: x
       key = ("ops", tuple(id(o) for o in ops))
-    eng = self._engine_for(total_circuit, ops, key)
     perm = total_circuit.bit_column_to_qubit()
     bits = unique_states.to(torch.int8)
     if perm != list(range(len(perm))):
@@ -121,7 +122,14 @@ class AnalyticQuantumInference(QuantumInference):
       permuted[:, perm] = bits
       bits = permuted
     symbol_values = total_circuit.symbol_values.to(torch.float32)
-    expectations = _ExpectationFunction.apply(symbol_values, eng, bits, self.gradient_method)
+    # one engine call measures at most MAX_OPS_PER_CALL observables (its LDS accumulators);
+    # longer lists -- e.g. the 1350 shards of a third-order KOBE on 20 qubits -- go in slices
+    parts = []
+    for lo in range(0, max(len(ops), 1), self.MAX_OPS_PER_CALL):
+      chunk = ops[lo:lo + self.MAX_OPS_PER_CALL]
+      eng = self._engine_for(total_circuit, chunk, key + (lo,))
+      parts.append(_ExpectationFunction.apply(symbol_values, eng, bits, self.gradient_method))
+    expectations = parts[0] if len(parts) == 1 else torch.cat(parts, 1)
     return post_process(expectations)
 
 

@@ -286,3 +286,34 @@ def test_qaia_expectation_and_tied_gradients_vs_oracle():
   np.testing.assert_allclose(jacs[0], want_eta, atol=2e-4)
   np.testing.assert_allclose(jacs[1], want_theta, atol=2e-4)
   np.testing.assert_allclose(jacs[2], want_gamma, atol=2e-4)
+
+
+def test_more_observables_than_one_engine_call_holds():
+  """A third-order KOBE on 14 qubits has 469 shards; with the per-call limit lowered to 200 the
+  host slices the list over three engine calls -- values and gradients must not notice."""
+  n = 14
+  qubits = ir.GridQubit.rect(1, n)
+  energy_h = models.KOBE(list(range(n)), 3)
+  rng = np.random.default_rng(4)
+  thetas = rng.uniform(-1, 1, energy_h.post_process[0].kernel.numel())
+  _set(energy_h.post_process[0].kernel, thetas)
+  circuit_h = models.DirectQuantumCircuit(hea_circuit(qubits, 1, "h"))
+  model_circuit = models.DirectQuantumCircuit(hea_circuit(qubits, 1, "m"))
+  _set(circuit_h.trainable_variables[0], rng.uniform(-1, 1, len(circuit_h.symbol_names)))
+  _set(model_circuit.trainable_variables[0], rng.uniform(-1, 1, len(model_circuit.symbol_names)))
+  ham = models.Hamiltonian(energy_h, circuit_h)
+  states = torch.from_numpy(rng.integers(0, 2, size=(3, n)).astype(np.int8))
+  results = []
+  for limit in (1024, 200):
+    qnn = inference.AnalyticQuantumInference(model_circuit)
+    qnn.MAX_OPS_PER_CALL = limit
+    for v in (energy_h.trainable_variables + circuit_h.trainable_variables + model_circuit.trainable_variables):
+      v.grad = None
+    out = qnn.expectation(states, ham)
+    out.sum().backward()
+    results.append((out.detach().cpu().numpy(), energy_h.post_process[0].kernel.grad.cpu().numpy().copy(),
+                    model_circuit.trainable_variables[0].grad.cpu().numpy().copy(), len(qnn._engines)))
+  assert results[0][3] == 1 and results[1][3] == 3
+  np.testing.assert_allclose(results[1][0], results[0][0], atol=1e-5)
+  np.testing.assert_allclose(results[1][1], results[0][1], atol=1e-5)
+  np.testing.assert_allclose(results[1][2], results[0][2], atol=1e-4)
