@@ -329,6 +329,31 @@ __device__ __forceinline__ void store_tile(const float2* __restrict__ tile, floa
   }
 }
 
+// Eight float4 of a thread's share of a tile, as named registers (a loop-carried array may end
+// up in scratch).  Loading a tile pair through two of these puts all 16 global loads of a thread
+// in flight before the first LDS write.
+struct TileRegs {
+  float4 p0, p1, p2, p3, p4, p5, p6, p7;
+};
+template <int K, int NT>
+__device__ __forceinline__ void prefetch_tile(TileRegs& r, const float2* __restrict__ st, const TileCtx& t, int tid) {
+  static_assert((1 << (K - 1)) / NT == 8, "a thread owns eight float4 of its tile");
+#define QHBM_PF(I) r.p##I = *reinterpret_cast<const float4*>(st + global_index(t, 2u * uint32_t(tid + I * NT)));
+  QHBM_PF(0) QHBM_PF(1) QHBM_PF(2) QHBM_PF(3) QHBM_PF(4) QHBM_PF(5) QHBM_PF(6) QHBM_PF(7)
+#undef QHBM_PF
+}
+template <int K, int NT>
+__device__ __forceinline__ void commit_tile(float2* __restrict__ tile, const TileRegs& r, int tid) {
+#define QHBM_CM(I)                                                    \
+  {                                                                   \
+    const uint32_t sl = swz(2u * uint32_t(tid + I * NT));             \
+    tile[sl] = make_float2(r.p##I.x, r.p##I.y);                       \
+    tile[sl ^ 1u] = make_float2(r.p##I.z, r.p##I.w);                  \
+  }
+  QHBM_CM(0) QHBM_CM(1) QHBM_CM(2) QHBM_CM(3) QHBM_CM(4) QHBM_CM(5) QHBM_CM(6) QHBM_CM(7)
+#undef QHBM_CM
+}
+
 __device__ __forceinline__ TileCtx make_tile_ctx(const PassArgs& a, const uint32_t* tables, uint32_t tile_id) {
   TileCtx t;
   uint32_t tb = 0;
@@ -676,7 +701,9 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
       }
     }
   } else {
-    load_tile<K, NT>(tile, st, t, tid);
+    TileRegs r;
+    prefetch_tile<K, NT>(r, st, t, tid);
+    commit_tile<K, NT>(tile, r, tid);
   }
   for (int i = tid; i < kMaxOps; i += NT) red[i] = 0.f;
   __syncthreads();
@@ -806,8 +833,13 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
   const TileCtx t = make_tile_ctx(a, tables, tile_id);
   float2* sp = psi + (size_t(s_local) << a.n);
   float2* sl = lam + (size_t(s_local) << a.n);
-  load_tile<K, NT>(tp, sp, t, tid);
-  load_tile<K, NT>(tl, sl, t, tid);
+  {
+    TileRegs rp, rl;
+    prefetch_tile<K, NT>(rp, sp, t, tid);
+    prefetch_tile<K, NT>(rl, sl, t, tid);
+    commit_tile<K, NT>(tp, rp, tid);
+    commit_tile<K, NT>(tl, rl, tid);
+  }
   for (uint32_t i = tid; i < a.n_slots; i += NT) sacc[i] = 0.f;
   __syncthreads();
 
