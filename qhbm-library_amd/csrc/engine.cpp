@@ -120,6 +120,11 @@ void fill_args(const Plan& plan, const Model& m, std::vector<PassArgs>* args, st
     a.n_nonlocal = uint32_t(p.nonlocal_pos.size());
     a.prog_off = uint32_t(prog->size());
     a.spread_off = uint32_t(tables->size());
+    a.spread_shift = 0;  // K == c: the only entry is 0
+    for (size_t i = size_t(p.c); i < p.local_pos.size(); ++i) {
+      if (i == size_t(p.c)) a.spread_shift = uint32_t(p.local_pos[i]);
+      else if (p.local_pos[i] != p.local_pos[i - 1] + 1) { a.spread_shift = 0xffffffffu; break; }
+    }
     a.n_ops = uint32_t(m.n_ops);
     a.slot_base = uint32_t(p.slot_base);
     a.n_slots = uint32_t(p.n_slots);

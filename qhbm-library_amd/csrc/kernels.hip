@@ -298,8 +298,13 @@ struct TileCtx {
   uint32_t cmask;
   uint32_t c;
   const uint32_t* spread;
+  uint32_t shift;  // ~0u: look the high part up in `spread`
 };
 
+// (local bits above c contiguous from bit `shift`: no table lookup in front of the global access)
+__device__ __forceinline__ uint32_t global_index_shift(const TileCtx& t, uint32_t l) {
+  return t.tile_base | (l & t.cmask) | ((l >> t.c) << t.shift);
+}
 __device__ __forceinline__ uint32_t global_index(const TileCtx& t, uint32_t l) {
   return t.tile_base | (l & t.cmask) | t.spread[l >> t.c];
 }
@@ -320,12 +325,22 @@ __device__ __forceinline__ void load_tile(float2* __restrict__ tile, const float
 template <int K, int NT>
 __device__ __forceinline__ void store_tile(const float2* __restrict__ tile, float2* __restrict__ st,
                                            const TileCtx& t, int tid) {
+  if (t.shift != 0xffffffffu) {  // wave-uniform
 #pragma unroll 4
-  for (int p = tid; p < (1 << (K - 1)); p += NT) {
-    const uint32_t l = 2u * p;
-    const uint32_t s = swz(l);
-    const float2 a = tile[s], b = tile[s ^ 1u];
-    *reinterpret_cast<float4*>(st + global_index(t, l)) = make_float4(a.x, a.y, b.x, b.y);
+    for (int p = tid; p < (1 << (K - 1)); p += NT) {
+      const uint32_t l = 2u * p;
+      const uint32_t s = swz(l);
+      const float2 a = tile[s], b = tile[s ^ 1u];
+      *reinterpret_cast<float4*>(st + global_index_shift(t, l)) = make_float4(a.x, a.y, b.x, b.y);
+    }
+  } else {
+#pragma unroll 4
+    for (int p = tid; p < (1 << (K - 1)); p += NT) {
+      const uint32_t l = 2u * p;
+      const uint32_t s = swz(l);
+      const float2 a = tile[s], b = tile[s ^ 1u];
+      *reinterpret_cast<float4*>(st + global_index(t, l)) = make_float4(a.x, a.y, b.x, b.y);
+    }
   }
 }
 
@@ -338,9 +353,15 @@ struct TileRegs {
 template <int K, int NT>
 __device__ __forceinline__ void prefetch_tile(TileRegs& r, const float2* __restrict__ st, const TileCtx& t, int tid) {
   static_assert((1 << (K - 1)) / NT == 8, "a thread owns eight float4 of its tile");
-#define QHBM_PF(I) r.p##I = *reinterpret_cast<const float4*>(st + global_index(t, 2u * uint32_t(tid + I * NT)));
-  QHBM_PF(0) QHBM_PF(1) QHBM_PF(2) QHBM_PF(3) QHBM_PF(4) QHBM_PF(5) QHBM_PF(6) QHBM_PF(7)
+  if (t.shift != 0xffffffffu) {  // wave-uniform
+#define QHBM_PF(I) r.p##I = *reinterpret_cast<const float4*>(st + global_index_shift(t, 2u * uint32_t(tid + I * NT)));
+    QHBM_PF(0) QHBM_PF(1) QHBM_PF(2) QHBM_PF(3) QHBM_PF(4) QHBM_PF(5) QHBM_PF(6) QHBM_PF(7)
 #undef QHBM_PF
+  } else {
+#define QHBM_PF(I) r.p##I = *reinterpret_cast<const float4*>(st + global_index(t, 2u * uint32_t(tid + I * NT)));
+    QHBM_PF(0) QHBM_PF(1) QHBM_PF(2) QHBM_PF(3) QHBM_PF(4) QHBM_PF(5) QHBM_PF(6) QHBM_PF(7)
+#undef QHBM_PF
+  }
 }
 template <int K, int NT>
 __device__ __forceinline__ void commit_tile(float2* __restrict__ tile, const TileRegs& r, int tid) {
@@ -362,6 +383,7 @@ __device__ __forceinline__ TileCtx make_tile_ctx(const PassArgs& a, const uint32
   t.c = a.c;
   t.cmask = (1u << a.c) - 1u;
   t.spread = tables + a.spread_off;
+  t.shift = a.spread_shift;
   return t;
 }
 
