@@ -249,11 +249,14 @@ def main():
     if args.mode == "shift":  # one base forward + 2 P shifted forwards
       fwd_alg *= 1 + 2 * n_params
     bwd_alg = spg * 48.0 * n_gate * amp
+    n_diag = sum(1 for g in gates if g[0] in (E.GATE_ZPOW, E.GATE_CZPOW, E.GATE_ZZPOW))
+    fwd_flops = spg * amp * (14.0 * (n_gate - n_diag) + 6.0 * n_diag)
     use_bwd = args.mode == "vqt" and kt["bwd_ms"] >= kt["fwd_ms"]
     if use_bwd:
       launches, ms, alg, name = kt["bwd_launches"], kt["bwd_ms"], bwd_alg, "pass_adj_kernel"
     else:
       launches, ms, alg, name = kt["fwd_launches"], kt["fwd_ms"], fwd_alg, "pass_fwd_kernel"
+    alg_flops = 3.0 * fwd_flops if use_bwd else fwd_flops * ((1 + 2 * n_params) if args.mode == "shift" else 1)
     per_step_launches = max(1, launches // max(1, args.steps))
     avg_ms = ms / max(1, launches)
     achieved = (alg / per_step_launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -302,6 +305,11 @@ def main():
             "algorithmic_bytes_per_launch": alg / per_step_launches,
             "tile_io_bytes_per_launch": io_bytes,
             "tile_io_GBps": io_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+            # the fused kernels are VALU-bound, so the same launch priced in SURVEY.md 8(d)'s
+            # algorithmic flops (28 per amplitude pair for a one-qubit gate, 6 per amplitude for a
+            # diagonal one; the adjoint sweeps every gate three times) against the fp32 vector peak
+            "algorithmic_TFLOPs": alg_flops / per_step_launches / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
+            "fp32_vector_peak_TFLOPs": 157.3,
         },
     }
     if args.verify:

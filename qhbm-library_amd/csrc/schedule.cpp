@@ -349,6 +349,7 @@ class Builder {
     p->prog.push_back(OP_ROUND | (uint32_t(insts.size()) << 8));
     p->prog.push_back(reg);
     p->prog.push_back(first);
+    p->round_regmasks.push_back(reg);
     ++p->n_rounds;
     p->n_instances += int(insts.size());
   }
@@ -596,7 +597,9 @@ std::string describe_plan(const Plan& p) {
     os << "] mat_ops=" << q.n_mat_ops << " diag_terms=" << q.n_diag_terms << " rounds=" << q.n_rounds
        << " instances=" << q.n_instances << " meas_groups=" << q.n_meas_groups
        << " meas_terms=" << q.n_meas_terms << " slots=" << q.n_slots
-       << (q.is_measure_only ? " [measure-only]" : "") << " words=" << q.prog.size() << "\n";
+       << (q.is_measure_only ? " [measure-only]" : "") << " words=" << q.prog.size() << " regs=";
+    for (size_t r = 0; r < q.round_regmasks.size(); ++r) os << (r ? "," : "") << std::hex << q.round_regmasks[r] << std::dec;
+    os << "\n";
   }
   return os.str();
 }
