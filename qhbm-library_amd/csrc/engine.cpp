@@ -200,10 +200,11 @@ int upload_model(qhbm_engine* h) {
 size_t state_bytes(const qhbm_engine* h) { return size_t(8) << h->fwd.plan.n_eff; }
 
 uint32_t chunk_states(const qhbm_engine* h, int U) {
-  if (h->opt_chunk > 0) return uint32_t(std::min<int64_t>(h->opt_chunk, U));
+  // (a chunk is also a grid dimension of the per-state kernels: at most 65535)
+  if (h->opt_chunk > 0) return uint32_t(std::min<int64_t>(std::min<int64_t>(h->opt_chunk, U), 65535));
   const size_t budget = size_t(h->opt_budget_mb) << 20;
   const size_t fit = std::max<size_t>(1, budget / state_bytes(h));
-  return uint32_t(std::min<size_t>(fit, size_t(U)));
+  return uint32_t(std::min<size_t>(std::min<size_t>(fit, size_t(U)), 65535));
 }
 
 hipEvent_t* timer_begin(qhbm_engine* h, int kind, hipStream_t s) {
@@ -276,7 +277,8 @@ int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_pa
   HIPCHK(h->state_grad.reserve(size_t(U) * std::max<uint32_t>(n_slots, 1)));
   HIPCHK(hipMemsetAsync(h->state_grad.p, 0, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), stream));
   uint32_t cs = chunk_states(h, U);
-  if (h->opt_chunk <= 0) cs = uint32_t(std::min<size_t>(size_t(U), std::max<size_t>(1, (size_t(h->opt_budget_mb) << 20) / (2 * state_bytes(h)))));  // two buffers per state
+  if (h->opt_chunk <= 0)  // two buffers per state
+    cs = uint32_t(std::min<size_t>(std::min<size_t>(size_t(U), 65535), std::max<size_t>(1, (size_t(h->opt_budget_mb) << 20) / (2 * state_bytes(h)))));
   if (int rc = ensure_state_buffers(h, cs, true)) return rc;
   const uint32_t n_eff = uint32_t(f.plan.n_eff);
   for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += cs) {

@@ -249,3 +249,23 @@ def test_chunked_execution_matches():
   _, grad = eng.expectation_vjp(bits, params, up)
   want = np.einsum("bt,btp->p", up, want_jac)
   np.testing.assert_allclose(grad.cpu().numpy(), want, atol=2e-4 * max(1, np.abs(want).max()), rtol=0)
+
+
+def test_batch_larger_than_a_grid_dimension():
+  """70 000 states of a 10-qubit circuit: more than the 65 535 a grid y-dimension holds, so the
+  engine must chunk; every state is checked against the closed form of X**p."""
+  n, states = 10, 70000
+  gates = [(E.GATE_XPOW, q, -1, 0, 1.0, 0.0) for q in range(n)]
+  ops = [[(1.0, 0, 1 << q)] for q in range(n)]
+  eng = _engine(n, gates, 1, ops)
+  rng = np.random.default_rng(0)
+  bits = rng.integers(0, 2, size=(states, n)).astype(np.int8)
+  p = np.array([0.37], np.float32)
+  vals = eng.expectation(bits, p).cpu().numpy()
+  want = (1.0 - 2.0 * bits) * math.cos(math.pi * 0.37)
+  np.testing.assert_allclose(vals, want, atol=1e-5)
+  up = np.full((states, n), 1.0 / states, np.float32)
+  vals2, grad = eng.expectation_vjp(bits, p, up)
+  np.testing.assert_allclose(vals2.cpu().numpy(), want, atol=1e-5)
+  want_g = float(((1.0 - 2.0 * bits) * (-math.pi * math.sin(math.pi * 0.37))).sum() / states)
+  np.testing.assert_allclose(grad.cpu().numpy()[0], want_g, atol=1e-4 * max(1.0, abs(want_g)))
