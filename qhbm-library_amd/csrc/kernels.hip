@@ -710,17 +710,24 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
   float2* st = psi + (size_t(s_local) << a.n);
 
   if (a.flags & PASS_INIT_BASIS) {
+    const uint32_t idx = uni(basis_index(bits + size_t(state0 + s_local) * n_user, n_user));
+    uint32_t nl_mask = 0;
+    for (uint32_t i = 0; i < a.n_nonlocal; ++i) nl_mask |= 1u << a.nonlocal_pos[i];
+    if ((idx & nl_mask) != t.tile_base) {
+      // The basis amplitude lives in another tile: this one is zero and stays zero under the
+      // program (every op is linear), so only its image in HBM has to be written.
+      if (a.flags & PASS_STORE) {
+        for (int p = tid; p < (1 << (K - 1)); p += NT)
+          *reinterpret_cast<float4*>(st + global_index(t, 2u * p)) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      return;
+    }
     for (int l = tid; l < (1 << K); l += NT) tile[l] = make_float2(0.f, 0.f);
     __syncthreads();
     if (tid == 0) {
-      const uint32_t idx = basis_index(bits + size_t(state0 + s_local) * n_user, n_user);
-      uint32_t nl_mask = 0;
-      for (uint32_t i = 0; i < a.n_nonlocal; ++i) nl_mask |= 1u << a.nonlocal_pos[i];
-      if ((idx & nl_mask) == t.tile_base) {
-        uint32_t l = 0;
-        for (int i = 0; i < K; ++i) l |= ((idx >> a.local_pos[i]) & 1u) << i;
-        tile[swz(l)] = make_float2(1.f, 0.f);
-      }
+      uint32_t l = 0;
+      for (int i = 0; i < K; ++i) l |= ((idx >> a.local_pos[i]) & 1u) << i;
+      tile[swz(l)] = make_float2(1.f, 0.f);
     }
   } else {
     TileRegs r;
