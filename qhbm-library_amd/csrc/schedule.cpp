@@ -441,6 +441,37 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   std::vector<int> op_pass(ops.size(), 0);  // pass that executes each lowered op
   size_t n_done = 0;
 
+  // Measurement groups: terms of equal X-mask share conj(psi[l ^ x]) psi[l].
+  std::vector<MeasGroup> groups;
+  if (!adjoint) {
+    for (size_t ti = 0; ti < m.terms.size(); ++ti) {
+      const uint32_t x = m.terms[ti].x;
+      auto it = std::find_if(groups.begin(), groups.end(), [&](const MeasGroup& g) { return g.x == x; });
+      if (it == groups.end()) { groups.push_back(MeasGroup{x, {}}); it = groups.end() - 1; }
+      it->terms.push_back(int(ti));
+    }
+  }
+  // First pass after which group gi may be measured: every op that does not commute with one of
+  // its terms has run (ops on disjoint bits commute; so does a diagonal op that meets the term
+  // only where the term is Z).  Ops not yet scheduled count as running in pass `pending_pass`.
+  auto group_ready = [&](size_t gi, int pending_pass) {
+    int ready = 0;
+    for (int ti : groups[gi].terms) {
+      const uint32_t supp = m.terms[size_t(ti)].x | m.terms[size_t(ti)].z;
+      for (size_t oi = 0; oi < ops.size(); ++oi) {
+        if (!(ops[oi].bits & supp)) continue;
+        if (ops[oi].type == LOW_DIAG && !(ops[oi].bits & m.terms[size_t(ti)].x)) continue;
+        ready = std::max(ready, done[oi] ? op_pass[oi] : pending_pass);
+      }
+    }
+    return ready;
+  };
+  auto pass_set = [&](const Pass& q) {
+    uint32_t S = 0;
+    for (int bb : q.local_pos) S |= 1u << bb;
+    return S;
+  };
+
   while (n_done < ops.size()) {
     // ---- candidate local sets -------------------------------------------------
     std::vector<uint32_t> cands;
@@ -462,6 +493,36 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
         }
         for (int bit = n_eff - 1; bit >= 0 && popc(S) < K; --bit) if (!(S >> bit & 1)) S |= 1u << bit;
         cands.push_back(S);
+      }
+    }
+    if (!adjoint && K < n_eff && !groups.empty()) {
+      // If one tile can hold every remaining op, this is the last gate pass: spend its spare local
+      // bits on the X-masks of the groups no earlier pass can measure, so that the measurement
+      // needs no pass (a full read of the state) of its own -- only if ALL of them fit (a
+      // scattered local set that still leaves a measurement pass costs more than it saves).
+      // Listed first: ties go to it.
+      uint32_t S = (1u << c_min) - 1;
+      bool fits = true;
+      for (int oi : order) {
+        if (done[oi]) continue;
+        const LoweredOp& op = ops[oi];
+        const uint32_t need = op.type == LOW_DIAG ? (op.bits & S ? 0u : (op.bits & (0u - op.bits))) : op.bits;
+        if (popc(S | need) > K) { fits = false; break; }
+        S |= need;
+      }
+      if (fits) {
+        const int here = int(plan->passes.size());
+        for (size_t gi = 0; gi < groups.size() && fits; ++gi) {
+          const int ready = group_ready(gi, here);
+          bool earlier = false;
+          for (int pi = ready; pi < here && !earlier; ++pi) earlier = (groups[gi].x & ~pass_set(plan->passes[size_t(pi)])) == 0;
+          if (earlier) continue;
+          if (popc(S | groups[gi].x) <= K) S |= groups[gi].x; else fits = false;  // all or nothing
+        }
+      }
+      if (fits) {
+        for (int bit = n_eff - 1; bit >= 0 && popc(S) < K; --bit) if (!(S >> bit & 1)) S |= 1u << bit;
+        cands.insert(cands.begin(), S);
       }
     }
     uint32_t best_S = 0;
@@ -513,36 +574,16 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   plan->passes.front().flags |= PASS_INIT_BASIS;
   plan->passes.back().completes_circuit = true;
 
-  std::vector<MeasGroup> groups;
-  for (size_t ti = 0; ti < m.terms.size(); ++ti) {
-    const uint32_t x = m.terms[ti].x;
-    auto it = std::find_if(groups.begin(), groups.end(), [&](const MeasGroup& g) { return g.x == x; });
-    if (it == groups.end()) { groups.push_back(MeasGroup{x, {}}); it = groups.end() - 1; }
-    it->terms.push_back(int(ti));
-  }
   std::vector<char> gdone(groups.size(), 0);
   size_t g_left = groups.size();
-  // A term may be measured as soon as every op that does not commute with it has run: ops on
-  // disjoint bits commute, and so does a diagonal op that meets the term only where the term
-  // is Z.  Each X-mask group goes to the earliest pass after that point whose tile holds its
-  // flipped bits -- usually a pass that exists anyway, so the HEA + nearest-neighbour sums of
-  // the benchmarks need no measurement-only pass (one full read of the state saved).
+  // Each X-mask group goes to the earliest pass after its last non-commuting op whose tile holds
+  // its flipped bits -- usually a pass that exists anyway.
   {
     std::vector<std::vector<int>> early(plan->passes.size());
     for (size_t gi = 0; gi < groups.size(); ++gi) {
-      int ready = 0;
-      for (int ti : groups[gi].terms) {
-        const uint32_t supp = m.terms[size_t(ti)].x | m.terms[size_t(ti)].z;
-        for (size_t oi = 0; oi < ops.size(); ++oi) {
-          if (!(ops[oi].bits & supp)) continue;
-          if (ops[oi].type == LOW_DIAG && !(ops[oi].bits & m.terms[size_t(ti)].x)) continue;
-          ready = std::max(ready, op_pass[oi]);
-        }
-      }
+      const int ready = group_ready(gi, int(plan->passes.size()) - 1);
       for (size_t pi = size_t(ready); pi + 1 < plan->passes.size(); ++pi) {  // the last pass is handled below
-        uint32_t S = 0;
-        for (int bb : plan->passes[pi].local_pos) S |= 1u << bb;
-        if ((groups[gi].x & ~S) == 0) {
+        if ((groups[gi].x & ~pass_set(plan->passes[pi])) == 0) {
           early[pi].push_back(int(gi));
           gdone[gi] = 1;
           --g_left;
