@@ -134,6 +134,22 @@ void fill_args(const Plan& plan, const Model& m, std::vector<PassArgs>* args, st
     tables->insert(tables->end(), p.spread.begin(), p.spread.end());
     args->push_back(a);
   }
+  if (plan.adjoint) {
+    // Amplitude-space pruning of the tail of the backward sweep.  At the start of adjoint pass p,
+    // psi is (the circuit's FIRST ops, those of passes p..last) applied to the basis state, and no
+    // bit that is non-local in all of those passes has been acted on other than diagonally: psi is
+    // zero wherever such a bit differs from the input bitstring, so those tiles add nothing to any
+    // gradient, and lambda there is only ever paired with zero psi in later passes (the masks are
+    // nested).  The kernel skips them outright.
+    uint32_t common = ~0u;
+    for (size_t i = args->size(); i-- > 0;) {
+      uint32_t nl = 0;
+      for (uint32_t k = 0; k < (*args)[i].n_nonlocal; ++k) nl |= 1u << (*args)[i].nonlocal_pos[k];
+      common &= nl;
+      (*args)[i].zero_mask = common;
+      if (!common) break;
+    }
+  }
 }
 
 int build_plans(qhbm_engine* h) {
@@ -290,7 +306,7 @@ int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_pa
       hipEvent_t* ev = timer_begin(h, 1, stream);
       PassArgs ba = b.args[i];
       if (h->opt_force_general) ba.flags |= PASS_GENERAL;
-      HIPCHK(launch_pass_adj(b.plan.K, ba, c, h->psi.p, h->lam.p, b.prog.p, b.tables.p, b.coef.p,
+      HIPCHK(launch_pass_adj(b.plan.K, ba, c, h->psi.p, h->lam.p, d_bits, h->model.n, b.prog.p, b.tables.p, b.coef.p,
                              h->state_grad.p, n_slots, s0, stream));
       timer_end(ev, stream);
     }

@@ -29,6 +29,7 @@ hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, f
                            int n_user, const uint32_t* prog, const uint32_t* tables, const float* coef,
                            float* out, uint32_t state0, hipStream_t stream);
 hipError_t launch_pass_adj(int K, const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
+                           const int8_t* bits, int n_user,
                            const uint32_t* prog, const uint32_t* tables, const float* coef,
                            float* state_grad, uint32_t n_slots_total,
                            uint32_t state0, hipStream_t stream);

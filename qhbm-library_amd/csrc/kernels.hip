@@ -842,7 +842,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
 // ================================================================================
 template <int K, bool GEN>
 __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kernel(
-    PassArgs a, float2* __restrict__ psi, float2* __restrict__ lam,
+    PassArgs a, float2* __restrict__ psi, float2* __restrict__ lam, const int8_t* __restrict__ bits, int n_user,
     const uint32_t* __restrict__ prog_base, const uint32_t* __restrict__ tables,
     const float* __restrict__ coef, float* __restrict__ state_grad /*[U, n_slots_total]*/,
     uint32_t n_slots_total, uint32_t state0) {
@@ -860,6 +860,10 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
   const uint32_t tile_id = blockIdx.x & ((1u << a.n_nonlocal) - 1u);
   const uint32_t s_local = blockIdx.x >> a.n_nonlocal;
   const TileCtx t = make_tile_ctx(a, tables, tile_id);
+  if (a.zero_mask) {  // tail of the sweep: psi is identically zero on this tile (engine.cpp fill_args)
+    const uint32_t idx = uni(basis_index(bits + size_t(state0 + s_local) * n_user, n_user));
+    if ((idx ^ t.tile_base) & a.zero_mask) return;
+  }
   float2* sp = psi + (size_t(s_local) << a.n);
   float2* sl = lam + (size_t(s_local) << a.n);
   {
@@ -1348,7 +1352,7 @@ hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, f
 
 template <int K, bool GEN>
 static hipError_t launch_adj_t(const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
-                               const uint32_t* prog, const uint32_t* tables, const float* coef,
+                               const int8_t* bits, int n_user, const uint32_t* prog, const uint32_t* tables, const float* coef,
                                float* state_grad, uint32_t n_slots_total,
                                uint32_t state0, hipStream_t stream) {
   const size_t lds = adj_lds_bytes(K);
@@ -1360,24 +1364,24 @@ static hipError_t launch_adj_t(const PassArgs& a, uint32_t n_states, float2* psi
     attr_done = true;
   }
   const uint32_t grid = n_states << a.n_nonlocal;
-  hipLaunchKernelGGL((pass_adj_kernel<K, GEN>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, lam, prog,
-                     tables, coef, state_grad, n_slots_total, state0);
+  hipLaunchKernelGGL((pass_adj_kernel<K, GEN>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, lam, bits,
+                     n_user, prog, tables, coef, state_grad, n_slots_total, state0);
   return hipGetLastError();
 }
 
 hipError_t launch_pass_adj(int K, const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
-                           const uint32_t* prog, const uint32_t* tables, const float* coef,
+                           const int8_t* bits, int n_user, const uint32_t* prog, const uint32_t* tables, const float* coef,
                            float* state_grad, uint32_t n_slots_total,
                            uint32_t state0, hipStream_t stream) {
   switch (K) {
-    case 10: return (a.flags & PASS_GENERAL) ? launch_adj_t<10, true>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream)
-                                            : launch_adj_t<10, false>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream);
-    case 11: return (a.flags & PASS_GENERAL) ? launch_adj_t<11, true>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream)
-                                            : launch_adj_t<11, false>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream);
-    case 12: return (a.flags & PASS_GENERAL) ? launch_adj_t<12, true>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream)
-                                            : launch_adj_t<12, false>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream);
-    case 13: return (a.flags & PASS_GENERAL) ? launch_adj_t<13, true>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream)
-                                            : launch_adj_t<13, false>(a, n_states, psi, lam, prog, tables, coef, state_grad, n_slots_total, state0, stream);
+    case 10: return (a.flags & PASS_GENERAL) ? launch_adj_t<10, true>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, state_grad, n_slots_total, state0, stream)
+                                            : launch_adj_t<10, false>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, state_grad, n_slots_total, state0, stream);
+    case 11: return (a.flags & PASS_GENERAL) ? launch_adj_t<11, true>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, state_grad, n_slots_total, state0, stream)
+                                            : launch_adj_t<11, false>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, state_grad, n_slots_total, state0, stream);
+    case 12: return (a.flags & PASS_GENERAL) ? launch_adj_t<12, true>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, state_grad, n_slots_total, state0, stream)
+                                            : launch_adj_t<12, false>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, state_grad, n_slots_total, state0, stream);
+    case 13: return (a.flags & PASS_GENERAL) ? launch_adj_t<13, true>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, state_grad, n_slots_total, state0, stream)
+                                            : launch_adj_t<13, false>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, state_grad, n_slots_total, state0, stream);
     default: return hipErrorInvalidValue;
   }
 }

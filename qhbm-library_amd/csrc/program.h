@@ -133,6 +133,7 @@ struct PassArgs {
   uint32_t n_nonlocal;     // n - K
   uint32_t prog_off;       // word offset of this pass's program
   uint32_t spread_off;     // offset of spread_hi[2^(K-c)] in the tables buffer
+  uint32_t zero_mask;      // adjoint: index bits non-local in this and every later pass (see fill_args)
   uint32_t spread_shift;   // local bits above c contiguous from bit s: spread_hi[j] = j << s (no lookup); else ~0u
   uint32_t n_ops;          // observables (row length of out)
   uint32_t slot_base;      // adjoint: first gradient slot of this pass
