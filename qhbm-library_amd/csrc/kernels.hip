@@ -148,13 +148,42 @@ __device__ __forceinline__ v2f conj_cs(v2f cs) { return v2f{cs.x, -cs.y}; }
 // compiler keep the file as ONE 1024-bit tuple and copy it on every update).
 template <int N> using iseq = std::make_integer_sequence<int, N>;
 
-template <int R, int RB, int... P>
-__device__ __forceinline__ void apply_x_(v2f (&a)[1 << R], v2f cs, std::integer_sequence<int, P...>) {
-  (x_pair(a[ins0<RB>(P)], a[ins0<RB>(P) | (1 << RB)], cs), ...);
+// Four pairs per asm statement: the compiler pads every inline-asm block with an s_nop (it cannot
+// see the hazards inside), so fewer, longer blocks issue fewer of them; the eight independent
+// multiplies also go first, ahead of the FMAs that consume them.
+__device__ __forceinline__ void x_pair4(v2f& a0, v2f& a1, v2f& b0, v2f& b1, v2f& c0, v2f& c1, v2f& d0, v2f& d1, v2f cs) {
+  v2f t0, t1, t2, t3, t4, t5, t6, t7;
+  asm("v_pk_mul_f32 %[t0], %[a0], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t1], %[a1], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t2], %[b0], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t3], %[b1], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t4], %[c0], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t5], %[c1], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t6], %[d0], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t7], %[d1], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %[a0], %[a0], %[cs], %[t1] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[a1], %[a1], %[cs], %[t0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[b0], %[b0], %[cs], %[t3] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[b1], %[b1], %[cs], %[t2] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[c0], %[c0], %[cs], %[t5] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[c1], %[c1], %[cs], %[t4] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[d0], %[d0], %[cs], %[t7] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[d1], %[d1], %[cs], %[t6] op_sel_hi:[1,0,1]"
+      : [a0] "+v"(a0), [a1] "+v"(a1), [b0] "+v"(b0), [b1] "+v"(b1), [c0] "+v"(c0), [c1] "+v"(c1),
+        [d0] "+v"(d0), [d1] "+v"(d1), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
+        [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7)
+      : [cs] "s"(cs));
+}
+template <int R, int RB, int... Q>
+__device__ __forceinline__ void apply_x_(v2f (&a)[1 << R], v2f cs, std::integer_sequence<int, Q...>) {
+  static_assert(R == 4, "x_pair4 covers the eight pairs of a 16-amplitude register file in two calls");
+  (x_pair4(a[ins0<RB>(4 * Q)], a[ins0<RB>(4 * Q) | (1 << RB)], a[ins0<RB>(4 * Q + 1)], a[ins0<RB>(4 * Q + 1) | (1 << RB)],
+           a[ins0<RB>(4 * Q + 2)], a[ins0<RB>(4 * Q + 2) | (1 << RB)], a[ins0<RB>(4 * Q + 3)],
+           a[ins0<RB>(4 * Q + 3) | (1 << RB)], cs), ...);
 }
 // c*I - i*s*X  on register bit RB
 template <int R, int RB>
-__device__ __forceinline__ void apply_x(v2f (&a)[1 << R], v2f cs) { apply_x_<R, RB>(a, cs, iseq<(1 << (R - 1))>{}); }
+__device__ __forceinline__ void apply_x(v2f (&a)[1 << R], v2f cs) { apply_x_<R, RB>(a, cs, iseq<(1 << (R - 3))>{}); }
 
 template <int R, int RB, int... P>
 __device__ __forceinline__ void apply_y_(v2f (&a)[1 << R], v2f cs, std::integer_sequence<int, P...>) {
