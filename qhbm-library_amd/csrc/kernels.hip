@@ -229,9 +229,25 @@ __device__ __forceinline__ void apply_ph1_(v2f (&a)[1 << R], v2f cs, std::intege
 template <int R, int RB>
 __device__ __forceinline__ void apply_ph1(v2f (&a)[1 << R], v2f cs) { apply_ph1_<R, RB>(a, cs, iseq<(1 << (R - 1))>{}); }
 
-template <int R, int RB, int... P>
-__device__ __forceinline__ void apply_ph1_v_(v2f (&a)[1 << R], v2f cs, std::integer_sequence<int, P...>) {
-  (phase_v(a[ins0<RB>(P) | (1 << RB)], cs), ...);
+// a_k <- (c + i s) a_k for eight amplitudes in one asm statement (see x_pair4).
+__device__ __forceinline__ void phase_v8(v2f& a0, v2f& a1, v2f& a2, v2f& a3, v2f& a4, v2f& a5, v2f& a6, v2f& a7, v2f cs) {
+  v2f t0, t1, t2, t3, t4, t5, t6, t7;
+#define QHBM_PH_MUL(K_) "v_pk_mul_f32 %[t" #K_ "], %[a" #K_ "], %[cs] op_sel_hi:[1,0]\n\t"
+#define QHBM_PH_FMA(K_) "v_pk_fma_f32 %[a" #K_ "], %[a" #K_ "], %[cs], %[t" #K_ "] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+  asm(QHBM_PH_MUL(0) QHBM_PH_MUL(1) QHBM_PH_MUL(2) QHBM_PH_MUL(3) QHBM_PH_MUL(4) QHBM_PH_MUL(5) QHBM_PH_MUL(6) QHBM_PH_MUL(7)
+      QHBM_PH_FMA(0) QHBM_PH_FMA(1) QHBM_PH_FMA(2) QHBM_PH_FMA(3) QHBM_PH_FMA(4) QHBM_PH_FMA(5) QHBM_PH_FMA(6) "v_pk_fma_f32 %[a7], %[a7], %[cs], %[t7] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+      : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6),
+        [a7] "+v"(a7), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5),
+        [t6] "=&v"(t6), [t7] "=&v"(t7)
+      : [cs] "v"(cs));
+#undef QHBM_PH_MUL
+#undef QHBM_PH_FMA
+}
+template <int R, int RB>
+__device__ __forceinline__ void apply_ph1_v_(v2f (&a)[1 << R], v2f cs, std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>) {
+  constexpr int B = 1 << RB;
+  phase_v8(a[ins0<RB>(0) | B], a[ins0<RB>(1) | B], a[ins0<RB>(2) | B], a[ins0<RB>(3) | B], a[ins0<RB>(4) | B],
+           a[ins0<RB>(5) | B], a[ins0<RB>(6) | B], a[ins0<RB>(7) | B], cs);
 }
 // same with a per-thread coefficient
 template <int R, int RB>
