@@ -276,10 +276,25 @@ __device__ __forceinline__ void acc_re(v2f& acc, v2f l, v2f p) {
 __device__ __forceinline__ float re_conj(v2f l, v2f p) { return l.x * p.x + l.y * p.y; }  // Re(conj(l) p)
 
 // sum over selected registers of Im(conj(lam) psi); two packed accumulators break the chain
-template <int R, int RB, int... P>
-__device__ __forceinline__ float sum_w1_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], std::integer_sequence<int, P...>) {
+// Eight accumulations into two partial sums in one asm statement (see x_pair4).
+__device__ __forceinline__ void acc_im8(v2f& a0, v2f& a1, v2f l0, v2f p0, v2f l1, v2f p1, v2f l2, v2f p2, v2f l3, v2f p3,
+                                        v2f l4, v2f p4, v2f l5, v2f p5, v2f l6, v2f p6, v2f l7, v2f p7) {
+#define QHBM_ACC(A_, K_) "v_pk_fma_f32 %[" #A_ "], %[l" #K_ "], %[p" #K_ "], %[" #A_ "] op_sel:[0,1,0] op_sel_hi:[1,0,1]\n\t"
+  asm(QHBM_ACC(a0, 0) QHBM_ACC(a1, 1) QHBM_ACC(a0, 2) QHBM_ACC(a1, 3) QHBM_ACC(a0, 4) QHBM_ACC(a1, 5) QHBM_ACC(a0, 6)
+      "v_pk_fma_f32 %[a1], %[l7], %[p7], %[a1] op_sel:[0,1,0] op_sel_hi:[1,0,1]"
+      : [a0] "+v"(a0), [a1] "+v"(a1)
+      : [l0] "v"(l0), [p0] "v"(p0), [l1] "v"(l1), [p1] "v"(p1), [l2] "v"(l2), [p2] "v"(p2), [l3] "v"(l3), [p3] "v"(p3),
+        [l4] "v"(l4), [p4] "v"(p4), [l5] "v"(l5), [p5] "v"(p5), [l6] "v"(l6), [p6] "v"(p6), [l7] "v"(l7), [p7] "v"(p7));
+#undef QHBM_ACC
+}
+template <int R, int RB>
+__device__ __forceinline__ float sum_w1_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>) {
+  constexpr int B = 1 << RB;
   v2f a0 = v2f{0.f, 0.f}, a1 = v2f{0.f, 0.f};
-  (acc_im((P & 1) ? a1 : a0, l[ins0<RB>(P) | (1 << RB)], p[ins0<RB>(P) | (1 << RB)]), ...);
+  acc_im8(a0, a1, l[ins0<RB>(0) | B], p[ins0<RB>(0) | B], l[ins0<RB>(1) | B], p[ins0<RB>(1) | B], l[ins0<RB>(2) | B],
+          p[ins0<RB>(2) | B], l[ins0<RB>(3) | B], p[ins0<RB>(3) | B], l[ins0<RB>(4) | B], p[ins0<RB>(4) | B],
+          l[ins0<RB>(5) | B], p[ins0<RB>(5) | B], l[ins0<RB>(6) | B], p[ins0<RB>(6) | B], l[ins0<RB>(7) | B],
+          p[ins0<RB>(7) | B]);
   return (a0.x + a1.x) - (a0.y + a1.y);
 }
 template <int R, int RB>
@@ -301,8 +316,13 @@ __device__ __forceinline__ float sum_w2(const v2f (&p)[1 << R], const v2f (&l)[1
 // of the fast-path gates.  X: pairs swap.  Y: (Y psi)_0 = -i psi_1, (Y psi)_1 = i psi_0.
 template <int R, int RB, int... M>
 __device__ __forceinline__ float im_lam_x_psi_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], std::integer_sequence<int, M...>) {
-  v2f a0 = v2f{0.f, 0.f}, a1 = v2f{0.f, 0.f};
-  (acc_im((M & 1) ? a1 : a0, l[M], p[M ^ (1 << RB)]), ...);  // Im(conj(lam_m) * psi_{m ^ bit})
+  static_assert(sizeof...(M) == 16, "two statements of eight");
+  constexpr int B = 1 << RB;
+  v2f a0 = v2f{0.f, 0.f}, a1 = v2f{0.f, 0.f};  // Im(conj(lam_m) * psi_{m ^ bit}) over all m
+  acc_im8(a0, a1, l[0], p[0 ^ B], l[1], p[1 ^ B], l[2], p[2 ^ B], l[3], p[3 ^ B], l[4], p[4 ^ B], l[5], p[5 ^ B], l[6],
+          p[6 ^ B], l[7], p[7 ^ B]);
+  acc_im8(a0, a1, l[8], p[8 ^ B], l[9], p[9 ^ B], l[10], p[10 ^ B], l[11], p[11 ^ B], l[12], p[12 ^ B], l[13], p[13 ^ B],
+          l[14], p[14 ^ B], l[15], p[15 ^ B]);
   return (a0.x + a1.x) - (a0.y + a1.y);
 }
 template <int R, int RB>
