@@ -858,6 +858,8 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
         pc += 2;
         v2f w[NR];  // w = conj(psi[l ^ x]) * psi[l] at l = i*NT + tid
         meas_load<R, NT>(tile, uint32_t(tid), swz(xl), w);
+        uint32_t last_key = 0xffffffffu;  // (zhi, real/imag) of the signed register sum held in `sum`
+        float sum = 0.f;
         for (uint32_t k = 0; k < n_terms; ++k, pc += kMeasTermWords) {
           const uint32_t zl = uni(prog[pc]), zn = uni(prog[pc + 1]);
           const float cf = __uint_as_float(uni(prog[pc + 2]));
@@ -876,7 +878,11 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
           if (__popc(t.tile_base & zn) & 1) sfac = -sfac;
           if (__popc(uint32_t(tid) & zl) & 1) sfac = -sfac;
           const uint32_t zhi = zl >> (K - R);  // bits of l above the thread index
-          const float sum = (ny & 1) ? meas_sum<R, 1>(w, zhi) : meas_sum<R, 0>(w, zhi);
+          const uint32_t key = zhi | ((ny & 1u) << 16);
+          if (key != last_key) {  // terms of a group mostly differ in thread / tile bits only
+            sum = (ny & 1) ? meas_sum<R, 1>(w, zhi) : meas_sum<R, 0>(w, zhi);
+            last_key = key;
+          }
           acc = fmaf(sfac, sum, acc);
         }
       }
