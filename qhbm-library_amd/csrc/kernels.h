@@ -19,6 +19,7 @@ struct DevTerm {  // one Pauli term, amplitude-index bit space
 // never straddles a multiple of kObsTermChunk (the kernel stages that many terms in LDS at a time).
 struct ObsGroup {
   uint32_t x, end;
+  uint32_t has_imag;  // some term of the group has an odd number of Y factors (imaginary weight)
 };
 constexpr uint32_t kObsTermChunk = 1024;
 
