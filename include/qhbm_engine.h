@@ -135,6 +135,19 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U,
                          float* d_out_vals, float* d_grad, int method,
                          void* stream);
 
+/* The same pair as two calls for an autograd-style caller (forward now, backward later, as
+ * tf.custom_gradient / torch.autograd.Function drive qnn.py:134-138): qhbm_expectation_retain
+ * is qhbm_expectation but leaves the final states in the workspace when the batch fits one
+ * backward chunk; qhbm_expectation_vjp_retained then runs only lambda = O psi and the backward
+ * sweep on them (same bits and params as the retaining call) and consumes them.  It fails if
+ * nothing is retained -- any other compute call, or a batch too large, drops the states -- and
+ * the caller falls back to qhbm_expectation_vjp. */
+int qhbm_expectation_retain(qhbm_engine* h, const int8_t* d_bits, int U,
+                            const float* d_params, float* d_out, void* stream);
+int qhbm_expectation_vjp_retained(qhbm_engine* h, const int8_t* d_bits, int U,
+                                  const float* d_params, const float* d_upstream,
+                                  float* d_grad, void* stream);
+
 /* Full Jacobian d_jac[u, k, p] (tests / small n only; adjoint). */
 int qhbm_expectation_jacobian(qhbm_engine* h, const int8_t* d_bits, int U,
                               const float* d_params, float* d_out_vals,

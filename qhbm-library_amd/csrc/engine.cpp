@@ -69,6 +69,7 @@ struct qhbm_engine {
   // options
   int opt_tile = 0, opt_adj_tile = 0, opt_profile = 0, opt_round = 0;
   int opt_full_fwd = 60, opt_full_adj = 60, opt_force_general = 0;
+  int retained_U = 0;  // final states of the last qhbm_expectation_retain still sit in psi
   int64_t opt_chunk = 0;
   int64_t opt_budget_mb = 16384;
   // plans
@@ -154,6 +155,7 @@ void fill_args(const Plan& plan, const Model& m, std::vector<PassArgs>* args, st
 
 int build_plans(qhbm_engine* h) {
   if (h->plans_valid) return 0;
+  h->retained_U = 0;
   if (!h->have_circuit) return fail(h, "qhbm_set_circuit has not been called");
   if (h->model.n_ops > kMaxOps) return fail(h, "too many observables (max 1024)");
   std::string err;
@@ -267,6 +269,7 @@ int ensure_state_buffers(qhbm_engine* h, uint32_t cs, bool with_lam) {
 int forward(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, float* d_out,
             int shift_gate, double shift, hipStream_t stream) {
   DevicePlan& d = h->fwd;
+  h->retained_U = 0;
   HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, shift_gate,
                            shift, stream));
   HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), stream));
@@ -280,11 +283,39 @@ int forward(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, 
   return 0;
 }
 
+// lambda = O psi and the backward passes for one chunk whose final states sit in psi.
+int run_adjoint_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_t c, const float* d_upstream,
+                      hipStream_t stream) {
+  DevicePlan& b = h->adj;
+  const uint32_t n_slots = uint32_t(b.plan.slot_gate.size());
+  HIPCHK(launch_apply_observable(h->psi.p, h->lam.p, uint32_t(h->fwd.plan.n_eff), c, h->terms.p,
+                                 uint32_t(h->model.terms.size()), h->obs_groups.p, h->n_obs_groups, d_upstream,
+                                 uint32_t(h->model.n_ops), s0, stream));
+  for (size_t i = 0; i < b.plan.passes.size(); ++i) {
+    hipEvent_t* ev = timer_begin(h, 1, stream);
+    PassArgs ba = b.args[i];
+    if (h->opt_force_general) ba.flags |= PASS_GENERAL;
+    HIPCHK(launch_pass_adj(b.plan.K, ba, c, h->psi.p, h->lam.p, d_bits, h->model.n, b.prog.p, b.tables.p, b.coef.p,
+                           h->state_grad.p, n_slots, s0, stream));
+    timer_end(ev, stream);
+  }
+  return 0;
+}
+
+uint32_t adjoint_chunk_states(const qhbm_engine* h, int U) {
+  uint32_t cs = chunk_states(h, U);
+  if (h->opt_chunk <= 0)  // two buffers per state
+    cs = uint32_t(std::min<size_t>(std::min<size_t>(size_t(U), 65535),
+                                   std::max<size_t>(1, (size_t(h->opt_budget_mb) << 20) / (2 * state_bytes(h)))));
+  return cs;
+}
+
 // values + per-state gradient slots (adjoint) for a given upstream.
 int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params,
                   const float* d_upstream, float* d_out_vals, hipStream_t stream) {
   DevicePlan& f = h->fwd;
   DevicePlan& b = h->adj;
+  h->retained_U = 0;
   const uint32_t n_slots = uint32_t(b.plan.slot_gate.size());
   HIPCHK(launch_prep_coefs(f.jobs.p, int(f.plan.jobs.size()), d_params, f.coef.p, -1, 0.0, stream));
   HIPCHK(launch_combine_diag(f.coef.p, f.rec_offsets.p, int(f.plan.record_offsets.size()), stream));
@@ -293,24 +324,12 @@ int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_pa
   HIPCHK(hipMemsetAsync(d_out_vals, 0, size_t(U) * h->model.n_ops * sizeof(float), stream));
   HIPCHK(h->state_grad.reserve(size_t(U) * std::max<uint32_t>(n_slots, 1)));
   HIPCHK(hipMemsetAsync(h->state_grad.p, 0, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), stream));
-  uint32_t cs = chunk_states(h, U);
-  if (h->opt_chunk <= 0)  // two buffers per state
-    cs = uint32_t(std::min<size_t>(std::min<size_t>(size_t(U), 65535), std::max<size_t>(1, (size_t(h->opt_budget_mb) << 20) / (2 * state_bytes(h)))));
+  const uint32_t cs = adjoint_chunk_states(h, U);
   if (int rc = ensure_state_buffers(h, cs, true)) return rc;
-  const uint32_t n_eff = uint32_t(f.plan.n_eff);
   for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += cs) {
     const uint32_t c = std::min<uint32_t>(cs, uint32_t(U) - s0);
     if (int rc = run_forward_chunk(h, d_bits, s0, c, d_out_vals, true, stream)) return rc;
-    HIPCHK(launch_apply_observable(h->psi.p, h->lam.p, n_eff, c, h->terms.p, uint32_t(h->model.terms.size()),
-                                   h->obs_groups.p, h->n_obs_groups, d_upstream, uint32_t(h->model.n_ops), s0, stream));
-    for (size_t i = 0; i < b.plan.passes.size(); ++i) {
-      hipEvent_t* ev = timer_begin(h, 1, stream);
-      PassArgs ba = b.args[i];
-      if (h->opt_force_general) ba.flags |= PASS_GENERAL;
-      HIPCHK(launch_pass_adj(b.plan.K, ba, c, h->psi.p, h->lam.p, d_bits, h->model.n, b.prog.p, b.tables.p, b.coef.p,
-                             h->state_grad.p, n_slots, s0, stream));
-      timer_end(ev, stream);
-    }
+    if (int rc = run_adjoint_chunk(h, d_bits, s0, c, d_upstream, stream)) return rc;
   }
   return 0;
 }
@@ -445,6 +464,42 @@ int qhbm_expectation(qhbm_engine* h, const int8_t* d_bits, int U, const float* d
   return forward(h, d_bits, U, d_params, d_out, -1, 0.0, static_cast<hipStream_t>(stream));
 }
 
+int qhbm_expectation_retain(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, float* d_out,
+                            void* stream) {
+  if (int rc = check_call(h, U)) return rc;
+  if (U == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (adjoint_chunk_states(h, U) < uint32_t(U))  // the batch does not fit one backward chunk: nothing kept
+    return forward(h, d_bits, U, d_params, d_out, -1, 0.0, s);
+  DevicePlan& d = h->fwd;
+  h->retained_U = 0;
+  HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, -1, 0.0, s));
+  HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), s));
+  HIPCHK(hipMemsetAsync(d_out, 0, size_t(U) * h->model.n_ops * sizeof(float), s));
+  if (int rc = ensure_state_buffers(h, uint32_t(U), true)) return rc;  // psi AND lambda, so psi is not moved later
+  if (int rc = run_forward_chunk(h, d_bits, 0, uint32_t(U), d_out, true, s)) return rc;
+  h->retained_U = U;
+  return 0;
+}
+
+int qhbm_expectation_vjp_retained(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params,
+                                  const float* d_upstream, float* d_grad, void* stream) {
+  if (int rc = check_call(h, U)) return rc;
+  if (U <= 0 || h->retained_U != U) return fail(h, "no retained forward state for this batch");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DevicePlan& b = h->adj;
+  h->retained_U = 0;  // the backward sweep un-applies psi in place: the state is consumed
+  const uint32_t n_slots = uint32_t(b.plan.slot_gate.size());
+  HIPCHK(launch_prep_coefs(b.jobs.p, int(b.plan.jobs.size()), d_params, b.coef.p, -1, 0.0, s));
+  HIPCHK(launch_combine_diag(b.coef.p, b.rec_offsets.p, int(b.plan.record_offsets.size()), s));
+  HIPCHK(h->state_grad.reserve(size_t(U) * std::max<uint32_t>(n_slots, 1)));
+  HIPCHK(hipMemsetAsync(h->state_grad.p, 0, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), s));
+  if (int rc = run_adjoint_chunk(h, d_bits, 0, uint32_t(U), d_upstream, s)) return rc;
+  HIPCHK(launch_reduce_grad(h->state_grad.p, uint32_t(U), n_slots, h->param_slot_begin.p, h->param_slots.p,
+                            h->slot_factor.p, d_grad, h->model.n_params, 0, s));
+  return 0;
+}
+
 int qhbm_statevector(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params,
                      void* d_out_states, void* stream) {
   if (!h) return 1;
@@ -454,6 +509,7 @@ int qhbm_statevector(qhbm_engine* h, const int8_t* d_bits, int U, const float* d
   if (U == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   DevicePlan& d = h->fwd;
+  h->retained_U = 0;
   HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, -1, 0.0, s));
   HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), s));
   // expectation values of installed observables are a by-product; they land in a scratch buffer
@@ -508,6 +564,7 @@ int qhbm_sample(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_para
   if (U == 0 || n_shots == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   DevicePlan& d = h->fwd;
+  h->retained_U = 0;
   HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, shift_gate, shift, s));
   HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), s));
   const size_t nv = size_t(U) * std::max(h->model.n_ops, 1);

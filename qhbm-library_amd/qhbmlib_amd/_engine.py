@@ -34,6 +34,7 @@ ABI_SYMBOLS = (
     "qhbm_abi_version", "qhbm_create", "qhbm_destroy", "qhbm_last_error",
     "qhbm_set_circuit", "qhbm_set_observables", "qhbm_set_option",
     "qhbm_workspace_bytes", "qhbm_expectation", "qhbm_expectation_vjp",
+    "qhbm_expectation_retain", "qhbm_expectation_vjp_retained",
     "qhbm_expectation_jacobian", "qhbm_statevector", "qhbm_sample", "qhbm_parity_energy", "qhbm_parity_energy_vjp",
     "qhbm_num_passes", "qhbm_describe_schedule",
     "qhbm_kernel_time_ms",
@@ -78,6 +79,8 @@ def load_library():
                                        ctypes.POINTER(ctypes.c_size_t)]
   lib.qhbm_expectation.argtypes = [vp, vp, i32, vp, vp, vp]
   lib.qhbm_expectation_vjp.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp]
+  lib.qhbm_expectation_retain.argtypes = [vp, vp, i32, vp, vp, vp]
+  lib.qhbm_expectation_vjp_retained.argtypes = [vp, vp, i32, vp, vp, vp, vp]
   lib.qhbm_expectation_jacobian.argtypes = [vp, vp, i32, vp, vp, vp, vp]
   lib.qhbm_statevector.argtypes = [vp, vp, i32, vp, vp, vp]
   lib.qhbm_sample.argtypes = [vp, vp, i32, vp, i32, ctypes.c_uint64, i32, ctypes.c_double, vp, vp]
@@ -151,6 +154,7 @@ class Engine:
     self.n_qubits = 0
     self.n_params = 0
     self.n_ops = 0
+    self.retained = None
 
   def close(self):
     if getattr(self, "_h", None) is not None and self._h:
@@ -253,18 +257,42 @@ class Engine:
   def _stream(self):
     return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-  def expectation(self, bits, params):
+  def expectation(self, bits, params, retain=False):
+    """Values [batch, n_ops].  With `retain`, the final states stay in the workspace for one
+    `expectation_vjp_retained` (same bits and params); `self.retained` is then a token, or None
+    when the batch was too large to keep."""
     bits, params = self._prep(bits, params)
     out = torch.empty((bits.shape[0], self.n_ops), dtype=torch.float32,
                       device=self.device)
+    fn = self._lib.qhbm_expectation_retain if retain else self._lib.qhbm_expectation
+    self.retained = None
     with torch.cuda.device(self.device):
-      self._check(
-          self._lib.qhbm_expectation(self._h, bits.data_ptr(), bits.shape[0],
-                                     params.data_ptr(), out.data_ptr(),
-                                     self._stream()))
+      self._check(fn(self._h, bits.data_ptr(), bits.shape[0], params.data_ptr(), out.data_ptr(),
+                     self._stream()))
+    if retain and bits.shape[0] > 0:
+      self._retain_count = getattr(self, "_retain_count", 0) + 1
+      self.retained = self._retain_count
     return out
 
+  def expectation_vjp_retained(self, bits, params, upstream):
+    """grad[n_params] from the states kept by `expectation(..., retain=True)`; raises
+    EngineError if they are gone (then call `expectation_vjp`)."""
+    bits, params = self._prep(bits, params)
+    upstream = torch.as_tensor(upstream).to(
+        device=self.device, dtype=torch.float32).contiguous()
+    if tuple(upstream.shape) != (bits.shape[0], self.n_ops):
+      raise ValueError("upstream must have shape [batch, n_ops]")
+    grad = torch.zeros((self.n_params,), dtype=torch.float32, device=self.device)
+    self.retained = None
+    with torch.cuda.device(self.device):
+      self._check(
+          self._lib.qhbm_expectation_vjp_retained(self._h, bits.data_ptr(), bits.shape[0],
+                                                  params.data_ptr(), upstream.data_ptr(),
+                                                  grad.data_ptr(), self._stream()))
+    return grad
+
   def expectation_vjp(self, bits, params, upstream, method=GRAD_ADJOINT):
+    self.retained = None
     bits, params = self._prep(bits, params)
     upstream = torch.as_tensor(upstream).to(
         device=self.device, dtype=torch.float32).contiguous()
@@ -285,6 +313,7 @@ class Engine:
 
   def statevector(self, bits, params):
     """Final states C(params)|x_u>, complex64 [batch, 2^n] (qubit 0 = most significant bit)."""
+    self.retained = None
     bits, params = self._prep(bits, params)
     out = torch.empty((bits.shape[0], 1 << self.n_qubits), dtype=torch.complex64,
                       device=self.device)
@@ -298,6 +327,7 @@ class Engine:
   def sample(self, bits, params, n_shots, seed=0, shift_gate=-1, shift=0.0):
     """int8 [batch, n_shots, n_qubits]: computational-basis samples of C(params)|x_u>;
     `shift_gate`/`shift` select one parameter-shifted program (see include/qhbm_engine.h)."""
+    self.retained = None
     bits, params = self._prep(bits, params)
     out = torch.empty((bits.shape[0], int(n_shots), self.n_qubits), dtype=torch.int8,
                       device=self.device)
@@ -309,6 +339,7 @@ class Engine:
     return out
 
   def expectation_jacobian(self, bits, params):
+    self.retained = None
     bits, params = self._prep(bits, params)
     vals = torch.empty((bits.shape[0], self.n_ops), dtype=torch.float32,
                        device=self.device)

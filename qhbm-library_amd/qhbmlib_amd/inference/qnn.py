@@ -29,13 +29,21 @@ class _ExpectationFunction(torch.autograd.Function):
   def forward(ctx, symbol_values, engine, bits, method):
     ctx.engine, ctx.bits, ctx.method = engine, bits, method
     ctx.save_for_backward(symbol_values)
-    return engine.expectation(bits, symbol_values.detach())
+    # the forward leaves its final states in the engine's workspace: if nothing else runs on this
+    # engine before backward(), the backward sweep starts from them instead of simulating again
+    retain = method == _engine.GRAD_ADJOINT and ctx.needs_input_grad[0]
+    out = engine.expectation(bits, symbol_values.detach(), retain=retain)
+    ctx.token = engine.retained
+    return out
 
   @staticmethod
   def backward(ctx, upstream):
     (symbol_values,) = ctx.saved_tensors
-    _, grad = ctx.engine.expectation_vjp(ctx.bits, symbol_values.detach(), upstream.contiguous(),
-                                         ctx.method)
+    eng = ctx.engine
+    if ctx.token is not None and eng.retained == ctx.token:
+      grad = eng.expectation_vjp_retained(ctx.bits, symbol_values.detach(), upstream.contiguous())
+    else:
+      _, grad = eng.expectation_vjp(ctx.bits, symbol_values.detach(), upstream.contiguous(), ctx.method)
     return grad.to(symbol_values.device), None, None, None
 
 

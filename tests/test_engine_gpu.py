@@ -269,3 +269,35 @@ def test_batch_larger_than_a_grid_dimension():
   np.testing.assert_allclose(vals2.cpu().numpy(), want, atol=1e-5)
   want_g = float(((1.0 - 2.0 * bits) * (-math.pi * math.sin(math.pi * 0.37))).sum() / states)
   np.testing.assert_allclose(grad.cpu().numpy()[0], want_g, atol=1e-4 * max(1.0, abs(want_g)))
+
+
+def test_retained_forward_state():
+  """qhbm_expectation_retain + qhbm_expectation_vjp_retained equal the one-call VJP, the states
+  are consumed by one backward sweep, any other call drops them, and a batch that does not fit one
+  backward chunk is simply not retained."""
+  n, layers = 14, 3
+  gates, names = O.hea_gates(n, layers, "r")
+  rng = np.random.default_rng(9)
+  params = rng.uniform(-1, 1, len(names)).astype(np.float32)
+  ops = [O.xxz_chain_op(n), O.tfim_ring_op(n)]
+  bits = _random_bits(rng, 6, n)
+  up = rng.normal(size=(6, 2)).astype(np.float32)
+  eng = _engine(n, gates, len(names), ops, tile_qubits=11, adjoint_tile_qubits=10)
+  want_vals, want_grad = eng.expectation_vjp(bits, params, up)
+  vals = eng.expectation(bits, params, retain=True)
+  assert eng.retained is not None
+  grad = eng.expectation_vjp_retained(bits, params, up)
+  np.testing.assert_allclose(vals.cpu().numpy(), want_vals.cpu().numpy(), atol=1e-6)
+  np.testing.assert_allclose(grad.cpu().numpy(), want_grad.cpu().numpy(), atol=2e-6 * max(1.0, float(want_grad.abs().max())))
+  assert eng.retained is None
+  with pytest.raises(E.EngineError, match="no retained forward state"):
+    eng.expectation_vjp_retained(bits, params, up)            # consumed
+  eng.expectation(bits, params, retain=True)
+  eng.expectation(bits[:3], params)                            # another call drops the states
+  with pytest.raises(E.EngineError, match="no retained forward state"):
+    eng.expectation_vjp_retained(bits, params, up)
+  eng.set_option("chunk_states", 4)                            # 6 states do not fit one chunk
+  vals = eng.expectation(bits, params, retain=True)
+  np.testing.assert_allclose(vals.cpu().numpy(), want_vals.cpu().numpy(), atol=1e-6)
+  with pytest.raises(E.EngineError, match="no retained forward state"):
+    eng.expectation_vjp_retained(bits, params, up)

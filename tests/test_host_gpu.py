@@ -317,3 +317,28 @@ def test_more_observables_than_one_engine_call_holds():
   np.testing.assert_allclose(results[1][0], results[0][0], atol=1e-5)
   np.testing.assert_allclose(results[1][1], results[0][1], atol=1e-5)
   np.testing.assert_allclose(results[1][2], results[0][2], atol=1e-4)
+
+
+def test_autograd_backward_twice_and_interleaved_engines():
+  """The autograd function starts the backward sweep from the states its forward left in the
+  engine; a second backward (retain_graph) or an interleaved call must transparently re-simulate."""
+  n = 5
+  qubits = ir.GridQubit.rect(1, n)
+  circ = models.DirectQuantumCircuit(hea_circuit(qubits, 2, "a"))
+  _set(circ.trainable_variables[0], np.random.default_rng(2).uniform(-1, 1, len(circ.symbol_names)))
+  ops = [ir.PauliSum.from_pauli_strings([ir.PZ(q) for q in qubits])]
+  states = torch.tensor(list(itertools.product([0, 1], repeat=n))[:7], dtype=torch.int8)
+  qnn = inference.AnalyticQuantumInference(circ)
+  out = qnn.expectation(states, ops)
+  (g1,) = torch.autograd.grad(out.sum(), circ.trainable_variables, retain_graph=True)   # retained states
+  (g2,) = torch.autograd.grad(out.sum(), circ.trainable_variables, retain_graph=True)   # consumed: full VJP
+  np.testing.assert_allclose(g1.cpu().numpy(), g2.cpu().numpy(), atol=1e-6)
+  out_a = qnn.expectation(states, ops)
+  out_b = qnn.expectation(states[:3], ops)          # same engine: drops out_a's states
+  (ga,) = torch.autograd.grad(out_a.sum(), circ.trainable_variables)
+  (gb,) = torch.autograd.grad(out_b.sum(), circ.trainable_variables)
+  np.testing.assert_allclose(ga.cpu().numpy(), g1.cpu().numpy(), atol=1e-6)
+  flat = circ.pqc.flat_gates(circ.qubits, circ.symbol_names)
+  _, jac = O.expectation_jacobian(n, flat, circ.symbol_values.detach().numpy().astype(np.float64),
+                                  states[:3].numpy(), [op.masks(qubits) for op in ops])
+  np.testing.assert_allclose(gb.cpu().numpy(), jac.sum((0, 1)), atol=1e-4)
