@@ -191,6 +191,33 @@ class Builder {
           blocked |= op.bits;
         }
       }
+      if (!seq.empty() && K_ > R_) {
+        // The first-come register set above grows a trapezoid (4, 2 gates deep on a chain); a
+        // window of four consecutive local bits whose neighbours are already ahead can hold a
+        // diamond (2, 4, 2).  Try every window with the register set FIXED and keep the one that
+        // absorbs more one-qubit gates (ties: more ops) than the first-come set.
+        auto score = [&](const std::vector<size_t>& q) {
+          size_t mats = 0;
+          for (size_t i : q) mats += ops[absorbed[i]].type == LOW_MAT1;
+          return std::make_pair(mats, q.size());
+        };
+        auto best = score(seq);
+        for (int w = 0; w + R_ <= K_; ++w) {
+          const uint32_t fixed = ((1u << R_) - 1u) << w;
+          uint32_t blk = 0;
+          std::vector<size_t> cand;
+          for (size_t i = 0; i < absorbed.size(); ++i) {
+            if (emitted[i]) continue;
+            const LoweredOp& op = ops[absorbed[i]];
+            if (op.bits & blk) { blk |= op.bits; continue; }
+            if (op.type == LOW_MAT1 && (to_local(*p, op.bits) & fixed)) cand.push_back(i);
+            else if (op.type == LOW_DIAG && (to_local(*p, op.bits & S) & fixed)) cand.push_back(i);
+            else blk |= op.bits;
+          }
+          const auto sc = score(cand);
+          if (sc > best) { best = sc; seq.swap(cand); reg = fixed; }
+        }
+      }
       if (!seq.empty()) {
         for (int i = K_ - 1; i >= 0 && popc(reg) < R_; --i) if (!(reg >> i & 1)) reg |= 1u << i;
         emit_round(p, ops, absorbed, seq, reg, S);
