@@ -804,6 +804,9 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
 
   const uint32_t* prog = prog_base + a.prog_off;
   uint32_t pc = 0;
+  constexpr int NV = 1;
+  uint32_t cur[NV], nxt[NV];
+  uint32_t carried_off = 0xffffffffu;  // record offset whose words `cur` holds
   for (;;) {
     const uint32_t w0 = uni(prog[pc]);
     const uint32_t opc = w0 & 0xffu;
@@ -813,9 +816,10 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
       const uint32_t regmask = uni(prog[pc + 1]);
       uint32_t rec_off = uni(prog[pc + 2]);
       constexpr RecordLayout L(R, false);
-      constexpr int NV = 1;
-      uint32_t cur[NV], nxt[NV];
-      rec_load<NV>(recs, rec_off, lane, cur);
+      // The records of consecutive rounds are consecutive in the coefficient buffer, so the
+      // one-ahead prefetch of the previous round's last instance already holds this round's first
+      // record: reloading it would put a global-load latency in front of every round.
+      if (rec_off != carried_off) rec_load<NV>(recs, rec_off, lane, cur);
       uint32_t DB[R], T, TL;
       round_geometry<K, R>(regmask, tid, DB, &T, &TL);
       v2f amp[NR];
@@ -827,6 +831,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
 #pragma unroll
         for (int v = 0; v < NV; ++v) cur[v] = nxt[v];
       }
+      carried_off = rec_off;
       round_store<R>(tile, T, DB, amp);
       __syncthreads();
       pc += 3;
@@ -951,6 +956,9 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
 
   const uint32_t* prog = prog_base + a.prog_off;
   uint32_t pc = 0;
+  constexpr int NB = 1;
+  uint32_t cur[NB], nxt[NB], sv[1], svn[1];
+  uint32_t carried_off = 0xffffffffu;  // record offset whose words `cur` / `sv` hold
   for (;;) {
     const uint32_t w0 = uni(prog[pc]);
     const uint32_t opc = w0 & 0xffu;
@@ -960,10 +968,10 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
       const uint32_t regmask = uni(prog[pc + 1]);
       uint32_t rec_off = uni(prog[pc + 2]);
       constexpr RecordLayout L(R, true);
-      constexpr int NB = 1;
-      uint32_t cur[NB], nxt[NB], sv[1], svn[1];
-      rec_load<NB>(recs, rec_off, lane, cur);
-      rec_load<1>(recs, rec_off + L.slot0(), lane, sv);
+      if (rec_off != carried_off) {  // else: prefetched by the previous round's last instance
+        rec_load<NB>(recs, rec_off, lane, cur);
+        rec_load<1>(recs, rec_off + L.slot0(), lane, sv);
+      }
       uint32_t DB[R], T, TL;
       round_geometry<K, R>(regmask, tid, DB, &T, &TL);
       v2f p[NR], l[NR];
@@ -1076,6 +1084,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
         for (int v = 0; v < NB; ++v) cur[v] = nxt[v];
         sv[0] = svn[0];
       }
+      carried_off = rec_off;
       round_store<R>(tp, T, DB, p);
       round_store<R>(tl, T, DB, l);
       __syncthreads();
