@@ -812,7 +812,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
     const uint32_t opc = w0 & 0xffu;
     if (opc == OP_END) break;
     if (opc == OP_ROUND) {
-      const uint32_t n_inst = w0 >> 8;
+      const uint32_t n_inst = (w0 & ~kRoundNoBarrier) >> 8;
       const uint32_t regmask = uni(prog[pc + 1]);
       uint32_t rec_off = uni(prog[pc + 2]);
       constexpr RecordLayout L(R, false);
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
       }
       carried_off = rec_off;
       round_store<R>(tile, T, DB, amp);
-      __syncthreads();
+      if (!(w0 & kRoundNoBarrier)) __syncthreads();  // else the next round's waves read only their own writes
       pc += 3;
     } else if (opc == OP_GATE2) {
       if constexpr (GEN) {
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
     const uint32_t opc = w0 & 0xffu;
     if (opc == OP_END) break;
     if (opc == OP_ROUND) {
-      const uint32_t n_inst = w0 >> 8;
+      const uint32_t n_inst = (w0 & ~kRoundNoBarrier) >> 8;
       const uint32_t regmask = uni(prog[pc + 1]);
       uint32_t rec_off = uni(prog[pc + 2]);
       constexpr RecordLayout L(R, true);
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
       carried_off = rec_off;
       round_store<R>(tp, T, DB, p);
       round_store<R>(tl, T, DB, l);
-      __syncthreads();
+      if (!(w0 & kRoundNoBarrier)) __syncthreads();  // else the next round's waves read only their own writes
       pc += 3;
     } else {  // OP_GATE2
       if constexpr (GEN) {

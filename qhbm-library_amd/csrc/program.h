@@ -50,6 +50,7 @@ enum : uint32_t {
   OP_MEASURE = 3,  // [op | n_groups<<8] then groups x {[xl] [n_terms] terms x {[zl] [zn] [coef bits] [op_idx | ny<<24]}}
   OP_GATE2 = 4,    // [op | kind<<8] [pos_q0 | pos_q1<<8 (local bits)] [coef_off] [slot]
 };
+constexpr uint32_t kRoundNoBarrier = 1u << 31;  // OP_ROUND word 0: the next op is a round whose waves own the same amplitudes
 constexpr int kGate2Words = 4;
 constexpr int kMeasTermWords = 4;
 

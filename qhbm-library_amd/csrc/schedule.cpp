@@ -234,6 +234,23 @@ class Builder {
       }
       if (left == before) { *err = "internal: round packing made no progress"; return false; }
     }
+    // Barrier elision.  A thread's amplitudes are those whose non-register local bits spell its
+    // id, so a WAVE owns the amplitudes whose highest free bits spell the wave index.  When two
+    // consecutive rounds leave the same top bits free, every wave reads back only what it wrote
+    // itself (LDS serves one wave's accesses in order): no workgroup barrier between them.
+    const int wave_bits = K_ - R_ - 6;  // log2(waves per workgroup)
+    auto wave_mask = [&](uint32_t reg) {
+      uint32_t m = 0;
+      int taken = 0;
+      for (int b = K_ - 1; b >= 0 && taken < wave_bits; --b)
+        if (!(reg >> b & 1)) { m |= 1u << b; ++taken; }
+      return m;
+    };
+    for (size_t r = 0; r + 1 < p->round_words.size(); ++r) {
+      if (p->round_words[r + 1] != p->round_words[r] + 3) continue;  // something else sits in between
+      if (wave_bits <= 0 || wave_mask(p->round_regmasks[r]) == wave_mask(p->round_regmasks[r + 1]))
+        p->prog[p->round_words[r]] |= kRoundNoBarrier;
+    }
     return true;
   }
 
@@ -373,6 +390,7 @@ class Builder {
       const int slot = new_slot(p, op);
       if (adjoint_) rec[slot_lane] = uint32_t(slot);
     }
+    p->round_words.push_back(uint32_t(p->prog.size()));
     p->prog.push_back(OP_ROUND | (uint32_t(insts.size()) << 8));
     p->prog.push_back(reg);
     p->prog.push_back(first);

@@ -60,6 +60,7 @@ struct Pass {
   // statistics (DESIGN.md / bench roofline accounting)
   int n_mat_ops = 0, n_diag_terms = 0, n_rounds = 0, n_instances = 0;
   std::vector<uint32_t> round_regmasks;  // register-bit set of every OP_ROUND (introspection)
+  std::vector<uint32_t> round_words;     // index in `prog` of every OP_ROUND's first word
   int n_meas_groups = 0, n_meas_terms = 0;
   int slot_base = 0, n_slots = 0;
 };
