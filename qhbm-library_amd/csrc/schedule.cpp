@@ -574,11 +574,31 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     int best_mat = -1;
     size_t best_total = 0;
     std::vector<int> best_list;
+    // One pass of lookahead: a tile is ranked by the non-diagonal ops it absorbs PLUS the most a
+    // following contiguous-block tile could absorb (a pass is a full read and write of the state).
+    // Forward plans only: measured on the adjoint plan it saves a pass but costs two rounds (+6 %).
+    std::vector<uint32_t> blocks;
+    if (K < n_eff) {
+      const uint32_t low = (1u << c_min) - 1;
+      const int h = K - c_min;
+      for (int pp = c_min; pp + h <= n_eff; ++pp) blocks.push_back(low | (((1u << h) - 1) << pp));
+    }
     for (uint32_t S : cands) {
       int n_mat = 0;
       std::vector<int> lst = absorb(ops, order, done, S, all_bits, &n_mat);
-      if (n_mat > best_mat || (n_mat == best_mat && lst.size() > best_total)) {
-        best_mat = n_mat; best_total = lst.size(); best_S = S; best_list.swap(lst);
+      int next_best = 0;
+      if (!adjoint && !blocks.empty() && n_done + lst.size() < ops.size()) {
+        std::vector<char> done2(done);
+        for (int oi : lst) done2[oi] = 1;
+        for (uint32_t S2 : blocks) {
+          int m2 = 0;
+          absorb(ops, order, done2, S2, all_bits, &m2);
+          next_best = std::max(next_best, m2);
+        }
+      }
+      const int score = n_mat + next_best;
+      if (score > best_mat || (score == best_mat && lst.size() > best_total)) {
+        best_mat = score; best_total = lst.size(); best_S = S; best_list.swap(lst);
       }
     }
     if (best_list.empty()) { *err = "scheduler made no progress"; return false; }
