@@ -449,8 +449,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
 int qhbm_workspace_bytes(qhbm_engine* h, int U, int with_vjp, size_t* out) {
   if (!h || !out) return 1;
   if (int rc = build_plans(h)) return rc;
-  uint32_t cs = chunk_states(h, U);
-  if (with_vjp && h->opt_chunk <= 0) cs = std::max<uint32_t>(1, cs / 2);
+  const uint32_t cs = with_vjp ? adjoint_chunk_states(h, U) : chunk_states(h, U);  // as the calls chunk
   size_t b = size_t(cs) * state_bytes(h) * (with_vjp ? 2 : 1);
   if (with_vjp) b += size_t(U) * h->adj.plan.slot_gate.size() * sizeof(float);
   *out = b;
