@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define QHBM_ABI_VERSION 1
+#define QHBM_ABI_VERSION 2
 
 /* Gate kinds: the one-parameter "power gate" families of cirq 0.14.1 that
  * tensorflow-quantum 0.6.1 serialises.  A gate is
@@ -109,14 +109,21 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
 
 /* ---- tuning ------------------------------------------------------------ */
 /* Optional knobs (name -> value); unknown names are an error.
- *   "tile_qubits"   log2 amplitudes of one LDS tile (10..14), 0 = auto
- *   "chunk_states"  states simulated per launch group, 0 = auto
+ *   "tile_qubits"          log2 amplitudes of one LDS tile (10..14), 0 = auto
+ *   "adjoint_tile_qubits"  the same for the backward sweep (10..13), 0 = auto
+ *   "chunk_states"         states simulated per launch group, 0 = auto
+ *   "workspace_budget_mb"  cap on the statevector workspace; 0 = a third of the device's memory
+ *   "profile_events"       record HIP events around the pass kernels (qhbm_kernel_time_ms)
  */
 int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value);
 
 /* Bytes of device workspace the engine will hold for a batch of U states
  * (forward only, or forward + adjoint when with_vjp != 0). */
 int qhbm_workspace_bytes(qhbm_engine* h, int U, int with_vjp, size_t* out);
+
+/* Bytes of device memory the engine holds right now (statevector workspace and gradient
+ * partials); a host-side cache of engines uses it to bound its total footprint. */
+int qhbm_allocated_bytes(qhbm_engine* h, size_t* out);
 
 /* ---- hot path ---------------------------------------------------------- */
 /* out[u, k] = <x_u| C(params)^dagger  O_k  C(params) |x_u>
@@ -147,6 +154,10 @@ int qhbm_expectation_retain(qhbm_engine* h, const int8_t* d_bits, int U,
 int qhbm_expectation_vjp_retained(qhbm_engine* h, const int8_t* d_bits, int U,
                                   const float* d_params, const float* d_upstream,
                                   float* d_grad, void* stream);
+/* Number of states the workspace currently retains for qhbm_expectation_vjp_retained: U right
+ * after a qhbm_expectation_retain that kept its states, 0 otherwise (batch larger than one
+ * backward chunk, or any compute call since). */
+int qhbm_retained_states(qhbm_engine* h, int* out_U);
 
 /* Full Jacobian d_jac[u, k, p] (tests / small n only; adjoint). */
 int qhbm_expectation_jacobian(qhbm_engine* h, const int8_t* d_bits, int U,

@@ -71,7 +71,7 @@ struct qhbm_engine {
   int opt_full_fwd = 60, opt_full_adj = 60, opt_force_general = 0;
   int retained_U = 0;  // final states of the last qhbm_expectation_retain still sit in psi
   int64_t opt_chunk = 0;
-  int64_t opt_budget_mb = 16384;
+  int64_t opt_budget_mb = 0;  // 0: a third of the device's memory, resolved at first use (budget_bytes)
   // plans
   bool plans_valid = false;
   DevicePlan fwd, adj;
@@ -218,10 +218,26 @@ int upload_model(qhbm_engine* h) {
 
 size_t state_bytes(const qhbm_engine* h) { return size_t(8) << h->fwd.plan.n_eff; }
 
+// Workspace budget in bytes.  Default: a third of the device's memory (96 GB of the MI355X's 288 GB,
+// so BASELINE config 3's 4096 states x (psi, lambda) x 8 MiB = 64 GiB stay resident in one chunk).
+size_t budget_bytes(const qhbm_engine* h) {
+  if (h->opt_budget_mb > 0) return size_t(h->opt_budget_mb) << 20;
+  static size_t device_third[64] = {0};
+  const int d = h->device >= 0 && h->device < 64 ? h->device : 0;
+  if (!device_third[d]) {
+    size_t free_b = 0, total_b = 0;
+    if (h->device >= 0 && hipSetDevice(h->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+        total_b)
+      device_third[d] = total_b / 3;
+    else device_third[d] = size_t(16) << 30;  // planning-only engine: the figure is only reported
+  }
+  return device_third[d];
+}
+
 uint32_t chunk_states(const qhbm_engine* h, int U) {
   // (a chunk is also a grid dimension of the per-state kernels: at most 65535)
   if (h->opt_chunk > 0) return uint32_t(std::min<int64_t>(std::min<int64_t>(h->opt_chunk, U), 65535));
-  const size_t budget = size_t(h->opt_budget_mb) << 20;
+  const size_t budget = budget_bytes(h);
   const size_t fit = std::max<size_t>(1, budget / state_bytes(h));
   return uint32_t(std::min<size_t>(std::min<size_t>(fit, size_t(U)), 65535));
 }
@@ -306,7 +322,7 @@ uint32_t adjoint_chunk_states(const qhbm_engine* h, int U) {
   uint32_t cs = chunk_states(h, U);
   if (h->opt_chunk <= 0)  // two buffers per state
     cs = uint32_t(std::min<size_t>(std::min<size_t>(size_t(U), 65535),
-                                   std::max<size_t>(1, (size_t(h->opt_budget_mb) << 20) / (2 * state_bytes(h)))));
+                                   std::max<size_t>(1, budget_bytes(h) / (2 * state_bytes(h)))));
   return cs;
 }
 
@@ -440,7 +456,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "adjoint_full_diag_threshold") { h->opt_full_adj = int(value); h->plans_valid = false; }
   else if (k == "adjoint_tile_qubits") { h->opt_adj_tile = int(value); h->plans_valid = false; }
   else if (k == "chunk_states") h->opt_chunk = value;
-  else if (k == "workspace_budget_mb") h->opt_budget_mb = std::max<int64_t>(1, value);
+  else if (k == "workspace_budget_mb") h->opt_budget_mb = std::max<int64_t>(0, value);  // 0 = default
   else if (k == "profile_events") h->opt_profile = int(value);
   else return fail(h, "unknown option '" + k + "'");
   return 0;
@@ -453,6 +469,19 @@ int qhbm_workspace_bytes(qhbm_engine* h, int U, int with_vjp, size_t* out) {
   size_t b = size_t(cs) * state_bytes(h) * (with_vjp ? 2 : 1);
   if (with_vjp) b += size_t(U) * h->adj.plan.slot_gate.size() * sizeof(float);
   *out = b;
+  return 0;
+}
+
+int qhbm_allocated_bytes(qhbm_engine* h, size_t* out) {
+  if (!h || !out) return 1;
+  *out = h->psi.n * sizeof(float2) + h->lam.n * sizeof(float2) + h->state_grad.n * sizeof(float) +
+         h->block_cum.n * sizeof(double);
+  return 0;
+}
+
+int qhbm_retained_states(qhbm_engine* h, int* out_U) {
+  if (!h || !out_U) return 1;
+  *out_U = h->retained_U;
   return 0;
 }
 

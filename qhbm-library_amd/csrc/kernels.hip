@@ -705,51 +705,6 @@ __device__ __forceinline__ float meas_sum(const v2f (&w)[1 << R], uint32_t zhi) 
   return meas_sum_<R, IM>(w, zhi, iseq<(1 << R)>{});
 }
 
-// One forward instance on the register file.  Returns the advanced entry pointer.
-template <int R>
-__device__ __forceinline__ const uint32_t* instance_fwd(const uint32_t* __restrict__ ip,
-                                                        const float* __restrict__ coef, v2f (&a)[1 << R],
-                                                        uint32_t tl, uint32_t tile_base) {
-  const uint32_t h0 = uni(ip[0]), h1 = uni(ip[1]);
-  ip += 2;
-  // One-qubit gates: a separate predicated slot class per kind (X, Y, dense), each a
-  // plain if-then triangle around in-place code -- no merge copies.
-  QHBM_FOR_RB(R,
-    if ((h0 >> J) & 1u) {
-      const v2f cs = load_cs(coef + uni(ip[0]));
-      ip += 2;
-      apply_x<R, J>(a, cs);
-    })
-  QHBM_FOR_RB(R,
-    if ((h1 >> (16 + J)) & 1u) {
-      const v2f cs = load_cs(coef + uni(ip[0]));
-      ip += 2;
-      apply_y<R, J>(a, cs);
-    })
-  QHBM_FOR_RB(R,
-    if ((h1 >> (24 + J)) & 1u) {
-      const float* cf = coef + uni(ip[0]);
-      ip += 2;
-      apply_mat1<R, J>(a, cf);
-    })
-  QHBM_FOR_RB(R,
-    if ((h0 >> (8 + J)) & 1u) {
-      const v2f cs = load_cs(coef + uni(ip[0]));
-      ip += 2;
-      apply_ph1<R, J>(a, cs);
-    })
-  QHBM_FOR_PAIR(R,
-    if ((h0 >> (16 + pair_index(JA, JB))) & 1u) {
-      const v2f cs = load_cs(coef + uni(ip[0]));
-      ip += 2;
-      apply_ph2<R, JA, JB>(a, cs);
-    })
-  QHBM_FOR_RB(R,
-    if ((h1 >> (2 * J)) & 1u) ip = cph_fwd<R, J>(ip, coef, a, tl, tile_base);
-    if ((h1 >> (2 * J + 1)) & 1u) ip = cph_fwd<R, J>(ip, coef, a, tl, tile_base);)
-  return ip;
-}
-
 }  // namespace
 
 // ================================================================================
@@ -1401,6 +1356,7 @@ __global__ __launch_bounds__(256) void shift_accumulate_kernel(
 // ================================================================================
 // Host-side launchers
 // ================================================================================
+constexpr int kMaxDevices = 64;
 size_t fwd_lds_bytes(int K) { return (size_t(1) << K) * 8 + size_t(kMaxOps) * 4; }
 size_t adj_lds_bytes(int K) { return (size_t(2) << K) * 8 + size_t(kMaxSlotsPerPass) * 4; }
 
@@ -1410,12 +1366,15 @@ static hipError_t launch_fwd_t(const PassArgs& a, uint32_t n_states, float2* psi
                                const float* coef, float* out, uint32_t state0,
                                hipStream_t stream) {
   const size_t lds = fwd_lds_bytes(K);
-  static bool attr_done = false;
-  if (!attr_done) {
+  // (the opt-in to more than 64 KiB of LDS is per device: one flag per device of the process)
+  static bool attr_done[kMaxDevices] = {};
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  if (dev < 0 || dev >= kMaxDevices || !attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_fwd_kernel<K, R, GEN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return e;
-    attr_done = true;
+    if (dev >= 0 && dev < kMaxDevices) attr_done[dev] = true;
   }
   const uint32_t grid = n_states << a.n_nonlocal;
   hipLaunchKernelGGL((pass_fwd_kernel<K, R, GEN>), dim3(grid), dim3(1 << (K - R)), lds, stream, a, psi, bits,
@@ -1446,12 +1405,15 @@ static hipError_t launch_adj_t(const PassArgs& a, uint32_t n_states, float2* psi
                                float* state_grad, uint32_t n_slots_total,
                                uint32_t state0, hipStream_t stream) {
   const size_t lds = adj_lds_bytes(K);
-  static bool attr_done = false;
-  if (!attr_done) {
+  // (the opt-in to more than 64 KiB of LDS is per device: one flag per device of the process)
+  static bool attr_done[kMaxDevices] = {};
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  if (dev < 0 || dev >= kMaxDevices || !attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_adj_kernel<K, GEN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return e;
-    attr_done = true;
+    if (dev >= 0 && dev < kMaxDevices) attr_done[dev] = true;
   }
   const uint32_t grid = n_states << a.n_nonlocal;
   hipLaunchKernelGGL((pass_adj_kernel<K, GEN>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, lam, bits,

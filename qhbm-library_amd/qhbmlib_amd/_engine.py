@@ -33,8 +33,8 @@ GRAD_PARAMETER_SHIFT = 1
 ABI_SYMBOLS = (
     "qhbm_abi_version", "qhbm_create", "qhbm_destroy", "qhbm_last_error",
     "qhbm_set_circuit", "qhbm_set_observables", "qhbm_set_option",
-    "qhbm_workspace_bytes", "qhbm_expectation", "qhbm_expectation_vjp",
-    "qhbm_expectation_retain", "qhbm_expectation_vjp_retained",
+    "qhbm_workspace_bytes", "qhbm_allocated_bytes", "qhbm_expectation", "qhbm_expectation_vjp",
+    "qhbm_expectation_retain", "qhbm_expectation_vjp_retained", "qhbm_retained_states",
     "qhbm_expectation_jacobian", "qhbm_statevector", "qhbm_sample", "qhbm_parity_energy", "qhbm_parity_energy_vjp",
     "qhbm_num_passes", "qhbm_describe_schedule",
     "qhbm_kernel_time_ms",
@@ -77,6 +77,8 @@ def load_library():
   lib.qhbm_set_option.argtypes = [vp, ctypes.c_char_p, i64]
   lib.qhbm_workspace_bytes.argtypes = [vp, i32, i32,
                                        ctypes.POINTER(ctypes.c_size_t)]
+  lib.qhbm_allocated_bytes.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t)]
+  lib.qhbm_retained_states.argtypes = [vp, ctypes.POINTER(i32)]
   lib.qhbm_expectation.argtypes = [vp, vp, i32, vp, vp, vp]
   lib.qhbm_expectation_vjp.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp]
   lib.qhbm_expectation_retain.argtypes = [vp, vp, i32, vp, vp, vp]
@@ -228,6 +230,18 @@ class Engine:
                                        ctypes.byref(out)))
     return out.value
 
+  def allocated_bytes(self):
+    """Device memory this engine holds right now (workspace + gradient partials)."""
+    out = ctypes.c_size_t()
+    self._check(self._lib.qhbm_allocated_bytes(self._h, ctypes.byref(out)))
+    return out.value
+
+  def retained_states(self):
+    """Number of final states the workspace keeps for `expectation_vjp_retained` (0: none)."""
+    out = ctypes.c_int()
+    self._check(self._lib.qhbm_retained_states(self._h, ctypes.byref(out)))
+    return out.value
+
   def kernel_time_ms(self, reset=True):
     f, b = ctypes.c_double(), ctypes.c_double()
     nf, nb = ctypes.c_int64(), ctypes.c_int64()
@@ -269,7 +283,8 @@ class Engine:
     with torch.cuda.device(self.device):
       self._check(fn(self._h, bits.data_ptr(), bits.shape[0], params.data_ptr(), out.data_ptr(),
                      self._stream()))
-    if retain and bits.shape[0] > 0:
+    # (the C side keeps nothing when the batch exceeds one backward chunk: ask, do not assume)
+    if retain and bits.shape[0] > 0 and self.retained_states() == bits.shape[0]:
       self._retain_count = getattr(self, "_retain_count", 0) + 1
       self.retained = self._retain_count
     return out

@@ -6,13 +6,16 @@ name: where the reference tiles protos and calls `tfq.layers.Expectation`
 symbol values to the HIP engine through the C ABI.  There is no CPU path.
 """
 import abc
+import collections
 import math
-from typing import List, Sequence, Union
+from typing import Sequence, Union
 
 import torch
+import torch.distributed as dist
 
 from qhbmlib_amd import _engine
 from qhbmlib_amd import ir
+from qhbmlib_amd import parallel
 from qhbmlib_amd import utils
 from qhbmlib_amd.models import circuit  # noqa: F401
 from qhbmlib_amd.models import energy
@@ -23,28 +26,72 @@ Observables = Union[Sequence[ir.PauliSumLike], hamiltonian.Hamiltonian]
 
 class _ExpectationFunction(torch.autograd.Function):
   """values[U, T] = engine(bits, symbol_values); backward = adjoint VJP in the engine
-  (the role TFQ's adjoint differentiator plays at qnn.py:90-99)."""
+  (the role TFQ's adjoint differentiator plays at qnn.py:90-99).
+
+  With a process group the unique rows are dealt out in contiguous blocks
+  (`parallel.partition`): every rank simulates its block, the values are all-gathered and the
+  [P] gradient is all-reduced, so `vqt()` / `qmhl()` scale over the GPUs of a node without user
+  code.  Every rank must pass the same bitstrings."""
 
   @staticmethod
-  def forward(ctx, symbol_values, engine, bits, method):
-    ctx.engine, ctx.bits, ctx.method = engine, bits, method
+  def forward(ctx, symbol_values, engine, bits, method, group):
+    ctx.engine, ctx.method, ctx.group = engine, method, group
+    ctx.rows = None
+    if group is not None:
+      blocks = parallel.partition(bits.shape[0], dist.get_world_size(group))
+      ctx.rows = blocks[dist.get_rank(group)]
+      ctx.blocks = blocks
+      bits = bits[ctx.rows[0]:ctx.rows[1]]
+    ctx.bits = bits
     ctx.save_for_backward(symbol_values)
     # the forward leaves its final states in the engine's workspace: if nothing else runs on this
     # engine before backward(), the backward sweep starts from them instead of simulating again
     retain = method == _engine.GRAD_ADJOINT and ctx.needs_input_grad[0]
     out = engine.expectation(bits, symbol_values.detach(), retain=retain)
     ctx.token = engine.retained
+    if group is not None:
+      out = parallel.all_gather_rows(out, ctx.blocks, group)
     return out
 
   @staticmethod
   def backward(ctx, upstream):
     (symbol_values,) = ctx.saved_tensors
     eng = ctx.engine
+    upstream = upstream.contiguous()
+    if ctx.rows is not None:
+      upstream = upstream[ctx.rows[0]:ctx.rows[1]].contiguous()
+    grad = None
     if ctx.token is not None and eng.retained == ctx.token:
-      grad = eng.expectation_vjp_retained(ctx.bits, symbol_values.detach(), upstream.contiguous())
-    else:
-      _, grad = eng.expectation_vjp(ctx.bits, symbol_values.detach(), upstream.contiguous(), ctx.method)
-    return grad.to(symbol_values.device), None, None, None
+      try:
+        grad = eng.expectation_vjp_retained(ctx.bits, symbol_values.detach(), upstream)
+      except _engine.EngineError:
+        grad = None  # the states are gone after all: simulate again
+    if grad is None:
+      _, grad = eng.expectation_vjp(ctx.bits, symbol_values.detach(), upstream, ctx.method)
+    if ctx.group is not None:
+      parallel.all_reduce_sum(grad, ctx.group)
+    return grad.to(symbol_values.device), None, None, None, None
+
+
+class ResolvedCircuits(tuple):
+  """What `QuantumCircuit.__call__(bitstrings)` hands to `_expectation` where the reference hands
+  `[U]` serialized protos (circuit.py:129-136): the unique bitstrings and the circuit they
+  initialise.  Unpacks as `(bitstrings, circuit)`."""
+
+  def __new__(cls, bitstrings, circuit):  # pylint: disable=redefined-outer-name
+    return super().__new__(cls, (bitstrings, circuit))
+
+  @property
+  def bitstrings(self):
+    return self[0]
+
+  @property
+  def circuit(self):
+    return self[1]
+
+  @property
+  def num_circuits(self):
+    return int(self[0].shape[0])
 
 
 class QuantumInference(torch.nn.Module, abc.ABC):
@@ -62,54 +109,125 @@ class QuantumInference(torch.nn.Module, abc.ABC):
 
   def expectation(self, initial_states: torch.Tensor, observables: Observables):
     """[batch_size, n_ops] of <x_i| C^dagger O_j C |x_i>, rows in input order
-    (qnn.py:50-80).  `observables` is a list of PauliSums or a Hamiltonian."""
+    (qnn.py:50-80).  `observables` is a list of PauliSums or a Hamiltonian.
+
+    Same steps as the reference: dedup, total circuit, `circuits = total_circuit(unique_states)`,
+    symbol values tiled to [num_circuits, P] (here a stride-0 view, no copy), the abstract
+    `_expectation(circuits, symbol_names, symbol_values, observables)`, expand."""
     initial_states = torch.as_tensor(initial_states)
     unique_states, idx, _ = utils.unique_bitstrings_with_counts(initial_states)
     if isinstance(observables, hamiltonian.Hamiltonian):
       total_circuit = self.circuit + observables.circuit_dagger
     else:
       total_circuit = self.circuit
-    unique_expectations = self._expectation(unique_states, total_circuit, observables)
+    circuits = ResolvedCircuits(*total_circuit(unique_states))
+    tiled_values = total_circuit.symbol_values.unsqueeze(0).expand(circuits.num_circuits, -1)
+    unique_expectations = self._expectation(circuits, total_circuit.symbol_names, tiled_values, observables)
     return utils.expand_unique_results(unique_expectations, idx)
 
   @abc.abstractmethod
-  def _expectation(self, unique_states, total_circuit, observables):
+  def _expectation(self, circuits, symbol_names, symbol_values, observables):
+    """The plugin point, with the reference's signature (qnn.py:82-84): `circuits` is a
+    `ResolvedCircuits` (bitstrings [U, n] int8 + the total circuit), `symbol_names` the [P] names,
+    `symbol_values` [U, P] with identical rows, `observables` as given to `expectation`.
+    Returns [U, n_ops]."""
     raise NotImplementedError()
+
+
+def _row_of_tiled(symbol_values: torch.Tensor, total_circuit) -> torch.Tensor:
+  """The [P] parameter vector behind the [U, P] tile of qnn.py:75-76 (the engine broadcasts it)."""
+  if symbol_values.dim() == 1:
+    return symbol_values
+  if symbol_values.shape[0] == 0:
+    return total_circuit.symbol_values
+  if symbol_values.stride(0) != 0 and not bool((symbol_values == symbol_values[:1]).all()):
+    raise ValueError("the engine takes one parameter vector per call: rows of symbol_values differ")
+  return symbol_values[0]
+
+
+def _engine_bits(total_circuit, states):
+  """Bitstring columns in engine-qubit order."""
+  perm = total_circuit.bit_column_to_qubit()
+  bits = states.to(torch.int8)
+  if perm != list(range(len(perm))):
+    permuted = torch.zeros_like(bits)
+    permuted[:, perm] = bits
+    bits = permuted
+  return bits
+
+
+class _EngineCache:
+  """Engines keyed by CONTENT -- (n, flat gate list, n symbols, Pauli masks of every op) -- never
+  by object identity: CPython reuses the ids of freed operator lists, and `PauliSum.__iadd__`
+  mutates in place.  Least-recently-used engines are dropped when the cache holds more than
+  `max_engines` or their workspaces more than `max_bytes`; a dropped engine frees its device
+  memory when the last autograd graph that still references it is gone."""
+
+  def __init__(self, max_engines=4, max_bytes=160 << 30):
+    self.max_engines, self.max_bytes = max_engines, max_bytes
+    self._engines = collections.OrderedDict()
+
+  def __len__(self):
+    return len(self._engines)
+
+  def get(self, key, make):
+    eng = self._engines.get(key)
+    if eng is None:
+      eng = make()
+      self._engines[key] = eng
+    self._engines.move_to_end(key)
+    while len(self._engines) > 1 and (
+        len(self._engines) > self.max_engines or
+        sum(e.allocated_bytes() for e in self._engines.values()) > self.max_bytes):
+      self._engines.popitem(last=False)
+    return eng
 
 
 class AnalyticQuantumInference(QuantumInference):
   """Exact expectation values with adjoint gradients on the MI355X engine
   (qnn.py:87-139).  `gradient_method` may be set to
   `_engine.GRAD_PARAMETER_SHIFT` to use two shifted forwards per gate occurrence
-  instead (the rule of tfq.differentiators.ParameterShift, qnn.py:168)."""
+  instead (the rule of tfq.differentiators.ParameterShift, qnn.py:168).
+
+  `process_group`: a `torch.distributed` group (or True for the default group) over which the
+  unique bitstrings are sharded, one process per GPU; None (default) runs on this process's GPU
+  only."""
 
   MAX_OPS_PER_CALL = 1024  # kMaxOps of the engine (csrc/program.h)
 
   def __init__(self, input_circuit: circuit.QuantumCircuit, name: Union[None, str] = None,
-               device: Union[None, int] = None, gradient_method: int = _engine.GRAD_ADJOINT):
+               device: Union[None, int] = None, gradient_method: int = _engine.GRAD_ADJOINT,
+               process_group=None, max_cached_engines: int = 4):
     super().__init__(input_circuit, name)
     self._device = device
     self.gradient_method = gradient_method
-    self._engines = {}
+    self._process_group = process_group
+    self._engines = _EngineCache(max_cached_engines)
 
-  def _engine_for(self, total_circuit, ops: List[ir.PauliSum], key):
-    cached = self._engines.get(key)
-    if cached is not None:
-      return cached
-    if not torch.cuda.is_available():
-      raise _engine.EngineError(
-          "AnalyticQuantumInference needs an MI355X: the expectation engine is HIP-only "
-          "and has no CPU fallback")
-    dev = torch.cuda.current_device() if self._device is None else self._device
-    eng = _engine.Engine(dev)
-    qubits = total_circuit.qubits
-    eng.set_circuit(len(qubits), total_circuit.pqc.flat_gates(qubits, total_circuit.symbol_names),
-                    len(total_circuit.symbol_names))
-    eng.set_observables([ir.as_pauli_sum(op).masks(qubits) for op in ops])
-    self._engines[key] = eng
-    return eng
+  def _group(self):
+    g = self._process_group
+    if g is None or g is False:
+      return None
+    if not (dist.is_available() and dist.is_initialized()):
+      raise _engine.EngineError("process_group given but torch.distributed is not initialised")
+    return dist.group.WORLD if g is True else g
 
-  def _expectation(self, unique_states, total_circuit, observables):
+  def _engine_for(self, n_qubits, flat_gates, n_symbols, op_masks):
+    key = (n_qubits, tuple(flat_gates), n_symbols, tuple(tuple(m) for m in op_masks))
+
+    def make():
+      if not torch.cuda.is_available():
+        raise _engine.EngineError(
+            "AnalyticQuantumInference needs an MI355X: the expectation engine is HIP-only "
+            "and has no CPU fallback")
+      dev = torch.cuda.current_device() if self._device is None else self._device
+      eng = _engine.Engine(dev)
+      eng.set_circuit(n_qubits, flat_gates, n_symbols)
+      eng.set_observables([list(m) for m in op_masks])
+      return eng
+    return self._engines.get(key, make)
+
+  def _expectation(self, circuits, symbol_names, symbol_values, observables):
     """See qnn.py:114-139.  A Hamiltonian is only accepted if its energy inherits from
     PauliMixin."""
     if isinstance(observables, hamiltonian.Hamiltonian):
@@ -118,25 +236,22 @@ class AnalyticQuantumInference(QuantumInference):
                         "Please use `SampledQuantumInference` instead.")
       ops = observables.operator_shards
       post_process = lambda y: observables.energy.operator_expectation(y).unsqueeze(-1)
-      key = ("hamiltonian", id(observables))
     else:
       ops = list(observables)
       post_process = lambda x: x
-      key = ("ops", tuple(id(o) for o in ops))
-    perm = total_circuit.bit_column_to_qubit()
-    bits = unique_states.to(torch.int8)
-    if perm != list(range(len(perm))):
-      permuted = torch.zeros_like(bits)
-      permuted[:, perm] = bits
-      bits = permuted
-    symbol_values = total_circuit.symbol_values.to(torch.float32)
+    unique_states, total_circuit = circuits
+    qubits = total_circuit.qubits
+    bits = _engine_bits(total_circuit, unique_states)
+    values = _row_of_tiled(symbol_values, total_circuit).to(torch.float32)
+    flat_gates = total_circuit.pqc.flat_gates(qubits, list(symbol_names))
+    group = self._group()
     # one engine call measures at most MAX_OPS_PER_CALL observables (its LDS accumulators);
     # longer lists -- e.g. the 1350 shards of a third-order KOBE on 20 qubits -- go in slices
     parts = []
     for lo in range(0, max(len(ops), 1), self.MAX_OPS_PER_CALL):
-      chunk = ops[lo:lo + self.MAX_OPS_PER_CALL]
-      eng = self._engine_for(total_circuit, chunk, key + (lo,))
-      parts.append(_ExpectationFunction.apply(symbol_values, eng, bits, self.gradient_method))
+      masks = [ir.as_pauli_sum(op).masks(qubits) for op in ops[lo:lo + self.MAX_OPS_PER_CALL]]
+      eng = self._engine_for(len(qubits), flat_gates, len(symbol_names), masks)
+      parts.append(_ExpectationFunction.apply(values, eng, bits, self.gradient_method, group))
     expectations = parts[0] if len(parts) == 1 else torch.cat(parts, 1)
     return post_process(expectations)
 
@@ -198,15 +313,7 @@ class SampledQuantumInference(QuantumInference):
       self._engines[key] = eng
     return eng
 
-  @staticmethod
-  def _engine_bits(total_circuit, states):
-    perm = total_circuit.bit_column_to_qubit()
-    bits = states.to(torch.int8)
-    if perm != list(range(len(perm))):
-      permuted = torch.zeros_like(bits)
-      permuted[:, perm] = bits
-      bits = permuted
-    return bits
+  _engine_bits = staticmethod(_engine_bits)
 
   def _pauli_estimator(self, total_circuit, bits, values, strings):
     """estimator(shift_gate, shift) -> [U, len(strings)] sampled <P> of each Pauli string.
@@ -240,12 +347,14 @@ class SampledQuantumInference(QuantumInference):
       return out
     return estimator, base
 
-  def _expectation(self, unique_states, total_circuit, observables):
+  def _expectation(self, circuits, symbol_names, symbol_values, observables):
     """qnn.py:228-264.  Pauli-sum observables and PauliMixin Hamiltonians are estimated term by
     term; any other Hamiltonian averages `energy(x)` over shots of circuit + hamiltonian.circuit_dagger
     (`_sampled_expectation`, qnn.py:170-226)."""
+    unique_states, total_circuit = circuits
+    del symbol_names  # the circuit's own order
     bits = self._engine_bits(total_circuit, unique_states)
-    symbol_values = total_circuit.symbol_values.to(torch.float32)
+    symbol_values = _row_of_tiled(symbol_values, total_circuit).to(torch.float32)
     values = symbol_values.detach()
     if isinstance(observables, hamiltonian.Hamiltonian) and not isinstance(observables.energy, energy.PauliMixin):
       qubits, names = total_circuit.qubits, total_circuit.symbol_names

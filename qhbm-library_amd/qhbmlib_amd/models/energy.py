@@ -2,6 +2,7 @@
 import abc
 from typing import List, Union
 
+import numpy as np
 import torch
 
 from qhbmlib_amd import ir
@@ -76,7 +77,9 @@ class PauliMixin(abc.ABC):
     key = str(device)
     if key not in cache:
       masks = [sum(1 << int(c) for c in ix) for ix in self._parity_index_sets()]
-      cache[key] = torch.tensor(masks, dtype=torch.int64, device=device)
+      # uint64 on the kernel side; column 63 sets the sign bit of the int64 torch stores it in
+      as_u64 = np.asarray(masks, dtype=np.uint64)
+      cache[key] = torch.from_numpy(as_u64.view(np.int64).copy()).to(device)
     return cache[key]
 
   def _gpu_energy(self, inputs):

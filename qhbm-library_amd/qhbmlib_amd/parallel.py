@@ -25,6 +25,40 @@ def partition(num_rows: int, world_size: int) -> List[Tuple[int, int]]:
   return out
 
 
+def _via_host(group) -> bool:
+  """gloo carries CPU tensors only: CUDA tensors take a host round trip (tests, single-GPU boxes);
+  nccl (= RCCL on ROCm) moves device memory over xGMI directly."""
+  return dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+  """In-place sum of `t` over the group."""
+  if t.is_cuda and _via_host(group):
+    c = t.cpu()
+    dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+    t.copy_(c)
+  else:
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+  return t
+
+
+def all_gather_rows(local: torch.Tensor, blocks: List[Tuple[int, int]], group=None) -> torch.Tensor:
+  """Concatenates the ranks' row blocks (`blocks[r]` = rank r's [lo, hi)) into the full tensor,
+  identical on every rank.  Blocks are padded to the widest one so a single all-gather serves."""
+  world = dist.get_world_size(group)
+  rank = dist.get_rank(group)
+  lo, hi = blocks[rank]
+  width = max(h - l for l, h in blocks)
+  host = local.is_cuda and _via_host(group)
+  src = local.cpu() if host else local
+  padded = torch.zeros((width,) + tuple(local.shape[1:]), dtype=src.dtype, device=src.device)
+  padded[:hi - lo] = src
+  gathered = [torch.empty_like(padded) for _ in range(world)]
+  dist.all_gather(gathered, padded, group=group)
+  out = torch.cat([g[:h - l] for g, (l, h) in zip(gathered, blocks)], 0)
+  return out.to(local.device) if host else out
+
+
 class ShardedExpectation:
   """Wraps a single-device `expectation_vjp(bits, params, upstream) -> (vals, grad)`
   (e.g. `Engine.expectation_vjp`) into the same call over the whole process group."""
@@ -43,12 +77,6 @@ class ShardedExpectation:
     blocks = partition(bits.shape[0], world)
     lo, hi = blocks[rank]
     vals_local, grad = self._local(bits[lo:hi], params, upstream[lo:hi])
-    n_ops = upstream.shape[1]
-    width = max(h - l for l, h in blocks)
-    padded = torch.zeros((width, n_ops), dtype=vals_local.dtype, device=vals_local.device)
-    padded[:hi - lo] = vals_local
-    gathered = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(gathered, padded, group=self._group)
-    dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self._group)
-    vals = torch.cat([g[:h - l] for g, (l, h) in zip(gathered, blocks)], 0)
+    vals = all_gather_rows(vals_local, blocks, self._group)
+    all_reduce_sum(grad, self._group)
     return vals, grad

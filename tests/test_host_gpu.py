@@ -342,3 +342,66 @@ def test_autograd_backward_twice_and_interleaved_engines():
   _, jac = O.expectation_jacobian(n, flat, circ.symbol_values.detach().numpy().astype(np.float64),
                                   states[:3].numpy(), [op.masks(qubits) for op in ops])
   np.testing.assert_allclose(gb.cpu().numpy(), jac.sum((0, 1)), atol=1e-4)
+
+
+# ---- engine cache keyed by content (id()-keyed cache returned stale engines) ---
+def test_fresh_operator_lists_never_hit_a_stale_engine():
+  """Rebuilds X, Y, Z operator lists (and Hamiltonian objects) every iteration on ONE qnn --
+  CPython hands the freed lists' ids to the new ones -- and checks the closed forms of
+  tests/inference/qnn_test.py:83-180 every time."""
+  num_bits = 3
+  qubits = ir.GridQubit.rect(1, num_bits)
+  p_qnn = models.DirectQuantumCircuit(ir.Circuit(ir.X(q)**ir.Symbol("p") for q in qubits), name="p_qnn")
+  _set(p_qnn.trainable_variables[0], [0.37])
+  states = torch.tensor(list(itertools.product([0, 1], repeat=num_bits)), dtype=torch.int8)
+  sin_pi_p, cos_pi_p = math.sin(math.pi * 0.37), math.cos(math.pi * 0.37)
+  qnn = inference.AnalyticQuantumInference(p_qnn)
+  for _ in range(10):
+    for pauli, val in ((ir.PX, lambda s: 0.0), (ir.PY, lambda s: -((-1.0)**s) * sin_pi_p),
+                       (ir.PZ, lambda s: ((-1.0)**s) * cos_pi_p)):
+      got = qnn.expectation(states, [1.0 * pauli(q) for q in qubits]).detach().cpu().numpy()
+      np.testing.assert_allclose(got, [[val(s) for s in bits] for bits in states.tolist()], atol=1e-5)
+    # in-place mutation of a PauliSum between calls
+    op = ir.PauliSum.from_pauli_strings([ir.PZ(qubits[0])])
+    z0 = qnn.expectation(states, [op]).detach().cpu().numpy()[:, 0]
+    op += ir.PZ(qubits[1])
+    z01 = qnn.expectation(states, [op]).detach().cpu().numpy()[:, 0]
+    np.testing.assert_allclose(z0, [((-1.0)**b[0]) * cos_pi_p for b in states.tolist()], atol=1e-5)
+    np.testing.assert_allclose(z01, [(((-1.0)**b[0]) + ((-1.0)**b[1])) * cos_pi_p for b in states.tolist()], atol=1e-5)
+    # fresh Hamiltonian objects with different thetas: identity circuit, Bernoulli energy
+    for theta in ([1.0, 0.0, 0.0], [0.0, 2.0, 0.0], [0.0, 0.0, -3.0]):
+      e = models.BernoulliEnergy(list(range(num_bits)))
+      _set(e.post_process[0].kernel, theta)
+      ident = models.DirectQuantumCircuit(ir.Circuit(ir.X(q)**(0.0 * ir.Symbol(f"i{q.col}")) for q in qubits))
+      ham = models.Hamiltonian(e, ident)
+      got = qnn.expectation(states, ham).detach().cpu().numpy()[:, 0]
+      k = int(np.argmax(np.abs(theta)))
+      np.testing.assert_allclose(got, [theta[k] * ((-1.0)**b[k]) * cos_pi_p for b in states.tolist()], atol=1e-5)
+  assert len(qnn._engines) <= qnn._engines.max_engines  # LRU bound
+
+
+def test_autograd_through_a_batch_larger_than_one_backward_chunk():
+  """ADVICE r1: with more unique states than one backward chunk holds the C side retains nothing;
+  the autograd function must notice and run the full VJP instead of raising."""
+  n = 5
+  qubits = ir.GridQubit.rect(1, n)
+  circ = models.DirectQuantumCircuit(hea_circuit(qubits, 2, "c"))
+  vals = np.random.default_rng(3).uniform(-1, 1, len(circ.symbol_names))
+  _set(circ.trainable_variables[0], vals)
+  ops = [ir.PauliSum.from_pauli_strings([ir.PZ(q) for q in qubits]), ir.PX(qubits[0]) * ir.PX(qubits[1])]
+  states = torch.tensor(list(itertools.product([0, 1], repeat=n)), dtype=torch.int8)
+  qnn = inference.AnalyticQuantumInference(circ)
+  qnn.expectation(states[:1], ops)  # creates the engine
+  (eng,) = list(qnn._engines._engines.values())
+  eng.set_option("chunk_states", 5)
+  out = qnn.expectation(states, ops)
+  assert eng.retained is None and eng.retained_states() == 0
+  w = torch.arange(out.numel(), dtype=torch.float32, device=out.device).reshape(out.shape) / out.numel()
+  (g,) = torch.autograd.grad((out * w).sum(), circ.trainable_variables)
+  flat = circ.pqc.flat_gates(circ.qubits, circ.symbol_names)
+  want, jac = O.expectation_jacobian(n, flat, vals, states.numpy(), [op.masks(qubits) for op in ops])
+  np.testing.assert_allclose(out.detach().cpu().numpy(), want, atol=1e-5)
+  np.testing.assert_allclose(g.cpu().numpy(), np.einsum("bt,btp->p", w.cpu().numpy(), jac), atol=1e-4)
+  eng.set_option("chunk_states", 0)
+  out = qnn.expectation(states, ops)
+  assert eng.retained is not None and eng.retained_states() == states.shape[0]
