@@ -5,22 +5,30 @@ One "step" = one VQT step's engine work over one batch of synthetic input:
 values [U, 1] of the target Hamiltonian AND the adjoint vector-Jacobian
 product (the [P] gradient of the VQT loss w.r.t. the circuit parameters), for
 U EBM bitstrings already resident in HBM.  With --gpus N the batch is sharded
-over N ranks (one process per GPU, weak scaling: --states-per-gpu is fixed)
-and each step ends with the exchange the path really has: an RCCL all-reduce
-of the [P] gradient and an all-gather of the per-state expectations.
+over N ranks (one process per GPU) and each step ends with the exchange the
+path really has: an RCCL all-reduce of the [P] gradient and an all-gather of
+the per-state expectations.
 
   value = (states over all ranks) x (Pauli terms) / step time      [evals/s]
 
-Workload (config.workload): BASELINE.json configs[2] -- 20-qubit XXZ chain,
-depth-16 hardware-efficient ansatz, 4096 samples sharded over 8 GPUs, i.e.
-512 states per GPU; it fits one GPU, so the same per-GPU shard is the N=1
-workload.  Synthetic inputs: phi ~ U[-1,1] seeded, distinct
-seeded bitstrings (U = B exactly).
+Workload (config.workload): BASELINE.json configs[2] as the metric states it --
+20-qubit XXZ chain, depth-16 hardware-efficient ansatz, a 4096-sample step.
+The whole batch fits one MI355X (4096 x 8 MiB x (psi, lambda) = 64 GiB), so
+N = 1 runs all 4096 states and N GPUs split the SAME 4096 (strong scaling,
+--states-total; N = 8 is exactly the config's 512 states per GPU).
+--states-per-gpu S switches to weak scaling.  Synthetic inputs:
+phi ~ U[-1,1] seeded, distinct seeded bitstrings (U = B exactly).
+
+Launched without torchrun, `--gpus N` (N > 1) starts its own N ranks through
+`python -m torch.distributed.run` as a child process -- decided before anything
+touches the GPU -- and fails loudly if fewer than N GPUs are visible.
 """
 import argparse
+import hashlib
 import json
-import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -126,6 +134,35 @@ def cpu_baseline(n, gates, n_params, op, params, sample_states, mode):
   }
 
 
+def self_launch(args):
+  """`bench.py --gpus N` outside torchrun: run the N ranks as a child torch.distributed.run (never an
+  exec, and before this process has touched a GPU) and exit with its code."""
+  import torch  # pylint: disable=import-outside-toplevel,redefined-outer-name
+  visible = torch.cuda.device_count()  # counting devices does not initialise the GPU
+  if visible < args.gpus and os.environ.get("QHBM_BENCH_SHARE_DEVICE") != "1":
+    raise SystemExit(f"bench.py --gpus {args.gpus}: only {visible} GPU(s) visible -- refusing to report a "
+                     f"{args.gpus}-GPU number from fewer devices")
+  with socket.socket() as sock:
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  raise SystemExit(subprocess.call(cmd))
+
+
+def stored_profile(name, n, layers, hamiltonian, mode):
+  """profiles/<name>.json if it was taken on this workload (same circuit, observable, mode)."""
+  path = os.path.join(ROOT, "profiles", name)
+  try:
+    with open(path) as f:
+      tj = json.load(f)
+  except (OSError, ValueError):
+    return None
+  same = (tj.get("n_qubits") == n and tj.get("layers", 16) == layers and
+          tj.get("hamiltonian", "xxz") == hamiltonian and tj.get("mode", "vqt") == mode)
+  return tj if same else None
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -133,21 +170,31 @@ def main():
   ap.add_argument("--warmup", type=int, default=2)
   ap.add_argument("--qubits", type=int, default=20)
   ap.add_argument("--layers", type=int, default=16)
-  ap.add_argument("--states-per-gpu", type=int, default=512)
+  ap.add_argument("--states-total", type=int, default=4096,
+                  help="states of one step over ALL ranks (strong scaling; BASELINE config 3: 4096)")
+  ap.add_argument("--states-per-gpu", type=int, default=0,
+                  help="fixed states per rank instead (weak scaling)")
   ap.add_argument("--hamiltonian", choices=["xxz", "tfim", "random512"], default="xxz")
   ap.add_argument("--mode", choices=["vqt", "forward", "shift"], default="vqt")
   ap.add_argument("--tile-qubits", type=int, default=0)
   ap.add_argument("--adjoint-tile-qubits", type=int, default=0)
+  ap.add_argument("--engine-option", action="append", default=[], metavar="NAME=VALUE",
+                  help="qhbm_set_option knob for experiments (repeatable), e.g. adjoint_exchange=0")
   ap.add_argument("--cpu-sample-states", type=int, default=64)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--verify", action="store_true",
                   help="rank 0 re-evaluates the whole batch alone and compares with the sharded result")
   args = ap.parse_args()
 
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    self_launch(args)
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   world = int(os.environ.get("WORLD_SIZE", "1"))
-  if world != args.gpus and world > 1:
+  if world != args.gpus:
+    if rank == 0:
+      print(f"bench.py: --gpus {args.gpus} but launched with WORLD_SIZE={world}; running {world} ranks",
+            file=sys.stderr)
     args.gpus = world
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
@@ -163,34 +210,22 @@ def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(backend, rank=rank, world_size=world)
 
-  def all_reduce_sum(t):
-    if backend == "gloo":
-      c = t.cpu()
-      dist.all_reduce(c)
-      t.copy_(c)
-    else:
-      dist.all_reduce(t)
-
-  def all_gather(outs, t):
-    if backend == "gloo":
-      couts = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
-      dist.all_gather(couts, t.cpu())
-      for o, c in zip(outs, couts):
-        o.copy_(c)
-    else:
-      dist.all_gather(outs, t)
-
   from qhbmlib_amd import _engine as E  # pylint: disable=import-outside-toplevel
+  from qhbmlib_amd import parallel  # pylint: disable=import-outside-toplevel
 
-  n, layers, spg = args.qubits, args.layers, args.states_per_gpu
+  n, layers = args.qubits, args.layers
+  weak = args.states_per_gpu > 0
+  total_states = args.states_per_gpu * world if weak else args.states_total
+  blocks = parallel.partition(total_states, world)
+  lo, hi = blocks[rank]
+  spg = hi - lo
   gates, n_params = hea_gates(n, layers)
   op = {"xxz": xxz_op, "tfim": tfim_op, "random512": lambda m: random_pauli_op(m, 512, 24)}[args.hamiltonian](n)
   rng = np.random.default_rng(1234)
   params_np = rng.uniform(-1, 1, n_params).astype(np.float32)
-  all_bits = distinct_bitstrings(n, spg * world, 4321)
-  bits = torch.from_numpy(all_bits[rank * spg:(rank + 1) * spg]).cuda()
+  all_bits = distinct_bitstrings(n, total_states, 4321)
+  bits = torch.from_numpy(all_bits[lo:hi]).cuda()
   params = torch.from_numpy(params_np).cuda()
-  total_states = spg * world
   upstream = torch.full((spg, 1), 1.0 / total_states, device="cuda")
 
   eng = E.Engine(local_rank)
@@ -198,11 +233,13 @@ def main():
     eng.set_option("tile_qubits", args.tile_qubits)
   if args.adjoint_tile_qubits:
     eng.set_option("adjoint_tile_qubits", args.adjoint_tile_qubits)
+  for item in args.engine_option:
+    key, _, val = item.partition("=")
+    eng.set_option(key, int(val))
   eng.set_circuit(n, gates, n_params)
   eng.set_observables([op])
   eng.set_option("profile_events", 1)
   fwd_passes, bwd_passes = eng.num_passes()
-  gathered = [torch.empty((spg, 1), device="cuda") for _ in range(world)] if world > 1 else None
 
   def step():
     if args.mode == "forward":
@@ -213,8 +250,8 @@ def main():
                                        method=E.GRAD_PARAMETER_SHIFT if args.mode == "shift" else E.GRAD_ADJOINT)
     if world > 1:
       if grad is not None:
-        all_reduce_sum(grad)
-      all_gather(gathered, vals)
+        parallel.all_reduce_sum(grad)
+      vals = parallel.all_gather_rows(vals, blocks)
     return vals, grad
 
   for _ in range(args.warmup):
@@ -242,38 +279,50 @@ def main():
     n_terms = len(op)
     evals_per_step = total_states * n_terms
     ms_per_step = dt / args.steps * 1e3
-    # ---- roofline of the dominant kernel (algorithmic bytes) ----
+    # ---- roofline of the dominant kernel -------------------------------------------------------
+    # Bytes a launch must move: every tile it touches read once and written once (qhbm_traffic_model;
+    # it agrees with the rocprofv3 FETCH_SIZE / WRITE_SIZE counters of profiles/ to < 1 %).  The
+    # per-gate byte model of SURVEY.md 8(d) -- what an UNFUSED gate-by-gate sweep would move -- is
+    # reported beside it as `unfused_bytes_per_launch`; their ratio is the fusion factor, not a
+    # roofline fraction.
     n_gate = len(gates)
     amp = float(1 << n)
-    fwd_alg = spg * (16.0 * n_gate + 8.0 * n_terms + 8.0) * amp  # per step, this rank
-    if args.mode == "shift":  # one base forward + 2 P shifted forwards
-      fwd_alg *= 1 + 2 * n_params
-    bwd_alg = spg * 48.0 * n_gate * amp
-    n_diag = sum(1 for g in gates if g[0] in (E.GATE_ZPOW, E.GATE_CZPOW, E.GATE_ZZPOW))
-    fwd_flops = spg * amp * (14.0 * (n_gate - n_diag) + 6.0 * n_diag)
+    shift_factor = (1 + 2 * n_params) if args.mode == "shift" else 1
+    fwd_unfused = spg * (16.0 * n_gate + 8.0 * n_terms + 8.0) * amp * shift_factor
+    bwd_unfused = spg * 48.0 * n_gate * amp
+    tm = eng.traffic_model(spg, with_vjp=args.mode == "vqt")
     use_bwd = args.mode == "vqt" and kt["bwd_ms"] >= kt["fwd_ms"]
     if use_bwd:
-      launches, ms, alg, name = kt["bwd_launches"], kt["bwd_ms"], bwd_alg, "pass_adj_kernel"
+      launches, ms, unfused, name, model = kt["bwd_launches"], kt["bwd_ms"], bwd_unfused, "pass_adj_kernel", tm["bwd_bytes"]
     else:
-      launches, ms, alg, name = kt["fwd_launches"], kt["fwd_ms"], fwd_alg, "pass_fwd_kernel"
-    alg_flops = 3.0 * fwd_flops if use_bwd else fwd_flops * ((1 + 2 * n_params) if args.mode == "shift" else 1)
+      launches, ms, unfused, name, model = (kt["fwd_launches"], kt["fwd_ms"], fwd_unfused, "pass_fwd_kernel",
+                                            tm["fwd_bytes"] * shift_factor)
     per_step_launches = max(1, launches // max(1, args.steps))
     avg_ms = ms / max(1, launches)
-    achieved = (alg / per_step_launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    # physical HBM traffic of one launch if every tile is read and written once
-    io_bytes = spg * amp * 8.0 * 2.0 * (2.0 if use_bwd else 1.0)
-    # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
-    # passes of this same command; scripts/profile_bench.sh + scripts/summarize_profile.py).
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-      try:
-        with open(tpath) as f:
-          tj = json.load(f)
-        if tj.get("states_per_gpu") == spg and tj.get("n_qubits") == n and args.hamiltonian == "xxz":
-          traffic = tj.get(name, {}).get("hbm_bytes_per_launch")
-      except Exception:  # pylint: disable=broad-except
-        traffic = None
+    bytes_per_launch = model / per_step_launches
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # PMC traffic and VALU utilisation come from committed rocprofv3 runs of THIS command
+    # (scripts/profile_bench.sh -> profiles/): stored values, not measured in this run.
+    traffic, traffic_src, valu = None, None, None
+    tj = stored_profile("traffic.json", n, layers, args.hamiltonian, args.mode)
+    if tj and name in tj:
+      scale = spg / float(tj["states_per_gpu"])
+      traffic = tj[name]["hbm_bytes_per_launch"] * scale
+      traffic_src = (f"stored profile profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                     f"{tj['states_per_gpu']} states, git {tj.get('git_head', '?')}, bench.py sha "
+                     f"{tj.get('bench_py_sha16', '?')}), scaled x{scale:g} in states; NOT measured in this run")
+    vj = stored_profile("valu.json", n, layers, args.hamiltonian, args.mode)
+    if vj and name in vj:
+      valu = dict(vj[name], source=f"stored profile profiles/valu.json (git {vj.get('git_head', '?')})")
+    with open(os.path.abspath(__file__), "rb") as f:
+      bench_sha = hashlib.sha256(f.read()).hexdigest()[:16]
+    ham_name = {"xxz": "XXZ(delta=0.5) open chain", "tfim": "TFIM ring",
+                "random512": "random 512-term Pauli sum"}[args.hamiltonian]
+    mode_name = {"vqt": "VQT step = values + adjoint VJP", "forward": "forward values only",
+                 "shift": "values + parameter-shift VJP"}[args.mode]
+    is_c3 = (n, layers, args.hamiltonian, args.mode) == (20, 16, "xxz", "vqt")
+    label = ("BASELINE configs[2] (20-qubit XXZ, depth 16, 4096-sample VQT step)" if is_c3 and total_states == 4096
+             else "BASELINE configs[2] circuit at a different batch" if is_c3 else "custom workload")
     line = {
         "metric": "circuit-expectation evals/sec (samples×Pauli terms) at n qubits; VQT step time",
         "value": evals_per_step / (dt / args.steps),
@@ -283,33 +332,33 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if weak else "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": (f"BASELINE configs[2] shard: {n}-qubit "
-                         f"{ {'xxz': 'XXZ(delta=0.5) open chain', 'tfim': 'TFIM ring', 'random512': 'random 512-term Pauli sum'}[args.hamiltonian]}, "
-                         f"HEA depth {layers} ({n_params} params), {spg} states/GPU, "
-                         f"{ {'vqt': 'VQT step = values + adjoint VJP', 'forward': 'forward values only', 'shift': 'values + parameter-shift VJP'}[args.mode]}"),
-            "n_qubits": n, "layers": layers, "states_per_gpu": spg, "pauli_terms": n_terms,
+            "workload": (f"{label}: {n}-qubit {ham_name}, HEA depth {layers} ({n_params} params), "
+                         f"{total_states} states in total = {spg} on rank 0 of {world}, {mode_name}"),
+            "n_qubits": n, "layers": layers, "states_total": total_states, "states_per_gpu": spg,
+            "pauli_terms": n_terms, "hamiltonian": args.hamiltonian,
             "mode": args.mode, "parallelism": f"batch-sharded x{world}",
             "forward_passes": fwd_passes, "adjoint_passes": bwd_passes,
+            "bench_py_sha16": bench_sha, "engine_options": args.engine_option,
         },
         "vqt_step_ms": ms_per_step if args.mode == "vqt" else None,
-        "kernel_ms_per_step": {"forward": kt["fwd_ms"] / args.steps, "adjoint": kt["bwd_ms"] / args.steps},
+        "kernel_ms_per_step": {"forward": kt["fwd_ms"] / args.steps, "adjoint": kt["bwd_ms"] / args.steps,
+                               "apply_observable": kt["obs_ms"] / args.steps},
         "roofline": {
             "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_ms": avg_ms, "launches_per_step": per_step_launches,
-            "algorithmic_bytes_per_launch": alg / per_step_launches,
-            "tile_io_bytes_per_launch": io_bytes,
-            "tile_io_GBps": io_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
-            # the fused kernels are VALU-bound, so the same launch priced in SURVEY.md 8(d)'s
-            # algorithmic flops (28 per amplitude pair for a one-qubit gate, 6 per amplitude for a
-            # diagonal one; the adjoint sweeps every gate three times) against the fp32 vector peak
-            "algorithmic_TFLOPs": alg_flops / per_step_launches / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
-            "fp32_vector_peak_TFLOPs": 157.3,
+            "bytes_per_launch": bytes_per_launch,
+            "bytes_definition": "every tile the launch touches read once + written once (qhbm_traffic_model); "
+                                "achieved = bytes_per_launch / avg_launch_ms (HIP events on the launch stream)",
+            "unfused_bytes_per_launch": unfused / per_step_launches,
+            "fusion_factor": unfused / model if model > 0 else None,
+            "valu": valu,
         },
     }
     if args.verify:
@@ -322,8 +371,7 @@ def main():
         ref_vals, ref_grad = eng.expectation_vjp(
             full_bits, params, full_up,
             method=E.GRAD_PARAMETER_SHIFT if args.mode == "shift" else E.GRAD_ADJOINT)
-      got_vals = torch.cat(gathered) if world > 1 else vals
-      err_v = float((got_vals - ref_vals).abs().max())
+      err_v = float((vals - ref_vals).abs().max())
       err_g = float((grad - ref_grad).abs().max()) if ref_grad is not None else 0.0
       line["verify"] = {"max_err_values": err_v, "max_err_grad": err_g,
                         "ok": bool(err_v < 1e-4 * len(op) and err_g < 1e-4)}

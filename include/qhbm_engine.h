@@ -207,12 +207,19 @@ int qhbm_parity_energy_vjp(const int8_t* d_bits, int64_t n_rows, int n_bits,
 int qhbm_num_passes(qhbm_engine* h, int* forward_passes, int* backward_passes);
 /* Human-readable description of the schedule, written into buf. */
 int qhbm_describe_schedule(qhbm_engine* h, char* buf, size_t buf_len);
-/* Accumulated HIP-event time (ms) and launch count of the pass kernels since
- * the last call with reset != 0.  Timing is only recorded when the option
- * "profile_events" is non-zero; it synchronises the stream. */
+/* Accumulated HIP-event time (ms) and launch count of the pass kernels (forward passes, adjoint
+ * passes, lambda = O psi) since the last call with reset != 0.  Timing is only recorded when the
+ * option "profile_events" is non-zero; it synchronises the stream.  Any out pointer may be NULL. */
 int qhbm_kernel_time_ms(qhbm_engine* h, int reset, double* fwd_ms,
                         int64_t* fwd_launches, double* bwd_ms,
-                        int64_t* bwd_launches);
+                        int64_t* bwd_launches, double* obs_ms,
+                        int64_t* obs_launches);
+/* HBM bytes one call on U states must move under the installed schedule if every tile a pass
+ * touches is read once and written once (tiles the kernels skip as identically zero excluded):
+ * summed over the forward passes, lambda = O psi, and the adjoint passes (with_vjp != 0).  This
+ * is the byte count bench.py's roofline divides by the measured kernel time. */
+int qhbm_traffic_model(qhbm_engine* h, int U, int with_vjp, double* fwd_bytes,
+                       double* obs_bytes, double* bwd_bytes);
 
 #ifdef __cplusplus
 }

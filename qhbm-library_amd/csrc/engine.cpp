@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -56,7 +57,7 @@ struct DevicePlan {
 
 struct TimedEvent {
   hipEvent_t a, b;
-  int kind;  // 0 forward pass, 1 adjoint pass
+  int kind;  // 0 forward pass, 1 adjoint pass, 2 lambda = O psi
 };
 
 }  // namespace
@@ -69,6 +70,7 @@ struct qhbm_engine {
   // options
   int opt_tile = 0, opt_adj_tile = 0, opt_profile = 0, opt_round = 0;
   int opt_full_fwd = 60, opt_full_adj = 60, opt_force_general = 0;
+  int opt_adj_exchange = 1;  // lean adjoint passes: register-resident tile pair + one LDS exchange buffer
   int retained_U = 0;  // final states of the last qhbm_expectation_retain still sit in psi
   int64_t opt_chunk = 0;
   int64_t opt_budget_mb = 0;  // 0: a third of the device's memory, resolved at first use (budget_bytes)
@@ -80,6 +82,10 @@ struct qhbm_engine {
   uint32_t n_obs_groups = 0;
   DevBuf<float2> psi, lam;
   DevBuf<float> state_grad, slot_factor, vals_tmp, vals_p, vals_m, upstream_tmp, phase_cs;
+  DevBuf<float> tile_grad;              // [chunk states * tiles, slots of one adjoint pass]
+  DevBuf<unsigned long long> vals64;    // [U, n_ops] fixed-point accumulators of the expectation values
+  DevBuf<float> op_scale, op_inv_scale; // per op: 2^(+-shift), see program.h kValueFracBits
+  std::vector<float> h_op_scale, h_op_inv_scale;
   DevBuf<double> block_cum;
   DevBuf<int> param_slot_begin, param_slots;
   std::vector<TimedEvent> events;
@@ -202,6 +208,8 @@ int upload_model(qhbm_engine* h) {
     HIPCHK(h->terms.upload(t));
     HIPCHK(h->obs_groups.upload(groups));
     h->n_obs_groups = uint32_t(groups.size());
+    HIPCHK(h->op_scale.upload(h->h_op_scale));
+    HIPCHK(h->op_inv_scale.upload(h->h_op_inv_scale));
   }
   // parameter -> slots map for the adjoint reduction
   const Plan& ap = h->adj.plan;
@@ -255,8 +263,8 @@ hipEvent_t* timer_begin(qhbm_engine* h, int kind, hipStream_t s) {
 void timer_end(hipEvent_t* e, hipStream_t s) { if (e) (void)hipEventRecord(*e, s); }
 
 // Forward passes for one chunk.
-int run_forward_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_t cs, float* d_out,
-                      bool keep_state, hipStream_t stream) {
+int run_forward_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_t cs, bool keep_state,
+                      hipStream_t stream) {
   DevicePlan& d = h->fwd;
   const size_t np = d.plan.passes.size();
   bool measure_only_after = false;
@@ -269,9 +277,24 @@ int run_forward_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_
     if (!p.is_measure_only && (!p.completes_circuit || keep_state || measure_only_after)) a.flags |= PASS_STORE;
     hipEvent_t* ev = timer_begin(h, 0, stream);
     HIPCHK(launch_pass_fwd(d.plan.K, d.plan.R, a, cs, h->psi.p, d_bits, h->model.n, d.prog.p, d.tables.p, d.coef.p,
-                           d_out, s0, stream));
+                           h->op_scale.p, h->vals64.p, s0, stream));
     timer_end(ev, stream);
   }
+  return 0;
+}
+
+// Expectation values accumulate in fixed point (program.h kValueFracBits) while the passes run ...
+int values_begin(qhbm_engine* h, int U, hipStream_t stream) {
+  const size_t nv = size_t(U) * size_t(std::max(h->model.n_ops, 1));
+  HIPCHK(h->vals64.reserve(nv));
+  HIPCHK(hipMemsetAsync(h->vals64.p, 0, nv * sizeof(unsigned long long), stream));
+  return 0;
+}
+// ... and are converted to fp32 [U, n_ops] once at the end.
+int values_end(qhbm_engine* h, int U, float* d_out, hipStream_t stream) {
+  if (!d_out || h->model.n_ops <= 0) return 0;
+  HIPCHK(launch_values_from_fixed(h->vals64.p, h->op_inv_scale.p, d_out, uint32_t(U) * uint32_t(h->model.n_ops),
+                                  uint32_t(h->model.n_ops), stream));
   return 0;
 }
 
@@ -289,14 +312,14 @@ int forward(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, 
   HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, shift_gate,
                            shift, stream));
   HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), stream));
-  if (h->model.n_ops) HIPCHK(hipMemsetAsync(d_out, 0, size_t(U) * h->model.n_ops * sizeof(float), stream));
+  if (int rc = values_begin(h, U, stream)) return rc;
   const uint32_t cs = chunk_states(h, U);
   if (int rc = ensure_state_buffers(h, cs, false)) return rc;
   for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += cs) {
     const uint32_t c = std::min<uint32_t>(cs, uint32_t(U) - s0);
-    if (int rc = run_forward_chunk(h, d_bits, s0, c, d_out, false, stream)) return rc;
+    if (int rc = run_forward_chunk(h, d_bits, s0, c, false, stream)) return rc;
   }
-  return 0;
+  return values_end(h, U, d_out, stream);
 }
 
 // lambda = O psi and the backward passes for one chunk whose final states sit in psi.
@@ -304,16 +327,26 @@ int run_adjoint_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_
                       hipStream_t stream) {
   DevicePlan& b = h->adj;
   const uint32_t n_slots = uint32_t(b.plan.slot_gate.size());
-  HIPCHK(launch_apply_observable(h->psi.p, h->lam.p, uint32_t(h->fwd.plan.n_eff), c, h->terms.p,
-                                 uint32_t(h->model.terms.size()), h->obs_groups.p, h->n_obs_groups, d_upstream,
-                                 uint32_t(h->model.n_ops), s0, stream));
+  {
+    hipEvent_t* ev = timer_begin(h, 2, stream);
+    HIPCHK(launch_apply_observable(h->psi.p, h->lam.p, uint32_t(h->fwd.plan.n_eff), c, h->terms.p,
+                                   uint32_t(h->model.terms.size()), h->obs_groups.p, h->n_obs_groups, d_upstream,
+                                   uint32_t(h->model.n_ops), s0, stream));
+    timer_end(ev, stream);
+  }
+  size_t rows = 0;  // tile_grad: one row of the pass's slots per workgroup
+  for (const PassArgs& ba : b.args) rows = std::max(rows, (size_t(c) << ba.n_nonlocal) * std::max<uint32_t>(ba.n_slots, 1));
+  HIPCHK(h->tile_grad.reserve(rows));
   for (size_t i = 0; i < b.plan.passes.size(); ++i) {
     hipEvent_t* ev = timer_begin(h, 1, stream);
     PassArgs ba = b.args[i];
     if (h->opt_force_general) ba.flags |= PASS_GENERAL;
-    HIPCHK(launch_pass_adj(b.plan.K, ba, c, h->psi.p, h->lam.p, d_bits, h->model.n, b.prog.p, b.tables.p, b.coef.p,
-                           h->state_grad.p, n_slots, s0, stream));
+    HIPCHK(launch_pass_adj(b.plan.K, h->opt_adj_exchange != 0, ba, c, h->psi.p, h->lam.p, d_bits, h->model.n, b.prog.p,
+                           b.tables.p, b.coef.p, h->tile_grad.p, s0, stream));
     timer_end(ev, stream);
+    // tiles of a state are added in tile order (bit-reproducible, no atomics)
+    HIPCHK(launch_reduce_tiles(h->tile_grad.p, c, 1u << ba.n_nonlocal, ba.n_slots, h->state_grad.p, n_slots, ba.slot_base,
+                               s0, stream));
   }
   return 0;
 }
@@ -337,17 +370,17 @@ int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_pa
   HIPCHK(launch_combine_diag(f.coef.p, f.rec_offsets.p, int(f.plan.record_offsets.size()), stream));
   HIPCHK(launch_prep_coefs(b.jobs.p, int(b.plan.jobs.size()), d_params, b.coef.p, -1, 0.0, stream));
   HIPCHK(launch_combine_diag(b.coef.p, b.rec_offsets.p, int(b.plan.record_offsets.size()), stream));
-  HIPCHK(hipMemsetAsync(d_out_vals, 0, size_t(U) * h->model.n_ops * sizeof(float), stream));
+  if (int rc = values_begin(h, U, stream)) return rc;
   HIPCHK(h->state_grad.reserve(size_t(U) * std::max<uint32_t>(n_slots, 1)));
   HIPCHK(hipMemsetAsync(h->state_grad.p, 0, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), stream));
   const uint32_t cs = adjoint_chunk_states(h, U);
   if (int rc = ensure_state_buffers(h, cs, true)) return rc;
   for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += cs) {
     const uint32_t c = std::min<uint32_t>(cs, uint32_t(U) - s0);
-    if (int rc = run_forward_chunk(h, d_bits, s0, c, d_out_vals, true, stream)) return rc;
+    if (int rc = run_forward_chunk(h, d_bits, s0, c, true, stream)) return rc;
     if (int rc = run_adjoint_chunk(h, d_bits, s0, c, d_upstream, stream)) return rc;
   }
-  return 0;
+  return values_end(h, U, d_out_vals, stream);
 }
 
 int check_call(qhbm_engine* h, int U) {
@@ -439,6 +472,18 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
       terms.push_back(t);
     }
   }
+  // fixed-point scale of every op's accumulator: partial sums are bounded by B = sum |c_k|
+  h->h_op_scale.assign(size_t(n_ops), 0.f);
+  h->h_op_inv_scale.assign(size_t(n_ops), 0.f);
+  for (int k = 0; k < n_ops; ++k) {
+    double bound = 0.0;
+    for (int j = term_offsets[k]; j < term_offsets[k + 1]; ++j) bound += std::fabs(double(coeffs[j]));
+    int e = 0;
+    if (bound > 0.0) (void)std::frexp(bound, &e);  // bound <= 2^e
+    e = std::max(-60, std::min(60, e));
+    h->h_op_scale[size_t(k)] = float(std::ldexp(1.0, kValueFracBits - e));
+    h->h_op_inv_scale[size_t(k)] = float(std::ldexp(1.0, e - kValueFracBits));
+  }
   h->model.n_ops = n_ops;
   h->model.terms = std::move(terms);
   h->plans_valid = false;
@@ -455,6 +500,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "full_diag_threshold") { h->opt_full_fwd = int(value); h->plans_valid = false; }
   else if (k == "adjoint_full_diag_threshold") { h->opt_full_adj = int(value); h->plans_valid = false; }
   else if (k == "adjoint_tile_qubits") { h->opt_adj_tile = int(value); h->plans_valid = false; }
+  else if (k == "adjoint_exchange") h->opt_adj_exchange = int(value);
   else if (k == "chunk_states") h->opt_chunk = value;
   else if (k == "workspace_budget_mb") h->opt_budget_mb = std::max<int64_t>(0, value);  // 0 = default
   else if (k == "profile_events") h->opt_profile = int(value);
@@ -467,7 +513,14 @@ int qhbm_workspace_bytes(qhbm_engine* h, int U, int with_vjp, size_t* out) {
   if (int rc = build_plans(h)) return rc;
   const uint32_t cs = with_vjp ? adjoint_chunk_states(h, U) : chunk_states(h, U);  // as the calls chunk
   size_t b = size_t(cs) * state_bytes(h) * (with_vjp ? 2 : 1);
-  if (with_vjp) b += size_t(U) * h->adj.plan.slot_gate.size() * sizeof(float);
+  if (with_vjp) {
+    b += size_t(U) * h->adj.plan.slot_gate.size() * sizeof(float);
+    size_t rows = 0;  // per-tile gradient rows of the widest adjoint pass
+    for (const Pass& p : h->adj.plan.passes)
+      rows = std::max(rows, (size_t(cs) << p.nonlocal_pos.size()) * size_t(std::max(p.n_slots, 1)));
+    b += rows * sizeof(float);
+  }
+  b += size_t(U) * size_t(std::max(h->model.n_ops, 1)) * sizeof(unsigned long long);
   *out = b;
   return 0;
 }
@@ -475,7 +528,7 @@ int qhbm_workspace_bytes(qhbm_engine* h, int U, int with_vjp, size_t* out) {
 int qhbm_allocated_bytes(qhbm_engine* h, size_t* out) {
   if (!h || !out) return 1;
   *out = h->psi.n * sizeof(float2) + h->lam.n * sizeof(float2) + h->state_grad.n * sizeof(float) +
-         h->block_cum.n * sizeof(double);
+         h->tile_grad.n * sizeof(float) + h->vals64.n * sizeof(unsigned long long) + h->block_cum.n * sizeof(double);
   return 0;
 }
 
@@ -503,9 +556,10 @@ int qhbm_expectation_retain(qhbm_engine* h, const int8_t* d_bits, int U, const f
   h->retained_U = 0;
   HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, -1, 0.0, s));
   HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), s));
-  HIPCHK(hipMemsetAsync(d_out, 0, size_t(U) * h->model.n_ops * sizeof(float), s));
+  if (int rc = values_begin(h, U, s)) return rc;
   if (int rc = ensure_state_buffers(h, uint32_t(U), true)) return rc;  // psi AND lambda, so psi is not moved later
-  if (int rc = run_forward_chunk(h, d_bits, 0, uint32_t(U), d_out, true, s)) return rc;
+  if (int rc = run_forward_chunk(h, d_bits, 0, uint32_t(U), true, s)) return rc;
+  if (int rc = values_end(h, U, d_out, s)) return rc;
   h->retained_U = U;
   return 0;
 }
@@ -540,16 +594,14 @@ int qhbm_statevector(qhbm_engine* h, const int8_t* d_bits, int U, const float* d
   h->retained_U = 0;
   HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, -1, 0.0, s));
   HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), s));
-  // expectation values of installed observables are a by-product; they land in a scratch buffer
-  const size_t nv = size_t(U) * std::max(h->model.n_ops, 1);
-  HIPCHK(h->vals_tmp.reserve(nv));
-  HIPCHK(hipMemsetAsync(h->vals_tmp.p, 0, nv * sizeof(float), s));
+  // expectation values of installed observables are a by-product; they stay in the fixed-point scratch
+  if (int rc = values_begin(h, U, s)) return rc;
   const uint32_t cs = chunk_states(h, U);
   if (int rc = ensure_state_buffers(h, cs, false)) return rc;
   const size_t row = size_t(8) << h->model.n, pitch = size_t(8) << d.plan.n_eff;
   for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += cs) {
     const uint32_t c = std::min<uint32_t>(cs, uint32_t(U) - s0);
-    if (int rc = run_forward_chunk(h, d_bits, s0, c, h->vals_tmp.p, true, s)) return rc;
+    if (int rc = run_forward_chunk(h, d_bits, s0, c, true, s)) return rc;
     // idle padding qubits (n < 10) are the high index bits and stay |0>: keep the first 2^n amplitudes
     HIPCHK(hipMemcpy2DAsync(static_cast<char*>(d_out_states) + size_t(s0) * row, row, h->psi.p, pitch, row, c,
                             hipMemcpyDeviceToDevice, s));
@@ -595,16 +647,14 @@ int qhbm_sample(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_para
   h->retained_U = 0;
   HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, shift_gate, shift, s));
   HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), s));
-  const size_t nv = size_t(U) * std::max(h->model.n_ops, 1);
-  HIPCHK(h->vals_tmp.reserve(nv));
-  HIPCHK(hipMemsetAsync(h->vals_tmp.p, 0, nv * sizeof(float), s));
+  if (int rc = values_begin(h, U, s)) return rc;
   const uint32_t cs = std::min<uint32_t>(chunk_states(h, U), 65535u);
   if (int rc = ensure_state_buffers(h, cs, false)) return rc;
   const uint32_t n_eff = uint32_t(d.plan.n_eff);
   HIPCHK(h->block_cum.reserve(size_t(cs) << (n_eff - 10)));
   for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += cs) {
     const uint32_t c = std::min<uint32_t>(cs, uint32_t(U) - s0);
-    if (int rc = run_forward_chunk(h, d_bits, s0, c, h->vals_tmp.p, true, s)) return rc;
+    if (int rc = run_forward_chunk(h, d_bits, s0, c, true, s)) return rc;
     // shots are drawn in slices of <= 65535 (grid.x); the shot index feeds the counter RNG
     HIPCHK(launch_sample(h->psi.p, n_eff, h->model.n, c, h->block_cum.p, uint32_t(n_shots), seed, s0,
                          d_out_samples, s));
@@ -695,10 +745,10 @@ int qhbm_describe_schedule(qhbm_engine* h, char* buf, size_t buf_len) {
 }
 
 int qhbm_kernel_time_ms(qhbm_engine* h, int reset, double* fwd_ms, int64_t* fwd_launches, double* bwd_ms,
-                        int64_t* bwd_launches) {
+                        int64_t* bwd_launches, double* obs_ms, int64_t* obs_launches) {
   if (!h) return 1;
-  double ms[2] = {0.0, 0.0};
-  int64_t cnt[2] = {0, 0};
+  double ms[3] = {0.0, 0.0, 0.0};
+  int64_t cnt[3] = {0, 0, 0};
   if (h->device >= 0 && !h->events.empty()) {
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipEventSynchronize(h->events.back().b));
@@ -711,10 +761,40 @@ int qhbm_kernel_time_ms(qhbm_engine* h, int reset, double* fwd_ms, int64_t* fwd_
   if (fwd_launches) *fwd_launches = cnt[0];
   if (bwd_ms) *bwd_ms = ms[1];
   if (bwd_launches) *bwd_launches = cnt[1];
+  if (obs_ms) *obs_ms = ms[2];
+  if (obs_launches) *obs_launches = cnt[2];
   if (reset) {
     h->free_events.insert(h->free_events.end(), h->events.begin(), h->events.end());
     h->events.clear();
   }
+  return 0;
+}
+
+int qhbm_traffic_model(qhbm_engine* h, int U, int with_vjp, double* fwd_bytes, double* obs_bytes,
+                       double* bwd_bytes) {
+  if (!h) return 1;
+  if (int rc = build_plans(h)) return rc;
+  const double tile_all = double(state_bytes(h)) * double(U);  // every tile of every state, once
+  double f = 0.0, o = 0.0, b = 0.0;
+  bool measure_only_after = false;
+  for (const Pass& p : h->fwd.plan.passes) measure_only_after |= p.is_measure_only;
+  for (const Pass& p : h->fwd.plan.passes) {
+    if (!(p.flags & PASS_INIT_BASIS)) f += tile_all;  // the first pass writes the basis state, reads nothing
+    if (!p.is_measure_only && (!p.completes_circuit || with_vjp || measure_only_after)) f += tile_all;
+  }
+  if (with_vjp) {
+    o = 2.0 * tile_all;  // psi read (gathered through L2), lambda written
+    std::vector<PassArgs> args;
+    std::vector<uint32_t> prog, tables;
+    fill_args(h->adj.plan, h->model, &args, &prog, &tables);
+    for (size_t i = 0; i < args.size(); ++i) {
+      const double live = 1.0 / double(1ull << __builtin_popcount(args[i].zero_mask));  // tiles not skipped
+      b += live * tile_all * 2.0 * ((h->adj.plan.passes[i].flags & PASS_STORE) ? 2.0 : 1.0);
+    }
+  }
+  if (fwd_bytes) *fwd_bytes = f;
+  if (obs_bytes) *obs_bytes = o;
+  if (bwd_bytes) *bwd_bytes = b;
   return 0;
 }
 

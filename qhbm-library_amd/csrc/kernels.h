@@ -24,16 +24,22 @@ struct ObsGroup {
 constexpr uint32_t kObsTermChunk = 1024;
 
 size_t fwd_lds_bytes(int K);
-size_t adj_lds_bytes(int K);
+size_t adj_lds_bytes(int K, bool exchange);
 
+// op_scale[k] = 2^(kValueFracBits - ceil(log2 sum|c|)) of op k; out64 [U, n_ops] fixed-point accumulators.
 hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
                            int n_user, const uint32_t* prog, const uint32_t* tables, const float* coef,
-                           float* out, uint32_t state0, hipStream_t stream);
-hipError_t launch_pass_adj(int K, const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
-                           const int8_t* bits, int n_user,
-                           const uint32_t* prog, const uint32_t* tables, const float* coef,
-                           float* state_grad, uint32_t n_slots_total,
-                           uint32_t state0, hipStream_t stream);
+                           const float* op_scale, unsigned long long* out64, uint32_t state0, hipStream_t stream);
+hipError_t launch_values_from_fixed(const unsigned long long* acc, const float* inv_scale, float* out, uint32_t count,
+                                    uint32_t n_ops, hipStream_t stream);
+// tile_grad [n_states * tiles, a.n_slots]: one gradient row per workgroup.  `exchange` selects the
+// register-resident tile pair with one LDS exchange buffer (lean programs only).
+hipError_t launch_pass_adj(int K, bool exchange, const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
+                           const int8_t* bits, int n_user, const uint32_t* prog, const uint32_t* tables,
+                           const float* coef, float* tile_grad, uint32_t state0, hipStream_t stream);
+hipError_t launch_reduce_tiles(const float* tile_grad, uint32_t n_states, uint32_t n_tiles, uint32_t n_slots,
+                               float* state_grad, uint32_t n_slots_total, uint32_t slot_base, uint32_t state0,
+                               hipStream_t stream);
 hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,

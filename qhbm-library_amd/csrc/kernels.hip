@@ -53,16 +53,25 @@ __device__ __forceinline__ float wave_sum(float v) {
          __int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48));
 }
 
+// Fixed-point image of a partial expectation value (two's complement in an unsigned word).
+__device__ __forceinline__ unsigned long long to_fixed(float v, float scale) {
+  return static_cast<unsigned long long>(__float2ll_rn(v * scale));
+}
+
 // Waves per SIMD the register allocator must leave room for: as many workgroups per CU
 // as the LDS footprint admits (160 KiB per CU), capped at 4 waves per SIMD.
 constexpr int wg_per_cu(int lds_bytes) { return (160 * 1024) / lds_bytes < 1 ? 1 : (160 * 1024) / lds_bytes; }
 constexpr int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+constexpr int fwd_lds(int K) { return (8 << K) + 8 * kMaxOps; }
+// adjoint, two-tile layout: (psi, lambda) tiles + one gradient cell per slot and wave
+constexpr int adj_lds(int K) { return (16 << K) + 4 * kMaxSlotsPerPass * ((1 << (K - 4)) / 64 < 1 ? 1 : (1 << (K - 4)) / 64); }
+// adjoint, exchange layout: ONE tile-sized exchange buffer (the tile pair lives in registers)
+constexpr int adjx_lds(int K) { return (8 << K) + 4 * kMaxSlotsPerPass * ((1 << (K - 4)) / 64 < 1 ? 1 : (1 << (K - 4)) / 64); }
 constexpr int fwd_min_waves(int K, int R) {
-  return clampi(wg_per_cu((8 << K) + 4096) * (1 << (K - R)) / 256, 1, 4);
+  return clampi(wg_per_cu(fwd_lds(K)) * (1 << (K - R)) / 256, 1, 4);
 }
-constexpr int adj_min_waves(int K) {
-  return clampi(wg_per_cu((16 << K) + 8192) * (1 << (K - 4)) / 256, 1, 4);
-}
+constexpr int adj_min_waves(int K) { return clampi(wg_per_cu(adj_lds(K)) * (1 << (K - 4)) / 256, 1, 4); }
+constexpr int adjx_min_waves(int K) { return clampi(wg_per_cu(adjx_lds(K)) * (1 << (K - 4)) / 256, 1, 4); }
 
 // Static iteration over register bits / register-bit pairs WITHOUT lambdas (a lambda
 // capturing the register arrays by reference pins them to scratch memory).
@@ -559,18 +568,22 @@ __device__ __forceinline__ void rec_load(const uint32_t* __restrict__ recs, uint
   for (int i = 0; i < NV; ++i) rv[i] = recs[off + 64u * i + uint32_t(lane)];
 }
 
-// Gradient partial of one slot: wave sum (DPP rows + readlane), one LDS atomic per wave.
-__device__ __forceinline__ void add_slot(float* sacc, uint32_t slot_base, int tid, uint32_t slot, float v) {
+// Gradient partial of one slot: wave sum (DPP rows + readlane).  Every wave executes every gate of
+// the pass exactly once, so it OWNS one LDS cell per slot (cells[slot][wave]) and stores into it --
+// no atomics; the kernel epilogue adds a slot's cells in wave order, so the tile's gradient is
+// bit-identical from run to run.
+template <int NW>
+__device__ __forceinline__ void add_slot(float* cells, uint32_t slot_base, int tid, uint32_t slot, float v) {
   v = wave_sum(v);
-  if ((tid & 63) == 0) atomicAdd(&sacc[slot - slot_base], v);
+  if ((tid & 63) == 0) cells[(slot - slot_base) * NW + (uint32_t(tid) >> 6)] = v;
 }
 
 // Gradient partials of the four slots of record slot group G, reduced over the wave TOGETHER:
 // two select+quad_perm butterflies leave lane l with the quad sum of g[l & 3]; row_ror 4 / 8 sum
 // the four quads of a row; permlane16/32 swaps (gfx950) sum the four rows.  Lanes 4G..4G+3 --
-// the lanes whose slot-vector word `sv` IS the slot of g[l & 3] -- then issue one ds_add_f32.
-// 23 instructions for four slots; one slot at a time (wave_sum + readlanes + single-lane atomic)
-// was 45 each and cost 17 % of the VQT step.
+// the lanes whose slot-vector word `sv` IS the slot of g[l & 3] -- then store into their wave's
+// cells (see add_slot).  23 instructions for four slots; one slot at a time (wave_sum + readlanes
+// + single-lane store) was 45 each and cost 17 % of the VQT step.
 template <int CTRL>
 __device__ __forceinline__ float dpp_get(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
@@ -581,9 +594,9 @@ __device__ __forceinline__ float rows_sum(float u) {
   r = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-template <int G>
-__device__ __forceinline__ void add_slots4(float* sacc, uint32_t slot_base, int lane, uint32_t sv, float scale,
-                                           float g0, float g1, float g2, float g3) {
+template <int G, int NW>
+__device__ __forceinline__ void add_slots4(float* cells, uint32_t slot_base, int lane, uint32_t wave, uint32_t sv,
+                                           float scale, float g0, float g1, float g2, float g3) {
   const bool b0 = lane & 1, b1 = lane & 2;
   float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2;
   t0 += dpp_get<0xB1>(b0 ? g0 : g1);  // quad_perm:[1,0,3,2]
@@ -593,7 +606,7 @@ __device__ __forceinline__ void add_slots4(float* sacc, uint32_t slot_base, int 
   u += dpp_get<0x124>(u);             // row_ror:4
   u += dpp_get<0x128>(u);             // row_ror:8
   u = rows_sum(u);
-  if ((lane >> 2) == G && sv != 0xffffffffu) atomicAdd(&sacc[sv - slot_base], scale * u);
+  if ((lane >> 2) == G && sv != 0xffffffffu) cells[(sv - slot_base) * NW + wave] = scale * u;
 }
 
 // FULL diagonal table: amplitude with register value m (1..15) times FULL[m-1].
@@ -714,12 +727,15 @@ template <int K, int R, bool GEN>
 __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_kernel(
     PassArgs a, float2* __restrict__ psi, const int8_t* __restrict__ bits, int n_user,
     const uint32_t* __restrict__ prog_base, const uint32_t* __restrict__ tables,
-    const float* __restrict__ coef, float* __restrict__ out, uint32_t state0) {
+    const float* __restrict__ coef, const float* __restrict__ op_scale, unsigned long long* __restrict__ out64,
+    uint32_t state0) {
   constexpr int NT = 1 << (K - R);
   constexpr int NR = 1 << R;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* tile = reinterpret_cast<float2*>(smem);
-  float* red = reinterpret_cast<float*>(tile + (1 << K));
+  // per-op accumulators of this tile, 64-bit fixed point (program.h kValueFracBits): integer adds
+  // commute, so neither the order of the waves here nor that of the tiles below changes a bit
+  unsigned long long* red = reinterpret_cast<unsigned long long*>(tile + (1 << K));
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -754,7 +770,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
     prefetch_tile<K, NT>(r, st, t, tid);
     commit_tile<K, NT>(tile, r, tid);
   }
-  for (int i = tid; i < kMaxOps; i += NT) red[i] = 0.f;
+  for (int i = tid; i < kMaxOps; i += NT) red[i] = 0ull;
   __syncthreads();
 
   const uint32_t* prog = prog_base + a.prog_off;
@@ -828,7 +844,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
           if (op != cur_op) {
             if (cur_op != 0xffffffffu) {
               const float v = wave_sum(acc);
-              if ((tid & 63) == 0) atomicAdd(&red[cur_op], v);
+              if ((tid & 63) == 0) atomicAdd(&red[cur_op], to_fixed(v, op_scale[cur_op]));
             }
             acc = 0.f;
             cur_op = op;
@@ -848,7 +864,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
       }
       if (cur_op != 0xffffffffu) {
         const float v = wave_sum(acc);
-        if ((tid & 63) == 0) atomicAdd(&red[cur_op], v);
+        if ((tid & 63) == 0) atomicAdd(&red[cur_op], to_fixed(v, op_scale[cur_op]));
       }
       __syncthreads();
     }
@@ -857,43 +873,290 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
   if (a.n_ops) {
     __syncthreads();
     for (uint32_t i = tid; i < a.n_ops; i += NT) {
-      const float v = red[i];
-      if (v != 0.f) atomicAdd(&out[size_t(state0 + s_local) * a.n_ops + i], v);
+      const unsigned long long v = red[i];
+      if (v) atomicAdd(&out64[size_t(state0 + s_local) * a.n_ops + i], v);
     }
   }
   if (a.flags & PASS_STORE) store_tile<K, NT>(tile, st, t, tid);
 }
 
 // ================================================================================
-// Adjoint pass kernel: tile pair (psi, lambda); program already in reverse order.
+// Adjoint pass kernels: tile pair (psi, lambda); program already in reverse order.
 // For each parametrised gate:  dE/dt = -2*pi * Im <lam| A |psi>  with psi, lam taken
 // AFTER the gate and A = sum_k e_k P_k, then both are multiplied by U^dagger.
 // For a diagonal term with angle t on the index set {bits all 1}:
 //   dE/dt = -2*pi * sum_{selected l} Im(conj(lam_l) psi_l).
+//
+// Gradient partials leave a workgroup as one row of `tile_grad` [state, tile, slot of this pass]
+// (no atomics anywhere: cells per wave in LDS, summed in wave order; reduce_tiles_kernel then adds
+// the tiles of a state in tile order), so gradients are bit-identical from run to run and for any
+// sharding of the batch over GPUs.
 // ================================================================================
-template <int K, bool GEN>
-__global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kernel(
+// One adjoint instance on the register-resident tile pair: for every parametrised micro-op the
+// gradient partial Im<lam|A|psi> (reduced over the wave into its slot cell), then U^dagger on both.
+template <int R, int NW, bool GEN>
+__device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uint32_t (&sv)[1],
+                                             const uint32_t* __restrict__ recs, uint32_t rec_off, int lane,
+                                             uint32_t wave, v2f (&p)[1 << R], v2f (&l)[1 << R], uint32_t TL,
+                                             uint32_t tile_base, float* cells, uint32_t slot_base) {
+  constexpr RecordLayout L(R, true);
+  constexpr int NR = 1 << R;
+  constexpr int NB = 1;
+  constexpr int S0 = L.slot0();
+  constexpr float kM2Pi = -2.f * kPi;
+  const uint32_t h0 = rec_word<0>(cur), h1 = rec_word<1>(cur);
+  // ---- CPH (slot groups 6, 7) ----
+  if (h1 & 0xffu) {
+    float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    QHBM_FOR_RB(R,
+      if ((h1 >> (2 * J)) & 1u)
+        g[2 * J] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J)>(cur), rec_word<L.pred(2 * J)>(cur), TL, tile_base);
+      if ((h1 >> (2 * J + 1)) & 1u)
+        g[2 * J + 1] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J + 1)>(cur), rec_word<L.pred(2 * J + 1)>(cur), TL,
+                                    tile_base);)
+    if (h1 & 0x0fu) add_slots4<L.group_cph(), NW>(cells, slot_base, lane, wave, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
+    if (h1 & 0xf0u) add_slots4<L.group_cph() + 1, NW>(cells, slot_base, lane, wave, sv[0], kM2Pi, g[4], g[5], g[6], g[7]);
+  }
+  if (h1 & kFullDiagFlag) {
+    // ---- all PH1/PH2 terms at once: w = Im(conj(lam) psi) per register value, per-term
+    // gradients are sums of w over the term's index set, then ONE conj-table multiply ----
+    float w[NR];
+    w_all_(w, p, l, iseq<NR>{});
+    if ((h0 >> 24) & 0x3fu) {
+      float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      QHBM_FOR_PAIR(R,
+        if ((h0 >> (24 + pair_index(JA, JB))) & 1u) g[pair_index(JA, JB)] = wsum2_<JA, JB>(w, iseq<4>{});)
+      if ((h0 >> 24) & 0x0fu) add_slots4<L.group_ph2(), NW>(cells, slot_base, lane, wave, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
+      if ((h0 >> 24) & 0x30u) add_slots4<L.group_ph2() + 1, NW>(cells, slot_base, lane, wave, sv[0], kM2Pi, g[4], g[5], 0.f, 0.f);
+    }
+    if ((h0 >> 4) & 0xfu) {
+      float g[4] = {0.f, 0.f, 0.f, 0.f};
+      QHBM_FOR_RB(R, if ((h0 >> (4 + J)) & 1u) g[J] = wsum1_<J>(w, iseq<8>{});)
+      add_slots4<L.group_ph1(), NW>(cells, slot_base, lane, wave, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
+    }
+    apply_full<NB>(p, cur, true);
+    apply_full<NB>(l, cur, true);
+  }
+  {
+  // ---- PH2 (slot groups 4, 5) ----
+  if ((h0 >> 16) & 0x3fu) {
+    float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    QHBM_FOR_PAIR(R,
+      if ((h0 >> (16 + pair_index(JA, JB))) & 1u) {
+        const v2f cs = conj_cs(rec_cs<L.ph2(pair_index(JA, JB))>(cur));
+        g[pair_index(JA, JB)] = sum_w2<R, JA, JB>(p, l);
+        apply_ph2<R, JA, JB>(p, cs);
+        apply_ph2<R, JA, JB>(l, cs);
+      })
+    if ((h0 >> 16) & 0x0fu) add_slots4<L.group_ph2(), NW>(cells, slot_base, lane, wave, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
+    if ((h0 >> 16) & 0x30u) add_slots4<L.group_ph2() + 1, NW>(cells, slot_base, lane, wave, sv[0], kM2Pi, g[4], g[5], 0.f, 0.f);
+  }
+  // ---- PH1 (slot group 3) ----
+  if ((h0 >> 8) & 0xfu) {
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    QHBM_FOR_RB(R,
+      if ((h0 >> (8 + J)) & 1u) {
+        const v2f cs = conj_cs(rec_cs<L.ph1(J)>(cur));
+        g[J] = sum_w1<R, J>(p, l);
+        apply_ph1<R, J>(p, cs);
+        apply_ph1<R, J>(l, cs);
+      })
+    add_slots4<L.group_ph1(), NW>(cells, slot_base, lane, wave, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
+  }
+  }
+  // ---- one-qubit gates (X, Y, dense slot classes: groups 0, 1, 2) ----
+  if (h0 & 0xfu) {
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    QHBM_FOR_RB(R,
+      if ((h0 >> J) & 1u) {
+        const v2f cs = conj_cs(rec_cs<L.x(J)>(cur));  // U^dagger = c*I + i*s*X
+        if (rec_word<L.slot_x(J) - S0>(sv) != 0xffffffffu) g[J] = im_lam_x_psi<R, J>(p, l);
+        apply_x<R, J>(p, cs);
+        apply_x<R, J>(l, cs);
+      })
+    add_slots4<L.group_x(), NW>(cells, slot_base, lane, wave, sv[0], kPi, g[0], g[1], g[2], g[3]);
+  }
+  if constexpr (GEN) {
+  if ((h1 >> 16) & 0xfu) {
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    QHBM_FOR_RB(R,
+      if ((h1 >> (16 + J)) & 1u) {
+        const v2f cs = conj_cs(rec_cs<L.y(J)>(cur));
+        if (rec_word<L.slot_y(J) - S0>(sv) != 0xffffffffu) g[J] = im_lam_y_psi<R, J>(p, l);
+        apply_y<R, J>(p, cs);
+        apply_y<R, J>(l, cs);
+      })
+    add_slots4<L.group_y(), NW>(cells, slot_base, lane, wave, sv[0], kPi, g[0], g[1], g[2], g[3]);
+  }
+  if ((h1 >> 24) & 0xfu) {  // dense: U^dagger (8 floats) then generator (8 floats) per register bit
+    uint32_t dv[1];
+    rec_load<1>(recs, rec_off + 128u, lane, dv);
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    QHBM_FOR_RB(R,
+      if ((h1 >> (24 + J)) & 1u) {
+        const Gen2 gen{rec_cs<16 * J + 8>(dv), rec_cs<16 * J + 10>(dv), rec_cs<16 * J + 12>(dv), rec_cs<16 * J + 14>(dv)};
+        if (rec_word<L.slot_dense(J) - S0>(sv) != 0xffffffffu) g[J] = im_lam_g1_psi<R, J>(p, l, gen);
+        apply_mat1<R, J>(p, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
+        apply_mat1<R, J>(l, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
+      })
+    add_slots4<L.group_dense(), NW>(cells, slot_base, lane, wave, sv[0], 1.f, g[0], g[1], g[2], g[3]);
+  }
+  }
+}
+
+// Writes the tile's gradient row: slot cells summed in wave order.
+template <int NT, int NW>
+__device__ __forceinline__ void flush_cells(const float* cells, float* __restrict__ grow, uint32_t n_slots, int tid) {
+  for (uint32_t i = tid; i < n_slots; i += NT) {
+    float v = cells[i * NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += cells[i * NW + w];
+    grow[i] = v;
+  }
+}
+
+// ---- exchange layout (default for passes without Y / dense gates) ---------------------------------
+// The (psi, lambda) tile pair lives in REGISTERS for the whole pass; LDS holds one tile-sized
+// exchange buffer through which psi, then lambda, change geometry between rounds.  Half the LDS
+// of the two-tile layout: four waves per SIMD instead of two (K = 12: 36 KiB per workgroup, four
+// workgroups per CU).  A round boundary whose waves keep their amplitudes needs no barrier at all;
+// otherwise three (store psi | load psi | store lambda | load lambda): a wave always writes the
+// region it last read, so nothing else can race.
+template <int K>
+__global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_kernel(
     PassArgs a, float2* __restrict__ psi, float2* __restrict__ lam, const int8_t* __restrict__ bits, int n_user,
     const uint32_t* __restrict__ prog_base, const uint32_t* __restrict__ tables,
-    const float* __restrict__ coef, float* __restrict__ state_grad /*[U, n_slots_total]*/,
-    uint32_t n_slots_total, uint32_t state0) {
+    const float* __restrict__ coef, float* __restrict__ tile_grad /*[states * tiles, n_slots]*/, uint32_t state0) {
   constexpr int R = 4;
   constexpr int NT = 1 << (K - R);
   constexpr int NR = 1 << R;
+  constexpr int NW = NT / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float2* tp = reinterpret_cast<float2*>(smem);
-  float2* tl = tp + (1 << K);
-  float* sacc = reinterpret_cast<float*>(tl + (1 << K));  // [kMaxSlotsPerPass]
+  float2* xt = reinterpret_cast<float2*>(smem);
+  float* cells = reinterpret_cast<float*>(xt + (1 << K));  // [kMaxSlotsPerPass][NW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+  const uint32_t wave = uni(uint32_t(tid) >> 6);
   const uint32_t* recs = reinterpret_cast<const uint32_t*>(coef);
   const uint32_t tile_id = blockIdx.x & ((1u << a.n_nonlocal) - 1u);
   const uint32_t s_local = blockIdx.x >> a.n_nonlocal;
   const TileCtx t = make_tile_ctx(a, tables, tile_id);
+  float* grow = tile_grad + size_t(blockIdx.x) * a.n_slots;
+  const uint32_t* prog = prog_base + a.prog_off;
+  uint32_t w0 = uni(prog[0]);
+  bool skip = (w0 & 0xffu) != OP_ROUND;  // (an empty program: nothing to un-apply)
   if (a.zero_mask) {  // tail of the sweep: psi is identically zero on this tile (engine.cpp fill_args)
     const uint32_t idx = uni(basis_index(bits + size_t(state0 + s_local) * n_user, n_user));
-    if ((idx ^ t.tile_base) & a.zero_mask) return;
+    skip |= ((idx ^ t.tile_base) & a.zero_mask) != 0;
+  }
+  if (skip) {
+    for (uint32_t i = tid; i < a.n_slots; i += NT) grow[i] = 0.f;
+    return;
+  }
+  float2* sp = psi + (size_t(s_local) << a.n);
+  float2* sl = lam + (size_t(s_local) << a.n);
+  TileRegs rp, rl;
+  prefetch_tile<K, NT>(rp, sp, t, tid);
+  prefetch_tile<K, NT>(rl, sl, t, tid);
+  for (uint32_t i = tid; i < a.n_slots * NW; i += NT) cells[i] = 0.f;
+
+  constexpr RecordLayout L(R, true);
+  uint32_t pc = 0;
+  uint32_t cur[1], nxt[1], sv[1], svn[1];
+  uint32_t rec_off = uni(prog[2]);
+  rec_load<1>(recs, rec_off, lane, cur);
+  rec_load<1>(recs, rec_off + L.slot0(), lane, sv);
+  uint32_t DB[R], T, TL;
+  round_geometry<K, R>(uni(prog[1]), tid, DB, &T, &TL);
+  v2f p[NR], l[NR];
+  commit_tile<K, NT>(xt, rp, tid);
+  __syncthreads();
+  round_load<R>(xt, T, DB, p);
+  __syncthreads();
+  commit_tile<K, NT>(xt, rl, tid);
+  __syncthreads();
+  round_load<R>(xt, T, DB, l);
+  for (;;) {
+    const uint32_t n_inst = (w0 & ~kRoundNoBarrier) >> 8;
+    for (uint32_t inst = 0; inst < n_inst; ++inst) {
+      rec_load<1>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
+      rec_load<1>(recs, rec_off + L.words() + L.slot0(), lane, svn);
+      instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells, a.slot_base);
+      rec_off += L.words();
+      cur[0] = nxt[0];
+      sv[0] = svn[0];
+    }
+    pc += 3;
+    const uint32_t w1 = uni(prog[pc]);
+    if ((w1 & 0xffu) != OP_ROUND) break;
+    // ---- change of geometry through the exchange buffer ----
+    const bool sync = !(w0 & kRoundNoBarrier);  // else the next round's waves own the same amplitudes
+    uint32_t DBn[R], Tn, TLn;
+    round_geometry<K, R>(uni(prog[pc + 1]), tid, DBn, &Tn, &TLn);
+    const uint32_t next_off = uni(prog[pc + 2]);
+    if (next_off != rec_off) {  // records of consecutive rounds are consecutive: normally already prefetched
+      rec_off = next_off;
+      rec_load<1>(recs, rec_off, lane, cur);
+      rec_load<1>(recs, rec_off + L.slot0(), lane, sv);
+    }
+    round_store<R>(xt, T, DB, p);
+    if (sync) __syncthreads();
+    round_load<R>(xt, Tn, DBn, p);
+    if (sync) __syncthreads();
+    round_store<R>(xt, T, DB, l);
+    if (sync) __syncthreads();
+    round_load<R>(xt, Tn, DBn, l);
+#pragma unroll
+    for (int j = 0; j < R; ++j) DB[j] = DBn[j];
+    T = Tn;
+    TL = TLn;
+    w0 = w1;
+  }
+  if (a.flags & PASS_STORE) {
+    round_store<R>(xt, T, DB, p);
+    __syncthreads();
+    store_tile<K, NT>(xt, sp, t, tid);
+    __syncthreads();
+    round_store<R>(xt, T, DB, l);
+    __syncthreads();
+    store_tile<K, NT>(xt, sl, t, tid);
+  } else {
+    __syncthreads();  // the cells of every wave are complete
+  }
+  flush_cells<NT, NW>(cells, grow, a.n_slots, tid);
+}
+
+// ---- two-tile layout: both tiles resident in LDS (programs with Y / dense 2x2 / dense two-qubit
+// ops, which work on the LDS tiles directly; also selectable for A/B measurements) -------------
+template <int K, bool GEN>
+__global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kernel(
+    PassArgs a, float2* __restrict__ psi, float2* __restrict__ lam, const int8_t* __restrict__ bits, int n_user,
+    const uint32_t* __restrict__ prog_base, const uint32_t* __restrict__ tables,
+    const float* __restrict__ coef, float* __restrict__ tile_grad /*[states * tiles, n_slots]*/, uint32_t state0) {
+  constexpr int R = 4;
+  constexpr int NT = 1 << (K - R);
+  constexpr int NR = 1 << R;
+  constexpr int NW = NT / 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* tp = reinterpret_cast<float2*>(smem);
+  float2* tl = tp + (1 << K);
+  float* cells = reinterpret_cast<float*>(tl + (1 << K));  // [kMaxSlotsPerPass][NW]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const uint32_t wave = uni(uint32_t(tid) >> 6);
+  const uint32_t* recs = reinterpret_cast<const uint32_t*>(coef);
+  const uint32_t tile_id = blockIdx.x & ((1u << a.n_nonlocal) - 1u);
+  const uint32_t s_local = blockIdx.x >> a.n_nonlocal;
+  const TileCtx t = make_tile_ctx(a, tables, tile_id);
+  float* grow = tile_grad + size_t(blockIdx.x) * a.n_slots;
+  if (a.zero_mask) {  // tail of the sweep: psi is identically zero on this tile (engine.cpp fill_args)
+    const uint32_t idx = uni(basis_index(bits + size_t(state0 + s_local) * n_user, n_user));
+    if ((idx ^ t.tile_base) & a.zero_mask) {
+      for (uint32_t i = tid; i < a.n_slots; i += NT) grow[i] = 0.f;
+      return;
+    }
   }
   float2* sp = psi + (size_t(s_local) << a.n);
   float2* sl = lam + (size_t(s_local) << a.n);
@@ -904,15 +1167,12 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
     commit_tile<K, NT>(tp, rp, tid);
     commit_tile<K, NT>(tl, rl, tid);
   }
-  for (uint32_t i = tid; i < a.n_slots; i += NT) sacc[i] = 0.f;
+  for (uint32_t i = tid; i < a.n_slots * NW; i += NT) cells[i] = 0.f;
   __syncthreads();
-
-  constexpr float kM2Pi = -2.f * kPi;
 
   const uint32_t* prog = prog_base + a.prog_off;
   uint32_t pc = 0;
-  constexpr int NB = 1;
-  uint32_t cur[NB], nxt[NB], sv[1], svn[1];
+  uint32_t cur[1], nxt[1], sv[1], svn[1];
   uint32_t carried_off = 0xffffffffu;  // record offset whose words `cur` / `sv` hold
   for (;;) {
     const uint32_t w0 = uni(prog[pc]);
@@ -924,7 +1184,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
       uint32_t rec_off = uni(prog[pc + 2]);
       constexpr RecordLayout L(R, true);
       if (rec_off != carried_off) {  // else: prefetched by the previous round's last instance
-        rec_load<NB>(recs, rec_off, lane, cur);
+        rec_load<1>(recs, rec_off, lane, cur);
         rec_load<1>(recs, rec_off + L.slot0(), lane, sv);
       }
       uint32_t DB[R], T, TL;
@@ -932,111 +1192,12 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
       v2f p[NR], l[NR];
       round_load<R>(tp, T, DB, p);
       round_load<R>(tl, T, DB, l);
-      constexpr int S0 = L.slot0();
       for (uint32_t inst = 0; inst < n_inst; ++inst) {
-        rec_load<NB>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
+        rec_load<1>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
         rec_load<1>(recs, rec_off + L.words() + L.slot0(), lane, svn);
-        const uint32_t h0 = rec_word<0>(cur), h1 = rec_word<1>(cur);
-        // ---- CPH (slot groups 6, 7) ----
-        if (h1 & 0xffu) {
-          float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          QHBM_FOR_RB(R,
-            if ((h1 >> (2 * J)) & 1u)
-              g[2 * J] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J)>(cur), rec_word<L.pred(2 * J)>(cur), TL, t.tile_base);
-            if ((h1 >> (2 * J + 1)) & 1u)
-              g[2 * J + 1] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J + 1)>(cur), rec_word<L.pred(2 * J + 1)>(cur), TL,
-                                          t.tile_base);)
-          if (h1 & 0x0fu) add_slots4<L.group_cph()>(sacc, a.slot_base, lane, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
-          if (h1 & 0xf0u) add_slots4<L.group_cph() + 1>(sacc, a.slot_base, lane, sv[0], kM2Pi, g[4], g[5], g[6], g[7]);
-        }
-        if (h1 & kFullDiagFlag) {
-          // ---- all PH1/PH2 terms at once: w = Im(conj(lam) psi) per register value, per-term
-          // gradients are sums of w over the term's index set, then ONE conj-table multiply ----
-          float w[NR];
-          w_all_(w, p, l, iseq<NR>{});
-          if ((h0 >> 24) & 0x3fu) {
-            float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            QHBM_FOR_PAIR(R,
-              if ((h0 >> (24 + pair_index(JA, JB))) & 1u) g[pair_index(JA, JB)] = wsum2_<JA, JB>(w, iseq<4>{});)
-            if ((h0 >> 24) & 0x0fu) add_slots4<L.group_ph2()>(sacc, a.slot_base, lane, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
-            if ((h0 >> 24) & 0x30u) add_slots4<L.group_ph2() + 1>(sacc, a.slot_base, lane, sv[0], kM2Pi, g[4], g[5], 0.f, 0.f);
-          }
-          if ((h0 >> 4) & 0xfu) {
-            float g[4] = {0.f, 0.f, 0.f, 0.f};
-            QHBM_FOR_RB(R, if ((h0 >> (4 + J)) & 1u) g[J] = wsum1_<J>(w, iseq<8>{});)
-            add_slots4<L.group_ph1()>(sacc, a.slot_base, lane, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
-          }
-          apply_full<NB>(p, cur, true);
-          apply_full<NB>(l, cur, true);
-        }
-        {
-        // ---- PH2 (slot groups 4, 5) ----
-        if ((h0 >> 16) & 0x3fu) {
-          float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          QHBM_FOR_PAIR(R,
-            if ((h0 >> (16 + pair_index(JA, JB))) & 1u) {
-              const v2f cs = conj_cs(rec_cs<L.ph2(pair_index(JA, JB))>(cur));
-              g[pair_index(JA, JB)] = sum_w2<R, JA, JB>(p, l);
-              apply_ph2<R, JA, JB>(p, cs);
-              apply_ph2<R, JA, JB>(l, cs);
-            })
-          if ((h0 >> 16) & 0x0fu) add_slots4<L.group_ph2()>(sacc, a.slot_base, lane, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
-          if ((h0 >> 16) & 0x30u) add_slots4<L.group_ph2() + 1>(sacc, a.slot_base, lane, sv[0], kM2Pi, g[4], g[5], 0.f, 0.f);
-        }
-        // ---- PH1 (slot group 3) ----
-        if ((h0 >> 8) & 0xfu) {
-          float g[4] = {0.f, 0.f, 0.f, 0.f};
-          QHBM_FOR_RB(R,
-            if ((h0 >> (8 + J)) & 1u) {
-              const v2f cs = conj_cs(rec_cs<L.ph1(J)>(cur));
-              g[J] = sum_w1<R, J>(p, l);
-              apply_ph1<R, J>(p, cs);
-              apply_ph1<R, J>(l, cs);
-            })
-          add_slots4<L.group_ph1()>(sacc, a.slot_base, lane, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
-        }
-        }
-        // ---- one-qubit gates (X, Y, dense slot classes: groups 0, 1, 2) ----
-        if (h0 & 0xfu) {
-          float g[4] = {0.f, 0.f, 0.f, 0.f};
-          QHBM_FOR_RB(R,
-            if ((h0 >> J) & 1u) {
-              const v2f cs = conj_cs(rec_cs<L.x(J)>(cur));  // U^dagger = c*I + i*s*X
-              if (rec_word<L.slot_x(J) - S0>(sv) != 0xffffffffu) g[J] = im_lam_x_psi<R, J>(p, l);
-              apply_x<R, J>(p, cs);
-              apply_x<R, J>(l, cs);
-            })
-          add_slots4<L.group_x()>(sacc, a.slot_base, lane, sv[0], kPi, g[0], g[1], g[2], g[3]);
-        }
-        if constexpr (GEN) {
-        if ((h1 >> 16) & 0xfu) {
-          float g[4] = {0.f, 0.f, 0.f, 0.f};
-          QHBM_FOR_RB(R,
-            if ((h1 >> (16 + J)) & 1u) {
-              const v2f cs = conj_cs(rec_cs<L.y(J)>(cur));
-              if (rec_word<L.slot_y(J) - S0>(sv) != 0xffffffffu) g[J] = im_lam_y_psi<R, J>(p, l);
-              apply_y<R, J>(p, cs);
-              apply_y<R, J>(l, cs);
-            })
-          add_slots4<L.group_y()>(sacc, a.slot_base, lane, sv[0], kPi, g[0], g[1], g[2], g[3]);
-        }
-        if ((h1 >> 24) & 0xfu) {  // dense: U^dagger (8 floats) then generator (8 floats) per register bit
-          uint32_t dv[1];
-          rec_load<1>(recs, rec_off + 128u, lane, dv);
-          float g[4] = {0.f, 0.f, 0.f, 0.f};
-          QHBM_FOR_RB(R,
-            if ((h1 >> (24 + J)) & 1u) {
-              const Gen2 gen{rec_cs<16 * J + 8>(dv), rec_cs<16 * J + 10>(dv), rec_cs<16 * J + 12>(dv), rec_cs<16 * J + 14>(dv)};
-              if (rec_word<L.slot_dense(J) - S0>(sv) != 0xffffffffu) g[J] = im_lam_g1_psi<R, J>(p, l, gen);
-              apply_mat1<R, J>(p, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
-              apply_mat1<R, J>(l, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
-            })
-          add_slots4<L.group_dense()>(sacc, a.slot_base, lane, sv[0], 1.f, g[0], g[1], g[2], g[3]);
-        }
-        }
+        instance_adj<R, NW, GEN>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells, a.slot_base);
         rec_off += L.words();
-#pragma unroll
-        for (int v = 0; v < NB; ++v) cur[v] = nxt[v];
+        cur[0] = nxt[0];
         sv[0] = svn[0];
       }
       carried_off = rec_off;
@@ -1069,20 +1230,44 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
 #pragma unroll
         for (int j = 0; j < 4; ++j) tl[ix[j]] = y[j];
       }
-      if (slot != 0xffffffffu) add_slot(sacc, a.slot_base, tid, slot, gacc);
+      if (slot != 0xffffffffu) add_slot<NW>(cells, a.slot_base, tid, slot, gacc);
       __syncthreads();
       }
       pc += kGate2Words;
     }
   }
   __syncthreads();
-  for (uint32_t i = tid; i < a.n_slots; i += NT) {
-    const float v = sacc[i];
-    if (v != 0.f) atomicAdd(&state_grad[size_t(state0 + s_local) * n_slots_total + a.slot_base + i], v);
-  }
+  flush_cells<NT, NW>(cells, grow, a.n_slots, tid);
   if (a.flags & PASS_STORE) {
     store_tile<K, NT>(tp, sp, t, tid);
     store_tile<K, NT>(tl, sl, t, tid);
+  }
+}
+
+// state_grad[state0 + s, slot_base + i] = sum over the tiles of state s, in tile order, of the
+// pass's tile_grad rows.  blockDim = (64 slots, 16 tile lanes): lane y adds tiles y, y + 16, ... in
+// order, then the 16 partials are added in lane order -- a fixed tree, bit-reproducible.
+__global__ __launch_bounds__(1024) void reduce_tiles_kernel(const float* __restrict__ tile_grad, uint32_t n_tiles,
+                                                            uint32_t n_slots, float* __restrict__ state_grad,
+                                                            uint32_t n_slots_total, uint32_t slot_base,
+                                                            uint32_t state0) {
+  __shared__ float part[16][64];
+  const uint32_t s = blockIdx.x;
+  const float* base = tile_grad + size_t(s) * n_tiles * n_slots;
+  for (uint32_t i0 = 0; i0 < n_slots; i0 += 64) {
+    const uint32_t i = i0 + threadIdx.x;
+    float acc = 0.f;
+    if (i < n_slots)
+      for (uint32_t tl = threadIdx.y; tl < n_tiles; tl += 16) acc += base[size_t(tl) * n_slots + i];
+    part[threadIdx.y][threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.y == 0 && i < n_slots) {
+      float v = part[0][threadIdx.x];
+#pragma unroll
+      for (int y = 1; y < 16; ++y) v += part[y][threadIdx.x];
+      state_grad[size_t(state0 + s) * n_slots_total + slot_base + i] = v;
+    }
+    __syncthreads();
   }
 }
 
@@ -1295,6 +1480,14 @@ __global__ void combine_diag_kernel(float* __restrict__ coef, const uint32_t* __
   rec[L.full(m) + 1] = float(ci);
 }
 
+// out[s, k] = fixed-point accumulator * 2^-shift_k  (the end of every forward)
+__global__ void values_from_fixed_kernel(const unsigned long long* __restrict__ acc, const float* __restrict__ inv_scale,
+                                         float* __restrict__ out, uint32_t count, uint32_t n_ops) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  out[i] = float(double(static_cast<long long>(acc[i])) * double(inv_scale[i % n_ops]));
+}
+
 // grad[p] = sum_s sum_slot(p) factor * state_grad[s, slot]   (fixed order: deterministic
 // given state_grad).  One block per parameter.
 __global__ __launch_bounds__(256) void reduce_grad_kernel(
@@ -1357,39 +1550,46 @@ __global__ __launch_bounds__(256) void shift_accumulate_kernel(
 // Host-side launchers
 // ================================================================================
 constexpr int kMaxDevices = 64;
-size_t fwd_lds_bytes(int K) { return (size_t(1) << K) * 8 + size_t(kMaxOps) * 4; }
-size_t adj_lds_bytes(int K) { return (size_t(2) << K) * 8 + size_t(kMaxSlotsPerPass) * 4; }
+size_t fwd_lds_bytes(int K) { return size_t(fwd_lds(K)); }
+size_t adj_lds_bytes(int K, bool exchange) { return size_t(exchange ? adjx_lds(K) : adj_lds(K)); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize (the opt-in to more than 64 KiB of LDS) is per device:
+// one flag per kernel instantiation and device of the process.
+template <typename Kernel>
+static hipError_t opt_in_lds(Kernel kernel, bool (&done)[kMaxDevices], size_t lds) {
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  if (dev < 0 || dev >= kMaxDevices || !done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < kMaxDevices) done[dev] = true;
+  }
+  return hipSuccess;
+}
 
 template <int K, int R, bool GEN>
 static hipError_t launch_fwd_t(const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
                                int n_user, const uint32_t* prog, const uint32_t* tables,
-                               const float* coef, float* out, uint32_t state0,
+                               const float* coef, const float* op_scale, unsigned long long* out64, uint32_t state0,
                                hipStream_t stream) {
   const size_t lds = fwd_lds_bytes(K);
-  // (the opt-in to more than 64 KiB of LDS is per device: one flag per device of the process)
   static bool attr_done[kMaxDevices] = {};
-  int dev = 0;
-  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-  if (dev < 0 || dev >= kMaxDevices || !attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_fwd_kernel<K, R, GEN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < kMaxDevices) attr_done[dev] = true;
-  }
+  if (hipError_t e = opt_in_lds(&pass_fwd_kernel<K, R, GEN>, attr_done, lds); e != hipSuccess) return e;
   const uint32_t grid = n_states << a.n_nonlocal;
   hipLaunchKernelGGL((pass_fwd_kernel<K, R, GEN>), dim3(grid), dim3(1 << (K - R)), lds, stream, a, psi, bits,
-                     n_user, prog, tables, coef, out, state0);
+                     n_user, prog, tables, coef, op_scale, out64, state0);
   return hipGetLastError();
 }
 
 hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
                            int n_user, const uint32_t* prog, const uint32_t* tables, const float* coef,
-                           float* out, uint32_t state0, hipStream_t stream) {
+                           const float* op_scale, unsigned long long* out64, uint32_t state0, hipStream_t stream) {
 #define QHBM_FWD_CASE(K_, R_)                                                                          \
   if (K == K_ && R == R_)                                                                              \
     return (a.flags & PASS_GENERAL)                                                                    \
-               ? launch_fwd_t<K_, R_, true>(a, n_states, psi, bits, n_user, prog, tables, coef, out, state0, stream)   \
-               : launch_fwd_t<K_, R_, false>(a, n_states, psi, bits, n_user, prog, tables, coef, out, state0, stream);
+               ? launch_fwd_t<K_, R_, true>(a, n_states, psi, bits, n_user, prog, tables, coef, op_scale, out64, state0, stream)   \
+               : launch_fwd_t<K_, R_, false>(a, n_states, psi, bits, n_user, prog, tables, coef, op_scale, out64, state0, stream);
   QHBM_FWD_CASE(10, 4)
   QHBM_FWD_CASE(11, 4)
   QHBM_FWD_CASE(12, 4)
@@ -1399,43 +1599,67 @@ hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, f
   return hipErrorInvalidValue;
 }
 
-template <int K, bool GEN>
-static hipError_t launch_adj_t(const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
-                               const int8_t* bits, int n_user, const uint32_t* prog, const uint32_t* tables, const float* coef,
-                               float* state_grad, uint32_t n_slots_total,
-                               uint32_t state0, hipStream_t stream) {
-  const size_t lds = adj_lds_bytes(K);
-  // (the opt-in to more than 64 KiB of LDS is per device: one flag per device of the process)
-  static bool attr_done[kMaxDevices] = {};
-  int dev = 0;
-  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-  if (dev < 0 || dev >= kMaxDevices || !attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_adj_kernel<K, GEN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < kMaxDevices) attr_done[dev] = true;
-  }
-  const uint32_t grid = n_states << a.n_nonlocal;
-  hipLaunchKernelGGL((pass_adj_kernel<K, GEN>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, lam, bits,
-                     n_user, prog, tables, coef, state_grad, n_slots_total, state0);
+hipError_t launch_values_from_fixed(const unsigned long long* acc, const float* inv_scale, float* out, uint32_t count,
+                                    uint32_t n_ops, hipStream_t stream) {
+  if (count == 0) return hipSuccess;
+  hipLaunchKernelGGL(values_from_fixed_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, acc, inv_scale, out,
+                     count, n_ops);
   return hipGetLastError();
 }
 
-hipError_t launch_pass_adj(int K, const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
-                           const int8_t* bits, int n_user, const uint32_t* prog, const uint32_t* tables, const float* coef,
-                           float* state_grad, uint32_t n_slots_total,
-                           uint32_t state0, hipStream_t stream) {
+template <int K, bool GEN>
+static hipError_t launch_adj_t(const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
+                               const int8_t* bits, int n_user, const uint32_t* prog, const uint32_t* tables,
+                               const float* coef, float* tile_grad, uint32_t state0, hipStream_t stream) {
+  const size_t lds = adj_lds_bytes(K, false);
+  static bool attr_done[kMaxDevices] = {};
+  if (hipError_t e = opt_in_lds(&pass_adj_kernel<K, GEN>, attr_done, lds); e != hipSuccess) return e;
+  const uint32_t grid = n_states << a.n_nonlocal;
+  hipLaunchKernelGGL((pass_adj_kernel<K, GEN>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, lam, bits,
+                     n_user, prog, tables, coef, tile_grad, state0);
+  return hipGetLastError();
+}
+
+template <int K>
+static hipError_t launch_adjx_t(const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
+                                const int8_t* bits, int n_user, const uint32_t* prog, const uint32_t* tables,
+                                const float* coef, float* tile_grad, uint32_t state0, hipStream_t stream) {
+  const size_t lds = adj_lds_bytes(K, true);
+  static bool attr_done[kMaxDevices] = {};
+  if (hipError_t e = opt_in_lds(&pass_adjx_kernel<K>, attr_done, lds); e != hipSuccess) return e;
+  const uint32_t grid = n_states << a.n_nonlocal;
+  hipLaunchKernelGGL((pass_adjx_kernel<K>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, lam, bits,
+                     n_user, prog, tables, coef, tile_grad, state0);
+  return hipGetLastError();
+}
+
+hipError_t launch_pass_adj(int K, bool exchange, const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
+                           const int8_t* bits, int n_user, const uint32_t* prog, const uint32_t* tables,
+                           const float* coef, float* tile_grad, uint32_t state0, hipStream_t stream) {
+#define QHBM_ADJ_CASE(K_)                                                                                           \
+  case K_:                                                                                                          \
+    if (a.flags & PASS_GENERAL)                                                                                     \
+      return launch_adj_t<K_, true>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, tile_grad, state0, stream);  \
+    return exchange                                                                                                 \
+               ? launch_adjx_t<K_>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, tile_grad, state0, stream)    \
+               : launch_adj_t<K_, false>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, tile_grad, state0, stream);
   switch (K) {
-    case 10: return (a.flags & PASS_GENERAL) ? launch_adj_t<10, true>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, state_grad, n_slots_total, state0, stream)
-                                            : launch_adj_t<10, false>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, state_grad, n_slots_total, state0, stream);
-    case 11: return (a.flags & PASS_GENERAL) ? launch_adj_t<11, true>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, state_grad, n_slots_total, state0, stream)
-                                            : launch_adj_t<11, false>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, state_grad, n_slots_total, state0, stream);
-    case 12: return (a.flags & PASS_GENERAL) ? launch_adj_t<12, true>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, state_grad, n_slots_total, state0, stream)
-                                            : launch_adj_t<12, false>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, state_grad, n_slots_total, state0, stream);
-    case 13: return (a.flags & PASS_GENERAL) ? launch_adj_t<13, true>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, state_grad, n_slots_total, state0, stream)
-                                            : launch_adj_t<13, false>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, state_grad, n_slots_total, state0, stream);
+    QHBM_ADJ_CASE(10)
+    QHBM_ADJ_CASE(11)
+    QHBM_ADJ_CASE(12)
+    QHBM_ADJ_CASE(13)
     default: return hipErrorInvalidValue;
   }
+#undef QHBM_ADJ_CASE
+}
+
+hipError_t launch_reduce_tiles(const float* tile_grad, uint32_t n_states, uint32_t n_tiles, uint32_t n_slots,
+                               float* state_grad, uint32_t n_slots_total, uint32_t slot_base, uint32_t state0,
+                               hipStream_t stream) {
+  if (n_states == 0 || n_slots == 0) return hipSuccess;
+  hipLaunchKernelGGL(reduce_tiles_kernel, dim3(n_states), dim3(64, 16), 0, stream, tile_grad, n_tiles, n_slots,
+                     state_grad, n_slots_total, slot_base, state0);
+  return hipGetLastError();
 }
 
 // ================================================================================

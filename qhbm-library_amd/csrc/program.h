@@ -30,8 +30,13 @@ namespace qhbm {
 constexpr int kMinTileBits = 10;  // states with fewer qubits are padded with idle qubits
 constexpr int kMaxTileBits = 14;
 constexpr int kMaxQubits = 32;    // amplitude indices are 32-bit
-constexpr int kMaxOps = 1024;           // observables per engine (LDS accumulators)
-constexpr int kMaxSlotsPerPass = 2048;  // gradient slots one adjoint pass may own
+constexpr int kMaxOps = 1024;           // observables per engine (LDS accumulators, 64-bit fixed point)
+constexpr int kMaxSlotsPerPass = 256;   // gradient slots one adjoint pass may own (one LDS cell per wave and slot)
+// Expectation values are accumulated across waves, tiles and passes as 64-bit FIXED-POINT integers
+// (integer addition is associative: the result does not depend on the order in which workgroups
+// finish, so a value is bit-identical from run to run and for any sharding of the batch).  An op's
+// partial sums are bounded by B = sum_k |c_k|; they are scaled by 2^(kValueFracBits - ceil(log2 B)).
+constexpr int kValueFracBits = 40;
 
 // ---- pass flags ------------------------------------------------------------
 enum : uint32_t {
@@ -138,7 +143,7 @@ struct PassArgs {
   uint32_t spread_shift;   // local bits above c contiguous from bit s: spread_hi[j] = j << s (no lookup); else ~0u
   uint32_t n_ops;          // observables (row length of out)
   uint32_t slot_base;      // adjoint: first gradient slot of this pass
-  uint32_t n_slots;        // adjoint: gradient slots written by this pass
+  uint32_t n_slots;        // adjoint: gradient slots written by this pass (row length of tile_grad)
   uint8_t nonlocal_pos[32];  // ascending bit positions of the nonlocal index bits
   uint8_t local_pos[16];     // ascending bit positions of the K local index bits
 };

@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "qhbm_expectation_retain", "qhbm_expectation_vjp_retained", "qhbm_retained_states",
     "qhbm_expectation_jacobian", "qhbm_statevector", "qhbm_sample", "qhbm_parity_energy", "qhbm_parity_energy_vjp",
     "qhbm_num_passes", "qhbm_describe_schedule",
-    "qhbm_kernel_time_ms",
+    "qhbm_kernel_time_ms", "qhbm_traffic_model",
 )
 
 
@@ -92,7 +92,9 @@ def load_library():
   lib.qhbm_describe_schedule.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
   lib.qhbm_kernel_time_ms.argtypes = [
       vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64),
+      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64),
       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
+  lib.qhbm_traffic_model.argtypes = [vp, i32, i32] + [ctypes.POINTER(ctypes.c_double)] * 3
   _lib = lib
   return lib
 
@@ -243,14 +245,22 @@ class Engine:
     return out.value
 
   def kernel_time_ms(self, reset=True):
-    f, b = ctypes.c_double(), ctypes.c_double()
-    nf, nb = ctypes.c_int64(), ctypes.c_int64()
+    f, b, o = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    nf, nb, no = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
     self._check(
         self._lib.qhbm_kernel_time_ms(self._h, int(reset), ctypes.byref(f),
                                       ctypes.byref(nf), ctypes.byref(b),
-                                      ctypes.byref(nb)))
+                                      ctypes.byref(nb), ctypes.byref(o), ctypes.byref(no)))
     return {"fwd_ms": f.value, "fwd_launches": nf.value, "bwd_ms": b.value,
-            "bwd_launches": nb.value}
+            "bwd_launches": nb.value, "obs_ms": o.value, "obs_launches": no.value}
+
+  def traffic_model(self, num_states, with_vjp=True):
+    """HBM bytes one call must move (every touched tile read and written once): dict of
+    forward / lambda = O psi / adjoint bytes (include/qhbm_engine.h qhbm_traffic_model)."""
+    f, o, b = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    self._check(self._lib.qhbm_traffic_model(self._h, int(num_states), int(with_vjp), ctypes.byref(f),
+                                             ctypes.byref(o), ctypes.byref(b)))
+    return {"fwd_bytes": f.value, "obs_bytes": o.value, "bwd_bytes": b.value}
 
   # ---- hot path --------------------------------------------------------------
   def _prep(self, bits, params):

@@ -1,0 +1,124 @@
+"""Golden vectors at the BASELINE.json sizes (n = 20 / 24 / 28), generated in the build
+container -- the reference cannot run here and the oracle is too slow to run
+at these sizes inside the GPU tests, so its outputs are committed as fixtures:
+
+    python tests/golden/make_golden_large.py c3      # ~10 min, 4 processes
+    python tests/golden/make_golden_large.py c4      # ~10 min
+    python tests/golden/make_golden_large.py c5      # ~10 min, one thread, 4.5 GiB
+
+  c3_n20_l16.npz  BASELINE config 3's circuit: 20 qubits, HEA depth 16 (944 parameters), XXZ
+                  chain.  4 states: values and per-state gradient rows by the numpy complex128
+                  oracle (oracle/qhbm_oracle.py), cross-checked here against the independent C
+                  fp32 restatement (oracle/qhbm_cpu.c) on every state; plus the 210 KOBE-2 shard
+                  values of one state through the modular-Hamiltonian circuit U(phi) V(phi_h)^dagger
+                  (1888 gates).
+  c4_n24_d2.npz   24 qubits, HEA depth 2, the random 512-term Pauli sum of config 4: all 512 term
+                  values and the VJP of their sum for one state (C oracle; 8 terms cross-checked
+                  against the numpy oracle).
+  c5_n28_d2.npz   28 qubits (2 GiB per state), HEA depth 2, TFIM ring: the 56 term values of one
+                  state (C oracle, whose same code is cross-checked at n = 20 and n = 24 above).
+
+Inputs follow SURVEY.md 8(d): phi ~ U[-1, 1] from a fixed seed, seeded bitstrings.  Gate lists are
+[G, 6] = (kind, q0, q1, param_idx, scalar, offset); ops are [T, 4] = (op, coeff, x_mask, z_mask).
+"""
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import qhbm_cpu as C  # noqa: E402
+from oracle import qhbm_oracle as O  # noqa: E402
+from tests.golden.make_golden import pack_ops, save  # noqa: E402
+
+
+def _c3_state(args):
+  n, gates, params, bits, op = args
+  vals, jac = O.expectation_jacobian(n, gates, params, bits[None, :], [op])
+  return vals[0, 0], jac[0, 0]
+
+
+def make_c3():
+  n, layers = 20, 16
+  rng = np.random.default_rng(2016)
+  gates, names = O.hea_gates(n, layers, "b")
+  params = rng.uniform(-1, 1, len(names))
+  bits = rng.integers(0, 2, size=(4, n)).astype(np.int8)
+  bits[0] = 0                      # |0...0>
+  bits[1] = 1                      # |1...1>: every tile but the last is zero after the first pass
+  op = O.xxz_chain_op(n)
+  t0 = time.time()
+  with mp.Pool(4) as pool:
+    res = pool.map(_c3_state, [(n, gates, params, b, op) for b in bits])
+  values = np.array([r[0] for r in res])
+  grads = np.stack([r[1] for r in res])
+  print(f"c3 numpy oracle: {time.time() - t0:.0f} s; values", values)
+  # cross-check: the C restatement, one VJP per state with unit upstream
+  for s in range(4):
+    cv, cg = C.expectation_vjp(n, gates, params, bits[s:s + 1], [op], np.ones((1, 1), np.float32))
+    assert abs(cv[0, 0] - values[s]) < 5e-5 * sum(abs(c) for c, _, _ in op), (s, cv, values[s])
+    assert np.abs(cg - grads[s]).max() < 1e-4 * max(1.0, np.abs(grads[s]).max()), np.abs(cg - grads[s]).max()
+  print("c3: C oracle agrees on all 4 states")
+  # modular Hamiltonian: bit . U(phi) . V(phi_h)^dagger, KOBE-2 shards, state 2
+  v_gates, v_names = O.hea_gates(n, layers, "h")
+  p_u = len(names)
+  v_shift = [(k, q0, q1, p + p_u, s, o) for (k, q0, q1, p, s, o) in v_gates]
+  v_params = rng.uniform(-1, 1, len(v_names))
+  total = gates + O.inverse_gates(v_shift)
+  all_params = np.concatenate([params, v_params])
+  shards = O.kobe_shards(n, 2)
+  t0 = time.time()
+  psi = O.simulate(n, total, all_params, bits[2])
+  shard_values = np.array([O.op_expectation(psi, sh) for sh in shards])
+  print(f"c3 shards: {time.time() - t0:.0f} s")
+  cs = C.expectation(n, total, all_params, bits[2:3], shards)
+  assert np.abs(cs[0] - shard_values).max() < 5e-5, np.abs(cs[0] - shard_values).max()
+  save("c3_n20_l16.npz", n=n, layers=layers, gates=np.array(gates, dtype=np.float64), params=params, bits=bits,
+       ops=pack_ops([op]), values=values, grads=grads, total_gates=np.array(total, dtype=np.float64),
+       total_params=all_params, kobe2_shards=pack_ops(shards), kobe2_state=2, kobe2_values=shard_values)
+
+
+def make_c4():
+  n, layers = 24, 2
+  rng = np.random.default_rng(2402)
+  gates, names = O.hea_gates(n, layers, "b")
+  params = rng.uniform(-1, 1, len(names))
+  bits = rng.integers(0, 2, size=(1, n)).astype(np.int8)
+  op = O.random_pauli_op(n, 512, 24)
+  per_term = [[t] for t in op]
+  t0 = time.time()
+  term_values = C.expectation(n, gates, params, bits, per_term)[0].astype(np.float64)
+  _, grad = C.expectation_vjp(n, gates, params, bits, [op], np.ones((1, 1), np.float32))
+  print(f"c4 C oracle: {time.time() - t0:.0f} s; sum {term_values.sum():.6f}")
+  t0 = time.time()
+  psi = O.simulate(n, gates, params, bits[0])
+  picks = [0, 1, 17, 100, 255, 256, 400, 511]
+  for k in picks:
+    want = O.op_expectation(psi, per_term[k])
+    assert abs(want - term_values[k]) < 2e-5 * max(1.0, abs(op[k][0])), (k, want, term_values[k])
+    term_values[k] = want
+  print(f"c4 numpy cross-check of {len(picks)} terms: {time.time() - t0:.0f} s")
+  save("c4_n24_d2.npz", n=n, layers=layers, gates=np.array(gates, dtype=np.float64), params=params, bits=bits,
+       ops=pack_ops([op]), term_values=term_values, grad=grad.astype(np.float64), numpy_checked=np.array(picks))
+
+
+def make_c5():
+  n, layers = 28, 2
+  rng = np.random.default_rng(2802)
+  gates, names = O.hea_gates(n, layers, "b")
+  params = rng.uniform(-1, 1, len(names))
+  bits = rng.integers(0, 2, size=(1, n)).astype(np.int8)
+  op = O.tfim_ring_op(n)
+  t0 = time.time()
+  term_values = C.expectation(n, gates, params, bits, [[t] for t in op], n_threads=1)[0].astype(np.float64)
+  print(f"c5 C oracle: {time.time() - t0:.0f} s; sum {term_values.sum():.6f}")
+  save("c5_n28_d2.npz", n=n, layers=layers, gates=np.array(gates, dtype=np.float64), params=params, bits=bits,
+       ops=pack_ops([op]), term_values=term_values)
+
+
+if __name__ == "__main__":
+  for which in sys.argv[1:] or ["c3", "c4", "c5"]:
+    {"c3": make_c3, "c4": make_c4, "c5": make_c5}[which]()

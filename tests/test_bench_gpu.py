@@ -31,7 +31,9 @@ def test_bench_single_process_line():
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
     assert key in line, key
   assert line["n_gpus"] == 1 and line["steps"] == 2 and line["scaling"] == "weak"
-  assert line["value"] > 0 and line["roofline"]["achieved"] > 0
+  assert line["value"] > 0 and 0 < line["roofline"]["frac"] <= 1.0   # a fraction of the HBM peak, not a fusion factor
+  assert line["roofline"]["achieved"] == pytest.approx(line["roofline"]["frac"] * line["roofline"]["peak"])
+  assert "12-qubit TFIM ring" in line["config"]["workload"] and line["config"]["states_total"] == 16
   assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
   assert line["verify"]["ok"], line["verify"]
 
@@ -50,3 +52,40 @@ def test_bench_two_ranks_as_the_driver_launches_it():
   assert line["n_gpus"] == 2
   assert line["config"]["parallelism"] == "batch-sharded x2"
   assert line["verify"]["ok"], line["verify"]
+
+
+def test_bench_gpus_flag_starts_its_own_ranks_and_shards_a_fixed_total():
+  """`bench.py --gpus 2` outside torchrun launches two ranks itself (strong scaling: 33 states split
+  17 + 16); on this one-GPU box that needs the share-device test hook, and WITHOUT it the run must
+  refuse rather than print an `n_gpus: 1` line."""
+  strong = ["--qubits", "12", "--layers", "2", "--states-total", "33", "--steps", "2", "--warmup", "1",
+            "--hamiltonian", "tfim", "--verify", "--no-cpu-baseline", "--gpus", "2"]
+  env = dict(os.environ, QHBM_BENCH_SHARE_DEVICE="1", QHBM_BENCH_BACKEND="gloo")
+  env.pop("WORLD_SIZE", None)
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + strong, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=env)
+  assert out.returncode == 0, out.stderr[-3000:]
+  line = _line(out.stdout)
+  assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+  assert line["config"]["states_total"] == 33 and line["config"]["states_per_gpu"] == 17
+  assert line["verify"]["ok"], line["verify"]
+  import torch
+  if torch.cuda.device_count() < 2:
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "QHBM_BENCH_SHARE_DEVICE", "QHBM_BENCH_BACKEND"):
+      env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + strong, capture_output=True, text=True,
+                         timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "GPU(s) visible" in out.stderr
+    assert '{"metric"' not in out.stdout
+
+
+def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
+  import torch
+  if torch.cuda.device_count() < 2:
+    pytest.skip("one GPU visible: the nccl (RCCL) variant needs two")
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"] + SMALL,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert out.returncode == 0, out.stderr[-3000:]
+  line = _line(out.stdout)
+  assert line["n_gpus"] == 2 and line["verify"]["ok"], line

@@ -125,3 +125,52 @@ def test_vqt_step_end_to_end_on_device_n20():
   second = time.perf_counter() - t0
   print(f"vqt n=20 L=16 {samples} samples: first step {first:.3f} s, next step {second:.3f} s")
   assert second < 3.0
+
+
+def test_vqt_step_n20_loss_and_both_gradients_against_oracle():
+  """The same model (KOBE-2 over 20 bits, HEA depth 16, XXZ) on a 40-sample draw, compared with the
+  oracle's VQT loss and gradients on the drawn multiset (vqt_loss.py:46-55 with ebm.py:262-329):
+  <H> and d/dphi from the C fp32 restatement (one state per host thread), the EBM side in numpy.
+  Tolerances: loss 5e-5 * (beta * sum|c_k| + 1); d/dphi 1e-4 * max(1, |grad|_inf); d/dtheta 2e-4."""
+  from oracle import qhbm_cpu as C
+  n, layers, samples, beta = 20, 16, 40, 0.7
+  qubits = ir.GridQubit.rect(1, n)
+  rng = np.random.default_rng(20)
+  ebm = models.KOBE(list(range(n)), 2)
+  thetas = rng.uniform(-0.1, 0.1, ebm.post_process[0].kernel.numel())
+  _set(ebm.post_process[0].kernel, thetas)
+  ebm = ebm.to("cuda")
+  circuit = models.DirectQuantumCircuit(hea_circuit(qubits, layers, "v"))
+  phi = rng.uniform(-1, 1, len(circuit.symbol_names)).astype(np.float32)
+  _set(circuit.trainable_variables[0], phi)
+  e_inf = inference.AnalyticEnergyInference(ebm, samples, initial_seed=11)
+  qhbm = inference.QHBM(e_inf, inference.AnalyticQuantumInference(circuit))
+  xxz = ir.PauliSum()
+  for a, b in zip(qubits, qubits[1:]):
+    xxz += ir.PX(a) * ir.PX(b) + ir.PY(a) * ir.PY(b) + 0.5 * ir.PZ(a) * ir.PZ(b)
+  loss = inference.vqt(qhbm, [xxz], beta)
+  loss.backward()
+  drawn = e_inf.sample(samples).cpu().numpy()   # fixed seed: the draw vqt() used
+  g_theta = ebm.post_process[0].kernel.grad.cpu().numpy()
+  g_phi = circuit.trainable_variables[0].grad.cpu().numpy()
+  # ---- oracle on the drawn multiset ----
+  uniq, _, counts = O.unique_bitstrings_with_counts(drawn)
+  gates = circuit.pqc.flat_gates(qubits, circuit.symbol_names)
+  op = xxz.masks(qubits)
+  weights = counts / counts.sum()
+  h, want_phi = C.expectation_vjp(n, gates, phi, uniq, [op], (beta * weights)[:, None].astype(np.float32))
+  index_sets = O.parity_indices(n, 2)
+  feats = O.parities(uniq, index_sets)                       # [U, 210] = dE/dtheta
+  f = beta * h[:, 0].astype(np.float64) - feats @ thetas
+  log_z, chunk = -np.inf, 1 << 16
+  for lo in range(0, 1 << n, chunk):                         # exact log Z over all 2^20 bitstrings
+    idx = np.arange(lo, lo + chunk)
+    bits = ((idx[:, None] >> np.arange(n - 1, -1, -1)[None, :]) & 1).astype(np.int8)
+    log_z = np.logaddexp(log_z, np.logaddexp.reduce(-(O.parities(bits, index_sets) @ thetas)))
+  want_loss = float(weights @ f - log_z)
+  avg_f = float(weights @ f)
+  want_theta = (weights @ feats) * avg_f - weights @ (feats * f[:, None])
+  norm = sum(abs(c) for c, _, _ in op)
+  assert abs(float(loss) - want_loss) <= 5e-5 * (beta * norm + 1.0), (float(loss), want_loss)
+  np.testing.assert_allclose(g_phi, want_phi, atol=1e-4 * max(1.0, np.abs(want_phi).max()), rtol=0)
+  np.testing.assert_allclose(g_theta, want_theta, atol=2e-4, rtol=0)
