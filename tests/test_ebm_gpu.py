@@ -171,6 +171,6 @@ def test_vqt_step_n20_loss_and_both_gradients_against_oracle():
   avg_f = float(weights @ f)
   want_theta = (weights @ feats) * avg_f - weights @ (feats * f[:, None])
   norm = sum(abs(c) for c, _, _ in op)
-  assert abs(float(loss) - want_loss) <= 5e-5 * (beta * norm + 1.0), (float(loss), want_loss)
+  assert abs(float(loss.detach()) - want_loss) <= 5e-5 * (beta * norm + 1.0), (float(loss.detach()), want_loss)
   np.testing.assert_allclose(g_phi, want_phi, atol=1e-4 * max(1.0, np.abs(want_phi).max()), rtol=0)
   np.testing.assert_allclose(g_theta, want_theta, atol=2e-4, rtol=0)

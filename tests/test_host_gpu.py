@@ -399,7 +399,7 @@ def test_autograd_through_a_batch_larger_than_one_backward_chunk():
   w = torch.arange(out.numel(), dtype=torch.float32, device=out.device).reshape(out.shape) / out.numel()
   (g,) = torch.autograd.grad((out * w).sum(), circ.trainable_variables)
   flat = circ.pqc.flat_gates(circ.qubits, circ.symbol_names)
-  want, jac = O.expectation_jacobian(n, flat, vals, states.numpy(), [op.masks(qubits) for op in ops])
+  want, jac = O.expectation_jacobian(n, flat, vals, states.numpy(), [ir.as_pauli_sum(op).masks(qubits) for op in ops])
   np.testing.assert_allclose(out.detach().cpu().numpy(), want, atol=1e-5)
   np.testing.assert_allclose(g.cpu().numpy(), np.einsum("bt,btp->p", w.cpu().numpy(), jac), atol=1e-4)
   eng.set_option("chunk_states", 0)
