@@ -77,7 +77,7 @@ struct qhbm_engine {
   // plans
   bool plans_valid = false;
   DevicePlan fwd, adj;
-  DevBuf<DevTerm> terms;
+  DevBuf<DevTerm> terms, global_terms;  // global_terms: measured on the final state in HBM (too wide for a tile)
   DevBuf<ObsGroup> obs_groups;
   uint32_t n_obs_groups = 0;
   DevBuf<float2> psi, lam;
@@ -211,6 +211,14 @@ int upload_model(qhbm_engine* h) {
     HIPCHK(h->op_scale.upload(h->h_op_scale));
     HIPCHK(h->op_inv_scale.upload(h->h_op_inv_scale));
   }
+  {
+    std::vector<DevTerm> gt;
+    for (int ti : h->fwd.plan.global_terms) {
+      const PauliTerm& pt = h->model.terms[size_t(ti)];
+      gt.push_back(DevTerm{pt.coeff, pt.x, pt.z, uint32_t(pt.ny), uint32_t(pt.op)});
+    }
+    HIPCHK(h->global_terms.upload(gt));
+  }
   // parameter -> slots map for the adjoint reduction
   const Plan& ap = h->adj.plan;
   std::vector<int> begin(size_t(h->model.n_params) + 1, 0), slots(ap.slot_gate.size());
@@ -267,7 +275,7 @@ int run_forward_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_
                       hipStream_t stream) {
   DevicePlan& d = h->fwd;
   const size_t np = d.plan.passes.size();
-  bool measure_only_after = false;
+  bool measure_only_after = !d.plan.global_terms.empty();  // they read the final state from HBM
   for (const Pass& p : d.plan.passes) measure_only_after |= p.is_measure_only;
   for (size_t i = 0; i < np; ++i) {
     const Pass& p = d.plan.passes[i];
@@ -280,6 +288,10 @@ int run_forward_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_
                            h->op_scale.p, h->vals64.p, s0, stream));
     timer_end(ev, stream);
   }
+  if (!d.plan.global_terms.empty())
+    HIPCHK(launch_measure_global(h->psi.p, uint32_t(d.plan.n_eff), cs, h->global_terms.p,
+                                 uint32_t(d.plan.global_terms.size()), h->op_scale.p, h->vals64.p,
+                                 uint32_t(h->model.n_ops), s0, stream));
   return 0;
 }
 
@@ -776,7 +788,7 @@ int qhbm_traffic_model(qhbm_engine* h, int U, int with_vjp, double* fwd_bytes, d
   if (int rc = build_plans(h)) return rc;
   const double tile_all = double(state_bytes(h)) * double(U);  // every tile of every state, once
   double f = 0.0, o = 0.0, b = 0.0;
-  bool measure_only_after = false;
+  bool measure_only_after = !h->fwd.plan.global_terms.empty();
   for (const Pass& p : h->fwd.plan.passes) measure_only_after |= p.is_measure_only;
   for (const Pass& p : h->fwd.plan.passes) {
     if (!(p.flags & PASS_INIT_BASIS)) f += tile_all;  // the first pass writes the basis state, reads nothing

@@ -44,6 +44,10 @@ hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, u
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
                                    hipStream_t stream);
+// Terms measured on the final state in HBM (X-mask wider than a tile); accumulates into out64.
+hipError_t launch_measure_global(const float2* psi, uint32_t n, uint32_t n_states, const DevTerm* terms,
+                                 uint32_t n_terms, const float* op_scale, unsigned long long* out64, uint32_t n_ops,
+                                 uint32_t state0, hipStream_t stream);
 hipError_t launch_parity_energy(const int8_t* bits, int64_t n_rows, int n, const uint64_t* masks,
                                 const float* thetas, int n_terms, float* energy, hipStream_t stream);
 hipError_t launch_parity_energy_vjp(const int8_t* bits, int64_t n_rows, int n, const uint64_t* masks, int n_terms,

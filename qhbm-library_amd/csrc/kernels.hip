@@ -1349,6 +1349,49 @@ __global__ __launch_bounds__(256) void apply_observable_kernel(
 }
 
 // ================================================================================
+// Pauli terms whose X-mask flips more qubits than a tile holds (schedule.cpp global_terms): measured
+// on the final state in HBM.  <psi|P|psi> = sum_j Re( i^ny (-1)^{popc(j & z)} conj(psi[j ^ x]) psi[j] ):
+// j ^ x of a run of consecutive j is a permuted run, so both reads are coalesced; the partner run
+// comes from wherever in the state the mask sends it (L2 / Infinity Cache).  A slow path -- one
+// sweep of the state per term -- that keeps TFQ's "any PauliSum" contract (qnn.py:134-138).
+// ================================================================================
+__global__ __launch_bounds__(256) void measure_global_kernel(
+    const float2* __restrict__ psi, uint32_t n, const DevTerm* __restrict__ terms, uint32_t n_terms,
+    const float* __restrict__ op_scale, unsigned long long* __restrict__ out64, uint32_t n_ops, uint32_t state0) {
+  const uint32_t s_local = blockIdx.y;
+  const float2* ps = psi + (size_t(s_local) << n);
+  const uint32_t j0 = blockIdx.x * 1024u + threadIdx.x;
+  float2 own[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) own[a] = ps[j0 + 256u * a];
+  for (uint32_t k = 0; k < n_terms; ++k) {
+    const DevTerm tm = terms[k];  // wave-uniform
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const uint32_t j = j0 + 256u * a;
+      const float2 q = ps[j ^ tm.x];
+      const float wr = q.x * own[a].x + q.y * own[a].y, wi = q.x * own[a].y - q.y * own[a].x;  // conj(q) * own
+      float v = (tm.ny & 1u) ? wi : wr;
+      if (tm.ny == 1u || tm.ny == 2u) v = -v;
+      acc += (__popc(j & tm.z) & 1) ? -v : v;
+    }
+    acc = wave_sum(acc * tm.coeff);
+    if ((threadIdx.x & 63u) == 0)
+      atomicAdd(&out64[size_t(state0 + s_local) * n_ops + tm.op], to_fixed(acc, op_scale[tm.op]));
+  }
+}
+
+hipError_t launch_measure_global(const float2* psi, uint32_t n, uint32_t n_states, const DevTerm* terms,
+                                 uint32_t n_terms, const float* op_scale, unsigned long long* out64, uint32_t n_ops,
+                                 uint32_t state0, hipStream_t stream) {
+  if (n_terms == 0 || n_states == 0) return hipSuccess;
+  hipLaunchKernelGGL(measure_global_kernel, dim3((1u << n) / 1024u, n_states), dim3(256), 0, stream, psi, n, terms,
+                     n_terms, op_scale, out64, n_ops, state0);
+  return hipGetLastError();
+}
+
+// ================================================================================
 // Per-call coefficient preparation (double precision, one thread per job).
 // ================================================================================
 namespace {

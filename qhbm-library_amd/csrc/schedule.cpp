@@ -682,8 +682,16 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     const size_t before = g_left;
     take(&p);
     if (g_left == before) {
-      *err = "a Pauli term flips more qubits than fit in one tile (" + std::to_string(K - 1) + ")";
-      return false;
+      // What is left flips more qubits than a tile holds: those terms are measured by the
+      // strided-gather kernel on the final state in HBM (kernels.hip measure_global_kernel).
+      for (size_t gi = 0; gi < groups.size(); ++gi) {
+        if (gdone[gi] || popc(1u | groups[gi].x) <= K) continue;
+        for (int ti : groups[gi].terms) plan->global_terms.push_back(ti);
+        gdone[gi] = 1;
+        --g_left;
+      }
+      if (g_left == before) { *err = "internal: measurement made no progress"; return false; }
+      continue;
     }
     plan->passes.push_back(std::move(p));
   }
@@ -695,7 +703,9 @@ std::string describe_plan(const Plan& p) {
   std::ostringstream os;
   os << (p.adjoint ? "adjoint" : "forward") << " plan: n=" << p.n << " n_eff=" << p.n_eff
      << " tile_bits=" << p.K << " round_bits=" << p.R << " passes=" << p.passes.size()
-     << " coef_floats=" << p.n_coef_floats << "\n";
+     << " coef_floats=" << p.n_coef_floats;
+  if (!p.global_terms.empty()) os << " global_terms=" << p.global_terms.size();
+  os << "\n";
   for (size_t i = 0; i < p.passes.size(); ++i) {
     const Pass& q = p.passes[i];
     os << "  pass " << i << ": c=" << q.c << " local=[";

@@ -74,6 +74,9 @@ struct Plan {
   std::vector<uint32_t> coef_init;  // static words of the coefficient buffer (records)
   std::vector<uint32_t> record_offsets;  // word offset of every instance record
   int full_threshold = 60;  // per-term cost above which an instance uses the FULL diagonal table
+  // forward: indices (into Model::terms) of the Pauli terms whose X-mask does not fit a tile; they
+  // are measured on the final state in HBM by the strided-gather kernel
+  std::vector<int> global_terms;
   // adjoint: gradient slot -> (gate, chain-rule factor to the exponent)
   std::vector<int> slot_gate;
   std::vector<float> slot_factor;

@@ -69,7 +69,8 @@ for name, c in per.items():
   if "SQ_INSTS_VALU" in c and avg_ns.get(name):
     cycles = avg_ns[name] * CLOCK_GHZ  # nominal clock; GRBM_GUI_ACTIVE gives the real one when collected
     if c.get("GRBM_GUI_ACTIVE"):
-      cycles = c["GRBM_GUI_ACTIVE"]
+      cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # the counter is summed over the 8 XCDs
+      k["effective_clock_GHz_under_profiler"] = cycles / avg_ns[name]
     k["valu_issue_frac"] = c["SQ_INSTS_VALU"] * ISSUE_CYCLES_PER_VALU / (cycles * SIMDS)
     if "SQ_ACTIVE_INST_VALU" in c:
       k["valu_active_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * SIMDS)
