@@ -159,6 +159,14 @@ int qhbm_expectation_vjp_retained(qhbm_engine* h, const int8_t* d_bits, int U,
  * backward chunk, or any compute call since). */
 int qhbm_retained_states(qhbm_engine* h, int* out_U);
 
+/* Per-state rows of the last adjoint VJP (qhbm_expectation_vjp with method 0, or
+ * qhbm_expectation_vjp_retained) on U states:
+ *   d_rows[u, p] = sum_k d_upstream[u, k] * d out[u, k] / d params[p]       [U, n_params] float
+ * so that sum_u d_rows[u, :] is that call's d_grad.  A multi-GPU host gathers the rows of every
+ * rank and adds them in global state order: the [P] gradient is then bit-identical for any number
+ * of ranks (SURVEY.md 8e "fixed-order summation"); an all-reduce of d_grad is the fast path. */
+int qhbm_state_gradients(qhbm_engine* h, int U, float* d_rows, void* stream);
+
 /* Full Jacobian d_jac[u, k, p] (tests / small n only; adjoint). */
 int qhbm_expectation_jacobian(qhbm_engine* h, const int8_t* d_bits, int U,
                               const float* d_params, float* d_out_vals,

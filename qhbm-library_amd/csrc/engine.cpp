@@ -72,6 +72,7 @@ struct qhbm_engine {
   int opt_full_fwd = 60, opt_full_adj = 60, opt_force_general = 0;
   int opt_adj_exchange = 1;  // lean adjoint passes: register-resident tile pair + one LDS exchange buffer
   int retained_U = 0;  // final states of the last qhbm_expectation_retain still sit in psi
+  int state_grad_U = 0;  // rows of state_grad the last adjoint VJP filled (qhbm_state_gradients)
   int64_t opt_chunk = 0;
   int64_t opt_budget_mb = 0;  // 0: a third of the device's memory, resolved at first use (budget_bytes)
   // plans
@@ -377,6 +378,7 @@ int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_pa
   DevicePlan& f = h->fwd;
   DevicePlan& b = h->adj;
   h->retained_U = 0;
+  h->state_grad_U = 0;
   const uint32_t n_slots = uint32_t(b.plan.slot_gate.size());
   HIPCHK(launch_prep_coefs(f.jobs.p, int(f.plan.jobs.size()), d_params, f.coef.p, -1, 0.0, stream));
   HIPCHK(launch_combine_diag(f.coef.p, f.rec_offsets.p, int(f.plan.record_offsets.size()), stream));
@@ -583,6 +585,7 @@ int qhbm_expectation_vjp_retained(qhbm_engine* h, const int8_t* d_bits, int U, c
   hipStream_t s = static_cast<hipStream_t>(stream);
   DevicePlan& b = h->adj;
   h->retained_U = 0;  // the backward sweep un-applies psi in place: the state is consumed
+  h->state_grad_U = 0;
   const uint32_t n_slots = uint32_t(b.plan.slot_gate.size());
   HIPCHK(launch_prep_coefs(b.jobs.p, int(b.plan.jobs.size()), d_params, b.coef.p, -1, 0.0, s));
   HIPCHK(launch_combine_diag(b.coef.p, b.rec_offsets.p, int(b.plan.record_offsets.size()), s));
@@ -591,6 +594,18 @@ int qhbm_expectation_vjp_retained(qhbm_engine* h, const int8_t* d_bits, int U, c
   if (int rc = run_adjoint_chunk(h, d_bits, 0, uint32_t(U), d_upstream, s)) return rc;
   HIPCHK(launch_reduce_grad(h->state_grad.p, uint32_t(U), n_slots, h->param_slot_begin.p, h->param_slots.p,
                             h->slot_factor.p, d_grad, h->model.n_params, 0, s));
+  h->state_grad_U = U;
+  return 0;
+}
+
+int qhbm_state_gradients(qhbm_engine* h, int U, float* d_rows, void* stream) {
+  if (!h || !d_rows) return 1;
+  if (int rc = need_device(h)) return rc;
+  if (U <= 0 || U != h->state_grad_U || !h->plans_valid)
+    return fail(h, "qhbm_state_gradients: the last call was not an adjoint VJP on this many states");
+  HIPCHK(launch_scatter_jac(h->state_grad.p, uint32_t(U), uint32_t(h->adj.plan.slot_gate.size()),
+                            h->param_slot_begin.p, h->param_slots.p, h->slot_factor.p, d_rows, 1u, 0u,
+                            uint32_t(h->model.n_params), static_cast<hipStream_t>(stream)));
   return 0;
 }
 
@@ -693,6 +708,7 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const floa
     if (int rc = adjoint_sweep(h, d_bits, U, d_params, d_upstream, d_out_vals, s)) return rc;
     HIPCHK(launch_reduce_grad(h->state_grad.p, uint32_t(U), uint32_t(h->adj.plan.slot_gate.size()),
                               h->param_slot_begin.p, h->param_slots.p, h->slot_factor.p, d_grad, P, 0, s));
+    h->state_grad_U = U;
     return 0;
   }
   if (method != QHBM_GRAD_PARAMETER_SHIFT) return fail(h, "unknown gradient method");

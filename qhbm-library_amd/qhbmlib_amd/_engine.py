@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "qhbm_abi_version", "qhbm_create", "qhbm_destroy", "qhbm_last_error",
     "qhbm_set_circuit", "qhbm_set_observables", "qhbm_set_option",
     "qhbm_workspace_bytes", "qhbm_allocated_bytes", "qhbm_expectation", "qhbm_expectation_vjp",
-    "qhbm_expectation_retain", "qhbm_expectation_vjp_retained", "qhbm_retained_states",
+    "qhbm_expectation_retain", "qhbm_expectation_vjp_retained", "qhbm_retained_states", "qhbm_state_gradients",
     "qhbm_expectation_jacobian", "qhbm_statevector", "qhbm_sample", "qhbm_parity_energy", "qhbm_parity_energy_vjp",
     "qhbm_num_passes", "qhbm_describe_schedule",
     "qhbm_kernel_time_ms", "qhbm_traffic_model",
@@ -83,6 +83,7 @@ def load_library():
   lib.qhbm_expectation_vjp.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp]
   lib.qhbm_expectation_retain.argtypes = [vp, vp, i32, vp, vp, vp]
   lib.qhbm_expectation_vjp_retained.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+  lib.qhbm_state_gradients.argtypes = [vp, i32, vp, vp]
   lib.qhbm_expectation_jacobian.argtypes = [vp, vp, i32, vp, vp, vp, vp]
   lib.qhbm_statevector.argtypes = [vp, vp, i32, vp, vp, vp]
   lib.qhbm_sample.argtypes = [vp, vp, i32, vp, i32, ctypes.c_uint64, i32, ctypes.c_double, vp, vp]
@@ -335,6 +336,13 @@ class Engine:
                                          grad.data_ptr(), int(method),
                                          self._stream()))
     return vals, grad
+
+  def state_gradients(self, num_states):
+    """[num_states, n_params] rows of the last adjoint VJP (their sum over states is its gradient)."""
+    rows = torch.empty((int(num_states), self.n_params), dtype=torch.float32, device=self.device)
+    with torch.cuda.device(self.device):
+      self._check(self._lib.qhbm_state_gradients(self._h, int(num_states), rows.data_ptr(), self._stream()))
+    return rows
 
   def statevector(self, bits, params):
     """Final states C(params)|x_u>, complex64 [batch, 2^n] (qubit 0 = most significant bit)."""

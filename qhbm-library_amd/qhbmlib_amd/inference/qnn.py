@@ -34,8 +34,8 @@ class _ExpectationFunction(torch.autograd.Function):
   code.  Every rank must pass the same bitstrings."""
 
   @staticmethod
-  def forward(ctx, symbol_values, engine, bits, method, group):
-    ctx.engine, ctx.method, ctx.group = engine, method, group
+  def forward(ctx, symbol_values, engine, bits, method, group, ordered):
+    ctx.engine, ctx.method, ctx.group, ctx.ordered = engine, method, group, ordered
     ctx.rows = None
     if group is not None:
       blocks = parallel.partition(bits.shape[0], dist.get_world_size(group))
@@ -69,8 +69,15 @@ class _ExpectationFunction(torch.autograd.Function):
     if grad is None:
       _, grad = eng.expectation_vjp(ctx.bits, symbol_values.detach(), upstream, ctx.method)
     if ctx.group is not None:
-      parallel.all_reduce_sum(grad, ctx.group)
-    return grad.to(symbol_values.device), None, None, None, None
+      if ctx.ordered and ctx.method == _engine.GRAD_ADJOINT:
+        # every rank's per-state rows, gathered in global state order and added in that order: the
+        # same [U, P] array and the same reduction for ANY number of ranks -> bit-identical
+        rows = eng.state_gradients(ctx.bits.shape[0]) if ctx.bits.shape[0] else grad.new_zeros((0, grad.numel()))
+        rows = parallel.all_gather_rows(rows, ctx.blocks, ctx.group)
+        grad = rows.to(torch.float64).sum(0).to(torch.float32)
+      else:
+        parallel.all_reduce_sum(grad, ctx.group)
+    return grad.to(symbol_values.device), None, None, None, None, None
 
 
 class ResolvedCircuits(tuple):
@@ -191,17 +198,20 @@ class AnalyticQuantumInference(QuantumInference):
 
   `process_group`: a `torch.distributed` group (or True for the default group) over which the
   unique bitstrings are sharded, one process per GPU; None (default) runs on this process's GPU
-  only."""
+  only.  `ordered_reduction` (default True) gathers per-state gradient rows and adds them in global
+  state order, so losses and gradients are bit-identical for 1, 2, 4 or 8 ranks; False all-reduces
+  the [P] gradient instead (a few hundred floats instead of [U, P], not order-stable)."""
 
   MAX_OPS_PER_CALL = 1024  # kMaxOps of the engine (csrc/program.h)
 
   def __init__(self, input_circuit: circuit.QuantumCircuit, name: Union[None, str] = None,
                device: Union[None, int] = None, gradient_method: int = _engine.GRAD_ADJOINT,
-               process_group=None, max_cached_engines: int = 4):
+               process_group=None, max_cached_engines: int = 4, ordered_reduction: bool = True):
     super().__init__(input_circuit, name)
     self._device = device
     self.gradient_method = gradient_method
     self._process_group = process_group
+    self.ordered_reduction = ordered_reduction
     self._engines = _EngineCache(max_cached_engines)
 
   def _group(self):
@@ -251,7 +261,7 @@ class AnalyticQuantumInference(QuantumInference):
     for lo in range(0, max(len(ops), 1), self.MAX_OPS_PER_CALL):
       masks = [ir.as_pauli_sum(op).masks(qubits) for op in ops[lo:lo + self.MAX_OPS_PER_CALL]]
       eng = self._engine_for(len(qubits), flat_gates, len(symbol_names), masks)
-      parts.append(_ExpectationFunction.apply(values, eng, bits, self.gradient_method, group))
+      parts.append(_ExpectationFunction.apply(values, eng, bits, self.gradient_method, group, self.ordered_reduction))
     expectations = parts[0] if len(parts) == 1 else torch.cat(parts, 1)
     return post_process(expectations)
 
