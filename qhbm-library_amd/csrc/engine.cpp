@@ -70,6 +70,7 @@ struct qhbm_engine {
   // options
   int opt_tile = 0, opt_adj_tile = 0, opt_profile = 0, opt_round = 0;
   int opt_full_fwd = 60, opt_full_adj = 60, opt_force_general = 0;
+  int opt_meas_tile = 0;     // tile qubits of measurement-only passes (0 = largest)
   int opt_adj_exchange = 1;  // lean adjoint passes: register-resident tile pair + one LDS exchange buffer
   int retained_U = 0;  // final states of the last qhbm_expectation_retain still sit in psi
   int state_grad_U = 0;  // rows of state_grad the last adjoint VJP filled (qhbm_state_gradients)
@@ -166,7 +167,8 @@ int build_plans(qhbm_engine* h) {
   if (!h->have_circuit) return fail(h, "qhbm_set_circuit has not been called");
   if (h->model.n_ops > kMaxOps) return fail(h, "too many observables (max 1024)");
   std::string err;
-  if (!build_plan(h->model, h->opt_tile, h->opt_round, false, &h->fwd.plan, &err, h->opt_full_fwd)) return fail(h, "forward plan: " + err);
+  if (!build_plan(h->model, h->opt_tile, h->opt_round, false, &h->fwd.plan, &err, h->opt_full_fwd, h->opt_meas_tile))
+    return fail(h, "forward plan: " + err);
   if (!build_plan(h->model, h->opt_adj_tile, 0, true, &h->adj.plan, &err, h->opt_full_adj)) return fail(h, "adjoint plan: " + err);
   h->fwd.uploaded = h->adj.uploaded = false;
   h->plans_valid = true;
@@ -285,7 +287,7 @@ int run_forward_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_
     if (h->opt_force_general) a.flags |= PASS_GENERAL;
     if (!p.is_measure_only && (!p.completes_circuit || keep_state || measure_only_after)) a.flags |= PASS_STORE;
     hipEvent_t* ev = timer_begin(h, 0, stream);
-    HIPCHK(launch_pass_fwd(d.plan.K, d.plan.R, a, cs, h->psi.p, d_bits, h->model.n, d.prog.p, d.tables.p, d.coef.p,
+    HIPCHK(launch_pass_fwd(p.K, d.plan.R, a, cs, h->psi.p, d_bits, h->model.n, d.prog.p, d.tables.p, d.coef.p,
                            h->op_scale.p, h->vals64.p, s0, stream));
     timer_end(ev, stream);
   }
@@ -515,6 +517,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "adjoint_full_diag_threshold") { h->opt_full_adj = int(value); h->plans_valid = false; }
   else if (k == "adjoint_tile_qubits") { h->opt_adj_tile = int(value); h->plans_valid = false; }
   else if (k == "adjoint_exchange") h->opt_adj_exchange = int(value);
+  else if (k == "measure_tile_qubits") { h->opt_meas_tile = int(value); h->plans_valid = false; }
   else if (k == "chunk_states") h->opt_chunk = value;
   else if (k == "workspace_budget_mb") h->opt_budget_mb = std::max<int64_t>(0, value);  // 0 = default
   else if (k == "profile_events") h->opt_profile = int(value);

@@ -447,7 +447,7 @@ class Builder {
 }  // namespace
 
 bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Plan* plan, std::string* err,
-                int full_threshold) {
+                int full_threshold, int meas_tile_bits) {
   *plan = Plan();
   plan->full_threshold = full_threshold;
   if (m.n < 1 || m.n > kMaxQubits - 1) { *err = "n_qubits must be in [1, 31]"; return false; }
@@ -669,31 +669,54 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     b.emit_measure(p, groups, which);
   };
   take(&plan->passes.back());
-  while (g_left) {
-    // measurement-only pass: the x-bits of as many groups as fit, then low bits
-    uint32_t S = 1u;  // bit 0 is always local (amplitudes move in 16-byte pairs)
-    for (size_t gi = 0; gi < groups.size(); ++gi) {
-      if (gdone[gi]) continue;
-      if (popc(S | groups[gi].x) <= K) S |= groups[gi].x;
-    }
-    for (int bit = 0; bit < n_eff && popc(S) < K; ++bit) if (!(S >> bit & 1)) S |= 1u << bit;
-    Pass p = b.begin_pass(S);
-    p.is_measure_only = true;
-    const size_t before = g_left;
-    take(&p);
-    if (g_left == before) {
-      // What is left flips more qubits than a tile holds: those terms are measured by the
-      // strided-gather kernel on the final state in HBM (kernels.hip measure_global_kernel).
-      for (size_t gi = 0; gi < groups.size(); ++gi) {
-        if (gdone[gi] || popc(1u | groups[gi].x) <= K) continue;
-        for (int ti : groups[gi].terms) plan->global_terms.push_back(ti);
-        gdone[gi] = 1;
-        --g_left;
+  // Measurement-only passes (a full read of the state each): the largest tile the forward kernel
+  // has (2^14 amplitudes) holds the most X-masks, and the low four index bits stay local so that a
+  // tile is made of >= 128-byte contiguous pieces -- with scattered 16-byte pieces (c = 1) these
+  // passes ran at a quarter of the HBM rate.  Groups too wide for that get a second chance with
+  // only bit 0 pinned; what still does not fit goes to the strided-gather kernel.
+  const int K_meas = std::min(n_eff, std::max(K, meas_tile_bits > 0 ? meas_tile_bits : kMaxTileBits));
+  Builder bm(m, K_meas, R, n_eff, adjoint, plan);
+  for (int c_pin : {c_min, 1}) {
+    const uint32_t pinned = (1u << std::min(c_pin, K_meas)) - 1u;
+    for (;;) {
+      // the x-bits of as many groups as fit (fewest new bits first), then low bits
+      uint32_t S = pinned;
+      bool any = false;
+      for (;;) {
+        int best_add = 1 << 30;
+        size_t best = groups.size();
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+          if (gdone[gi] || (groups[gi].x & ~S) == 0) continue;
+          if (popc(S | groups[gi].x) > K_meas) continue;
+          const int add = popc(groups[gi].x & ~S);
+          if (add < best_add) { best_add = add; best = gi; }
+        }
+        if (best == groups.size()) break;
+        S |= groups[best].x;
+        any = true;
       }
-      if (g_left == before) { *err = "internal: measurement made no progress"; return false; }
-      continue;
+      if (!any) {  // nothing left whose bits can be added: either all covered by `pinned`, or too wide
+        bool covered = false;
+        for (size_t gi = 0; gi < groups.size(); ++gi) covered |= !gdone[gi] && (groups[gi].x & ~S) == 0;
+        if (!covered) break;
+      }
+      for (int bit = 0; bit < n_eff && popc(S) < K_meas; ++bit) if (!(S >> bit & 1)) S |= 1u << bit;
+      Pass p = bm.begin_pass(S);
+      p.is_measure_only = true;
+      const size_t before = g_left;
+      take(&p);
+      if (g_left == before) break;
+      plan->passes.push_back(std::move(p));
     }
-    plan->passes.push_back(std::move(p));
+    if (!g_left) break;
+  }
+  // What is left flips more qubits than a tile holds: those terms are measured by the
+  // strided-gather kernel on the final state in HBM (kernels.hip measure_global_kernel).
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    if (gdone[gi]) continue;
+    for (int ti : groups[gi].terms) plan->global_terms.push_back(ti);
+    gdone[gi] = 1;
+    --g_left;
   }
   for (Pass& p : plan->passes) p.prog.push_back(OP_END);
   return true;
@@ -708,7 +731,7 @@ std::string describe_plan(const Plan& p) {
   os << "\n";
   for (size_t i = 0; i < p.passes.size(); ++i) {
     const Pass& q = p.passes[i];
-    os << "  pass " << i << ": c=" << q.c << " local=[";
+    os << "  pass " << i << ": K=" << q.K << " c=" << q.c << " local=[";
     for (size_t k = 0; k < q.local_pos.size(); ++k) os << (k ? "," : "") << q.local_pos[k];
     os << "] mat_ops=" << q.n_mat_ops << " diag_terms=" << q.n_diag_terms << " rounds=" << q.n_rounds
        << " instances=" << q.n_instances << " meas_groups=" << q.n_meas_groups

@@ -95,8 +95,9 @@ struct Model {
 // Builds the forward plan (circuit passes + measurement) or, with adjoint =
 // true, the backward plan over (psi, lambda) tile pairs.  `tile_bits` = 0
 // selects automatically.  Returns false and fills `err` on failure.
+// `meas_tile_bits`: tile size of measurement-only passes (0 = the largest the forward kernel has).
 bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Plan* out,
-                std::string* err, int full_threshold = 60);
+                std::string* err, int full_threshold = 60, int meas_tile_bits = 0);
 
 std::string describe_plan(const Plan& p);
 
