@@ -350,7 +350,9 @@ int run_adjoint_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_
     timer_end(ev, stream);
   }
   size_t rows = 0;  // tile_grad: one row of the pass's slots per workgroup
-  for (const PassArgs& ba : b.args) rows = std::max(rows, (size_t(c) << ba.n_nonlocal) * std::max<uint32_t>(ba.n_slots, 1));
+  for (const PassArgs& ba : b.args)
+    rows = std::max(rows, ((size_t(c) << ba.n_nonlocal) + reduce_tiles_scratch_rows(c, size_t(1) << ba.n_nonlocal)) *
+                              std::max<uint32_t>(ba.n_slots, 1));
   HIPCHK(h->tile_grad.reserve(rows));
   for (size_t i = 0; i < b.plan.passes.size(); ++i) {
     hipEvent_t* ev = timer_begin(h, 1, stream);
@@ -534,7 +536,8 @@ int qhbm_workspace_bytes(qhbm_engine* h, int U, int with_vjp, size_t* out) {
     b += size_t(U) * h->adj.plan.slot_gate.size() * sizeof(float);
     size_t rows = 0;  // per-tile gradient rows of the widest adjoint pass
     for (const Pass& p : h->adj.plan.passes)
-      rows = std::max(rows, (size_t(cs) << p.nonlocal_pos.size()) * size_t(std::max(p.n_slots, 1)));
+      rows = std::max(rows, ((size_t(cs) << p.nonlocal_pos.size()) +
+                             reduce_tiles_scratch_rows(cs, size_t(1) << p.nonlocal_pos.size())) * size_t(std::max(p.n_slots, 1)));
     b += rows * sizeof(float);
   }
   b += size_t(U) * size_t(std::max(h->model.n_ops, 1)) * sizeof(unsigned long long);

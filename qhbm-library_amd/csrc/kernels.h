@@ -37,7 +37,9 @@ hipError_t launch_values_from_fixed(const unsigned long long* acc, const float* 
 hipError_t launch_pass_adj(int K, bool exchange, const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
                            const int8_t* bits, int n_user, const uint32_t* prog, const uint32_t* tables,
                            const float* coef, float* tile_grad, uint32_t state0, hipStream_t stream);
-hipError_t launch_reduce_tiles(const float* tile_grad, uint32_t n_states, uint32_t n_tiles, uint32_t n_slots,
+// tile_grad must have room for reduce_tiles_scratch_rows(n_states, n_tiles) more rows of n_slots floats.
+size_t reduce_tiles_scratch_rows(size_t n_states, size_t n_tiles);
+hipError_t launch_reduce_tiles(float* tile_grad, uint32_t n_states, uint32_t n_tiles, uint32_t n_slots,
                                float* state_grad, uint32_t n_slots_total, uint32_t slot_base, uint32_t state0,
                                hipStream_t stream);
 hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, uint32_t n_states,

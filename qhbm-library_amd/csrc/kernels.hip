@@ -1244,30 +1244,30 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
   }
 }
 
-// state_grad[state0 + s, slot_base + i] = sum over the tiles of state s, in tile order, of the
-// pass's tile_grad rows.  blockDim = (64 slots, 16 tile lanes): lane y adds tiles y, y + 16, ... in
-// order, then the 16 partials are added in lane order -- a fixed tree, bit-reproducible.
-__global__ __launch_bounds__(1024) void reduce_tiles_kernel(const float* __restrict__ tile_grad, uint32_t n_tiles,
-                                                            uint32_t n_slots, float* __restrict__ state_grad,
-                                                            uint32_t n_slots_total, uint32_t slot_base,
-                                                            uint32_t state0) {
+// Sum of a state's tile_grad rows in a FIXED tree (bit-reproducible): a block adds a chunk of up to
+// kTileChunk consecutive tiles -- lane y takes tiles y, y + 16, ... in order, then the 16 partials are
+// added in lane order -- and writes row `chunk` of dst[s]; the host repeats the step on the chunk
+// sums until one row per state is left, which lands in state_grad.
+constexpr uint32_t kTileChunk = 256;
+__global__ __launch_bounds__(1024) void reduce_tiles_kernel(const float* __restrict__ src, uint32_t n_rows,
+                                                            uint32_t n_slots, float* __restrict__ dst,
+                                                            uint32_t dst_row_stride, uint32_t dst_state_stride,
+                                                            uint32_t dst_offset) {
   __shared__ float part[16][64];
-  const uint32_t s = blockIdx.x;
-  const float* base = tile_grad + size_t(s) * n_tiles * n_slots;
-  for (uint32_t i0 = 0; i0 < n_slots; i0 += 64) {
-    const uint32_t i = i0 + threadIdx.x;
-    float acc = 0.f;
-    if (i < n_slots)
-      for (uint32_t tl = threadIdx.y; tl < n_tiles; tl += 16) acc += base[size_t(tl) * n_slots + i];
-    part[threadIdx.y][threadIdx.x] = acc;
-    __syncthreads();
-    if (threadIdx.y == 0 && i < n_slots) {
-      float v = part[0][threadIdx.x];
+  const uint32_t s = blockIdx.z, chunk = blockIdx.y;
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  const uint32_t r0 = chunk * kTileChunk, r1 = min(n_rows, r0 + kTileChunk);
+  const float* base = src + size_t(s) * n_rows * n_slots;
+  float acc = 0.f;
+  if (i < n_slots)
+    for (uint32_t r = r0 + threadIdx.y; r < r1; r += 16) acc += base[size_t(r) * n_slots + i];
+  part[threadIdx.y][threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.y == 0 && i < n_slots) {
+    float v = part[0][threadIdx.x];
 #pragma unroll
-      for (int y = 1; y < 16; ++y) v += part[y][threadIdx.x];
-      state_grad[size_t(state0 + s) * n_slots_total + slot_base + i] = v;
-    }
-    __syncthreads();
+    for (int y = 1; y < 16; ++y) v += part[y][threadIdx.x];
+    dst[size_t(s) * dst_state_stride + size_t(chunk) * dst_row_stride + dst_offset + i] = v;
   }
 }
 
@@ -1696,12 +1696,35 @@ hipError_t launch_pass_adj(int K, bool exchange, const PassArgs& a, uint32_t n_s
 #undef QHBM_ADJ_CASE
 }
 
-hipError_t launch_reduce_tiles(const float* tile_grad, uint32_t n_states, uint32_t n_tiles, uint32_t n_slots,
+// tile_grad holds n_states * n_tiles rows followed by scratch for the chunk sums
+// (reduce_tiles_scratch_rows); the last step writes state_grad[state0 + s, slot_base + i].
+size_t reduce_tiles_scratch_rows(size_t n_states, size_t n_tiles) {
+  size_t rows = 0;
+  for (size_t r = n_tiles; r > kTileChunk;) {
+    r = (r + kTileChunk - 1) / kTileChunk;
+    rows += n_states * r;
+  }
+  return rows;
+}
+
+hipError_t launch_reduce_tiles(float* tile_grad, uint32_t n_states, uint32_t n_tiles, uint32_t n_slots,
                                float* state_grad, uint32_t n_slots_total, uint32_t slot_base, uint32_t state0,
                                hipStream_t stream) {
   if (n_states == 0 || n_slots == 0) return hipSuccess;
-  hipLaunchKernelGGL(reduce_tiles_kernel, dim3(n_states), dim3(64, 16), 0, stream, tile_grad, n_tiles, n_slots,
-                     state_grad, n_slots_total, slot_base, state0);
+  const float* src = tile_grad;
+  float* scratch = tile_grad + size_t(n_states) * n_tiles * n_slots;
+  uint32_t rows = n_tiles;
+  const uint32_t bx = (n_slots + 63) / 64;
+  while (rows > kTileChunk) {
+    const uint32_t chunks = (rows + kTileChunk - 1) / kTileChunk;
+    hipLaunchKernelGGL(reduce_tiles_kernel, dim3(bx, chunks, n_states), dim3(64, 16), 0, stream, src, rows, n_slots,
+                       scratch, n_slots, chunks * n_slots, 0u);
+    src = scratch;
+    scratch += size_t(n_states) * chunks * n_slots;
+    rows = chunks;
+  }
+  hipLaunchKernelGGL(reduce_tiles_kernel, dim3(bx, 1, n_states), dim3(64, 16), 0, stream, src, rows, n_slots,
+                     state_grad + size_t(state0) * n_slots_total, 0u, n_slots_total, slot_base);
   return hipGetLastError();
 }
 

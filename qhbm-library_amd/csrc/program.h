@@ -31,7 +31,9 @@ constexpr int kMinTileBits = 10;  // states with fewer qubits are padded with id
 constexpr int kMaxTileBits = 14;
 constexpr int kMaxQubits = 32;    // amplitude indices are 32-bit
 constexpr int kMaxOps = 1024;           // observables per engine (LDS accumulators, 64-bit fixed point)
-constexpr int kMaxSlotsPerPass = 256;   // gradient slots one adjoint pass may own (one LDS cell per wave and slot)
+// Gradient slots one adjoint pass may own: one LDS cell per wave and slot (K = 12, 4 waves: 6 KiB next
+// to the 32 KiB exchange tile, so four workgroups still share a CU's 160 KiB).
+constexpr int kMaxSlotsPerPass = 384;
 // Expectation values are accumulated across waves, tiles and passes as 64-bit FIXED-POINT integers
 // (integer addition is associative: the result does not depend on the order in which workgroups
 // finish, so a value is bit-identical from run to run and for any sharding of the batch).  An op's
