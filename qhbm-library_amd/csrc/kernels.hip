@@ -29,7 +29,6 @@ namespace qhbm {
 
 namespace {
 
-constexpr float kPi = 3.14159265358979323846f;
 
 __device__ __forceinline__ uint32_t swz(uint32_t l) { return l ^ ((l >> 5) & 31u); }
 
@@ -573,9 +572,9 @@ __device__ __forceinline__ void rec_load(const uint32_t* __restrict__ recs, uint
 // no atomics; the kernel epilogue adds a slot's cells in wave order, so the tile's gradient is
 // bit-identical from run to run.
 template <int NW>
-__device__ __forceinline__ void add_slot(float* cells, uint32_t slot_base, int tid, uint32_t slot, float v) {
+__device__ __forceinline__ void add_slot(float* cells, int tid, uint32_t slot, float v) {
   v = wave_sum(v);
-  if ((tid & 63) == 0) cells[(slot - slot_base) * NW + (uint32_t(tid) >> 6)] = v;
+  if ((tid & 63) == 0) cells[slot * NW + (uint32_t(tid) >> 6)] = v;
 }
 
 // Gradient partials of the four slots of record slot group G, reduced over the wave TOGETHER:
@@ -594,9 +593,11 @@ __device__ __forceinline__ float rows_sum(float u) {
   r = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// `sv` holds slots LOCAL to the pass (schedule.cpp), the chain-rule scale of the slot class (pi,
+// -2 pi) is folded into the plan's slot_factor: the store is two compares and one shift-add.
 template <int G, int NW>
-__device__ __forceinline__ void add_slots4(float* cells, uint32_t slot_base, int lane, uint32_t wave, uint32_t sv,
-                                           float scale, float g0, float g1, float g2, float g3) {
+__device__ __forceinline__ void add_slots4(float* cells, int lane, uint32_t wave, uint32_t sv,
+                                           float g0, float g1, float g2, float g3) {
   const bool b0 = lane & 1, b1 = lane & 2;
   float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2;
   t0 += dpp_get<0xB1>(b0 ? g0 : g1);  // quad_perm:[1,0,3,2]
@@ -606,7 +607,7 @@ __device__ __forceinline__ void add_slots4(float* cells, uint32_t slot_base, int
   u += dpp_get<0x124>(u);             // row_ror:4
   u += dpp_get<0x128>(u);             // row_ror:8
   u = rows_sum(u);
-  if ((lane >> 2) == G && sv != 0xffffffffu) cells[(sv - slot_base) * NW + wave] = scale * u;
+  if ((lane >> 2) == G && sv != 0xffffffffu) cells[sv * NW + wave] = u;
 }
 
 // FULL diagonal table: amplitude with register value m (1..15) times FULL[m-1].
@@ -898,12 +899,11 @@ template <int R, int NW, bool GEN>
 __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uint32_t (&sv)[1],
                                              const uint32_t* __restrict__ recs, uint32_t rec_off, int lane,
                                              uint32_t wave, v2f (&p)[1 << R], v2f (&l)[1 << R], uint32_t TL,
-                                             uint32_t tile_base, float* cells, uint32_t slot_base) {
+                                             uint32_t tile_base, float* cells) {
   constexpr RecordLayout L(R, true);
   constexpr int NR = 1 << R;
   constexpr int NB = 1;
   constexpr int S0 = L.slot0();
-  constexpr float kM2Pi = -2.f * kPi;
   const uint32_t h0 = rec_word<0>(cur), h1 = rec_word<1>(cur);
   // ---- CPH (slot groups 6, 7) ----
   if (h1 & 0xffu) {
@@ -914,8 +914,8 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
       if ((h1 >> (2 * J + 1)) & 1u)
         g[2 * J + 1] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J + 1)>(cur), rec_word<L.pred(2 * J + 1)>(cur), TL,
                                     tile_base);)
-    if (h1 & 0x0fu) add_slots4<L.group_cph(), NW>(cells, slot_base, lane, wave, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
-    if (h1 & 0xf0u) add_slots4<L.group_cph() + 1, NW>(cells, slot_base, lane, wave, sv[0], kM2Pi, g[4], g[5], g[6], g[7]);
+    if (h1 & 0x0fu) add_slots4<L.group_cph(), NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3]);
+    if (h1 & 0xf0u) add_slots4<L.group_cph() + 1, NW>(cells, lane, wave, sv[0], g[4], g[5], g[6], g[7]);
   }
   if (h1 & kFullDiagFlag) {
     // ---- all PH1/PH2 terms at once: w = Im(conj(lam) psi) per register value, per-term
@@ -926,13 +926,13 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
       float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       QHBM_FOR_PAIR(R,
         if ((h0 >> (24 + pair_index(JA, JB))) & 1u) g[pair_index(JA, JB)] = wsum2_<JA, JB>(w, iseq<4>{});)
-      if ((h0 >> 24) & 0x0fu) add_slots4<L.group_ph2(), NW>(cells, slot_base, lane, wave, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
-      if ((h0 >> 24) & 0x30u) add_slots4<L.group_ph2() + 1, NW>(cells, slot_base, lane, wave, sv[0], kM2Pi, g[4], g[5], 0.f, 0.f);
+      if ((h0 >> 24) & 0x0fu) add_slots4<L.group_ph2(), NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3]);
+      if ((h0 >> 24) & 0x30u) add_slots4<L.group_ph2() + 1, NW>(cells, lane, wave, sv[0], g[4], g[5], 0.f, 0.f);
     }
     if ((h0 >> 4) & 0xfu) {
       float g[4] = {0.f, 0.f, 0.f, 0.f};
       QHBM_FOR_RB(R, if ((h0 >> (4 + J)) & 1u) g[J] = wsum1_<J>(w, iseq<8>{});)
-      add_slots4<L.group_ph1(), NW>(cells, slot_base, lane, wave, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
+      add_slots4<L.group_ph1(), NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3]);
     }
     apply_full<NB>(p, cur, true);
     apply_full<NB>(l, cur, true);
@@ -948,8 +948,8 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
         apply_ph2<R, JA, JB>(p, cs);
         apply_ph2<R, JA, JB>(l, cs);
       })
-    if ((h0 >> 16) & 0x0fu) add_slots4<L.group_ph2(), NW>(cells, slot_base, lane, wave, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
-    if ((h0 >> 16) & 0x30u) add_slots4<L.group_ph2() + 1, NW>(cells, slot_base, lane, wave, sv[0], kM2Pi, g[4], g[5], 0.f, 0.f);
+    if ((h0 >> 16) & 0x0fu) add_slots4<L.group_ph2(), NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3]);
+    if ((h0 >> 16) & 0x30u) add_slots4<L.group_ph2() + 1, NW>(cells, lane, wave, sv[0], g[4], g[5], 0.f, 0.f);
   }
   // ---- PH1 (slot group 3) ----
   if ((h0 >> 8) & 0xfu) {
@@ -961,7 +961,7 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
         apply_ph1<R, J>(p, cs);
         apply_ph1<R, J>(l, cs);
       })
-    add_slots4<L.group_ph1(), NW>(cells, slot_base, lane, wave, sv[0], kM2Pi, g[0], g[1], g[2], g[3]);
+    add_slots4<L.group_ph1(), NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3]);
   }
   }
   // ---- one-qubit gates (X, Y, dense slot classes: groups 0, 1, 2) ----
@@ -974,7 +974,7 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
         apply_x<R, J>(p, cs);
         apply_x<R, J>(l, cs);
       })
-    add_slots4<L.group_x(), NW>(cells, slot_base, lane, wave, sv[0], kPi, g[0], g[1], g[2], g[3]);
+    add_slots4<L.group_x(), NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3]);
   }
   if constexpr (GEN) {
   if ((h1 >> 16) & 0xfu) {
@@ -986,7 +986,7 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
         apply_y<R, J>(p, cs);
         apply_y<R, J>(l, cs);
       })
-    add_slots4<L.group_y(), NW>(cells, slot_base, lane, wave, sv[0], kPi, g[0], g[1], g[2], g[3]);
+    add_slots4<L.group_y(), NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3]);
   }
   if ((h1 >> 24) & 0xfu) {  // dense: U^dagger (8 floats) then generator (8 floats) per register bit
     uint32_t dv[1];
@@ -999,7 +999,7 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
         apply_mat1<R, J>(p, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
         apply_mat1<R, J>(l, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
       })
-    add_slots4<L.group_dense(), NW>(cells, slot_base, lane, wave, sv[0], 1.f, g[0], g[1], g[2], g[3]);
+    add_slots4<L.group_dense(), NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3]);
   }
   }
 }
@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
     for (uint32_t inst = 0; inst < n_inst; ++inst) {
       rec_load<1>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
       rec_load<1>(recs, rec_off + L.words() + L.slot0(), lane, svn);
-      instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells, a.slot_base);
+      instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);
       rec_off += L.words();
       cur[0] = nxt[0];
       sv[0] = svn[0];
@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
       for (uint32_t inst = 0; inst < n_inst; ++inst) {
         rec_load<1>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
         rec_load<1>(recs, rec_off + L.words() + L.slot0(), lane, svn);
-        instance_adj<R, NW, GEN>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells, a.slot_base);
+        instance_adj<R, NW, GEN>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);
         rec_off += L.words();
         cur[0] = nxt[0];
         sv[0] = svn[0];
@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
 #pragma unroll
         for (int j = 0; j < 4; ++j) tl[ix[j]] = y[j];
       }
-      if (slot != 0xffffffffu) add_slot<NW>(cells, a.slot_base, tid, slot, gacc);
+      if (slot != 0xffffffffu) add_slot<NW>(cells, tid, slot, gacc);
       __syncthreads();
       }
       pc += kGate2Words;

@@ -254,15 +254,19 @@ class Builder {
     return true;
   }
 
-  int new_slot(Pass* p, const LoweredOp& op) {
+  // Allocates the gradient slot of a parametrised micro-op; returns its index LOCAL to the pass
+  // (what the records hold: the kernel's LDS cell and tile_grad column).  `scale` is the factor
+  // between the kernel's raw partial Im<lam|A|psi> and dE/dt of that op class: pi for the X / Y
+  // involutions, -2 pi for diagonal terms, 1 where the staged generator already carries it.
+  int new_slot(Pass* p, const LoweredOp& op, float scale) {
     if (!adjoint_) return -1;
     const Gate& G = m_.gates[op.gate];
     if (G.param_idx < 0) return -1;
     const int slot = static_cast<int>(plan_->slot_gate.size());
     plan_->slot_gate.push_back(op.gate);
-    plan_->slot_factor.push_back(G.scalar * (op.type == LOW_DIAG ? op.mult : 1.f));
+    plan_->slot_factor.push_back(scale * G.scalar * (op.type == LOW_DIAG ? op.mult : 1.f));
     ++p->n_slots;
-    return slot;
+    return slot - p->slot_base;
   }
 
   CoefJob base_job(const LoweredOp& op) {
@@ -387,7 +391,8 @@ class Builder {
       if (job.mop == MOP_PHASE) job.mult = op.mult;
       job.out_off = int32_t(rb) + lane;
       plan_->jobs.push_back(job);
-      const int slot = new_slot(p, op);
+      const float kPiF = 3.14159265358979323846f;
+      const int slot = new_slot(p, op, pl.kind <= 1 ? kPiF : (pl.kind == 2 ? 1.f : -2.f * kPiF));
       if (adjoint_) rec[slot_lane] = uint32_t(slot);
     }
     p->round_words.push_back(uint32_t(p->prog.size()));
@@ -405,7 +410,7 @@ class Builder {
     job.out_off = int32_t(alloc_coef(adjoint_ ? 64 : 32, 4));
     plan_->jobs.push_back(job);
     auto local_bit = [&](int gbit) { return uint32_t(__builtin_ctz(to_local(*p, 1u << gbit))); };
-    const int slot = new_slot(p, op);
+    const int slot = new_slot(p, op, 1.f);
     p->flags |= PASS_GENERAL;
     p->prog.push_back(OP_GATE2 | (uint32_t(op.kind) << 8));
     p->prog.push_back(local_bit(op.b0) | (local_bit(op.b1) << 8));
@@ -729,6 +734,30 @@ std::string describe_plan(const Plan& p) {
      << " coef_floats=" << p.n_coef_floats;
   if (!p.global_terms.empty()) os << " global_terms=" << p.global_terms.size();
   os << "\n";
+  {  // micro-op census over all instance records (cost model input)
+    const RecordLayout L(p.R, p.adjoint);
+    int n_inst = 0, n_full = 0, x = 0, ph1 = 0, ph2 = 0, fph1 = 0, fph2 = 0, cph = 0, groups = 0;
+    auto pc = [](uint32_t v) { return __builtin_popcount(v); };
+    for (uint32_t off : p.record_offsets) {
+      const uint32_t h0 = p.coef_init[off], h1 = p.coef_init[off + 1];
+      ++n_inst;
+      x += pc(h0 & 0xfu);
+      cph += pc(h1 & 0xffu);
+      groups += ((h0 & 0xfu) != 0) + ((h1 & 0x0fu) != 0) + ((h1 & 0xf0u) != 0);
+      if (h1 & kFullDiagFlag) {
+        ++n_full;
+        fph1 += pc((h0 >> 4) & 0xfu);
+        fph2 += pc((h0 >> 24) & 0x3fu);
+        groups += (((h0 >> 4) & 0xfu) != 0) + (((h0 >> 24) & 0x0fu) != 0) + (((h0 >> 24) & 0x30u) != 0);
+      } else {
+        ph1 += pc((h0 >> 8) & 0xfu);
+        ph2 += pc((h0 >> 16) & 0x3fu);
+        groups += (((h0 >> 8) & 0xfu) != 0) + (((h0 >> 16) & 0x0fu) != 0) + (((h0 >> 16) & 0x30u) != 0);
+      }
+    }
+    os << "  census: instances=" << n_inst << " (FULL " << n_full << ") X=" << x << " PH1=" << ph1 << " PH2=" << ph2
+       << " FULL-PH1=" << fph1 << " FULL-PH2=" << fph2 << " CPH=" << cph << " slot-groups=" << groups << "\n";
+  }
   for (size_t i = 0; i < p.passes.size(); ++i) {
     const Pass& q = p.passes[i];
     os << "  pass " << i << ": K=" << q.K << " c=" << q.c << " local=[";
