@@ -204,7 +204,7 @@ int upload_model(qhbm_engine* h) {
     std::stable_sort(t.begin(), t.end(), [](const DevTerm& a, const DevTerm& b) { return a.x < b.x; });
     std::vector<ObsGroup> groups;
     for (size_t k = 0; k < t.size(); ++k) {
-      if (k == 0 || t[k].x != t[k - 1].x || k % kObsTermChunk == 0) groups.push_back(ObsGroup{t[k].x, 0, 0});
+      if (k == 0 || t[k].x != t[k - 1].x || k % (kObsTermChunk / 2) == 0) groups.push_back(ObsGroup{t[k].x, 0, 0});
       groups.back().end = uint32_t(k + 1);
       groups.back().has_imag |= t[k].ny & 1u;
     }

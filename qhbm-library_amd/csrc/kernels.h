@@ -16,7 +16,7 @@ struct DevTerm {  // one Pauli term, amplitude-index bit space
 };
 
 // Terms of equal x mask, consecutive in the x-sorted term array: [previous end, end).  A group
-// never straddles a multiple of kObsTermChunk (the kernel stages that many terms in LDS at a time).
+// never straddles a multiple of kObsTermChunk / 2 (the kernel stages that many terms in LDS at a time).
 struct ObsGroup {
   uint32_t x, end;
   uint32_t has_imag;  // some term of the group has an odd number of Y factors (imaginary weight)

@@ -1276,23 +1276,32 @@ __global__ __launch_bounds__(1024) void reduce_tiles_kernel(const float* __restr
 // Terms arrive sorted by x mask and cut into GROUPS of equal x: one gather psi[j ^ x] per group
 // serves all of its terms (XXZ: 57 terms, 20 gathers), whose signed weights -- staged once per
 // workgroup in LDS as upstream * coeff * i^ny -- fold into one complex factor per amplitude.
-// Each thread owns kObsAmps amplitudes 256 apart, so a group issues that many independent
-// coalesced loads before any of them is needed.
+// A thread owns A amplitudes 256 apart, j = block * 256 * A | a << 8 | tid, so a group issues A
+// independent coalesced loads before any of them is needed.  The sign of a term at j ^ x is
+// (-1)^{popc((j ^ x) & z)}: the part from the block and `a` bits of j and from x & z is the same
+// for the whole workgroup, so it is folded into A pre-signed copies of the weight when the term is
+// staged; a thread evaluates only the parity of tid & z, once per term for all of its amplitudes
+// (3 + 2 A VALU per term instead of 4 per amplitude).
 // ================================================================================
-constexpr int kObsAmps = 4;
-constexpr uint32_t kObsChunk = kObsTermChunk;  // terms staged in LDS at a time (16 KiB)
+template <int A> struct ObsStage {
+  float4 term[kObsTermChunk / 2];     // z bits, weight (re), weight (im), --      (general path)
+  float flip[kObsTermChunk / 2][A];   // real weight, pre-signed for amplitude a    (real-weight path)
+};
+constexpr uint32_t kObsChunk = kObsTermChunk / 2;  // terms staged in LDS at a time
+template <int A>
 __global__ __launch_bounds__(256) void apply_observable_kernel(
     const float2* __restrict__ psi, float2* __restrict__ lam, uint32_t n, const DevTerm* __restrict__ terms,
     uint32_t n_terms, const ObsGroup* __restrict__ groups, uint32_t n_groups,
     const float* __restrict__ upstream, uint32_t n_ops, uint32_t state0) {
-  __shared__ float4 sterm[kObsChunk];
+  __shared__ ObsStage<A> st;
   const uint32_t s_local = blockIdx.y;
-  const uint32_t j0 = blockIdx.x * (256u * kObsAmps) + threadIdx.x;
+  const uint32_t jb = blockIdx.x * (256u * A);          // block bits of j
+  const uint32_t j0 = jb + threadIdx.x;
   const float2* ps = psi + (size_t(s_local) << n);
   const float* up = upstream + size_t(state0 + s_local) * n_ops;
-  float ar[kObsAmps], ai[kObsAmps];
+  float ar[A], ai[A];
 #pragma unroll
-  for (int a = 0; a < kObsAmps; ++a) ar[a] = ai[a] = 0.f;
+  for (int a = 0; a < A; ++a) ar[a] = ai[a] = 0.f;
   uint32_t g = 0;
   for (uint32_t k0 = 0; k0 < n_terms; k0 += kObsChunk) {
     const uint32_t k1 = min(n_terms, k0 + kObsChunk);
@@ -1301,51 +1310,57 @@ __global__ __launch_bounds__(256) void apply_observable_kernel(
       const DevTerm tm = terms[k];
       const float w = up[tm.op] * tm.coeff;
       const float m = (tm.ny & 2u) ? -w : w;
-      sterm[k - k0] = make_float4(__uint_as_float(tm.z), (tm.ny & 1u) ? 0.f : m, (tm.ny & 1u) ? m : 0.f, 0.f);
+      // parity of the workgroup-constant part: block bits of j and the x & z overlap (= ny)
+      const uint32_t base = (uint32_t(__popc(jb & tm.z)) + tm.ny) & 1u;
+      st.term[k - k0] = make_float4(__uint_as_float(tm.z), (tm.ny & 1u) ? 0.f : m, (tm.ny & 1u) ? m : 0.f,
+                                    __uint_as_float(base << 31));
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        const uint32_t par = (base + uint32_t(__popc((uint32_t(a) << 8) & tm.z))) & 1u;
+        st.flip[k - k0][a] = __uint_as_float(__float_as_uint(m) ^ (par << 31));
+      }
     }
     __syncthreads();
     uint32_t k = k0;
     for (; g < n_groups; ++g) {
       const ObsGroup gr = groups[g];  // wave-uniform
       if (gr.end > k1) break;
-      uint32_t src[kObsAmps];
-      float2 v[kObsAmps];
-      float cr[kObsAmps], ci[kObsAmps];
+      float2 v[A];
+      float cr[A], ci[A];
 #pragma unroll
-      for (int a = 0; a < kObsAmps; ++a) {
-        src[a] = (j0 + 256u * a) ^ gr.x;
-        v[a] = ps[src[a]];
+      for (int a = 0; a < A; ++a) {
+        v[a] = ps[(j0 + 256u * a) ^ gr.x];
         cr[a] = ci[a] = 0.f;
       }
       if (gr.has_imag) {
         for (; k < gr.end; ++k) {
-          const float4 t = sterm[k - k0];
+          const float4 t = st.term[k - k0];
           const uint32_t z = __float_as_uint(t.x);
+          const uint32_t sg0 = (uint32_t(__popc(threadIdx.x & z)) << 31) ^ __float_as_uint(t.w);
 #pragma unroll
-          for (int a = 0; a < kObsAmps; ++a) {
-            const uint32_t sgn = uint32_t(__popc(src[a] & z)) << 31;
+          for (int a = 0; a < A; ++a) {
+            const uint32_t sgn = sg0 ^ (uint32_t(__popc((uint32_t(a) << 8) & z)) << 31);
             cr[a] += __uint_as_float(__float_as_uint(t.y) ^ sgn);
             ci[a] += __uint_as_float(__float_as_uint(t.z) ^ sgn);
           }
         }
-      } else {  // real weights only (X/Z strings, even Y count): the common case, a third less work
+      } else {  // real weights only (X/Z strings, even Y count): the common case
         for (; k < gr.end; ++k) {
-          const float4 t = sterm[k - k0];
-          const uint32_t z = __float_as_uint(t.x);
+          const uint32_t z = __float_as_uint(st.term[k - k0].x);
+          const uint32_t sg0 = uint32_t(__popc(threadIdx.x & z)) << 31;
 #pragma unroll
-          for (int a = 0; a < kObsAmps; ++a)
-            cr[a] += __uint_as_float(__float_as_uint(t.y) ^ (uint32_t(__popc(src[a] & z)) << 31));
+          for (int a = 0; a < A; ++a) cr[a] += __uint_as_float(__float_as_uint(st.flip[k - k0][a]) ^ sg0);
         }
       }
 #pragma unroll
-      for (int a = 0; a < kObsAmps; ++a) {
+      for (int a = 0; a < A; ++a) {
         ar[a] += cr[a] * v[a].x - ci[a] * v[a].y;
         ai[a] += cr[a] * v[a].y + ci[a] * v[a].x;
       }
     }
   }
 #pragma unroll
-  for (int a = 0; a < kObsAmps; ++a) lam[(size_t(s_local) << n) + j0 + 256u * a] = make_float2(ar[a], ai[a]);
+  for (int a = 0; a < A; ++a) lam[(size_t(s_local) << n) + j0 + 256u * a] = make_float2(ar[a], ai[a]);
 }
 
 // ================================================================================
@@ -1999,9 +2014,13 @@ hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, u
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
                                    hipStream_t stream) {
-  const uint32_t blocks = (1u << n) / (256u * kObsAmps);
-  hipLaunchKernelGGL(apply_observable_kernel, dim3(blocks, n_states), dim3(256), 0, stream, psi, lam, n,
-                     terms, n_terms, groups, n_groups, upstream, n_ops, state0);
+  if (n >= 11) {
+    hipLaunchKernelGGL(apply_observable_kernel<8>, dim3((1u << n) / 2048u, n_states), dim3(256), 0, stream, psi, lam,
+                       n, terms, n_terms, groups, n_groups, upstream, n_ops, state0);
+  } else {
+    hipLaunchKernelGGL(apply_observable_kernel<4>, dim3((1u << n) / 1024u, n_states), dim3(256), 0, stream, psi, lam,
+                       n, terms, n_terms, groups, n_groups, upstream, n_ops, state0);
+  }
   return hipGetLastError();
 }
 
