@@ -143,6 +143,20 @@ void fill_args(const Plan& plan, const Model& m, std::vector<PassArgs>* args, st
     tables->insert(tables->end(), p.spread.begin(), p.spread.end());
     args->push_back(a);
   }
+  if (!plan.adjoint) {
+    // Amplitude-space pruning of the head of the forward sweep: an index bit no non-diagonal op has
+    // acted on yet still equals the input bitstring wherever psi is non-zero.  A tile of pass p that
+    // differs from the input on such a bit among its NON-LOCAL bits is identically zero, stays zero
+    // under the pass, and already reads as zeros in HBM (the first pass wrote them): the kernel
+    // returns at once.  Config 3: half the tiles of the second (and heaviest) forward pass.
+    uint32_t touched = 0;
+    for (size_t i = 0; i < args->size(); ++i) {
+      uint32_t nl = 0;
+      for (uint32_t k = 0; k < (*args)[i].n_nonlocal; ++k) nl |= 1u << (*args)[i].nonlocal_pos[k];
+      if (i > 0) (*args)[i].zero_mask = nl & ~touched;
+      touched |= plan.passes[i].mat_bits;
+    }
+  }
   if (plan.adjoint) {
     // Amplitude-space pruning of the tail of the backward sweep.  At the start of adjoint pass p,
     // psi is (the circuit's FIRST ops, those of passes p..last) applied to the basis state, and no
@@ -812,9 +826,16 @@ int qhbm_traffic_model(qhbm_engine* h, int U, int with_vjp, double* fwd_bytes, d
   double f = 0.0, o = 0.0, b = 0.0;
   bool measure_only_after = !h->fwd.plan.global_terms.empty();
   for (const Pass& p : h->fwd.plan.passes) measure_only_after |= p.is_measure_only;
-  for (const Pass& p : h->fwd.plan.passes) {
-    if (!(p.flags & PASS_INIT_BASIS)) f += tile_all;  // the first pass writes the basis state, reads nothing
-    if (!p.is_measure_only && (!p.completes_circuit || with_vjp || measure_only_after)) f += tile_all;
+  {
+    std::vector<PassArgs> fargs;
+    std::vector<uint32_t> fprog, ftables;
+    fill_args(h->fwd.plan, h->model, &fargs, &fprog, &ftables);
+    for (size_t i = 0; i < fargs.size(); ++i) {
+      const Pass& p = h->fwd.plan.passes[i];
+      const double live = 1.0 / double(1ull << __builtin_popcount(fargs[i].zero_mask));  // tiles not skipped
+      if (!(p.flags & PASS_INIT_BASIS)) f += live * tile_all;  // the first pass writes the basis state, reads nothing
+      if (!p.is_measure_only && (!p.completes_circuit || with_vjp || measure_only_after)) f += live * tile_all;
+    }
   }
   if (with_vjp) {
     o = 2.0 * tile_all;  // psi read (gathered through L2), lambda written

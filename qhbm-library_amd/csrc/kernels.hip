@@ -767,6 +767,10 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
       tile[swz(l)] = make_float2(1.f, 0.f);
     }
   } else {
+    if (a.zero_mask) {  // head of the sweep: psi is identically zero on this tile (engine.cpp fill_args)
+      const uint32_t idx = uni(basis_index(bits + size_t(state0 + s_local) * n_user, n_user));
+      if ((idx ^ t.tile_base) & a.zero_mask) return;
+    }
     TileRegs r;
     prefetch_tile<K, NT>(r, st, t, tid);
     commit_tile<K, NT>(tile, r, tid);

@@ -313,6 +313,7 @@ class Builder {
         in->mat[j].w0 = uint32_t(pl.kind);
         pl.j = j;
         ++p->n_mat_ops;
+        p->mat_bits |= op.bits;
       } else {  // diagonal term
         const uint32_t ll = to_local(*p, op.bits & S);
         const uint32_t in_reg = ll & reg;
@@ -417,6 +418,7 @@ class Builder {
     p->prog.push_back(uint32_t(job.out_off));
     p->prog.push_back(uint32_t(slot));
     ++p->n_mat_ops;
+    p->mat_bits |= op.bits;
     ++p->n_rounds;
   }
 

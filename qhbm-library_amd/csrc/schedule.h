@@ -63,6 +63,7 @@ struct Pass {
   std::vector<uint32_t> round_words;     // index in `prog` of every OP_ROUND's first word
   int n_meas_groups = 0, n_meas_terms = 0;
   int slot_base = 0, n_slots = 0;
+  uint32_t mat_bits = 0;  // index bits acted on by a non-diagonal op of this pass
 };
 
 struct Plan {
