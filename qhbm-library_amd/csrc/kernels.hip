@@ -577,37 +577,38 @@ __device__ __forceinline__ void add_slot(float* cells, int tid, uint32_t slot, f
   if ((tid & 63) == 0) cells[slot * NW + (uint32_t(tid) >> 6)] = v;
 }
 
-// Gradient partials of the four slots of record slot group G, reduced over the wave TOGETHER:
-// two select+quad_perm butterflies leave lane l with the quad sum of g[l & 3]; row_ror 4 / 8 sum
-// the four quads of a row; permlane16/32 swaps (gfx950) sum the four rows.  Lanes 4G..4G+3 --
-// the lanes whose slot-vector word `sv` IS the slot of g[l & 3] -- then store into their wave's
-// cells (see add_slot).  23 instructions for four slots; one slot at a time (wave_sum + readlanes
-// + single-lane store) was 45 each and cost 17 % of the VQT step.
+// Gradient partials of the EIGHT slots of record slot group G8 (program.h slot_lane8), reduced over
+// the wave together: two select+quad_perm butterflies leave lane l with the quad sums of values
+// (l & 3) and (l & 3) + 4; v_permlane16_swap (gfx950) adds the rows of a row pair and keeps value
+// (l & 3) in even rows, (l & 3) + 4 in odd rows; row_ror 4 / 8 sum the four quads of a row and
+// v_permlane32_swap the two row pairs.  The lanes whose slot-vector word `sv` IS the slot of the
+// value they hold then store into their wave's cells (see add_slot): 24 instructions + the store
+// for eight slots.  (Four slots at a time cost 23; with 2 of 4 filled on average the reductions
+// were 15 % of the adjoint's instructions.  `sv` holds slots LOCAL to the pass and the chain-rule
+// scale of the slot class is folded into the plan's slot_factor.)
 template <int CTRL>
 __device__ __forceinline__ float dpp_get(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ float rows_sum(float u) {
-  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u), __float_as_uint(u), false, false);
-  u = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// `sv` holds slots LOCAL to the pass (schedule.cpp), the chain-rule scale of the slot class (pi,
-// -2 pi) is folded into the plan's slot_factor: the store is two compares and one shift-add.
-template <int G, int NW>
-__device__ __forceinline__ void add_slots4(float* cells, int lane, uint32_t wave, uint32_t sv,
-                                           float g0, float g1, float g2, float g3) {
+template <int G8, int NW>
+__device__ __forceinline__ void add_slots8(float* cells, int lane, uint32_t wave, uint32_t sv, float g0, float g1,
+                                           float g2, float g3, float g4, float g5, float g6, float g7) {
   const bool b0 = lane & 1, b1 = lane & 2;
-  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2;
+  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2 = b0 ? g5 : g4, t3 = b0 ? g7 : g6;
   t0 += dpp_get<0xB1>(b0 ? g0 : g1);  // quad_perm:[1,0,3,2]
   t1 += dpp_get<0xB1>(b0 ? g2 : g3);
-  float u = b1 ? t1 : t0;
-  u += dpp_get<0x4E>(b1 ? t0 : t1);   // quad_perm:[2,3,0,1]
-  u += dpp_get<0x124>(u);             // row_ror:4
-  u += dpp_get<0x128>(u);             // row_ror:8
-  u = rows_sum(u);
-  if ((lane >> 2) == G && sv != 0xffffffffu) cells[sv * NW + wave] = u;
+  t2 += dpp_get<0xB1>(b0 ? g4 : g5);
+  t3 += dpp_get<0xB1>(b0 ? g6 : g7);
+  float u0 = b1 ? t1 : t0, u1 = b1 ? t3 : t2;
+  u0 += dpp_get<0x4E>(b1 ? t0 : t1);  // quad_perm:[2,3,0,1]
+  u1 += dpp_get<0x4E>(b1 ? t2 : t3);
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u0), __float_as_uint(u1), false, false);
+  float v = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // even rows: values 0..3, odd rows: 4..7
+  v += dpp_get<0x124>(v);                                   // row_ror:4
+  v += dpp_get<0x128>(v);                                   // row_ror:8
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  if (((lane >> 2) & 3) == (G8 & 3) && (lane >> 5) == (G8 >> 2) && sv != 0xffffffffu) cells[sv * NW + wave] = v;
 }
 
 // FULL diagonal table: amplitude with register value m (1..15) times FULL[m-1].
@@ -909,7 +910,7 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
   constexpr int NB = 1;
   constexpr int S0 = L.slot0();
   const uint32_t h0 = rec_word<0>(cur), h1 = rec_word<1>(cur);
-  // ---- CPH (slot groups 6, 7) ----
+  // ---- CPH (slot group 2) ----
   if (h1 & 0xffu) {
     float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     QHBM_FOR_RB(R,
@@ -918,33 +919,27 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
       if ((h1 >> (2 * J + 1)) & 1u)
         g[2 * J + 1] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J + 1)>(cur), rec_word<L.pred(2 * J + 1)>(cur), TL,
                                     tile_base);)
-    if (h1 & 0x0fu) add_slots4<L.group_cph(), NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3]);
-    if (h1 & 0xf0u) add_slots4<L.group_cph() + 1, NW>(cells, lane, wave, sv[0], g[4], g[5], g[6], g[7]);
+    add_slots8<2, NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
   }
+  float g1[4] = {0.f, 0.f, 0.f, 0.f};  // PH1 partials: reduced together with the X partials (slot group 0)
   if (h1 & kFullDiagFlag) {
     // ---- all PH1/PH2 terms at once: w = Im(conj(lam) psi) per register value, per-term
     // gradients are sums of w over the term's index set, then ONE conj-table multiply ----
     float w[NR];
     w_all_(w, p, l, iseq<NR>{});
     if ((h0 >> 24) & 0x3fu) {
-      float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       QHBM_FOR_PAIR(R,
         if ((h0 >> (24 + pair_index(JA, JB))) & 1u) g[pair_index(JA, JB)] = wsum2_<JA, JB>(w, iseq<4>{});)
-      if ((h0 >> 24) & 0x0fu) add_slots4<L.group_ph2(), NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3]);
-      if ((h0 >> 24) & 0x30u) add_slots4<L.group_ph2() + 1, NW>(cells, lane, wave, sv[0], g[4], g[5], 0.f, 0.f);
+      add_slots8<1, NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3], g[4], g[5], 0.f, 0.f);
     }
-    if ((h0 >> 4) & 0xfu) {
-      float g[4] = {0.f, 0.f, 0.f, 0.f};
-      QHBM_FOR_RB(R, if ((h0 >> (4 + J)) & 1u) g[J] = wsum1_<J>(w, iseq<8>{});)
-      add_slots4<L.group_ph1(), NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3]);
-    }
+    QHBM_FOR_RB(R, if ((h0 >> (4 + J)) & 1u) g1[J] = wsum1_<J>(w, iseq<8>{});)
     apply_full<NB>(p, cur, true);
     apply_full<NB>(l, cur, true);
   }
-  {
-  // ---- PH2 (slot groups 4, 5) ----
+  // ---- PH2 (slot group 1) ----
   if ((h0 >> 16) & 0x3fu) {
-    float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     QHBM_FOR_PAIR(R,
       if ((h0 >> (16 + pair_index(JA, JB))) & 1u) {
         const v2f cs = conj_cs(rec_cs<L.ph2(pair_index(JA, JB))>(cur));
@@ -952,58 +947,55 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
         apply_ph2<R, JA, JB>(p, cs);
         apply_ph2<R, JA, JB>(l, cs);
       })
-    if ((h0 >> 16) & 0x0fu) add_slots4<L.group_ph2(), NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3]);
-    if ((h0 >> 16) & 0x30u) add_slots4<L.group_ph2() + 1, NW>(cells, lane, wave, sv[0], g[4], g[5], 0.f, 0.f);
+    add_slots8<1, NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3], g[4], g[5], 0.f, 0.f);
   }
-  // ---- PH1 (slot group 3) ----
+  // ---- PH1 ----
   if ((h0 >> 8) & 0xfu) {
-    float g[4] = {0.f, 0.f, 0.f, 0.f};
     QHBM_FOR_RB(R,
       if ((h0 >> (8 + J)) & 1u) {
         const v2f cs = conj_cs(rec_cs<L.ph1(J)>(cur));
-        g[J] = sum_w1<R, J>(p, l);
+        g1[J] = sum_w1<R, J>(p, l);
         apply_ph1<R, J>(p, cs);
         apply_ph1<R, J>(l, cs);
       })
-    add_slots4<L.group_ph1(), NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3]);
   }
-  }
-  // ---- one-qubit gates (X, Y, dense slot classes: groups 0, 1, 2) ----
-  if (h0 & 0xfu) {
+  // ---- one-qubit gates: X (slot group 0, with the PH1 partials), Y and dense (slot group 3) ----
+  {
     float g[4] = {0.f, 0.f, 0.f, 0.f};
-    QHBM_FOR_RB(R,
-      if ((h0 >> J) & 1u) {
-        const v2f cs = conj_cs(rec_cs<L.x(J)>(cur));  // U^dagger = c*I + i*s*X
-        if (rec_word<L.slot_x(J) - S0>(sv) != 0xffffffffu) g[J] = im_lam_x_psi<R, J>(p, l);
-        apply_x<R, J>(p, cs);
-        apply_x<R, J>(l, cs);
-      })
-    add_slots4<L.group_x(), NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3]);
+    if (h0 & 0xfu) {
+      QHBM_FOR_RB(R,
+        if ((h0 >> J) & 1u) {
+          const v2f cs = conj_cs(rec_cs<L.x(J)>(cur));  // U^dagger = c*I + i*s*X
+          if (rec_word<L.slot_x(J) - S0>(sv) != 0xffffffffu) g[J] = im_lam_x_psi<R, J>(p, l);
+          apply_x<R, J>(p, cs);
+          apply_x<R, J>(l, cs);
+        })
+    }
+    if ((h0 & 0xf0fu) || ((h1 & kFullDiagFlag) && ((h0 >> 4) & 0xfu)))
+      add_slots8<0, NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3], g1[0], g1[1], g1[2], g1[3]);
   }
   if constexpr (GEN) {
-  if ((h1 >> 16) & 0xfu) {
-    float g[4] = {0.f, 0.f, 0.f, 0.f};
+  if ((h1 >> 16) & 0xf0fu) {
+    float gy[4] = {0.f, 0.f, 0.f, 0.f}, gd[4] = {0.f, 0.f, 0.f, 0.f};
     QHBM_FOR_RB(R,
       if ((h1 >> (16 + J)) & 1u) {
         const v2f cs = conj_cs(rec_cs<L.y(J)>(cur));
-        if (rec_word<L.slot_y(J) - S0>(sv) != 0xffffffffu) g[J] = im_lam_y_psi<R, J>(p, l);
+        if (rec_word<L.slot_y(J) - S0>(sv) != 0xffffffffu) gy[J] = im_lam_y_psi<R, J>(p, l);
         apply_y<R, J>(p, cs);
         apply_y<R, J>(l, cs);
       })
-    add_slots4<L.group_y(), NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3]);
-  }
-  if ((h1 >> 24) & 0xfu) {  // dense: U^dagger (8 floats) then generator (8 floats) per register bit
-    uint32_t dv[1];
-    rec_load<1>(recs, rec_off + 128u, lane, dv);
-    float g[4] = {0.f, 0.f, 0.f, 0.f};
-    QHBM_FOR_RB(R,
-      if ((h1 >> (24 + J)) & 1u) {
-        const Gen2 gen{rec_cs<16 * J + 8>(dv), rec_cs<16 * J + 10>(dv), rec_cs<16 * J + 12>(dv), rec_cs<16 * J + 14>(dv)};
-        if (rec_word<L.slot_dense(J) - S0>(sv) != 0xffffffffu) g[J] = im_lam_g1_psi<R, J>(p, l, gen);
-        apply_mat1<R, J>(p, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
-        apply_mat1<R, J>(l, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
-      })
-    add_slots4<L.group_dense(), NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3]);
+    if ((h1 >> 24) & 0xfu) {  // dense: U^dagger (8 floats) then generator (8 floats) per register bit
+      uint32_t dv[1];
+      rec_load<1>(recs, rec_off + 128u, lane, dv);
+      QHBM_FOR_RB(R,
+        if ((h1 >> (24 + J)) & 1u) {
+          const Gen2 gen{rec_cs<16 * J + 8>(dv), rec_cs<16 * J + 10>(dv), rec_cs<16 * J + 12>(dv), rec_cs<16 * J + 14>(dv)};
+          if (rec_word<L.slot_dense(J) - S0>(sv) != 0xffffffffu) gd[J] = im_lam_g1_psi<R, J>(p, l, gen);
+          apply_mat1<R, J>(p, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
+          apply_mat1<R, J>(l, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
+        })
+    }
+    add_slots8<3, NW>(cells, lane, wave, sv[0], gy[0], gy[1], gy[2], gy[3], gd[0], gd[1], gd[2], gd[3]);
   }
   }
 }

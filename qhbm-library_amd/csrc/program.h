@@ -89,7 +89,8 @@ constexpr int pair_index(int lo, int hi) { return hi * (hi - 1) / 2 + lo; }  // 
 //           ph1_mask = ph2_mask = 0, so table and per-term slots are independent triangles.
 //   vec 1:  (FULL only) the per-term phases PH1[4] PH2[6] that combine_diag_kernel multiplies
 //   vec 2:  DENSE[4] 2x2 blocks (8 floats; adjoint: U^dagger then generator, 16 floats)
-//   vec 3:  (adjoint) SLOT[32] = gradient slot per entry in groups of four lanes: X Y DENSE PH1 PH2[6+2 pad] CPH[8]
+//   vec 3:  (adjoint) SLOT[32] = gradient slot per entry, pass-local, laid out for the eight-wide wave
+//           reduction (slot_lane8): group 0 = X + PH1, 1 = PH2, 2 = CPH, 3 = Y + DENSE
 // Everything a round touches per instance sits in vec 0 (one coalesced 256-byte load per wave).
 constexpr int kRoundBits = 4;
 struct RecordLayout {
@@ -108,21 +109,19 @@ struct RecordLayout {
   constexpr int dense_words() const { return adjoint ? 16 : 8; }
   constexpr int dense(int j) const { return 128 + dense_words() * j; }
   constexpr int slot0() const { return 192; }
-  constexpr int slot_x(int j) const { return slot0() + j; }
-  constexpr int slot_y(int j) const { return slot0() + R + j; }
-  constexpr int slot_dense(int j) const { return slot0() + 2 * R + j; }
-  constexpr int slot_ph1(int j) const { return slot0() + 3 * R + j; }
-  constexpr int slot_ph2(int pi) const { return slot0() + 4 * R + pi; }
-  constexpr int slot_cph(int k) const { return slot0() + 4 * R + 8 + k; }
-  // Slot groups: lanes 4G..4G+3 of the slot vector hold the slots the adjoint kernel reduces
-  // together (R = 4: X, Y, dense, PH1, PH2[0..3], PH2[4..5], CPH[0..3], CPH[4..7]).
-  constexpr int group_x() const { return 0; }
-  constexpr int group_y() const { return R / 4; }
-  constexpr int group_dense() const { return 2 * R / 4; }
-  constexpr int group_ph1() const { return 3 * R / 4; }
-  constexpr int group_ph2() const { return 4 * R / 4; }
-  constexpr int group_cph() const { return 4 * R / 4 + 2; }
-  constexpr int n_slot_lanes() const { return 4 * R + 8 + 2 * R; }
+  // Gradient slots of an instance are reduced over the wave EIGHT at a time (kernels.hip add_slots8):
+  // value v of slot group g8 ends up in the lanes with bits (0, 1, 4) = v and bits (2, 3, 5) = g8, and
+  // the slot-vector word of that lane IS the slot.  Groups: 0 = X[4] + PH1[4], 1 = PH2[6],
+  // 2 = CPH[8], 3 = Y[4] + DENSE[4].
+  constexpr int slot_lane8(int g8, int v) const {
+    return slot0() + ((v & 3) | ((g8 & 3) << 2) | ((v >> 2) << 4) | ((g8 >> 2) << 5));
+  }
+  constexpr int slot_x(int j) const { return slot_lane8(0, j); }
+  constexpr int slot_ph1(int j) const { return slot_lane8(0, 4 + j); }
+  constexpr int slot_ph2(int pi) const { return slot_lane8(1, pi); }
+  constexpr int slot_cph(int k) const { return slot_lane8(2, k); }
+  constexpr int slot_y(int j) const { return slot_lane8(3, j); }
+  constexpr int slot_dense(int j) const { return slot_lane8(3, 4 + j); }
   // 3 / 5 vectors: an odd count keeps the 256-byte record vectors that every wave of the chip
   // streams at the same time spread over all L2 channels (a 1 KiB stride hits every 4th).
   constexpr int vecs() const { return adjoint ? 5 : 3; }

@@ -1,0 +1,88 @@
+"""Developer tool: builds ablated variants of the engine (pieces of the adjoint kernel compiled out --
+the RESULTS of these libraries are wrong, only their timing means something) into
+scripts/ablate/lib_<name>.so; time them on the GPU with
+    for f in scripts/ablate/lib_*.so; do QHBM_ENGINE_LIB=$f python scripts/vqt_time.py 512; done
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CSRC = os.path.join(ROOT, "qhbm-library_amd", "csrc")
+OUT = os.path.dirname(os.path.abspath(__file__))
+src = open(os.path.join(CSRC, "kernels.hip")).read()
+
+
+def once(text, old, new):
+  assert text.count(old) >= 1, old
+  return text.replace(old, new, 1)
+
+
+def inst(text):  # the body of instance_adj
+  a = text.index("__device__ __forceinline__ void instance_adj(")
+  b = text.index("// Writes the tile's gradient row")
+  return a, b
+
+
+def in_instance(text, old, new, count=-1):
+  a, b = inst(text)
+  body = text[a:b]
+  assert old in body, old
+  return text[:a] + body.replace(old, new, count) + text[b:]
+
+
+VARIANTS = {
+    "base": lambda t: t,
+    "no_reduce": lambda t: once(t, "  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2",
+                                "  if (sv == 0x12345u) return;\n  if (true) return;\n  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2"),
+    "no_butterfly": lambda t: once(t, "  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2",
+                                   "  if (lane >= 0) { const float vv = ((g0 + g1) + (g2 + g3)) + ((g4 + g5) + (g6 + g7)); if (((lane >> 2) & 3) == (G8 & 3) && (lane >> 5) == (G8 >> 2) && sv != 0xffffffffu) cells[sv * NW + wave] = vv; return; }\n  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2"),
+    "no_w_sums": lambda t: in_instance(in_instance(t, "g1[J] = wsum1_<J>(w, iseq<8>{});", "g1[J] = w[J];"), "g[pair_index(JA, JB)] = wsum2_<JA, JB>(w, iseq<4>{});", "g[pair_index(JA, JB)] = w[JA + JB];"),
+    "no_x_inner": lambda t: in_instance(t, "g[J] = im_lam_x_psi<R, J>(p, l);", "g[J] = p[0].x;"),
+    "no_x_on_lambda": lambda t: in_instance(t, "          apply_x<R, J>(l, cs);\n", ""),
+    "no_x_at_all": lambda t: in_instance(in_instance(in_instance(t, "          apply_x<R, J>(l, cs);\n", ""), "          apply_x<R, J>(p, cs);\n", ""),
+                                         "g[J] = im_lam_x_psi<R, J>(p, l);", "g[J] = p[0].x + cs.x;"),
+    "no_full": lambda t: in_instance(t, "  if (h1 & kFullDiagFlag) {", "  if ((h1 & kFullDiagFlag) && lane == 77) {"),
+    "no_cph": lambda t: in_instance(t, "  if (h1 & 0xffu) {", "  if ((h1 & 0xffu) && lane == 77) {", 1),
+    "no_ph1_ph2": lambda t: in_instance(in_instance(t, "  if ((h0 >> 16) & 0x3fu) {", "  if (((h0 >> 16) & 0x3fu) && lane == 77) {"),
+                                        "  if ((h0 >> 8) & 0xfu) {", "  if (((h0 >> 8) & 0xfu) && lane == 77) {"),
+    "no_exchange": lambda t: once(t, """    round_store<R>(xt, T, DB, p);
+    if (sync) __syncthreads();
+    round_load<R>(xt, Tn, DBn, p);
+    if (sync) __syncthreads();
+    round_store<R>(xt, T, DB, l);
+    if (sync) __syncthreads();
+    round_load<R>(xt, Tn, DBn, l);
+""", ""),
+    "no_barriers": lambda t: once(t, """    round_store<R>(xt, T, DB, p);
+    if (sync) __syncthreads();
+    round_load<R>(xt, Tn, DBn, p);
+    if (sync) __syncthreads();
+    round_store<R>(xt, T, DB, l);
+    if (sync) __syncthreads();
+    round_load<R>(xt, Tn, DBn, l);
+""", """    round_store<R>(xt, T, DB, p);
+    round_load<R>(xt, Tn, DBn, p);
+    round_store<R>(xt, T, DB, l);
+    round_load<R>(xt, Tn, DBn, l);
+"""),
+    "no_instances": lambda t: once(t, "      instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n      rec_off += L.words();\n      cur[0] = nxt[0];",
+                                   "      if (lane == 77) instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n      rec_off += L.words();\n      cur[0] = nxt[0];"),
+}
+
+which = sys.argv[1:] or list(VARIANTS)
+for name in which:
+  text = VARIANTS[name](src)
+  path = os.path.join(CSRC, f"_ablate_{name}.hip")
+  with open(path, "w") as f:
+    f.write(text)
+  obj = os.path.join(OUT, f"{name}.o")
+  flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-mllvm", "-disable-promote-alloca-to-vector=1",
+           "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+  subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-c", path, "-o", obj], cwd=CSRC)
+  subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", obj,
+                         os.path.join(CSRC, "engine.o"), os.path.join(CSRC, "schedule.o"), "-o",
+                         os.path.join(OUT, f"lib_{name}.so")], cwd=CSRC)
+  os.remove(path)
+  os.remove(obj)
+  print("built", name, flush=True)
