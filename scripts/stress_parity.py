@@ -5,7 +5,7 @@ from oracle import qhbm_oracle as O
 from qhbmlib_amd import _engine as E
 from tests.test_engine_gpu import random_circuit, _engine, check_values, check_jacobian
 bad=0
-for seed in range(24):
+for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):
   rng=np.random.default_rng(1000+seed)
   n=13+seed%2
   if seed%3==0:
@@ -15,8 +15,8 @@ for seed in range(24):
   params=rng.uniform(-1,1,P)
   ops=[O.random_pauli_op(n,10,seed,p_identity=0.7), O.xxz_chain_op(n)]
   bits=rng.integers(0,2,size=(2,n)).astype(np.int8)
-  for tile,adj in ((12,12),(11,11),(13,12)):
-    eng=_engine(n,gates,P,ops,tile_qubits=min(tile,n),adjoint_tile_qubits=min(adj,n-1))
+  for tile,adj in ((12,12),(11,11),(13,12),(10,10),(12,13)):
+    eng=_engine(n,gates,P,ops,tile_qubits=min(tile,n),adjoint_tile_qubits=min(adj,n-1), adjoint_exchange=seed%4!=3)
     try:
       check_values(eng,n,gates,params,bits,ops,rel=3e-5)
       check_jacobian(eng,n,gates,params,bits[:1],ops,rel=3e-4)
