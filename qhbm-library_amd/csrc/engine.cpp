@@ -83,7 +83,12 @@ struct qhbm_engine {
   DevBuf<ObsGroup> obs_groups;
   uint32_t n_obs_groups = 0;
   DevBuf<float2> psi, lam;
-  DevBuf<float> state_grad, slot_factor, vals_tmp, vals_p, vals_m, upstream_tmp, phase_cs;
+  DevBuf<float> state_grad, slot_factor, vals_tmp, upstream_tmp, phase_cs;
+  // parameter-shift batches: per-program coefficient buffers, shift tables, accumulators
+  DevBuf<float> coef_batch, shift_vals, shift_weight, vals_batch;
+  DevBuf<int> shift_gates, shift_param;
+  DevBuf<double> prog_acc;
+  size_t coef_batch_programs = 0;  // copies of the forward plan's static words already in coef_batch
   DevBuf<float> tile_grad;              // [chunk states * tiles, slots of one adjoint pass]
   DevBuf<unsigned long long> vals64;    // [U, n_ops] fixed-point accumulators of the expectation values
   DevBuf<float> op_scale, op_inv_scale; // per op: 2^(+-shift), see program.h kValueFracBits
@@ -185,6 +190,7 @@ int build_plans(qhbm_engine* h) {
     return fail(h, "forward plan: " + err);
   if (!build_plan(h->model, h->opt_adj_tile, 0, true, &h->adj.plan, &err, h->opt_full_adj)) return fail(h, "adjoint plan: " + err);
   h->fwd.uploaded = h->adj.uploaded = false;
+  h->coef_batch_programs = 0;
   h->plans_valid = true;
   return 0;
 }
@@ -340,7 +346,7 @@ int forward(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, 
   h->retained_U = 0;
   HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, shift_gate,
                            shift, stream));
-  HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), stream));
+  HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), 1u, 0u, stream));
   if (int rc = values_begin(h, U, stream)) return rc;
   const uint32_t cs = chunk_states(h, U);
   if (int rc = ensure_state_buffers(h, cs, false)) return rc;
@@ -399,9 +405,9 @@ int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_pa
   h->state_grad_U = 0;
   const uint32_t n_slots = uint32_t(b.plan.slot_gate.size());
   HIPCHK(launch_prep_coefs(f.jobs.p, int(f.plan.jobs.size()), d_params, f.coef.p, -1, 0.0, stream));
-  HIPCHK(launch_combine_diag(f.coef.p, f.rec_offsets.p, int(f.plan.record_offsets.size()), stream));
+  HIPCHK(launch_combine_diag(f.coef.p, f.rec_offsets.p, int(f.plan.record_offsets.size()), 1u, 0u, stream));
   HIPCHK(launch_prep_coefs(b.jobs.p, int(b.plan.jobs.size()), d_params, b.coef.p, -1, 0.0, stream));
-  HIPCHK(launch_combine_diag(b.coef.p, b.rec_offsets.p, int(b.plan.record_offsets.size()), stream));
+  HIPCHK(launch_combine_diag(b.coef.p, b.rec_offsets.p, int(b.plan.record_offsets.size()), 1u, 0u, stream));
   if (int rc = values_begin(h, U, stream)) return rc;
   HIPCHK(h->state_grad.reserve(size_t(U) * std::max<uint32_t>(n_slots, 1)));
   HIPCHK(hipMemsetAsync(h->state_grad.p, 0, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), stream));
@@ -589,7 +595,7 @@ int qhbm_expectation_retain(qhbm_engine* h, const int8_t* d_bits, int U, const f
   DevicePlan& d = h->fwd;
   h->retained_U = 0;
   HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, -1, 0.0, s));
-  HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), s));
+  HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), 1u, 0u, s));
   if (int rc = values_begin(h, U, s)) return rc;
   if (int rc = ensure_state_buffers(h, uint32_t(U), true)) return rc;  // psi AND lambda, so psi is not moved later
   if (int rc = run_forward_chunk(h, d_bits, 0, uint32_t(U), true, s)) return rc;
@@ -608,7 +614,7 @@ int qhbm_expectation_vjp_retained(qhbm_engine* h, const int8_t* d_bits, int U, c
   h->state_grad_U = 0;
   const uint32_t n_slots = uint32_t(b.plan.slot_gate.size());
   HIPCHK(launch_prep_coefs(b.jobs.p, int(b.plan.jobs.size()), d_params, b.coef.p, -1, 0.0, s));
-  HIPCHK(launch_combine_diag(b.coef.p, b.rec_offsets.p, int(b.plan.record_offsets.size()), s));
+  HIPCHK(launch_combine_diag(b.coef.p, b.rec_offsets.p, int(b.plan.record_offsets.size()), 1u, 0u, s));
   HIPCHK(h->state_grad.reserve(size_t(U) * std::max<uint32_t>(n_slots, 1)));
   HIPCHK(hipMemsetAsync(h->state_grad.p, 0, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), s));
   if (int rc = run_adjoint_chunk(h, d_bits, 0, uint32_t(U), d_upstream, s)) return rc;
@@ -640,7 +646,7 @@ int qhbm_statevector(qhbm_engine* h, const int8_t* d_bits, int U, const float* d
   DevicePlan& d = h->fwd;
   h->retained_U = 0;
   HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, -1, 0.0, s));
-  HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), s));
+  HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), 1u, 0u, s));
   // expectation values of installed observables are a by-product; they stay in the fixed-point scratch
   if (int rc = values_begin(h, U, s)) return rc;
   const uint32_t cs = chunk_states(h, U);
@@ -693,7 +699,7 @@ int qhbm_sample(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_para
   DevicePlan& d = h->fwd;
   h->retained_U = 0;
   HIPCHK(launch_prep_coefs(d.jobs.p, int(d.plan.jobs.size()), d_params, d.coef.p, shift_gate, shift, s));
-  HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), s));
+  HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), 1u, 0u, s));
   if (int rc = values_begin(h, U, s)) return rc;
   const uint32_t cs = std::min<uint32_t>(chunk_states(h, U), 65535u);
   if (int rc = ensure_state_buffers(h, cs, false)) return rc;
@@ -732,22 +738,91 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const floa
     return 0;
   }
   if (method != QHBM_GRAD_PARAMETER_SHIFT) return fail(h, "unknown gradient method");
-  // tfq ParameterShift / baselines/train.py:190-240: exponent c*s -> shift the gate's
-  // exponent by +-1/2, weight +-pi*c/2, one pair of forwards per gate occurrence.
+  // tfq ParameterShift / baselines/train.py:190-240: exponent c*s -> shift the gate's exponent by
+  // +-1/2, weight +-pi*c/2, one pair of forwards per gate occurrence.  The (state, shifted program)
+  // pairs are the batch: as many programs as the workspace holds run in ONE launch set, each on
+  // its own copy of the coefficient buffer (PassArgs::prog_states).
   if (int rc = forward(h, d_bits, U, d_params, d_out_vals, -1, 0.0, s)) return rc;
-  if (P) HIPCHK(hipMemsetAsync(d_grad, 0, size_t(P) * sizeof(float), s));
-  HIPCHK(h->vals_p.reserve(nv));
-  HIPCHK(h->vals_m.reserve(nv));
+  std::vector<int> sg, sp;
+  std::vector<float> sv, sw;
   for (size_t g = 0; g < h->model.gates.size(); ++g) {
     const Gate& G = h->model.gates[g];
     if (G.param_idx < 0 || G.kind == QHBM_GATE_I) continue;
     if (G.kind == QHBM_GATE_ISWAPPOW)
       return fail(h, "the two-term parameter-shift rule does not apply to ISWAPPOW; use the adjoint method");
-    if (int rc = forward(h, d_bits, U, d_params, h->vals_p.p, int(g), +0.5, s)) return rc;
-    if (int rc = forward(h, d_bits, U, d_params, h->vals_m.p, int(g), -0.5, s)) return rc;
-    HIPCHK(launch_shift_accumulate(h->vals_p.p, h->vals_m.p, d_upstream, uint32_t(nv),
-                                   float(1.5707963267948966 * double(G.scalar)), d_grad + G.param_idx, s));
+    sg.push_back(int(g)); sg.push_back(int(g));
+    sv.push_back(0.5f); sv.push_back(-0.5f);
+    sp.push_back(G.param_idx);
+    sw.push_back(float(1.5707963267948966 * double(G.scalar)));
   }
+  const uint32_t n_prog = uint32_t(sg.size()), n_shift_gates = uint32_t(sp.size());
+  if (n_prog == 0) {
+    if (P) HIPCHK(hipMemsetAsync(d_grad, 0, size_t(P) * sizeof(float), s));
+    return 0;
+  }
+  HIPCHK(hipStreamSynchronize(s));  // the uploads below are synchronous copies into buffers the stream may still read
+  HIPCHK(h->shift_gates.upload(sg));
+  HIPCHK(h->shift_vals.upload(sv));
+  HIPCHK(h->shift_param.upload(sp));
+  HIPCHK(h->shift_weight.upload(sw));
+  DevicePlan& d = h->fwd;
+  const uint32_t stride = uint32_t((d.plan.coef_init.size() + 64 + 63) / 64 * 64);
+  // batch geometry: Uc states x Pc programs per launch set
+  size_t cap = std::max<size_t>(1, budget_bytes(h) / state_bytes(h));
+  uint32_t max_nl = 0;
+  for (const PassArgs& a : d.args) max_nl = std::max(max_nl, a.n_nonlocal);
+  cap = std::min<size_t>(cap, (size_t(1) << 30) >> max_nl);  // grid.x = elements << n_nonlocal
+  cap = std::min<size_t>(cap, (size_t(2) << 30) / (size_t(stride) * sizeof(float)));  // <= 2 GiB of coefficient copies
+  if (h->opt_chunk > 0) cap = std::min<size_t>(cap, size_t(h->opt_chunk));
+  const uint32_t Uc = uint32_t(std::min<size_t>(size_t(U), cap));
+  const uint32_t Pc = uint32_t(std::max<size_t>(1, std::min<size_t>(n_prog, cap / Uc)));
+  if (int rc = ensure_state_buffers(h, Uc * Pc, false)) return rc;
+  const size_t nvb = size_t(Uc) * Pc * size_t(h->model.n_ops);
+  HIPCHK(h->vals64.reserve(nvb));
+  HIPCHK(h->vals_batch.reserve(nvb));
+  HIPCHK(h->prog_acc.reserve(n_prog));
+  HIPCHK(hipMemsetAsync(h->prog_acc.p, 0, size_t(n_prog) * sizeof(double), s));
+  if (h->coef_batch_programs < Pc) {
+    HIPCHK(h->coef_batch.reserve(size_t(Pc) * stride));
+    HIPCHK(launch_replicate(d.coef.p, h->coef_batch.p, uint32_t(d.plan.coef_init.size()), stride, Pc, s));
+    h->coef_batch_programs = Pc;
+  }
+  h->retained_U = 0;
+  h->state_grad_U = 0;
+  bool measure_only_after = !d.plan.global_terms.empty();
+  for (const Pass& p : d.plan.passes) measure_only_after |= p.is_measure_only;
+  for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += Uc) {
+    const uint32_t c = std::min<uint32_t>(Uc, uint32_t(U) - s0);
+    for (uint32_t q0 = 0; q0 < n_prog; q0 += Pc) {
+      const uint32_t nq = std::min<uint32_t>(Pc, n_prog - q0);
+      HIPCHK(launch_prep_coefs_batch(d.jobs.p, int(d.plan.jobs.size()), d_params, h->coef_batch.p, h->shift_gates.p + q0,
+                                     h->shift_vals.p + q0, nq, stride, s));
+      HIPCHK(launch_combine_diag(h->coef_batch.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), nq, stride, s));
+      HIPCHK(hipMemsetAsync(h->vals64.p, 0, size_t(nq) * c * size_t(h->model.n_ops) * sizeof(unsigned long long), s));
+      for (size_t i = 0; i < d.plan.passes.size(); ++i) {
+        const Pass& p = d.plan.passes[i];
+        PassArgs a = d.args[i];
+        a.flags = p.flags & (PASS_INIT_BASIS | PASS_GENERAL);
+        if (h->opt_force_general) a.flags |= PASS_GENERAL;
+        if (!p.is_measure_only && (!p.completes_circuit || measure_only_after)) a.flags |= PASS_STORE;
+        a.prog_states = c;
+        a.coef_stride = stride;
+        hipEvent_t* ev = timer_begin(h, 0, s);
+        HIPCHK(launch_pass_fwd(p.K, d.plan.R, a, nq * c, h->psi.p, d_bits, h->model.n, d.prog.p, d.tables.p,
+                               h->coef_batch.p, h->op_scale.p, h->vals64.p, s0, s));
+        timer_end(ev, s);
+      }
+      if (!d.plan.global_terms.empty())
+        HIPCHK(launch_measure_global(h->psi.p, uint32_t(d.plan.n_eff), nq * c, h->global_terms.p,
+                                     uint32_t(d.plan.global_terms.size()), h->op_scale.p, h->vals64.p,
+                                     uint32_t(h->model.n_ops), 0u, s));
+      HIPCHK(launch_values_from_fixed(h->vals64.p, h->op_inv_scale.p, h->vals_batch.p,
+                                      nq * c * uint32_t(h->model.n_ops), uint32_t(h->model.n_ops), s));
+      HIPCHK(launch_shift_program_accumulate(h->vals_batch.p, d_upstream, nq, c, uint32_t(h->model.n_ops), s0,
+                                             h->prog_acc.p + q0, s));
+    }
+  }
+  HIPCHK(launch_shift_combine(h->prog_acc.p, h->shift_param.p, h->shift_weight.p, int(n_shift_gates), d_grad, P, s));
   return 0;
 }
 

@@ -62,7 +62,19 @@ hipError_t launch_global_phase(const CoefJob* jobs, int n_jobs, const float* par
 hipError_t launch_scale_states(float2* st, size_t count, const float* cs, hipStream_t stream);
 hipError_t launch_prep_coefs(const CoefJob* jobs, int n_jobs, const float* params, float* coef,
                              int shift_gate, double shift, hipStream_t stream);
-hipError_t launch_combine_diag(float* coef, const uint32_t* rec_offsets, int n_records, hipStream_t stream);
+// n_programs coefficient buffers coef_stride floats apart (1, 0 for the usual single program)
+hipError_t launch_combine_diag(float* coef, const uint32_t* rec_offsets, int n_records, uint32_t n_programs,
+                               uint32_t coef_stride, hipStream_t stream);
+// Batched parameter-shift programs: program y shifts the exponent of gate shift_gates[y] by shifts[y].
+hipError_t launch_prep_coefs_batch(const CoefJob* jobs, int n_jobs, const float* params, float* coef,
+                                   const int* shift_gates, const float* shifts, uint32_t n_programs,
+                                   uint32_t coef_stride, hipStream_t stream);
+hipError_t launch_replicate(const float* src, float* dst, uint32_t words, uint32_t stride, uint32_t copies,
+                            hipStream_t stream);
+hipError_t launch_shift_program_accumulate(const float* vals, const float* upstream, uint32_t n_programs, uint32_t c,
+                                           uint32_t n_ops, uint32_t s0, double* prog_acc, hipStream_t stream);
+hipError_t launch_shift_combine(const double* prog_acc, const int* gate_param, const float* gate_weight,
+                                int n_shift_gates, float* grad, int n_params, hipStream_t stream);
 hipError_t launch_reduce_grad(const float* state_grad, uint32_t U, uint32_t n_slots,
                               const int* param_slot_begin, const int* param_slots,
                               const float* slot_factor, float* grad, int n_params, int accumulate,
@@ -71,7 +83,6 @@ hipError_t launch_scatter_jac(const float* state_grad, uint32_t U, uint32_t n_sl
                               const int* param_slot_begin, const int* param_slots,
                               const float* slot_factor, float* jac, uint32_t n_ops, uint32_t op,
                               uint32_t n_params, hipStream_t stream);
-hipError_t launch_shift_accumulate(const float* vp, const float* vm, const float* upstream,
-                                   uint32_t count, float weight, float* grad_p, hipStream_t stream);
+
 
 }  // namespace qhbm

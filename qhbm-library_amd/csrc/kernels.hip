@@ -741,14 +741,21 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const uint32_t* recs = reinterpret_cast<const uint32_t*>(coef);
   const uint32_t tile_id = blockIdx.x & ((1u << a.n_nonlocal) - 1u);
   const uint32_t s_local = blockIdx.x >> a.n_nonlocal;
+  uint32_t bits_row = state0 + s_local, out_row = state0 + s_local;
+  if (a.prog_states) {  // batched programs (PassArgs::prog_states): own coefficients, shared bitstrings
+    const uint32_t q = s_local / a.prog_states;
+    bits_row = state0 + (s_local - q * a.prog_states);
+    out_row = s_local;
+    coef += size_t(q) * a.coef_stride;
+  }
+  const uint32_t* recs = reinterpret_cast<const uint32_t*>(coef);
   const TileCtx t = make_tile_ctx(a, tables, tile_id);
   float2* st = psi + (size_t(s_local) << a.n);
 
   if (a.flags & PASS_INIT_BASIS) {
-    const uint32_t idx = uni(basis_index(bits + size_t(state0 + s_local) * n_user, n_user));
+    const uint32_t idx = uni(basis_index(bits + size_t(bits_row) * n_user, n_user));
     uint32_t nl_mask = 0;
     for (uint32_t i = 0; i < a.n_nonlocal; ++i) nl_mask |= 1u << a.nonlocal_pos[i];
     if ((idx & nl_mask) != t.tile_base) {
@@ -769,7 +776,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
     }
   } else {
     if (a.zero_mask) {  // head of the sweep: psi is identically zero on this tile (engine.cpp fill_args)
-      const uint32_t idx = uni(basis_index(bits + size_t(state0 + s_local) * n_user, n_user));
+      const uint32_t idx = uni(basis_index(bits + size_t(bits_row) * n_user, n_user));
       if ((idx ^ t.tile_base) & a.zero_mask) return;
     }
     TileRegs r;
@@ -880,7 +887,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
     __syncthreads();
     for (uint32_t i = tid; i < a.n_ops; i += NT) {
       const unsigned long long v = red[i];
-      if (v) atomicAdd(&out64[size_t(state0 + s_local) * a.n_ops + i], v);
+      if (v) atomicAdd(&out64[size_t(out_row) * a.n_ops + i], v);
     }
   }
   if (a.flags & PASS_STORE) store_tile<K, NT>(tile, st, t, tid);
@@ -1426,11 +1433,19 @@ __device__ void involution2(int kind, int (&perm)[4], Cplx (&ph)[4]) {
 }
 }  // namespace
 
+// blockIdx.y = program of a batch (parameter-shift): program y shifts the exponent of gate
+// shift_gates[y] by shifts[y] and writes its coefficients at coef + y * coef_stride.
 __global__ void prep_coefs_kernel(const CoefJob* __restrict__ jobs, int n_jobs,
                                   const float* __restrict__ params, float* __restrict__ coef,
-                                  int shift_gate, double shift) {
+                                  int shift_gate, double shift, const int* __restrict__ shift_gates,
+                                  const float* __restrict__ shifts, uint32_t coef_stride) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_jobs) return;
+  if (shift_gates) {
+    shift_gate = shift_gates[blockIdx.y];
+    shift = double(shifts[blockIdx.y]);
+    coef += size_t(blockIdx.y) * coef_stride;
+  }
   const CoefJob jb = jobs[j];
   double t = double(jb.offset);
   if (jb.param_idx >= 0) t += double(jb.scalar) * double(params[jb.param_idx]);
@@ -1510,7 +1525,8 @@ __global__ void prep_coefs_kernel(const CoefJob* __restrict__ jobs, int n_jobs,
 // FULL[m-1] = product of the instance's PH1 / PH2 phases contained in register value m
 // (program.h RecordLayout).  One block per record, run after prep_coefs_kernel.
 __global__ void combine_diag_kernel(float* __restrict__ coef, const uint32_t* __restrict__ rec_offsets,
-                                    int n_records) {
+                                    int n_records, uint32_t coef_stride) {
+  coef += size_t(blockIdx.y) * coef_stride;  // program of a batch
   const int r = blockIdx.x;
   const int m = threadIdx.x;
   if (r >= n_records || m == 0 || m > 15) return;
@@ -1582,22 +1598,6 @@ __global__ void scatter_jac_kernel(const float* __restrict__ state_grad, uint32_
     acc += slot_factor[slot] * state_grad[size_t(s) * n_slots + slot];
   }
   jac[(size_t(s) * n_ops + op) * n_params + p] = acc;
-}
-
-// grad[p] += weight * sum_{s,k} upstream[s,k] * (vals_plus - vals_minus)[s,k]   (parameter shift)
-__global__ __launch_bounds__(256) void shift_accumulate_kernel(
-    const float* __restrict__ vp, const float* __restrict__ vm, const float* __restrict__ upstream,
-    uint32_t count, float weight, float* __restrict__ grad_p) {
-  __shared__ double part[256];
-  double acc = 0.0;
-  for (uint32_t i = threadIdx.x; i < count; i += 256) acc += double(upstream[i]) * (double(vp[i]) - double(vm[i]));
-  part[threadIdx.x] = acc;
-  __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
-    if (int(threadIdx.x) < o) part[threadIdx.x] += part[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *grad_p += weight * float(part[0]);
 }
 
 // ================================================================================
@@ -2024,13 +2024,82 @@ hipError_t launch_prep_coefs(const CoefJob* jobs, int n_jobs, const float* param
                              int shift_gate, double shift, hipStream_t stream) {
   if (n_jobs == 0) return hipSuccess;
   hipLaunchKernelGGL(prep_coefs_kernel, dim3((n_jobs + 127) / 128), dim3(128), 0, stream, jobs, n_jobs,
-                     params, coef, shift_gate, shift);
+                     params, coef, shift_gate, shift, static_cast<const int*>(nullptr),
+                     static_cast<const float*>(nullptr), 0u);
   return hipGetLastError();
 }
 
-hipError_t launch_combine_diag(float* coef, const uint32_t* rec_offsets, int n_records, hipStream_t stream) {
-  if (n_records == 0) return hipSuccess;
-  hipLaunchKernelGGL(combine_diag_kernel, dim3(n_records), dim3(16), 0, stream, coef, rec_offsets, n_records);
+hipError_t launch_prep_coefs_batch(const CoefJob* jobs, int n_jobs, const float* params, float* coef,
+                                   const int* shift_gates, const float* shifts, uint32_t n_programs,
+                                   uint32_t coef_stride, hipStream_t stream) {
+  if (n_jobs == 0 || n_programs == 0) return hipSuccess;
+  hipLaunchKernelGGL(prep_coefs_kernel, dim3((n_jobs + 127) / 128, n_programs), dim3(128), 0, stream, jobs, n_jobs,
+                     params, coef, -1, 0.0, shift_gates, shifts, coef_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_combine_diag(float* coef, const uint32_t* rec_offsets, int n_records, uint32_t n_programs,
+                               uint32_t coef_stride, hipStream_t stream) {
+  if (n_records == 0 || n_programs == 0) return hipSuccess;
+  hipLaunchKernelGGL(combine_diag_kernel, dim3(n_records, n_programs), dim3(16), 0, stream, coef, rec_offsets,
+                     n_records, coef_stride);
+  return hipGetLastError();
+}
+
+// dst[y * stride + i] = src[i]: the static words of a plan's coefficient buffer, once per program copy
+__global__ void replicate_kernel(const float* __restrict__ src, float* __restrict__ dst, uint32_t words, uint32_t stride) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < words) dst[size_t(blockIdx.y) * stride + i] = src[i];
+}
+hipError_t launch_replicate(const float* src, float* dst, uint32_t words, uint32_t stride, uint32_t copies,
+                            hipStream_t stream) {
+  if (!words || !copies) return hipSuccess;
+  hipLaunchKernelGGL(replicate_kernel, dim3((words + 255) / 256, copies), dim3(256), 0, stream, src, dst, words, stride);
+  return hipGetLastError();
+}
+
+// Parameter-shift bookkeeping.  prog_acc[q0 + q] += sum_{u, k} upstream[s0 + u, k] * vals[q, u, k]
+// (one block per program of the batch; double accumulation in a fixed order) ...
+__global__ __launch_bounds__(256) void shift_program_accumulate_kernel(const float* __restrict__ vals,
+                                                                       const float* __restrict__ upstream, uint32_t c,
+                                                                       uint32_t n_ops, uint32_t s0,
+                                                                       double* __restrict__ prog_acc) {
+  __shared__ double part[256];
+  const float* v = vals + size_t(blockIdx.x) * c * n_ops;
+  const float* up = upstream + size_t(s0) * n_ops;
+  double acc = 0.0;
+  for (uint32_t i = threadIdx.x; i < c * n_ops; i += 256) acc += double(up[i]) * double(v[i]);
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (int(threadIdx.x) < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) prog_acc[blockIdx.x] += part[0];
+}
+// ... and grad[p] = sum over the gates g driven by p (in gate order) of weight_g * (acc[2g] - acc[2g+1]).
+__global__ void shift_combine_kernel(const double* __restrict__ prog_acc, const int* __restrict__ gate_param,
+                                     const float* __restrict__ gate_weight, int n_shift_gates, float* __restrict__ grad,
+                                     int n_params) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_params) return;
+  double acc = 0.0;
+  for (int g = 0; g < n_shift_gates; ++g)
+    if (gate_param[g] == p) acc += double(gate_weight[g]) * (prog_acc[2 * g] - prog_acc[2 * g + 1]);
+  grad[p] = float(acc);
+}
+hipError_t launch_shift_program_accumulate(const float* vals, const float* upstream, uint32_t n_programs, uint32_t c,
+                                           uint32_t n_ops, uint32_t s0, double* prog_acc, hipStream_t stream) {
+  if (!n_programs) return hipSuccess;
+  hipLaunchKernelGGL(shift_program_accumulate_kernel, dim3(n_programs), dim3(256), 0, stream, vals, upstream, c, n_ops,
+                     s0, prog_acc);
+  return hipGetLastError();
+}
+hipError_t launch_shift_combine(const double* prog_acc, const int* gate_param, const float* gate_weight,
+                                int n_shift_gates, float* grad, int n_params, hipStream_t stream) {
+  if (!n_params) return hipSuccess;
+  hipLaunchKernelGGL(shift_combine_kernel, dim3((n_params + 127) / 128), dim3(128), 0, stream, prog_acc, gate_param,
+                     gate_weight, n_shift_gates, grad, n_params);
   return hipGetLastError();
 }
 
@@ -2052,13 +2121,6 @@ hipError_t launch_scatter_jac(const float* state_grad, uint32_t U, uint32_t n_sl
   if (total == 0) return hipSuccess;
   hipLaunchKernelGGL(scatter_jac_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, state_grad, U,
                      n_slots, param_slot_begin, param_slots, slot_factor, jac, n_ops, op, n_params);
-  return hipGetLastError();
-}
-
-hipError_t launch_shift_accumulate(const float* vp, const float* vm, const float* upstream,
-                                   uint32_t count, float weight, float* grad_p, hipStream_t stream) {
-  hipLaunchKernelGGL(shift_accumulate_kernel, dim3(1), dim3(256), 0, stream, vp, vm, upstream, count,
-                     weight, grad_p);
   return hipGetLastError();
 }
 

@@ -145,6 +145,11 @@ struct PassArgs {
   uint32_t n_ops;          // observables (row length of out)
   uint32_t slot_base;      // adjoint: first gradient slot of this pass
   uint32_t n_slots;        // adjoint: gradient slots written by this pass (row length of tile_grad)
+  // Batched programs (parameter-shift): batch element e = blockIdx.x >> n_nonlocal runs program
+  // e / prog_states on state (state0 + e % prog_states), reads its coefficients at
+  // coef + (e / prog_states) * coef_stride and writes output row e.  0 = one program, rows by state.
+  uint32_t prog_states;
+  uint32_t coef_stride;    // floats between the coefficient buffers of consecutive programs
   uint8_t nonlocal_pos[32];  // ascending bit positions of the nonlocal index bits
   uint8_t local_pos[16];     // ascending bit positions of the K local index bits
 };
