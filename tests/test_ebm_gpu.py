@@ -20,7 +20,7 @@ def _set(param, values):
     param.copy_(torch.as_tensor(np.asarray(values), dtype=torch.float32))
 
 
-@pytest.mark.parametrize("n,order", [(1, 1), (5, 2), (12, 3), (20, 2), (40, 2)])
+@pytest.mark.parametrize("n,order", [(1, 1), (5, 2), (12, 3), (20, 2), (40, 2), (64, 1)])  # 64: column 63 is the sign bit of the int64 mask
 def test_kobe_energy_kernel_matches_layers_and_oracle(n, order):
   rng = np.random.default_rng(n)
   cpu = models.KOBE(list(range(n)), order)
