@@ -104,21 +104,8 @@ template <int RB> constexpr int ins0(int p) { return ((p >> RB) << (RB + 1)) | (
 // wave-uniform SGPR pair, or a VGPR pair for thread-predicated phases.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// (a0, a1) <- (c a0 - i s a1, c a1 - i s a0).  -i s (x + i y) = (s y, -s x): both rotated
-// products go to temporaries first, then each amplitude is updated in place -- four packed
-// ops, no register copy.
-#define QHBM_X_PAIR(CONSTRAINT)                                                                   \
-  v2f t0, t1;                                                                                     \
-  asm("v_pk_mul_f32 %[t0], %[a0], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"            \
-      "v_pk_mul_f32 %[t1], %[a1], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"            \
-      "v_pk_fma_f32 %[a0], %[a0], %[cs], %[t1] op_sel_hi:[1,0,1]\n\t"                             \
-      "v_pk_fma_f32 %[a1], %[a1], %[cs], %[t0] op_sel_hi:[1,0,1]"                                  \
-      : [a0] "+v"(a0), [a1] "+v"(a1), [t0] "=&v"(t0), [t1] "=&v"(t1)                              \
-      : [cs] CONSTRAINT(cs));
-
-__device__ __forceinline__ void x_pair(v2f& a0, v2f& a1, v2f cs) { QHBM_X_PAIR("s") }
-
-// (a0, a1) <- (c a0 - s a1, s a0 + c a1)
+// Y**t on a pair: (a0, a1) <- (c a0 - s a1, s a0 + c a1).  Rotated products go to temporaries
+// first, then each amplitude is updated in place -- four packed ops per pair, no register copy.
 __device__ __forceinline__ void y_pair(v2f& a0, v2f& a1, v2f cs) {
   v2f t0, t1;
   asm("v_pk_mul_f32 %[t0], %[a0], %[cs] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
@@ -137,17 +124,6 @@ __device__ __forceinline__ void phase_s(v2f& a, v2f cs) {
       : [a] "+v"(a), [t] "=&v"(t)
       : [cs] "s"(cs));
 }
-__device__ __forceinline__ void phase_v(v2f& a, v2f cs) {
-  v2f t;
-  asm("v_pk_mul_f32 %[t], %[a], %[cs] op_sel_hi:[1,0]\n\t"
-      "v_pk_fma_f32 %[a], %[a], %[cs], %[t] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
-      : [a] "+v"(a), [t] "=&v"(t)
-      : [cs] "v"(cs));
-}
-
-__device__ __forceinline__ v2f load_cs(const float* __restrict__ cf) {
-  return *reinterpret_cast<const v2f*>(cf);
-}
 __device__ __forceinline__ v2f conj_cs(v2f cs) { return v2f{cs.x, -cs.y}; }
 
 // All loops over the register file are integer_sequence folds: every index is a
@@ -156,7 +132,8 @@ __device__ __forceinline__ v2f conj_cs(v2f cs) { return v2f{cs.x, -cs.y}; }
 // compiler keep the file as ONE 1024-bit tuple and copy it on every update).
 template <int N> using iseq = std::make_integer_sequence<int, N>;
 
-// Four pairs per asm statement: the compiler pads every inline-asm block with an s_nop (it cannot
+// X**t, (a0, a1) <- (c a0 - i s a1, c a1 - i s a0) with -i s (x + i y) = (s y, -s x), on four pairs
+// per asm statement: the compiler pads every inline-asm block with an s_nop (it cannot
 // see the hazards inside), so fewer, longer blocks issue fewer of them; the eight independent
 // multiplies also go first, ahead of the FMAs that consume them.
 __device__ __forceinline__ void x_pair4(v2f& a0, v2f& a1, v2f& b0, v2f& b1, v2f& c0, v2f& c1, v2f& d0, v2f& d1, v2f cs) {
@@ -281,7 +258,6 @@ __device__ __forceinline__ void acc_im(v2f& acc, v2f l, v2f p) {
 __device__ __forceinline__ void acc_re(v2f& acc, v2f l, v2f p) {
   asm("v_pk_fma_f32 %[acc], %[l], %[p], %[acc]" : [acc] "+v"(acc) : [l] "v"(l), [p] "v"(p));
 }
-__device__ __forceinline__ float re_conj(v2f l, v2f p) { return l.x * p.x + l.y * p.y; }  // Re(conj(l) p)
 
 // sum over selected registers of Im(conj(lam) psi); two packed accumulators break the chain
 // Eight accumulations into two partial sums in one asm statement (see x_pair4).
@@ -380,19 +356,6 @@ __device__ __forceinline__ uint32_t global_index_shift(const TileCtx& t, uint32_
 }
 __device__ __forceinline__ uint32_t global_index(const TileCtx& t, uint32_t l) {
   return t.tile_base | (l & t.cmask) | t.spread[l >> t.c];
-}
-
-template <int K, int NT>
-__device__ __forceinline__ void load_tile(float2* __restrict__ tile, const float2* __restrict__ st,
-                                          const TileCtx& t, int tid) {
-#pragma unroll 4
-  for (int p = tid; p < (1 << (K - 1)); p += NT) {
-    const uint32_t l = 2u * p;
-    const float4 v = *reinterpret_cast<const float4*>(st + global_index(t, l));
-    const uint32_t s = swz(l);
-    tile[s] = make_float2(v.x, v.y);
-    tile[s ^ 1u] = make_float2(v.z, v.w);
-  }
 }
 
 template <int K, int NT>
