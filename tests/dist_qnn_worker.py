@@ -20,6 +20,9 @@ from tests.test_host_api import hea_circuit  # noqa: E402
 
 
 def main():
+  import time
+  t0 = time.time()
+  T = lambda m: print(f"[worker {time.time() - t0:7.2f}s] {m}", flush=True) if os.environ.get("QHBM_TEST_TRACE") else None
   out_path = sys.argv[1]
   backend = os.environ.get("QHBM_TEST_BACKEND", "gloo")
   dist.init_process_group(backend)
@@ -38,14 +41,20 @@ def main():
   uniq = rng.integers(0, 2, size=(11, n)).astype(np.int8)
   states = torch.from_numpy(np.concatenate([uniq, uniq[[3, 3, 7]]]))     # duplicates, as EBM samples have
   weights = torch.from_numpy(rng.normal(size=(states.shape[0], 2)).astype(np.float32))
+  T("model built")
   qnn = inference.AnalyticQuantumInference(circ, process_group=True)
   out = qnn.expectation(states, [xxz, zsum])
+  T("forward done")
   (out * weights.to(out.device)).sum().backward()
+  T("backward done")
   if rank == 0:
     np.savez(out_path, world=world, values=out.detach().cpu().numpy(),
              grad=circ.trainable_variables[0].grad.cpu().numpy())
+  T("saved")
   dist.barrier()
+  T("barrier")
   dist.destroy_process_group()
+  T("destroyed")
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(world, out_path):
+def _run(world, out_path, backend="gloo"):
   with socket.socket() as s:
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -22,7 +22,7 @@ def _run(world, out_path):
          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_qnn_worker.py"),
          out_path]
   out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
-                       env=dict(os.environ, QHBM_TEST_BACKEND="gloo"))
+                       env=dict(os.environ, QHBM_TEST_BACKEND=backend))
   assert out.returncode == 0, out.stderr[-3000:]
   return dict(np.load(out_path))
 
@@ -33,6 +33,11 @@ def test_sharded_expectation_is_bit_identical_for_any_number_of_ranks(tmp_path):
   for r in runs[1:]:
     np.testing.assert_array_equal(r["values"], runs[0]["values"])     # atol = 0
     np.testing.assert_array_equal(r["grad"], runs[0]["grad"])
+  # the RCCL code path (device tensors straight into the collectives, no host staging): one rank is all
+  # a one-GPU box can run over nccl, and it must give the same bits
+  rccl = _run(1, str(tmp_path / "rccl.npz"), backend="nccl")
+  np.testing.assert_array_equal(rccl["values"], runs[0]["values"])
+  np.testing.assert_array_equal(rccl["grad"], runs[0]["grad"])
   # and they are right: the numpy oracle on the same model
   from oracle import qhbm_oracle as O
   n, layers = 14, 2
