@@ -304,16 +304,20 @@ def main():
     # PMC traffic and VALU utilisation come from committed rocprofv3 runs of THIS command
     # (scripts/profile_bench.sh -> profiles/): stored values, not measured in this run.
     traffic, traffic_src, valu = None, None, None
+    def family(profile):  # "pass_adj_kernel" also matches the exchange-layout kernel "pass_adjx_kernel"
+      keys = [k for k in (profile or {}) if k.startswith(name[:-len("_kernel")]) and isinstance(profile[k], dict)]
+      return max(keys, key=lambda k: profile[k].get("calls", 0)) if keys else None
+
     tj = stored_profile("traffic.json", n, layers, args.hamiltonian, args.mode)
-    if tj and name in tj:
+    if family(tj):
       scale = spg / float(tj["states_per_gpu"])
-      traffic = tj[name]["hbm_bytes_per_launch"] * scale
+      traffic = tj[family(tj)]["hbm_bytes_per_launch"] * scale
       traffic_src = (f"stored profile profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                      f"{tj['states_per_gpu']} states, git {tj.get('git_head', '?')}, bench.py sha "
                      f"{tj.get('bench_py_sha16', '?')}), scaled x{scale:g} in states; NOT measured in this run")
     vj = stored_profile("valu.json", n, layers, args.hamiltonian, args.mode)
-    if vj and name in vj:
-      valu = dict(vj[name], source=f"stored profile profiles/valu.json (git {vj.get('git_head', '?')})")
+    if family(vj):
+      valu = dict(vj[family(vj)], source=f"stored profile profiles/valu.json (git {vj.get('git_head', '?')})")
     with open(os.path.abspath(__file__), "rb") as f:
       bench_sha = hashlib.sha256(f.read()).hexdigest()[:16]
     ham_name = {"xxz": "XXZ(delta=0.5) open chain", "tfim": "TFIM ring",
