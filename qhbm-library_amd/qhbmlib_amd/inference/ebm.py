@@ -282,9 +282,15 @@ class GibbsWithGradientsKernel:
     del init_state
     return []
 
+  def _device(self):
+    """Where the energy's variables live: the chain state stays on the host (its random stream is a
+    host generator), energy evaluations run on the energy's device."""
+    first = next(iter(self._energy.parameters()), None)
+    return torch.device("cpu") if first is None else first.device
+
   def _get_index_proposal_probs(self, x):
     """Equation 6 of the paper with the Taylor estimate of equation 3 (ebm.py:618-650)."""
-    x_float = torch.as_tensor(x).to(torch.float32).detach().clone().requires_grad_(True)
+    x_float = torch.as_tensor(x).to(device=self._device(), dtype=torch.float32).detach().clone().requires_grad_(True)
     with torch.enable_grad():
       current_energy = self._energy(x_float.unsqueeze(0)).squeeze()
       (e_grad,) = torch.autograd.grad(current_energy, x_float)
@@ -297,13 +303,14 @@ class GibbsWithGradientsKernel:
     del previous_kernel_results
     current_state = torch.as_tensor(current_state).to(torch.int8)
     with torch.no_grad():
-      probs = self._get_index_proposal_probs(current_state)
+      current_state = current_state.cpu()
+      probs = self._get_index_proposal_probs(current_state).cpu()
       i = int(torch.multinomial(probs, 1, generator=self._generator))
       x_prime = current_state.clone()
       x_prime[i] = 1 - x_prime[i]
-      probs_prime = self._get_index_proposal_probs(x_prime)
+      probs_prime = self._get_index_proposal_probs(x_prime).cpu()
       q_ratio = probs_prime[i] / probs[i]
-      energies = self._energy(torch.stack([x_prime, current_state]))
+      energies = self._energy(torch.stack([x_prime, current_state]).to(self._device())).cpu()
       accept_prob = torch.clamp(torch.exp(-energies[0] + energies[1]) * q_ratio, max=1.0)
       roll = torch.rand((), generator=self._generator)
       next_state = x_prime if bool(roll <= accept_prob.cpu()) else current_state

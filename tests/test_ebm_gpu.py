@@ -174,3 +174,33 @@ def test_vqt_step_n20_loss_and_both_gradients_against_oracle():
   assert abs(float(loss.detach()) - want_loss) <= 5e-5 * (beta * norm + 1.0), (float(loss.detach()), want_loss)
   np.testing.assert_allclose(g_phi, want_phi, atol=1e-4 * max(1.0, np.abs(want_phi).max()), rtol=0)
   np.testing.assert_allclose(g_theta, want_theta, atol=2e-4, rtol=0)
+
+
+def test_gibbs_with_gradients_with_the_energy_on_the_device():
+  """ebm_test.py:879-947 with the EBM resident on the GPU: the chain's energy differences go through
+  qhbm_parity_energy (integer CUDA bitstrings), its index proposals through the torch layers on the
+  device; the sampled distribution must match the exact one.  6000 correlated samples: entropy within
+  rtol 8e-2, probabilities within 4e-2 (the same chain on the CPU lands 5.5 % / 2.2e-2 off with this
+  seed and 1.5 % / 5e-3 off after 30000 samples), every bitstring visited."""
+  num_bits = 4
+  rng = np.random.default_rng(4)
+  energy = models.KOBE(list(range(num_bits)), 2)
+  thetas = rng.uniform(-0.8, 0.8, energy.post_process[0].kernel.numel())
+  _set(energy.post_process[0].kernel, thetas)
+  energy = energy.to("cuda")
+  n_samples = 6000
+  layer = inference.GibbsWithGradientsInference(energy, n_samples, 500, initial_seed=9)
+  samples = layer.sample(n_samples)
+  assert samples.shape == (n_samples, num_bits) and samples.dtype == torch.int8
+  all_bits = O.all_bitstrings(num_bits)
+  p = np.exp(-O.kobe_energy(all_bits, thetas, 2))
+  p /= p.sum()
+  counts = np.zeros(2**num_bits)
+  idx = (samples.numpy().astype(np.int64) * (1 << np.arange(num_bits - 1, -1, -1))).sum(1)
+  np.add.at(counts, idx, 1)
+  q = counts / counts.sum()
+  assert (counts > 0).all()
+  entropy = lambda d: float(-(d[d > 0] * np.log(d[d > 0])).sum())
+  np.testing.assert_allclose(entropy(q), entropy(p), rtol=8e-2)
+  np.testing.assert_allclose(q, p, atol=4e-2)
+  assert abs(entropy(q) - np.log(2**num_bits)) > 0.2 * np.log(2**num_bits)   # and it is not uniform
