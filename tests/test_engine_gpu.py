@@ -360,3 +360,28 @@ def test_results_are_bit_reproducible_and_independent_of_chunking():
   v4, j4 = eng.expectation_jacobian(bits[5:], params)
   assert torch.equal(v1[5:], v4) and torch.equal(j1[5:], j4)
   assert torch.equal(eng.expectation(bits[2:4], params), v1[2:4])
+
+
+def test_parameter_shift_batches_states_and_programs():
+  """The shift VJP runs (state, shifted program) pairs as one batch; whatever the batch geometry --
+  all programs at once, three or seven elements per launch set (`chunk_states`), one tile or many --
+  it must equal the adjoint VJP and the oracle's shift rule (qnn.py:168; baselines/train.py:190-240)."""
+  rng = np.random.default_rng(31)
+  n, layers = 11, 2
+  gates, names = O.hea_gates(n, layers, "p")
+  gates = gates + [(O.GATE_XXPOW, 2, 7, 3, 0.7, 0.1), (O.GATE_ZZPOW, 0, 10, 5, -1.3, 0.0)]   # tied parameters too
+  params = rng.uniform(-1, 1, len(names))
+  ops = [O.xxz_chain_op(n), O.tfim_ring_op(n)]
+  bits = _random_bits(rng, 5, n)
+  up = rng.normal(size=(5, 2)).astype(np.float32)
+  want_vals, want_jac = O.expectation_jacobian(n, gates, params, bits, ops)
+  want = np.einsum("bt,btp->p", up, want_jac)
+  tol = 1e-4 * max(1.0, np.abs(want).max())
+  for tile in (0, 10):
+    for chunk in (0, 3, 7):
+      eng = _engine(n, gates, len(names), ops, tile_qubits=tile, chunk_states=chunk)
+      vals, grad = eng.expectation_vjp(bits, params, up, method=E.GRAD_PARAMETER_SHIFT)
+      np.testing.assert_allclose(vals.cpu().numpy(), want_vals, atol=1e-4)
+      np.testing.assert_allclose(grad.cpu().numpy(), want, atol=tol)
+      # and the engine is still usable for ordinary calls afterwards
+      np.testing.assert_allclose(eng.expectation(bits, params).cpu().numpy(), want_vals, atol=1e-4)
