@@ -385,3 +385,24 @@ def test_parameter_shift_batches_states_and_programs():
       np.testing.assert_allclose(grad.cpu().numpy(), want, atol=tol)
       # and the engine is still usable for ordinary calls afterwards
       np.testing.assert_allclose(eng.expectation(bits, params).cpu().numpy(), want_vals, atol=1e-4)
+
+
+def test_random_circuits_of_every_gate_kind_at_18_qubits_against_c_oracle():
+  """The general kernel variants (Y, H, CNOT / SWAP / ISWAP / XX / YY / ZZ powers: dense two-qubit
+  ops on the LDS tiles, the two-tile adjoint layout) on multi-pass plans at a size where only the C
+  restatement is quick enough to be the checker: values and the VJP of three random circuits."""
+  from oracle import qhbm_cpu as C
+  n, n_params = 18, 10
+  for seed in range(3):
+    rng = np.random.default_rng(1800 + seed)
+    gates = random_circuit(rng, n, 90, n_params)
+    params = rng.uniform(-1, 1, n_params).astype(np.float32)
+    ops = [O.random_pauli_op(n, 12, seed, p_identity=0.7), O.xxz_chain_op(n)]
+    bits = _random_bits(rng, 3, n)
+    up = rng.normal(size=(3, 2)).astype(np.float32)
+    want_vals, want_grad = C.expectation_vjp(n, gates, params, bits, ops, up)
+    for opts in ({}, {"tile_qubits": 11, "adjoint_tile_qubits": 11}):
+      eng = _engine(n, gates, n_params, ops, **opts)
+      vals, grad = eng.expectation_vjp(bits, params, up)
+      np.testing.assert_allclose(vals.cpu().numpy(), want_vals, atol=5e-5 * max(1.0, _op_norm(ops).max()))
+      np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=2e-4 * max(1.0, np.abs(want_grad).max()))
