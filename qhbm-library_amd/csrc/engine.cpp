@@ -146,6 +146,8 @@ void fill_args(const Plan& plan, const Model& m, std::vector<PassArgs>* args, st
     for (size_t i = 0; i < p.local_pos.size(); ++i) a.local_pos[i] = uint8_t(p.local_pos[i]);
     prog->insert(prog->end(), p.prog.begin(), p.prog.end());
     tables->insert(tables->end(), p.spread.begin(), p.spread.end());
+    a.tl_off = uint32_t(tables->size());
+    tables->insert(tables->end(), p.round_tl.begin(), p.round_tl.end());
     args->push_back(a);
   }
   if (!plan.adjoint) {

@@ -424,15 +424,14 @@ __device__ __forceinline__ TileCtx make_tile_ctx(const PassArgs& a, const uint32
 }
 
 // Round geometry.  Thread `tid` owns the 2^R amplitudes whose local index has
-// tid's bits deposited on the non-register positions (TL); register value m adds
-// the bits of m on the register positions.  In swizzled slot space both parts
+// tid's bits deposited on the non-register positions (TL, read from the scheduler's per-round table);
+// register value m adds the bits of m on the register positions.  In swizzled slot space both parts
 // combine by XOR, so the 2^R slots are visited in Gray-code order with one
 // v_xor per access: slot(gray(i)) = slot(gray(i-1)) ^ DB[ctz(i)].  Slots are kept
 // as BYTE offsets (x8) so an access needs no further address arithmetic.
 template <int K, int R>
-__device__ __forceinline__ void round_geometry(uint32_t regmask, int tid, uint32_t (&DB)[R],
-                                               uint32_t* T, uint32_t* TL) {
-  uint32_t mk = regmask;
+__device__ __forceinline__ void round_geometry(uint32_t regmask, uint32_t tl, uint32_t (&DB)[R], uint32_t* T) {
+  uint32_t mk = regmask;  // wave-uniform: scalar arithmetic
   DB[0] = swz(mk & (0u - mk)) << 3;  // lowest set bit, swizzled, in bytes
   mk &= mk - 1;
   DB[1] = swz(mk & (0u - mk)) << 3;
@@ -444,15 +443,6 @@ __device__ __forceinline__ void round_geometry(uint32_t regmask, int tid, uint32
     mk &= mk - 1;
     DB[R > 4 ? 4 : 0] = swz(mk & (0u - mk)) << 3;
   }
-  uint32_t freem = ~regmask & ((1u << K) - 1u);
-  uint32_t tl = 0;
-#pragma unroll
-  for (int j = 0; j < K - R; ++j) {
-    const uint32_t low = freem & (0u - freem);
-    freem &= freem - 1;
-    tl |= ((uint32_t(tid) >> j) & 1u) ? low : 0u;
-  }
-  *TL = tl;
   *T = swz(tl) << 3;
 }
 
@@ -767,8 +757,9 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
       // one-ahead prefetch of the previous round's last instance already holds this round's first
       // record: reloading it would put a global-load latency in front of every round.
       if (rec_off != carried_off) rec_load<NV>(recs, rec_off, lane, cur);
-      uint32_t DB[R], T, TL;
-      round_geometry<K, R>(regmask, tid, DB, &T, &TL);
+      uint32_t DB[R], T;
+      const uint32_t TL = tables[a.tl_off + uni(prog[pc + 3]) + uint32_t(tid)];
+      round_geometry<K, R>(regmask, TL, DB, &T);
       v2f amp[NR];
       round_load<R>(tile, T, DB, amp);
       for (uint32_t i = 0; i < n_inst; ++i) {
@@ -781,7 +772,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
       carried_off = rec_off;
       round_store<R>(tile, T, DB, amp);
       if (!(w0 & kRoundNoBarrier)) __syncthreads();  // else the next round's waves read only their own writes
-      pc += 3;
+      pc += kRoundWords;
     } else if (opc == OP_GATE2) {
       if constexpr (GEN) {
         const uint32_t pw = uni(prog[pc + 1]);
@@ -1033,8 +1024,9 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   uint32_t rec_off = uni(prog[2]);
   rec_load<1>(recs, rec_off, lane, cur);
   rec_load<1>(recs, rec_off + L.slot0(), lane, sv);
-  uint32_t DB[R], T, TL;
-  round_geometry<K, R>(uni(prog[1]), tid, DB, &T, &TL);
+  const uint32_t* tlt = tables + a.tl_off + uint32_t(tid);
+  uint32_t DB[R], T, TL = tlt[uni(prog[3])];
+  round_geometry<K, R>(uni(prog[1]), TL, DB, &T);
   v2f p[NR], l[NR];
   commit_tile<K, NT>(xt, rp, tid);
   __syncthreads();
@@ -1053,13 +1045,14 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
       cur[0] = nxt[0];
       sv[0] = svn[0];
     }
-    pc += 3;
+    pc += kRoundWords;
     const uint32_t w1 = uni(prog[pc]);
     if ((w1 & 0xffu) != OP_ROUND) break;
     // ---- change of geometry through the exchange buffer ----
     const bool sync = !(w0 & kRoundNoBarrier);  // else the next round's waves own the same amplitudes
-    uint32_t DBn[R], Tn, TLn;
-    round_geometry<K, R>(uni(prog[pc + 1]), tid, DBn, &Tn, &TLn);
+    uint32_t DBn[R], Tn;
+    const uint32_t TLn = tlt[uni(prog[pc + 3])];
+    round_geometry<K, R>(uni(prog[pc + 1]), TLn, DBn, &Tn);
     const uint32_t next_off = uni(prog[pc + 2]);
     if (next_off != rec_off) {  // records of consecutive rounds are consecutive: normally already prefetched
       rec_off = next_off;
@@ -1153,8 +1146,9 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
         rec_load<1>(recs, rec_off, lane, cur);
         rec_load<1>(recs, rec_off + L.slot0(), lane, sv);
       }
-      uint32_t DB[R], T, TL;
-      round_geometry<K, R>(regmask, tid, DB, &T, &TL);
+      uint32_t DB[R], T;
+      const uint32_t TL = tables[a.tl_off + uni(prog[pc + 3]) + uint32_t(tid)];
+      round_geometry<K, R>(regmask, TL, DB, &T);
       v2f p[NR], l[NR];
       round_load<R>(tp, T, DB, p);
       round_load<R>(tl, T, DB, l);
@@ -1170,7 +1164,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
       round_store<R>(tp, T, DB, p);
       round_store<R>(tl, T, DB, l);
       if (!(w0 & kRoundNoBarrier)) __syncthreads();  // else the next round's waves read only their own writes
-      pc += 3;
+      pc += kRoundWords;
     } else {  // OP_GATE2
       if constexpr (GEN) {
       const uint32_t pw = uni(prog[pc + 1]);

@@ -51,13 +51,17 @@ enum : uint32_t {
 // ---- opcodes (low 8 bits of an instruction's first word) --------------------
 enum : uint32_t {
   OP_END = 0,
-  // [op | n_inst<<8] [regmask] [first_record]: n_inst consecutive fixed-layout RECORDS in the
-  // coefficient buffer (see RecordLayout) drive the round.
+  // [op | n_inst<<8] [regmask] [first_record] [tl_table]: n_inst consecutive fixed-layout RECORDS in
+  // the coefficient buffer (see RecordLayout) drive the round; tl_table = offset (in the pass's part
+  // of the tables buffer, PassArgs::tl_off) of the round's thread -> local-index table TL[tid]: the
+  // bits of tid deposited on the non-register local bits, computed once by the scheduler instead of
+  // ~50 VALU per thread and round.
   OP_ROUND = 1,
   OP_MEASURE = 3,  // [op | n_groups<<8] then groups x {[xl] [n_terms] terms x {[zl] [zn] [coef bits] [op_idx | ny<<24]}}
   OP_GATE2 = 4,    // [op | kind<<8] [pos_q0 | pos_q1<<8 (local bits)] [coef_off] [slot]
 };
 constexpr uint32_t kRoundNoBarrier = 1u << 31;  // OP_ROUND word 0: the next op is a round whose waves own the same amplitudes
+constexpr int kRoundWords = 4;
 constexpr int kGate2Words = 4;
 constexpr int kMeasTermWords = 4;
 
@@ -140,6 +144,7 @@ struct PassArgs {
   uint32_t n_nonlocal;     // n - K
   uint32_t prog_off;       // word offset of this pass's program
   uint32_t spread_off;     // offset of spread_hi[2^(K-c)] in the tables buffer
+  uint32_t tl_off;         // offset of this pass's round TL tables in the tables buffer (OP_ROUND word 3)
   uint32_t zero_mask;      // adjoint: index bits non-local in this and every later pass (see fill_args)
   uint32_t spread_shift;   // local bits above c contiguous from bit s: spread_hi[j] = j << s (no lookup); else ~0u
   uint32_t n_ops;          // observables (row length of out)

@@ -247,7 +247,7 @@ class Builder {
       return m;
     };
     for (size_t r = 0; r + 1 < p->round_words.size(); ++r) {
-      if (p->round_words[r + 1] != p->round_words[r] + 3) continue;  // something else sits in between
+      if (p->round_words[r + 1] != p->round_words[r] + kRoundWords) continue;  // something else sits in between
       if (wave_bits <= 0 || wave_mask(p->round_regmasks[r]) == wave_mask(p->round_regmasks[r + 1]))
         p->prog[p->round_words[r]] |= kRoundNoBarrier;
     }
@@ -400,6 +400,16 @@ class Builder {
     p->prog.push_back(OP_ROUND | (uint32_t(insts.size()) << 8));
     p->prog.push_back(reg);
     p->prog.push_back(first);
+    p->prog.push_back(uint32_t(p->round_tl.size()));
+    {  // TL[tid]: bit j of tid goes to the j-th lowest local bit that is not a register bit
+      int free_pos[16], nf = 0;
+      for (int b = 0; b < K_; ++b) if (!(reg >> b & 1)) free_pos[nf++] = b;
+      for (uint32_t tid = 0; tid < (1u << (K_ - R_)); ++tid) {
+        uint32_t tl = 0;
+        for (int j = 0; j < nf; ++j) if (tid >> j & 1) tl |= 1u << free_pos[j];
+        p->round_tl.push_back(tl);
+      }
+    }
     p->round_regmasks.push_back(reg);
     ++p->n_rounds;
     p->n_instances += int(insts.size());

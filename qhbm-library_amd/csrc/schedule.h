@@ -55,6 +55,7 @@ struct Pass {
   std::vector<int> nonlocal_pos;  // ascending, size n - K
   std::vector<uint32_t> prog;     // instruction words, OP_END terminated
   std::vector<uint32_t> spread;   // spread_hi[2^(K-c)]
+  std::vector<uint32_t> round_tl; // TL[tid] tables of the rounds, 2^(K-R) entries each (OP_ROUND word 3)
   bool is_measure_only = false;
   bool completes_circuit = false;
   // statistics (DESIGN.md / bench roofline accounting)

@@ -70,6 +70,26 @@ VARIANTS = {
                                    "      if (lane == 77) instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n      rec_off += L.words();\n      cur[0] = nxt[0];"),
 }
 
+def in_fwd_instance(text, old, new, count=-1):
+  a = text.index("__device__ __forceinline__ void instance_fwd(")
+  b = text.index("// Measurement helpers")
+  body = text[a:b]
+  assert old in body, old
+  return text[:a] + body.replace(old, new, count) + text[b:]
+
+
+VARIANTS.update({
+    "fwd_no_instances": lambda t: once(t, "        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);",
+                                       "        if (lane == 77) instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);"),
+    "fwd_no_x": lambda t: in_fwd_instance(t, "if ((h0 >> J) & 1u) apply_x<R, J>(a, rec_cs<L.x(J)>(rv));", "if (((h0 >> J) & 1u) && lane == 77) apply_x<R, J>(a, rec_cs<L.x(J)>(rv));"),
+    "fwd_no_full": lambda t: in_fwd_instance(t, "if (h1 & kFullDiagFlag) apply_full<NV>(a, rv, false);", "if ((h1 & kFullDiagFlag) && lane == 77) apply_full<NV>(a, rv, false);"),
+    "fwd_no_cph": lambda t: in_fwd_instance(t, "  if (h1 & 0xffu) {", "  if ((h1 & 0xffu) && lane == 77) {"),
+    "fwd_no_barriers": lambda t: once(t, "      if (!(w0 & kRoundNoBarrier)) __syncthreads();  // else the next round's waves read only their own writes\n      pc += 3;\n    } else if (opc == OP_GATE2) {",
+                                      "      pc += 3;\n    } else if (opc == OP_GATE2) {"),
+    "fwd_no_round_trips": lambda t: once(once(t, "      round_load<R>(tile, T, DB, amp);\n      for (uint32_t i = 0; i < n_inst; ++i) {", "      if (pc == 0) round_load<R>(tile, T, DB, amp);\n      for (uint32_t i = 0; i < n_inst; ++i) {"),
+                                         "      round_store<R>(tile, T, DB, amp);\n      if (!(w0 & kRoundNoBarrier)) __syncthreads();", "      if (lane == 77) round_store<R>(tile, T, DB, amp);\n      if (!(w0 & kRoundNoBarrier)) __syncthreads();"),
+})
+
 which = sys.argv[1:] or list(VARIANTS)
 for name in which:
   text = VARIANTS[name](src)
