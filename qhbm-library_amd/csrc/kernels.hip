@@ -513,6 +513,24 @@ template <int W, int NV>
 __device__ __forceinline__ v2f rec_cs(const uint32_t (&rv)[NV]) {
   return v2f{__uint_as_float(rec_word<W>(rv)), __uint_as_float(rec_word<W + 1>(rv))};
 }
+// The same fields straight from memory at a wave-uniform address `rb` = recs + rec_off: the compiler
+// turns them into scalar loads through the constant cache (s_load_dword..x8, no VALU) -- with both
+// sweeps VALU-issue bound this beats the v_readlane decode by 2 % (it did not in round 1, when the
+// kernels still waited on memory); the coalesced vector fetch stays for the per-lane slot vector.
+// -DQHBM_SCALAR_RECORDS=0 restores the v_readlane decode for A/B measurements.
+#ifndef QHBM_SCALAR_RECORDS
+#define QHBM_SCALAR_RECORDS 1
+#endif
+struct RecBase { const uint32_t* p; };
+template <int W, int NV>
+__device__ __forceinline__ uint32_t rec_word(const uint32_t (&rv)[NV], RecBase rb) {
+  if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];
+  else return rec_word<W>(rv);
+}
+template <int W, int NV>
+__device__ __forceinline__ v2f rec_cs(const uint32_t (&rv)[NV], RecBase rb) {
+  return v2f{__uint_as_float(rec_word<W>(rv, rb)), __uint_as_float(rec_word<W + 1>(rv, rb))};
+}
 template <int NV>
 __device__ __forceinline__ void rec_load(const uint32_t* __restrict__ recs, uint32_t off, int lane,
                                          uint32_t (&rv)[NV]) {
@@ -566,14 +584,14 @@ __device__ __forceinline__ void add_slots8(float* cells, int lane, uint32_t wave
 
 // FULL diagonal table: amplitude with register value m (1..15) times FULL[m-1].
 template <int NV, int... M>
-__device__ __forceinline__ void apply_full_(v2f (&a)[16], const uint32_t (&rv)[NV], bool conj,
+__device__ __forceinline__ void apply_full_(v2f (&a)[16], const uint32_t (&rv)[NV], RecBase rb, bool conj,
                                             std::integer_sequence<int, M...>) {
   constexpr RecordLayout L(4, false);
-  (phase_s(a[M + 1], conj ? conj_cs(rec_cs<L.full(M + 1)>(rv)) : rec_cs<L.full(M + 1)>(rv)), ...);
+  (phase_s(a[M + 1], conj ? conj_cs(rec_cs<L.full(M + 1)>(rv, rb)) : rec_cs<L.full(M + 1)>(rv, rb)), ...);
 }
 template <int NV>
-__device__ __forceinline__ void apply_full(v2f (&a)[16], const uint32_t (&rv)[NV], bool conj) {
-  apply_full_<NV>(a, rv, conj, iseq<15>{});
+__device__ __forceinline__ void apply_full(v2f (&a)[16], const uint32_t (&rv)[NV], RecBase rb, bool conj) {
+  apply_full_<NV>(a, rv, rb, conj, iseq<15>{});
 }
 template <int... M>
 __device__ __forceinline__ void w_all_(float (&w)[16], const v2f (&p)[16], const v2f (&l)[16],
@@ -616,13 +634,14 @@ __device__ __forceinline__ void instance_fwd(const uint32_t (&rv)[NV], const uin
                                              uint32_t rec_off, int lane, v2f (&a)[1 << R], uint32_t tl,
                                              uint32_t tile_base) {
   constexpr RecordLayout L(R, false);
-  const uint32_t h0 = rec_word<0>(rv), h1 = rec_word<1>(rv);
+  const RecBase rb{recs + rec_off};
+  const uint32_t h0 = rec_word<0>(rv, rb), h1 = rec_word<1>(rv, rb);
   // One-qubit gates: a separate predicated slot class per kind (X, Y, dense), each a plain
   // if-then triangle around in-place code -- no merge copies.
-  QHBM_FOR_RB(R, if ((h0 >> J) & 1u) apply_x<R, J>(a, rec_cs<L.x(J)>(rv));)
+  QHBM_FOR_RB(R, if ((h0 >> J) & 1u) apply_x<R, J>(a, rec_cs<L.x(J)>(rv, rb));)
   if constexpr (GEN) {
   if ((h1 >> 16) & 0xfu) {
-    QHBM_FOR_RB(R, if ((h1 >> (16 + J)) & 1u) apply_y<R, J>(a, rec_cs<L.y(J)>(rv));)
+    QHBM_FOR_RB(R, if ((h1 >> (16 + J)) & 1u) apply_y<R, J>(a, rec_cs<L.y(J)>(rv, rb));)
   }
   if ((h1 >> 24) & 0xfu) {  // dense 2x2 gates (rare): their coefficients sit in the record's third part
     uint32_t dv[1];
@@ -633,18 +652,18 @@ __device__ __forceinline__ void instance_fwd(const uint32_t (&rv)[NV], const uin
   }
   }
   // (a FULL instance has its PH1 / PH2 masks zeroed in word 0: independent triangles, no else)
-  if (h1 & kFullDiagFlag) apply_full<NV>(a, rv, false);
-  QHBM_FOR_RB(R, if ((h0 >> (8 + J)) & 1u) apply_ph1<R, J>(a, rec_cs<L.ph1(J)>(rv));)
+  if (h1 & kFullDiagFlag) apply_full<NV>(a, rv, rb, false);
+  QHBM_FOR_RB(R, if ((h0 >> (8 + J)) & 1u) apply_ph1<R, J>(a, rec_cs<L.ph1(J)>(rv, rb));)
   if ((h0 >> 16) & 0x3fu) {
     QHBM_FOR_PAIR(R,
-      if ((h0 >> (16 + pair_index(JA, JB))) & 1u) apply_ph2<R, JA, JB>(a, rec_cs<L.ph2(pair_index(JA, JB))>(rv));)
+      if ((h0 >> (16 + pair_index(JA, JB))) & 1u) apply_ph2<R, JA, JB>(a, rec_cs<L.ph2(pair_index(JA, JB))>(rv, rb));)
   }
   if (h1 & 0xffu) {
     QHBM_FOR_RB(R,
       if ((h1 >> (2 * J)) & 1u)
-        cph_fwd<R, J>(a, rec_cs<L.cph(2 * J)>(rv), rec_word<L.pred(2 * J)>(rv), tl, tile_base);
+        cph_fwd<R, J>(a, rec_cs<L.cph(2 * J)>(rv, rb), rec_word<L.pred(2 * J)>(rv, rb), tl, tile_base);
       if ((h1 >> (2 * J + 1)) & 1u)
-        cph_fwd<R, J>(a, rec_cs<L.cph(2 * J + 1)>(rv), rec_word<L.pred(2 * J + 1)>(rv), tl, tile_base);)
+        cph_fwd<R, J>(a, rec_cs<L.cph(2 * J + 1)>(rv, rb), rec_word<L.pred(2 * J + 1)>(rv, rb), tl, tile_base);)
   }
 }
 
@@ -870,15 +889,16 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
   constexpr int NR = 1 << R;
   constexpr int NB = 1;
   constexpr int S0 = L.slot0();
-  const uint32_t h0 = rec_word<0>(cur), h1 = rec_word<1>(cur);
+  const RecBase rb{recs + rec_off};
+  const uint32_t h0 = rec_word<0>(cur, rb), h1 = rec_word<1>(cur, rb);
   // ---- CPH (slot group 2) ----
   if (h1 & 0xffu) {
     float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     QHBM_FOR_RB(R,
       if ((h1 >> (2 * J)) & 1u)
-        g[2 * J] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J)>(cur), rec_word<L.pred(2 * J)>(cur), TL, tile_base);
+        g[2 * J] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J)>(cur, rb), rec_word<L.pred(2 * J)>(cur, rb), TL, tile_base);
       if ((h1 >> (2 * J + 1)) & 1u)
-        g[2 * J + 1] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J + 1)>(cur), rec_word<L.pred(2 * J + 1)>(cur), TL,
+        g[2 * J + 1] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J + 1)>(cur, rb), rec_word<L.pred(2 * J + 1)>(cur, rb), TL,
                                     tile_base);)
     add_slots8<2, NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
   }
@@ -895,15 +915,15 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
       add_slots8<1, NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3], g[4], g[5], 0.f, 0.f);
     }
     QHBM_FOR_RB(R, if ((h0 >> (4 + J)) & 1u) g1[J] = wsum1_<J>(w, iseq<8>{});)
-    apply_full<NB>(p, cur, true);
-    apply_full<NB>(l, cur, true);
+    apply_full<NB>(p, cur, rb, true);
+    apply_full<NB>(l, cur, rb, true);
   }
   // ---- PH2 (slot group 1) ----
   if ((h0 >> 16) & 0x3fu) {
     float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     QHBM_FOR_PAIR(R,
       if ((h0 >> (16 + pair_index(JA, JB))) & 1u) {
-        const v2f cs = conj_cs(rec_cs<L.ph2(pair_index(JA, JB))>(cur));
+        const v2f cs = conj_cs(rec_cs<L.ph2(pair_index(JA, JB))>(cur, rb));
         g[pair_index(JA, JB)] = sum_w2<R, JA, JB>(p, l);
         apply_ph2<R, JA, JB>(p, cs);
         apply_ph2<R, JA, JB>(l, cs);
@@ -914,7 +934,7 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
   if ((h0 >> 8) & 0xfu) {
     QHBM_FOR_RB(R,
       if ((h0 >> (8 + J)) & 1u) {
-        const v2f cs = conj_cs(rec_cs<L.ph1(J)>(cur));
+        const v2f cs = conj_cs(rec_cs<L.ph1(J)>(cur, rb));
         g1[J] = sum_w1<R, J>(p, l);
         apply_ph1<R, J>(p, cs);
         apply_ph1<R, J>(l, cs);
@@ -926,7 +946,7 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
     if (h0 & 0xfu) {
       QHBM_FOR_RB(R,
         if ((h0 >> J) & 1u) {
-          const v2f cs = conj_cs(rec_cs<L.x(J)>(cur));  // U^dagger = c*I + i*s*X
+          const v2f cs = conj_cs(rec_cs<L.x(J)>(cur, rb));  // U^dagger = c*I + i*s*X
           if (rec_word<L.slot_x(J) - S0>(sv) != 0xffffffffu) g[J] = im_lam_x_psi<R, J>(p, l);
           apply_x<R, J>(p, cs);
           apply_x<R, J>(l, cs);
@@ -940,7 +960,7 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
     float gy[4] = {0.f, 0.f, 0.f, 0.f}, gd[4] = {0.f, 0.f, 0.f, 0.f};
     QHBM_FOR_RB(R,
       if ((h1 >> (16 + J)) & 1u) {
-        const v2f cs = conj_cs(rec_cs<L.y(J)>(cur));
+        const v2f cs = conj_cs(rec_cs<L.y(J)>(cur, rb));
         if (rec_word<L.slot_y(J) - S0>(sv) != 0xffffffffu) gy[J] = im_lam_y_psi<R, J>(p, l);
         apply_y<R, J>(p, cs);
         apply_y<R, J>(l, cs);
