@@ -350,34 +350,32 @@ struct TileCtx {
   uint32_t shift;  // ~0u: look the high part up in `spread`
 };
 
+// Local index -> global index WITHOUT the tile's own bits.  Both forms are bitwise (OR-decomposable):
+// f(a | b) = f(a) | f(b) for disjoint a, b.  A thread's eight float4 sit at l = 2 * tid + (I << (K - 3)):
+// f(2 * tid) is computed once per thread, f(I << (K - 3)) is wave-uniform (scalar arithmetic or a
+// scalar table load) and goes into the base pointer, so the eight accesses of a tile share one
+// 32-bit VGPR offset and cost no VALU address arithmetic (global_load ... v_off, s[base]).
 // (local bits above c contiguous from bit `shift`: no table lookup in front of the global access)
-__device__ __forceinline__ uint32_t global_index_shift(const TileCtx& t, uint32_t l) {
-  return t.tile_base | (l & t.cmask) | ((l >> t.c) << t.shift);
+__device__ __forceinline__ uint32_t tile_offset(const TileCtx& t, uint32_t l) {
+  return (l & t.cmask) | (t.shift != 0xffffffffu ? ((l >> t.c) << t.shift) : t.spread[l >> t.c]);
 }
-__device__ __forceinline__ uint32_t global_index(const TileCtx& t, uint32_t l) {
-  return t.tile_base | (l & t.cmask) | t.spread[l >> t.c];
-}
+__device__ __forceinline__ uint32_t global_index(const TileCtx& t, uint32_t l) { return t.tile_base | tile_offset(t, l); }
 
 template <int K, int NT>
 __device__ __forceinline__ void store_tile(const float2* __restrict__ tile, float2* __restrict__ st,
                                            const TileCtx& t, int tid) {
-  if (t.shift != 0xffffffffu) {  // wave-uniform
-#pragma unroll 4
-    for (int p = tid; p < (1 << (K - 1)); p += NT) {
-      const uint32_t l = 2u * p;
-      const uint32_t s = swz(l);
-      const float2 a = tile[s], b = tile[s ^ 1u];
-      *reinterpret_cast<float4*>(st + global_index_shift(t, l)) = make_float4(a.x, a.y, b.x, b.y);
-    }
-  } else {
-#pragma unroll 4
-    for (int p = tid; p < (1 << (K - 1)); p += NT) {
-      const uint32_t l = 2u * p;
-      const uint32_t s = swz(l);
-      const float2 a = tile[s], b = tile[s ^ 1u];
-      *reinterpret_cast<float4*>(st + global_index(t, l)) = make_float4(a.x, a.y, b.x, b.y);
-    }
+  static_assert((1 << (K - 1)) / NT == 8, "a thread owns eight float4 of its tile");
+  const uint32_t g0 = tile_offset(t, 2u * uint32_t(tid));
+  const uint32_t s0 = swz(2u * uint32_t(tid));
+#define QHBM_ST(I)                                                                                     \
+  {                                                                                                    \
+    float2* sb = st + (t.tile_base | uni(tile_offset(t, uint32_t(I) << (K - 3))));                     \
+    const uint32_t s = s0 ^ swz(uint32_t(I) << (K - 3));                                               \
+    const float2 a = tile[s], b = tile[s ^ 1u];                                                        \
+    *reinterpret_cast<float4*>(sb + g0) = make_float4(a.x, a.y, b.x, b.y);                             \
   }
+  QHBM_ST(0) QHBM_ST(1) QHBM_ST(2) QHBM_ST(3) QHBM_ST(4) QHBM_ST(5) QHBM_ST(6) QHBM_ST(7)
+#undef QHBM_ST
 }
 
 // Eight float4 of a thread's share of a tile, as named registers (a loop-carried array may end
@@ -389,21 +387,21 @@ struct TileRegs {
 template <int K, int NT>
 __device__ __forceinline__ void prefetch_tile(TileRegs& r, const float2* __restrict__ st, const TileCtx& t, int tid) {
   static_assert((1 << (K - 1)) / NT == 8, "a thread owns eight float4 of its tile");
-  if (t.shift != 0xffffffffu) {  // wave-uniform
-#define QHBM_PF(I) r.p##I = *reinterpret_cast<const float4*>(st + global_index_shift(t, 2u * uint32_t(tid + I * NT)));
-    QHBM_PF(0) QHBM_PF(1) QHBM_PF(2) QHBM_PF(3) QHBM_PF(4) QHBM_PF(5) QHBM_PF(6) QHBM_PF(7)
-#undef QHBM_PF
-  } else {
-#define QHBM_PF(I) r.p##I = *reinterpret_cast<const float4*>(st + global_index(t, 2u * uint32_t(tid + I * NT)));
-    QHBM_PF(0) QHBM_PF(1) QHBM_PF(2) QHBM_PF(3) QHBM_PF(4) QHBM_PF(5) QHBM_PF(6) QHBM_PF(7)
-#undef QHBM_PF
+  const uint32_t g0 = tile_offset(t, 2u * uint32_t(tid));
+#define QHBM_PF(I)                                                                                       \
+  {                                                                                                      \
+    const float2* sb = st + (t.tile_base | uni(tile_offset(t, uint32_t(I) << (K - 3))));                 \
+    r.p##I = *reinterpret_cast<const float4*>(sb + g0);                                                  \
   }
+  QHBM_PF(0) QHBM_PF(1) QHBM_PF(2) QHBM_PF(3) QHBM_PF(4) QHBM_PF(5) QHBM_PF(6) QHBM_PF(7)
+#undef QHBM_PF
 }
 template <int K, int NT>
 __device__ __forceinline__ void commit_tile(float2* __restrict__ tile, const TileRegs& r, int tid) {
+  const uint32_t s0 = swz(2u * uint32_t(tid));
 #define QHBM_CM(I)                                                    \
   {                                                                   \
-    const uint32_t sl = swz(2u * uint32_t(tid + I * NT));             \
+    const uint32_t sl = s0 ^ swz(uint32_t(I) << (K - 3));             \
     tile[sl] = make_float2(r.p##I.x, r.p##I.y);                       \
     tile[sl ^ 1u] = make_float2(r.p##I.z, r.p##I.w);                  \
   }
