@@ -114,6 +114,10 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
  *   "chunk_states"         states simulated per launch group, 0 = auto
  *   "workspace_budget_mb"  cap on the statevector workspace; 0 = a third of the device's memory
  *   "profile_events"       record HIP events around the pass kernels (qhbm_kernel_time_ms)
+ * Developer knobs for A/B measurements (defaults are the measured best): "measure_tile_qubits"
+ * (tile of measurement-only passes, 0 = largest), "adjoint_exchange" (1 = register-resident tile
+ * pair with one LDS exchange buffer, 0 = both tiles in LDS), "full_diag_threshold" /
+ * "adjoint_full_diag_threshold", "round_qubits" (must be 4), "force_general_kernels".
  */
 int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value);
 
