@@ -78,6 +78,7 @@ struct qhbm_engine {
   int64_t opt_budget_mb = 0;  // 0: a third of the device's memory, resolved at first use (budget_bytes)
   // plans
   bool plans_valid = false;
+  bool model_uploaded = false;  // everything upload_model copies to the device is current
   DevicePlan fwd, adj;
   DevBuf<DevTerm> terms, global_terms;  // global_terms: measured on the final state in HBM (too wide for a tile)
   DevBuf<ObsGroup> obs_groups;
@@ -89,6 +90,8 @@ struct qhbm_engine {
   DevBuf<int> shift_gates, shift_param;
   DevBuf<double> prog_acc;
   size_t coef_batch_programs = 0;  // copies of the forward plan's static words already in coef_batch
+  bool shift_ready = false;        // shift tables on the device match the model
+  uint32_t shift_programs = 0, shift_gate_count = 0;
   DevBuf<float> tile_grad;              // [chunk states * tiles, slots of one adjoint pass]
   DevBuf<unsigned long long> vals64;    // [U, n_ops] fixed-point accumulators of the expectation values
   DevBuf<float> op_scale, op_inv_scale; // per op: 2^(+-shift), see program.h kValueFracBits
@@ -192,6 +195,8 @@ int build_plans(qhbm_engine* h) {
     return fail(h, "forward plan: " + err);
   if (!build_plan(h->model, h->opt_adj_tile, 0, true, &h->adj.plan, &err, h->opt_full_adj)) return fail(h, "adjoint plan: " + err);
   h->fwd.uploaded = h->adj.uploaded = false;
+  h->model_uploaded = false;
+  h->shift_ready = false;
   h->coef_batch_programs = 0;
   h->plans_valid = true;
   return 0;
@@ -214,8 +219,12 @@ int upload_plan(qhbm_engine* h, DevicePlan* d) {
   return 0;
 }
 
+// Copies plans, observable tables and the parameter -> slot map to the device ONCE per model: a
+// compute call on an unchanged model issues no host copy and no synchronisation (it can be captured
+// into a hipGraph by the caller).
 int upload_model(qhbm_engine* h) {
   if (int rc = build_plans(h)) return rc;
+  if (h->model_uploaded) return 0;
   if (int rc = upload_plan(h, &h->fwd)) return rc;
   if (int rc = upload_plan(h, &h->adj)) return rc;
   if (!h->terms.p) {
@@ -254,6 +263,7 @@ int upload_model(qhbm_engine* h) {
   HIPCHK(h->param_slot_begin.upload(begin));
   HIPCHK(h->param_slots.upload(slots));
   HIPCHK(h->slot_factor.upload(ap.slot_factor));
+  h->model_uploaded = true;
   return 0;
 }
 
@@ -745,28 +755,33 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const floa
   // pairs are the batch: as many programs as the workspace holds run in ONE launch set, each on
   // its own copy of the coefficient buffer (PassArgs::prog_states).
   if (int rc = forward(h, d_bits, U, d_params, d_out_vals, -1, 0.0, s)) return rc;
-  std::vector<int> sg, sp;
-  std::vector<float> sv, sw;
-  for (size_t g = 0; g < h->model.gates.size(); ++g) {
-    const Gate& G = h->model.gates[g];
-    if (G.param_idx < 0 || G.kind == QHBM_GATE_I) continue;
-    if (G.kind == QHBM_GATE_ISWAPPOW)
-      return fail(h, "the two-term parameter-shift rule does not apply to ISWAPPOW; use the adjoint method");
-    sg.push_back(int(g)); sg.push_back(int(g));
-    sv.push_back(0.5f); sv.push_back(-0.5f);
-    sp.push_back(G.param_idx);
-    sw.push_back(float(1.5707963267948966 * double(G.scalar)));
+  if (!h->shift_ready) {  // shift tables: once per model
+    std::vector<int> sg, sp;
+    std::vector<float> sv, sw;
+    for (size_t g = 0; g < h->model.gates.size(); ++g) {
+      const Gate& G = h->model.gates[g];
+      if (G.param_idx < 0 || G.kind == QHBM_GATE_I) continue;
+      if (G.kind == QHBM_GATE_ISWAPPOW)
+        return fail(h, "the two-term parameter-shift rule does not apply to ISWAPPOW; use the adjoint method");
+      sg.push_back(int(g)); sg.push_back(int(g));
+      sv.push_back(0.5f); sv.push_back(-0.5f);
+      sp.push_back(G.param_idx);
+      sw.push_back(float(1.5707963267948966 * double(G.scalar)));
+    }
+    HIPCHK(hipStreamSynchronize(s));  // synchronous copies into buffers an earlier call on this stream may still read
+    HIPCHK(h->shift_gates.upload(sg));
+    HIPCHK(h->shift_vals.upload(sv));
+    HIPCHK(h->shift_param.upload(sp));
+    HIPCHK(h->shift_weight.upload(sw));
+    h->shift_programs = uint32_t(sg.size());
+    h->shift_gate_count = uint32_t(sp.size());
+    h->shift_ready = true;
   }
-  const uint32_t n_prog = uint32_t(sg.size()), n_shift_gates = uint32_t(sp.size());
+  const uint32_t n_prog = h->shift_programs, n_shift_gates = h->shift_gate_count;
   if (n_prog == 0) {
     if (P) HIPCHK(hipMemsetAsync(d_grad, 0, size_t(P) * sizeof(float), s));
     return 0;
   }
-  HIPCHK(hipStreamSynchronize(s));  // the uploads below are synchronous copies into buffers the stream may still read
-  HIPCHK(h->shift_gates.upload(sg));
-  HIPCHK(h->shift_vals.upload(sv));
-  HIPCHK(h->shift_param.upload(sp));
-  HIPCHK(h->shift_weight.upload(sw));
   DevicePlan& d = h->fwd;
   const uint32_t stride = uint32_t((d.plan.coef_init.size() + 64 + 63) / 64 * 64);
   // batch geometry: Uc states x Pc programs per launch set

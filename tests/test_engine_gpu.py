@@ -406,3 +406,34 @@ def test_random_circuits_of_every_gate_kind_at_18_qubits_against_c_oracle():
       vals, grad = eng.expectation_vjp(bits, params, up)
       np.testing.assert_allclose(vals.cpu().numpy(), want_vals, atol=5e-5 * max(1.0, _op_norm(ops).max()))
       np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=2e-4 * max(1.0, np.abs(want_grad).max()))
+
+
+def test_a_compute_call_is_asynchronous_and_graph_capturable():
+  """After the first call on a model the engine issues no host copy, allocation or synchronisation:
+  a VJP call can be captured into a HIP graph on the caller's stream and replayed with new inputs in
+  the same buffers (DESIGN.md 'HIP streams and graphs'); the replay equals an eager call bit for bit."""
+  rng = np.random.default_rng(12)
+  n, layers = 12, 3
+  gates, names = O.hea_gates(n, layers, "g")
+  ops = [O.tfim_ring_op(n)]
+  eng = _engine(n, gates, len(names), ops)
+  bits = torch.from_numpy(_random_bits(rng, 64, n)).cuda()
+  params = torch.from_numpy(rng.uniform(-1, 1, len(names)).astype(np.float32)).cuda()
+  up = torch.full((64, 1), 1.0 / 64, device="cuda")
+  eng.expectation_vjp(bits, params, up)       # first call: plans, uploads, workspace
+  graph = torch.cuda.CUDAGraph()
+  side = torch.cuda.Stream()
+  with torch.cuda.stream(side):
+    eng.expectation_vjp(bits, params, up)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=side):
+      g_vals, g_grad = eng.expectation_vjp(bits, params, up)
+  torch.cuda.synchronize()
+  new_params = torch.from_numpy(rng.uniform(-1, 1, len(names)).astype(np.float32)).cuda()
+  params.copy_(new_params)                    # same buffer, new values: the graph reads them at replay
+  graph.replay()
+  torch.cuda.synchronize()
+  vals, grad = eng.expectation_vjp(bits, params, up)
+  assert torch.equal(g_vals, vals) and torch.equal(g_grad, grad)
+  want = O.expectation(n, gates, new_params.cpu().numpy().astype(np.float64), bits.cpu().numpy(), ops)
+  np.testing.assert_allclose(vals.cpu().numpy(), want, atol=1e-4)
