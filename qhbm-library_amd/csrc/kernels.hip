@@ -132,32 +132,25 @@ __device__ __forceinline__ v2f conj_cs(v2f cs) { return v2f{cs.x, -cs.y}; }
 // compiler keep the file as ONE 1024-bit tuple and copy it on every update).
 template <int N> using iseq = std::make_integer_sequence<int, N>;
 
-// X**t, (a0, a1) <- (c a0 - i s a1, c a1 - i s a0) with -i s (x + i y) = (s y, -s x), on four pairs
-// per asm statement: the compiler pads every inline-asm block with an s_nop (it cannot
-// see the hazards inside), so fewer, longer blocks issue fewer of them; the eight independent
-// multiplies also go first, ahead of the FMAs that consume them.
-__device__ __forceinline__ void x_pair4(v2f& a0, v2f& a1, v2f& b0, v2f& b1, v2f& c0, v2f& c1, v2f& d0, v2f& d1, v2f cs) {
-  v2f t0, t1, t2, t3, t4, t5, t6, t7;
-  asm("v_pk_mul_f32 %[t0], %[a0], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
-      "v_pk_mul_f32 %[t1], %[a1], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
-      "v_pk_mul_f32 %[t2], %[b0], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
-      "v_pk_mul_f32 %[t3], %[b1], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
-      "v_pk_mul_f32 %[t4], %[c0], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
-      "v_pk_mul_f32 %[t5], %[c1], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
-      "v_pk_mul_f32 %[t6], %[d0], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
-      "v_pk_mul_f32 %[t7], %[d1], %[cs] op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
-      "v_pk_fma_f32 %[a0], %[a0], %[cs], %[t1] op_sel_hi:[1,0,1]\n\t"
-      "v_pk_fma_f32 %[a1], %[a1], %[cs], %[t0] op_sel_hi:[1,0,1]\n\t"
-      "v_pk_fma_f32 %[b0], %[b0], %[cs], %[t3] op_sel_hi:[1,0,1]\n\t"
-      "v_pk_fma_f32 %[b1], %[b1], %[cs], %[t2] op_sel_hi:[1,0,1]\n\t"
-      "v_pk_fma_f32 %[c0], %[c0], %[cs], %[t5] op_sel_hi:[1,0,1]\n\t"
-      "v_pk_fma_f32 %[c1], %[c1], %[cs], %[t4] op_sel_hi:[1,0,1]\n\t"
-      "v_pk_fma_f32 %[d0], %[d0], %[cs], %[t7] op_sel_hi:[1,0,1]\n\t"
-      "v_pk_fma_f32 %[d1], %[d1], %[cs], %[t6] op_sel_hi:[1,0,1]"
+// X**t core c*I - i*s*X (theta = pi t / 2 reduced to [-pi/2, pi/2], prep_coefs_kernel) as THREE SHEARS,
+//   [[c, -is], [-is, c]] = [[1, u], [0, 1]] [[1, 0], [v, 1]] [[1, u], [0, 1]],  u = -i tan(theta/2), v = -i sin(theta),
+// each one in-place packed FMA per pair (-i w (x + i y) = (w y, -w x)): 1.5 packed ops per amplitude
+// instead of the 2 of the direct form, no temporaries, determinant exactly 1.  ts = (tan(theta/2),
+// sin(theta)) is a wave-uniform SGPR pair; U^dagger is the same with ts negated.  Four pairs per asm
+// statement: the compiler pads every inline-asm block with an s_nop (it cannot see the hazards
+// inside), so fewer, longer blocks issue fewer of them, and dependent FMAs sit four apart.
+__device__ __forceinline__ void x_pair4(v2f& a0, v2f& a1, v2f& b0, v2f& b1, v2f& c0, v2f& c1, v2f& d0, v2f& d1, v2f ts) {
+#define QHBM_SH_T(D_, S_) "v_pk_fma_f32 %[" #D_ "], %[" #S_ "], %[ts], %[" #D_ "] op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]\n\t"
+#define QHBM_SH_S(D_, S_) "v_pk_fma_f32 %[" #D_ "], %[" #S_ "], %[ts], %[" #D_ "] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
+  asm(QHBM_SH_T(a0, a1) QHBM_SH_T(b0, b1) QHBM_SH_T(c0, c1) QHBM_SH_T(d0, d1)
+      QHBM_SH_S(a1, a0) QHBM_SH_S(b1, b0) QHBM_SH_S(c1, c0) QHBM_SH_S(d1, d0)
+      QHBM_SH_T(a0, a1) QHBM_SH_T(b0, b1) QHBM_SH_T(c0, c1)
+      "v_pk_fma_f32 %[d0], %[d1], %[ts], %[d0] op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]"
       : [a0] "+v"(a0), [a1] "+v"(a1), [b0] "+v"(b0), [b1] "+v"(b1), [c0] "+v"(c0), [c1] "+v"(c1),
-        [d0] "+v"(d0), [d1] "+v"(d1), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
-        [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7)
-      : [cs] "s"(cs));
+        [d0] "+v"(d0), [d1] "+v"(d1)
+      : [ts] "s"(ts));
+#undef QHBM_SH_T
+#undef QHBM_SH_S
 }
 template <int R, int RB, int... Q>
 __device__ __forceinline__ void apply_x_(v2f (&a)[1 << R], v2f cs, std::integer_sequence<int, Q...>) {
@@ -166,7 +159,7 @@ __device__ __forceinline__ void apply_x_(v2f (&a)[1 << R], v2f cs, std::integer_
            a[ins0<RB>(4 * Q + 2)], a[ins0<RB>(4 * Q + 2) | (1 << RB)], a[ins0<RB>(4 * Q + 3)],
            a[ins0<RB>(4 * Q + 3) | (1 << RB)], cs), ...);
 }
-// c*I - i*s*X  on register bit RB
+// c*I - i*s*X  on register bit RB  (cs = (tan(theta/2), sin(theta)), see x_pair4)
 template <int R, int RB>
 __device__ __forceinline__ void apply_x(v2f (&a)[1 << R], v2f cs) { apply_x_<R, RB>(a, cs, iseq<(1 << (R - 3))>{}); }
 
@@ -944,7 +937,8 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
     if (h0 & 0xfu) {
       QHBM_FOR_RB(R,
         if ((h0 >> J) & 1u) {
-          const v2f cs = conj_cs(rec_cs<L.x(J)>(cur, rb));  // U^dagger = c*I + i*s*X
+          const v2f xs = rec_cs<L.x(J)>(cur, rb);
+          const v2f cs = v2f{-xs.x, -xs.y};  // U^dagger = c*I + i*s*X: both shear coefficients negated
           if (rec_word<L.slot_x(J) - S0>(sv) != 0xffffffffu) g[J] = im_lam_x_psi<R, J>(p, l);
           apply_x<R, J>(p, cs);
           apply_x<R, J>(l, cs);
@@ -1433,9 +1427,17 @@ __global__ void prep_coefs_kernel(const CoefJob* __restrict__ jobs, int n_jobs,
     o[1] = float(sn);
     return;
   }
+  if (jb.mop == MOP_X) {  // X**t has period 2 in t: theta = pi t / 2 in [-pi/2, pi/2], |tan(theta/2)| <= 1
+    const double tr = t - 2.0 * rint(0.5 * t);
+    double s2, c2;
+    sincospi(0.5 * tr, &s2, &c2);
+    o[0] = float(s2 / (1.0 + c2));  // tan(theta / 2)
+    o[1] = float(s2);               // sin(theta)           (x_pair4's three shears)
+    return;
+  }
   double sh, ch;  // sin, cos of pi*t/2
   sincospi(0.5 * t, &sh, &ch);
-  if (jb.mop == MOP_X || jb.mop == MOP_Y) {
+  if (jb.mop == MOP_Y) {
     o[0] = float(ch);
     o[1] = float(sh);
     return;
@@ -1728,6 +1730,7 @@ __global__ void global_phase_kernel(const CoefJob* __restrict__ jobs, int n_jobs
     if (jb.mop != MOP_X && jb.mop != MOP_Y) continue;
     double t = double(jb.offset);
     if (jb.param_idx >= 0) t += double(jb.scalar) * double(params[jb.param_idx]);
+    if (jb.mop == MOP_X) t -= 2.0 * rint(0.5 * t);  // the reduced exponent prep_coefs_kernel applies
     acc += 0.5 * t;
   }
   part[threadIdx.x] = acc;

@@ -67,7 +67,7 @@ constexpr int kMeasTermWords = 4;
 
 // ---- one-qubit micro-ops / coefficient-job tags ------------------------------
 enum : uint32_t {
-  MOP_X = 1,      // c*I - i*s*X on a register bit     (coef: c, s)
+  MOP_X = 1,      // c*I - i*s*X on a register bit     (coef: tan(theta/2), sin(theta): three shears)
   MOP_Y = 2,      // c*I - i*s*Y                         (coef: c, s)
   MOP_MAT1 = 3,   // dense 2x2                           (coef: 8 floats, row-major re,im)
   MOP_MAT2 = 4,   // coefficient-job tag of a dense 4x4 (32 floats); executed by OP_GATE2
