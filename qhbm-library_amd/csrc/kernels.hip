@@ -584,18 +584,53 @@ template <int NV>
 __device__ __forceinline__ void apply_full(v2f (&a)[16], const uint32_t (&rv)[NV], RecBase rb, bool conj) {
   apply_full_<NV>(a, rv, rb, conj, iseq<15>{});
 }
-template <int... M>
-__device__ __forceinline__ void w_all_(float (&w)[16], const v2f (&p)[16], const v2f (&l)[16],
-                                       std::integer_sequence<int, M...>) {
-  ((w[M] = im_conj(l[M], p[M])), ...);
+// q[m] = (lam.re * psi.im, lam.im * psi.re): Im(conj(lam) psi) = q.x - q.y, subtracted once per SUM, not
+// per amplitude -- eight packed multiplies per asm statement (plain C++ here makes the SLP vectoriser
+// gather the scalars with 32 v_mov before it packs them).
+__device__ __forceinline__ void q8(v2f& q0, v2f& q1, v2f& q2, v2f& q3, v2f& q4, v2f& q5, v2f& q6, v2f& q7, v2f l0, v2f p0,
+                                   v2f l1, v2f p1, v2f l2, v2f p2, v2f l3, v2f p3, v2f l4, v2f p4, v2f l5, v2f p5, v2f l6,
+                                   v2f p6, v2f l7, v2f p7) {
+#define QHBM_Q(K_) "v_pk_mul_f32 %[q" #K_ "], %[l" #K_ "], %[p" #K_ "] op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+  asm(QHBM_Q(0) QHBM_Q(1) QHBM_Q(2) QHBM_Q(3) QHBM_Q(4) QHBM_Q(5) QHBM_Q(6)
+      "v_pk_mul_f32 %[q7], %[l7], %[p7] op_sel:[0,1] op_sel_hi:[1,0]"
+      : [q0] "=&v"(q0), [q1] "=&v"(q1), [q2] "=&v"(q2), [q3] "=&v"(q3), [q4] "=&v"(q4), [q5] "=&v"(q5), [q6] "=&v"(q6),
+        [q7] "=&v"(q7)
+      : [l0] "v"(l0), [p0] "v"(p0), [l1] "v"(l1), [p1] "v"(p1), [l2] "v"(l2), [p2] "v"(p2), [l3] "v"(l3), [p3] "v"(p3),
+        [l4] "v"(l4), [p4] "v"(p4), [l5] "v"(l5), [p5] "v"(p5), [l6] "v"(l6), [p6] "v"(p6), [l7] "v"(l7), [p7] "v"(p7));
+#undef QHBM_Q
 }
-template <int RB, int... P>
-__device__ __forceinline__ float wsum1_(const float (&w)[16], std::integer_sequence<int, P...>) {
-  return (w[ins0<RB>(P) | (1 << RB)] + ...);
+// Superset sums over three index bits, in place: z[k] <- sum of z[k'] over k' containing k.
+__device__ __forceinline__ void zeta3(v2f& z0, v2f& z1, v2f& z2, v2f& z3, v2f& z4, v2f& z5, v2f& z6, v2f& z7) {
+  z0 += z1; z2 += z3; z4 += z5; z6 += z7;
+  z0 += z2; z1 += z3; z4 += z6; z5 += z7;
+  z0 += z4; z1 += z5; z2 += z6; z3 += z7;
 }
-template <int RA, int RB, int... P>
-__device__ __forceinline__ float wsum2_(const float (&w)[16], std::integer_sequence<int, P...>) {
-  return (w[ins11<RA, RB>(P)] + ...);
+// Gradient partials of ALL one- and two-bit phase terms on the four register bits at once (FULL
+// instances): with A[k] = q[2k] + q[2k+1] and B[k] = q[2k+1] (k = register bits 1..3), the superset
+// sums of B are the terms that contain bit 0 and those of A the ones that do not -- 28 live packed
+// adds for the ten sums.  g1[J] = PH1 on bit J, g2[pair_index(JA, JB)] = PH2 on (JA, JB); sums of
+// terms the instance does not have are computed too and never stored (their slot is 0xffffffff).
+__device__ __forceinline__ void full_partials(const v2f (&p)[16], const v2f (&l)[16], float (&g1)[4], float (&g2)[6]) {
+  v2f q[16];
+  q8(q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], l[0], p[0], l[1], p[1], l[2], p[2], l[3], p[3], l[4], p[4], l[5],
+     p[5], l[6], p[6], l[7], p[7]);
+  q8(q[8], q[9], q[10], q[11], q[12], q[13], q[14], q[15], l[8], p[8], l[9], p[9], l[10], p[10], l[11], p[11], l[12],
+     p[12], l[13], p[13], l[14], p[14], l[15], p[15]);
+  v2f A0 = q[0] + q[1], A1 = q[2] + q[3], A2 = q[4] + q[5], A3 = q[6] + q[7], A4 = q[8] + q[9], A5 = q[10] + q[11],
+      A6 = q[12] + q[13], A7 = q[14] + q[15];
+  v2f B0 = q[1], B1 = q[3], B2 = q[5], B3 = q[7], B4 = q[9], B5 = q[11], B6 = q[13], B7 = q[15];
+  zeta3(A0, A1, A2, A3, A4, A5, A6, A7);
+  zeta3(B0, B1, B2, B3, B4, B5, B6, B7);
+  g1[0] = B0.x - B0.y;
+  g1[1] = A1.x - A1.y;
+  g1[2] = A2.x - A2.y;
+  g1[3] = A4.x - A4.y;
+  g2[0] = B1.x - B1.y;  // (0, 1)
+  g2[1] = B2.x - B2.y;  // (0, 2)
+  g2[2] = A3.x - A3.y;  // (1, 2)
+  g2[3] = B4.x - B4.y;  // (0, 3)
+  g2[4] = A5.x - A5.y;  // (1, 3)
+  g2[5] = A6.x - A6.y;  // (2, 3)
 }
 
 // Controlled phase: register bit J AND (a thread bit | a tile bit).  One code path for both
@@ -877,7 +912,6 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
                                              uint32_t wave, v2f (&p)[1 << R], v2f (&l)[1 << R], uint32_t TL,
                                              uint32_t tile_base, float* cells) {
   constexpr RecordLayout L(R, true);
-  constexpr int NR = 1 << R;
   constexpr int NB = 1;
   constexpr int S0 = L.slot0();
   const RecBase rb{recs + rec_off};
@@ -895,17 +929,11 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
   }
   float g1[4] = {0.f, 0.f, 0.f, 0.f};  // PH1 partials: reduced together with the X partials (slot group 0)
   if (h1 & kFullDiagFlag) {
-    // ---- all PH1/PH2 terms at once: w = Im(conj(lam) psi) per register value, per-term
-    // gradients are sums of w over the term's index set, then ONE conj-table multiply ----
-    float w[NR];
-    w_all_(w, p, l, iseq<NR>{});
-    if ((h0 >> 24) & 0x3fu) {
-      float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      QHBM_FOR_PAIR(R,
-        if ((h0 >> (24 + pair_index(JA, JB))) & 1u) g[pair_index(JA, JB)] = wsum2_<JA, JB>(w, iseq<4>{});)
-      add_slots8<1, NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3], g[4], g[5], 0.f, 0.f);
-    }
-    QHBM_FOR_RB(R, if ((h0 >> (4 + J)) & 1u) g1[J] = wsum1_<J>(w, iseq<8>{});)
+    // ---- all PH1/PH2 terms at once: the per-term gradients are sums of Im(conj(lam) psi) over
+    // the term's index set (full_partials), then ONE conj-table multiply ----
+    float g[6];
+    full_partials(p, l, g1, g);
+    if ((h0 >> 24) & 0x3fu) add_slots8<1, NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3], g[4], g[5], 0.f, 0.f);
     apply_full<NB>(p, cur, rb, true);
     apply_full<NB>(l, cur, rb, true);
   }

@@ -37,7 +37,6 @@ VARIANTS = {
                                 "  if (sv == 0x12345u) return;\n  if (true) return;\n  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2"),
     "no_butterfly": lambda t: once(t, "  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2",
                                    "  if (lane >= 0) { const float vv = ((g0 + g1) + (g2 + g3)) + ((g4 + g5) + (g6 + g7)); if (((lane >> 2) & 3) == (G8 & 3) && (lane >> 5) == (G8 >> 2) && sv != 0xffffffffu) cells[sv * NW + wave] = vv; return; }\n  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2"),
-    "no_w_sums": lambda t: in_instance(in_instance(t, "g1[J] = wsum1_<J>(w, iseq<8>{});", "g1[J] = w[J];"), "g[pair_index(JA, JB)] = wsum2_<JA, JB>(w, iseq<4>{});", "g[pair_index(JA, JB)] = w[JA + JB];"),
     "no_x_inner": lambda t: in_instance(t, "g[J] = im_lam_x_psi<R, J>(p, l);", "g[J] = p[0].x;"),
     "no_x_on_lambda": lambda t: in_instance(t, "          apply_x<R, J>(l, cs);\n", ""),
     "no_x_at_all": lambda t: in_instance(in_instance(in_instance(t, "          apply_x<R, J>(l, cs);\n", ""), "          apply_x<R, J>(p, cs);\n", ""),
