@@ -235,9 +235,25 @@ int upload_model(qhbm_engine* h) {
     std::stable_sort(t.begin(), t.end(), [](const DevTerm& a, const DevTerm& b) { return a.x < b.x; });
     std::vector<ObsGroup> groups;
     for (size_t k = 0; k < t.size(); ++k) {
-      if (k == 0 || t[k].x != t[k - 1].x || k % (kObsTermChunk / 2) == 0) groups.push_back(ObsGroup{t[k].x, 0, 0});
+      if (k == 0 || t[k].x != t[k - 1].x || k % (kObsTermChunk / 2) == 0) groups.push_back(ObsGroup{t[k].x, 0, 0, 0, 0});
       groups.back().end = uint32_t(k + 1);
       groups.back().has_imag |= t[k].ny & 1u;
+    }
+    {  // order the terms of every real-weight group by sign class (kernels.h ObsGroup)
+      const uint32_t amask = (obs_amps_per_thread(uint32_t(h->fwd.plan.n_eff)) - 1u) << 8;
+      auto cls = [&](const DevTerm& d) { return (d.z & 0xffu) == 0 ? 0 : ((d.z & amask) == 0 ? 1 : 2); };
+      size_t begin = 0;
+      for (ObsGroup& g : groups) {
+        if (!g.has_imag) {
+          std::stable_sort(t.begin() + begin, t.begin() + g.end,
+                           [&](const DevTerm& a, const DevTerm& b) { return cls(a) < cls(b); });
+          for (size_t k = begin; k < g.end; ++k) {
+            g.n_h += cls(t[k]) == 0;
+            g.n_l += cls(t[k]) == 1;
+          }
+        }
+        begin = g.end;
+      }
     }
     HIPCHK(h->terms.upload(t));
     HIPCHK(h->obs_groups.upload(groups));

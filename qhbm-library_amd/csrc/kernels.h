@@ -17,10 +17,16 @@ struct DevTerm {  // one Pauli term, amplitude-index bit space
 
 // Terms of equal x mask, consecutive in the x-sorted term array: [previous end, end).  A group
 // never straddles a multiple of kObsTermChunk / 2 (the kernel stages that many terms in LDS at a time).
+// Within a group of real weights the terms are ordered by how their sign (-1)^{popc(j & z)} varies
+// inside a workgroup of apply_observable_kernel (j = block | a << 8 | tid): first the n_h terms whose z
+// misses the thread bits (one pre-summed weight per amplitude slot a), then the n_l terms whose z
+// misses the `a` bits (one signed sum per thread), then the rest (per amplitude).
 struct ObsGroup {
   uint32_t x, end;
   uint32_t has_imag;  // some term of the group has an odd number of Y factors (imaginary weight)
+  uint32_t n_h, n_l;
 };
+constexpr uint32_t obs_amps_per_thread(uint32_t n) { return n >= 11 ? 8u : 4u; }  // A of apply_observable_kernel<A>
 constexpr uint32_t kObsTermChunk = 1024;
 
 size_t fwd_lds_bytes(int K);

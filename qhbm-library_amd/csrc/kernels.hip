@@ -1281,7 +1281,11 @@ __global__ __launch_bounds__(1024) void reduce_tiles_kernel(const float* __restr
 // (-1)^{popc((j ^ x) & z)}: the part from the block and `a` bits of j and from x & z is the same
 // for the whole workgroup, so it is folded into A pre-signed copies of the weight when the term is
 // staged; a thread evaluates only the parity of tid & z, once per term for all of its amplitudes
-// (3 + 2 A VALU per term instead of 4 per amplitude).
+// (3 + 2 A VALU per term instead of 4 per amplitude).  The kernel is VALU-bound on exactly these
+// sums, so the terms of a group come sorted by sign class (kernels.h ObsGroup): the ones whose z
+// misses the thread bits are pre-summed per amplitude slot once per workgroup, the ones whose z
+// misses the `a` bits cost one signed sum per THREAD, only the rest are added per amplitude (XXZ at
+// 20 qubits: 2 of the 57 terms), and lambda accumulates with one packed FMA per amplitude and group.
 // ================================================================================
 template <int A> struct ObsStage {
   float4 term[kObsTermChunk / 2];     // z bits, weight (re), weight (im), --      (general path)
@@ -1295,13 +1299,24 @@ __global__ __launch_bounds__(256) void apply_observable_kernel(
     const float* __restrict__ upstream, uint32_t n_ops, uint32_t state0) {
   __shared__ ObsStage<A> st;
   const uint32_t s_local = blockIdx.y;
-  const uint32_t jb = blockIdx.x * (256u * A);          // block bits of j
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give XCD k the k-th
+  // CONTIGUOUS eighth of the state, so that the partner runs j ^ x of every mask below that eighth's
+  // size are fetched (by this or a neighbouring workgroup) into the SAME L2 -- consecutive block ids
+  // would put the partners of masks just above the block size on eight different XCDs.
+  const uint32_t bx = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint32_t jb = bx * (256u * A);                   // block bits of j
   const uint32_t j0 = jb + threadIdx.x;
   const float2* ps = psi + (size_t(s_local) << n);
   const float* up = upstream + size_t(state0 + s_local) * n_ops;
-  float ar[A], ai[A];
+  // The kernel is bound by L2 -> L1 traffic (one gather of the state per mask, no reuse in L1): the
+  // block's own amplitudes are staged in LDS once and every mask that stays inside the block reads
+  // them there (XXZ at 20 qubits: 11 of the 20 gathers).
+  __shared__ v2f own[256 * A];
 #pragma unroll
-  for (int a = 0; a < A; ++a) ar[a] = ai[a] = 0.f;
+  for (int a = 0; a < A; ++a) own[threadIdx.x + 256u * a] = *reinterpret_cast<const v2f*>(&ps[j0 + 256u * a]);
+  v2f acc[A];
+#pragma unroll
+  for (int a = 0; a < A; ++a) acc[a] = v2f{0.f, 0.f};
   uint32_t g = 0;
   for (uint32_t k0 = 0; k0 < n_terms; k0 += kObsChunk) {
     const uint32_t k1 = min(n_terms, k0 + kObsChunk);
@@ -1321,18 +1336,35 @@ __global__ __launch_bounds__(256) void apply_observable_kernel(
       }
     }
     __syncthreads();
+    // one pre-summed weight per amplitude slot for the thread-independent terms of every real group
+    // of the chunk, written over the first of them (flip[begin][a])
+    for (uint32_t gi = g + threadIdx.x / uint32_t(A); gi < n_groups; gi += 256u / uint32_t(A)) {
+      const ObsGroup gr = groups[gi];
+      if (gr.end > k1) break;
+      if (gr.n_h > 1u) {
+        const uint32_t kb = gi ? groups[gi - 1u].end : 0u, a = threadIdx.x % uint32_t(A);
+        float sum = st.flip[kb - k0][a];
+        for (uint32_t k = kb + 1u; k < kb + gr.n_h; ++k) sum += st.flip[k - k0][a];
+        st.flip[kb - k0][a] = sum;
+      }
+    }
+    __syncthreads();
     uint32_t k = k0;
     for (; g < n_groups; ++g) {
       const ObsGroup gr = groups[g];  // wave-uniform
       if (gr.end > k1) break;
-      float2 v[A];
-      float cr[A], ci[A];
+      v2f v[A];
+      if (gr.x < 256u * A) {  // the mask permutes the workgroup's own block: served from its LDS copy
 #pragma unroll
-      for (int a = 0; a < A; ++a) {
-        v[a] = ps[(j0 + 256u * a) ^ gr.x];
-        cr[a] = ci[a] = 0.f;
+        for (int a = 0; a < A; ++a) v[a] = own[(threadIdx.x + 256u * a) ^ gr.x];
+      } else {
+#pragma unroll
+        for (int a = 0; a < A; ++a) v[a] = *reinterpret_cast<const v2f*>(&ps[(j0 + 256u * a) ^ gr.x]);
       }
       if (gr.has_imag) {
+        float cr[A], ci[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) cr[a] = ci[a] = 0.f;
         for (; k < gr.end; ++k) {
           const float4 t = st.term[k - k0];
           const uint32_t z = __float_as_uint(t.x);
@@ -1344,23 +1376,31 @@ __global__ __launch_bounds__(256) void apply_observable_kernel(
             ci[a] += __uint_as_float(__float_as_uint(t.z) ^ sgn);
           }
         }
+#pragma unroll
+        for (int a = 0; a < A; ++a) acc[a] += v2f{cr[a] * v[a].x - ci[a] * v[a].y, cr[a] * v[a].y + ci[a] * v[a].x};
       } else {  // real weights only (X/Z strings, even Y count): the common case
-        for (; k < gr.end; ++k) {
+        float c[A];
+        float s = 0.f;  // terms whose sign depends on the thread only: one signed sum for all A amplitudes
+        const uint32_t kl = k + gr.n_h, km = kl + gr.n_l;
+        for (uint32_t q = kl; q < km; ++q) {
+          const uint32_t z = __float_as_uint(st.term[q - k0].x);
+          s += __uint_as_float(__float_as_uint(st.flip[q - k0][0]) ^ (uint32_t(__popc(threadIdx.x & z)) << 31));
+        }
+#pragma unroll
+        for (int a = 0; a < A; ++a) c[a] = gr.n_h ? st.flip[k - k0][a] + s : s;
+        for (k = km; k < gr.end; ++k) {
           const uint32_t z = __float_as_uint(st.term[k - k0].x);
           const uint32_t sg0 = uint32_t(__popc(threadIdx.x & z)) << 31;
 #pragma unroll
-          for (int a = 0; a < A; ++a) cr[a] += __uint_as_float(__float_as_uint(st.flip[k - k0][a]) ^ sg0);
+          for (int a = 0; a < A; ++a) c[a] += __uint_as_float(__float_as_uint(st.flip[k - k0][a]) ^ sg0);
         }
-      }
 #pragma unroll
-      for (int a = 0; a < A; ++a) {
-        ar[a] += cr[a] * v[a].x - ci[a] * v[a].y;
-        ai[a] += cr[a] * v[a].y + ci[a] * v[a].x;
+        for (int a = 0; a < A; ++a) acc[a] += c[a] * v[a];  // one packed FMA per amplitude
       }
     }
   }
 #pragma unroll
-  for (int a = 0; a < A; ++a) lam[(size_t(s_local) << n) + j0 + 256u * a] = make_float2(ar[a], ai[a]);
+  for (int a = 0; a < A; ++a) lam[(size_t(s_local) << n) + j0 + 256u * a] = make_float2(acc[a].x, acc[a].y);
 }
 
 // ================================================================================

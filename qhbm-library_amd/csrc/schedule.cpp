@@ -751,27 +751,29 @@ std::string describe_plan(const Plan& p) {
   os << "\n";
   {  // micro-op census over all instance records (cost model input)
     const RecordLayout L(p.R, p.adjoint);
-    int n_inst = 0, n_full = 0, x = 0, ph1 = 0, ph2 = 0, fph1 = 0, fph2 = 0, cph = 0, groups = 0;
+    int n_inst = 0, n_full = 0, x = 0, ph1 = 0, ph2 = 0, fph1 = 0, fph2 = 0, cph = 0, cph_tile = 0, groups = 0;
     auto pc = [](uint32_t v) { return __builtin_popcount(v); };
     for (uint32_t off : p.record_offsets) {
       const uint32_t h0 = p.coef_init[off], h1 = p.coef_init[off + 1];
       ++n_inst;
       x += pc(h0 & 0xfu);
       cph += pc(h1 & 0xffu);
-      groups += ((h0 & 0xfu) != 0) + ((h1 & 0x0fu) != 0) + ((h1 & 0xf0u) != 0);
+      for (int k = 0; k < 8; ++k)
+        if ((h1 >> k & 1u) && (p.coef_init[off + L.pred(k)] >> 8)) ++cph_tile;  // predicate on a tile bit: workgroup-uniform
+      groups += ((h0 & 0xf0fu) != 0 || ((h1 & kFullDiagFlag) && ((h0 >> 4) & 0xfu))) + ((h1 & 0xffu) != 0);
       if (h1 & kFullDiagFlag) {
         ++n_full;
         fph1 += pc((h0 >> 4) & 0xfu);
         fph2 += pc((h0 >> 24) & 0x3fu);
-        groups += (((h0 >> 4) & 0xfu) != 0) + (((h0 >> 24) & 0x0fu) != 0) + (((h0 >> 24) & 0x30u) != 0);
+        groups += ((h0 >> 24) & 0x3fu) != 0;
       } else {
         ph1 += pc((h0 >> 8) & 0xfu);
         ph2 += pc((h0 >> 16) & 0x3fu);
-        groups += (((h0 >> 8) & 0xfu) != 0) + (((h0 >> 16) & 0x0fu) != 0) + (((h0 >> 16) & 0x30u) != 0);
+        groups += ((h0 >> 16) & 0x3fu) != 0;
       }
     }
     os << "  census: instances=" << n_inst << " (FULL " << n_full << ") X=" << x << " PH1=" << ph1 << " PH2=" << ph2
-       << " FULL-PH1=" << fph1 << " FULL-PH2=" << fph2 << " CPH=" << cph << " slot-groups=" << groups << "\n";
+       << " FULL-PH1=" << fph1 << " FULL-PH2=" << fph2 << " CPH=" << cph << " (tile predicate " << cph_tile << ") slot-groups=" << groups << "\n";
   }
   for (size_t i = 0; i < p.passes.size(); ++i) {
     const Pass& q = p.passes[i];

@@ -37,6 +37,11 @@ VARIANTS = {
                                 "  if (sv == 0x12345u) return;\n  if (true) return;\n  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2"),
     "no_butterfly": lambda t: once(t, "  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2",
                                    "  if (lane >= 0) { const float vv = ((g0 + g1) + (g2 + g3)) + ((g4 + g5) + (g6 + g7)); if (((lane >> 2) & 3) == (G8 & 3) && (lane >> 5) == (G8 >> 2) && sv != 0xffffffffu) cells[sv * NW + wave] = vv; return; }\n  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2"),
+    # potential of wave-uniform CPH predicates (wrong results): predicate := a wave bit, skipped per wave when off
+    "cph_wave_uniform": lambda t: t.replace("  const bool on = (((pred >> 8) ? tile_base : tl) >> (pred & 0xffu)) & 1u;\n  const float g = on ? sum_w1<R, J>(p, l) : 0.f;",
+                                            "  const bool on = (((pred >> 8) ? tile_base >> (pred & 0xffu) : (threadIdx.x >> 6))) & 1u;\n  if (__builtin_amdgcn_ballot_w64(on) == 0) return 0.f;\n  const float g = on ? sum_w1<R, J>(p, l) : 0.f;")
+                                   .replace("  const bool on = (((pred >> 8) ? tile_base : tl) >> (pred & 0xffu)) & 1u;\n  apply_ph1_v<R, J>(a, v2f{on ? cs.x : 1.f, on ? cs.y : 0.f});",
+                                            "  const bool on = (((pred >> 8) ? tile_base >> (pred & 0xffu) : (threadIdx.x >> 6))) & 1u;\n  if (__builtin_amdgcn_ballot_w64(on) == 0) return;\n  apply_ph1_v<R, J>(a, v2f{on ? cs.x : 1.f, on ? cs.y : 0.f});"),
     "no_x_inner": lambda t: in_instance(t, "g[J] = im_lam_x_psi<R, J>(p, l);", "g[J] = p[0].x;"),
     "no_x_on_lambda": lambda t: in_instance(t, "          apply_x<R, J>(l, cs);\n", ""),
     "no_x_at_all": lambda t: in_instance(in_instance(in_instance(t, "          apply_x<R, J>(l, cs);\n", ""), "          apply_x<R, J>(p, cs);\n", ""),
