@@ -117,7 +117,9 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
  * Developer knobs for A/B measurements (defaults are the measured best): "measure_tile_qubits"
  * (tile of measurement-only passes, 0 = largest), "adjoint_exchange" (1 = register-resident tile
  * pair with one LDS exchange buffer, 0 = both tiles in LDS), "full_diag_threshold" /
- * "adjoint_full_diag_threshold", "round_qubits" (must be 4), "force_general_kernels".
+ * "adjoint_full_diag_threshold", "round_qubits" (must be 4), "force_general_kernels",
+ * "cph_wave_bits" (1 = the scheduler maps the partner bits of boundary controlled phases to wave
+ * bits, so their predicates are wave-uniform and half the waves skip them).
  */
 int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value);
 

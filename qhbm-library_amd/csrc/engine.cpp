@@ -71,6 +71,7 @@ struct qhbm_engine {
   int opt_tile = 0, opt_adj_tile = 0, opt_profile = 0, opt_round = 0;
   int opt_full_fwd = 60, opt_full_adj = 60, opt_force_general = 0;
   int opt_meas_tile = 0;     // tile qubits of measurement-only passes (0 = largest)
+  int opt_cph_wave_bits = 1; // boundary controlled-phase predicates on wave bits (schedule.h Plan::cph_wave_bits)
   int opt_adj_exchange = 1;  // lean adjoint passes: register-resident tile pair + one LDS exchange buffer
   int retained_U = 0;  // final states of the last qhbm_expectation_retain still sit in psi
   int state_grad_U = 0;  // rows of state_grad the last adjoint VJP filled (qhbm_state_gradients)
@@ -191,9 +192,11 @@ int build_plans(qhbm_engine* h) {
   if (!h->have_circuit) return fail(h, "qhbm_set_circuit has not been called");
   if (h->model.n_ops > kMaxOps) return fail(h, "too many observables (max 1024)");
   std::string err;
-  if (!build_plan(h->model, h->opt_tile, h->opt_round, false, &h->fwd.plan, &err, h->opt_full_fwd, h->opt_meas_tile))
+  if (!build_plan(h->model, h->opt_tile, h->opt_round, false, &h->fwd.plan, &err, h->opt_full_fwd, h->opt_meas_tile,
+                  h->opt_cph_wave_bits != 0))
     return fail(h, "forward plan: " + err);
-  if (!build_plan(h->model, h->opt_adj_tile, 0, true, &h->adj.plan, &err, h->opt_full_adj)) return fail(h, "adjoint plan: " + err);
+  if (!build_plan(h->model, h->opt_adj_tile, 0, true, &h->adj.plan, &err, h->opt_full_adj, 0, h->opt_cph_wave_bits != 0))
+    return fail(h, "adjoint plan: " + err);
   h->fwd.uploaded = h->adj.uploaded = false;
   h->model_uploaded = false;
   h->shift_ready = false;
@@ -568,6 +571,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "adjoint_tile_qubits") { h->opt_adj_tile = int(value); h->plans_valid = false; }
   else if (k == "adjoint_exchange") h->opt_adj_exchange = int(value);
   else if (k == "measure_tile_qubits") { h->opt_meas_tile = int(value); h->plans_valid = false; }
+  else if (k == "cph_wave_bits") { h->opt_cph_wave_bits = int(value); h->plans_valid = false; }
   else if (k == "chunk_states") h->opt_chunk = value;
   else if (k == "workspace_budget_mb") h->opt_budget_mb = std::max<int64_t>(0, value);  // 0 = default
   else if (k == "profile_events") h->opt_profile = int(value);

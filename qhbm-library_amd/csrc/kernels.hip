@@ -635,11 +635,14 @@ __device__ __forceinline__ void full_partials(const v2f (&p)[16], const v2f (&l)
 
 // Controlled phase: register bit J AND (a thread bit | a tile bit).  One code path for both
 // predicate kinds (a two-way branch would make the structuriser copy the register file): the
-// phase degenerates to 1 where the predicate is false.
+// phase degenerates to 1 where the predicate is false.  The scheduler maps the predicate bits of a
+// round to WAVE bits where it can, so most predicates are uniform over a wave and half the waves
+// skip the micro-op altogether.
 template <int R, int J>
 __device__ __forceinline__ void cph_fwd(v2f (&a)[1 << R], v2f cs, uint32_t pred, uint32_t tl,
                                         uint32_t tile_base) {
   const bool on = (((pred >> 8) ? tile_base : tl) >> (pred & 0xffu)) & 1u;
+  if (__builtin_amdgcn_ballot_w64(on) == 0) return;  // off in the whole wave (tile bit, or a wave bit: schedule.cpp emit_round)
   apply_ph1_v<R, J>(a, v2f{on ? cs.x : 1.f, on ? cs.y : 0.f});
 }
 
@@ -647,6 +650,7 @@ template <int R, int J>
 __device__ __forceinline__ float cph_adj(v2f (&p)[1 << R], v2f (&l)[1 << R], v2f cs, uint32_t pred,
                                          uint32_t tl, uint32_t tile_base) {
   const bool on = (((pred >> 8) ? tile_base : tl) >> (pred & 0xffu)) & 1u;
+  if (__builtin_amdgcn_ballot_w64(on) == 0) return 0.f;  // off in the whole wave: nothing to do
   const float g = on ? sum_w1<R, J>(p, l) : 0.f;
   const v2f c2 = v2f{on ? cs.x : 1.f, on ? -cs.y : 0.f};
   apply_ph1_v<R, J>(p, c2);

@@ -235,20 +235,13 @@ class Builder {
       if (left == before) { *err = "internal: round packing made no progress"; return false; }
     }
     // Barrier elision.  A thread's amplitudes are those whose non-register local bits spell its
-    // id, so a WAVE owns the amplitudes whose highest free bits spell the wave index.  When two
-    // consecutive rounds leave the same top bits free, every wave reads back only what it wrote
-    // itself (LDS serves one wave's accesses in order): no workgroup barrier between them.
+    // id, so a WAVE owns the amplitudes whose wave bits (emit_round: round_wavemasks) spell the wave
+    // index.  When two consecutive rounds use the same wave bits, every wave reads back only what it
+    // wrote itself (LDS serves one wave's accesses in order): no workgroup barrier between them.
     const int wave_bits = K_ - R_ - 6;  // log2(waves per workgroup)
-    auto wave_mask = [&](uint32_t reg) {
-      uint32_t m = 0;
-      int taken = 0;
-      for (int b = K_ - 1; b >= 0 && taken < wave_bits; --b)
-        if (!(reg >> b & 1)) { m |= 1u << b; ++taken; }
-      return m;
-    };
     for (size_t r = 0; r + 1 < p->round_words.size(); ++r) {
       if (p->round_words[r + 1] != p->round_words[r] + kRoundWords) continue;  // something else sits in between
-      if (wave_bits <= 0 || wave_mask(p->round_regmasks[r]) == wave_mask(p->round_regmasks[r + 1]))
+      if (wave_bits <= 0 || p->round_wavemasks[r] == p->round_wavemasks[r + 1])
         p->prog[p->round_words[r]] |= kRoundNoBarrier;
     }
     return true;
@@ -401,14 +394,40 @@ class Builder {
     p->prog.push_back(reg);
     p->prog.push_back(first);
     p->prog.push_back(uint32_t(p->round_tl.size()));
-    {  // TL[tid]: bit j of tid goes to the j-th lowest local bit that is not a register bit
+    {  // TL[tid]: the thread's local index.  Lane bits (tid 0..5) go to the lowest free local bits,
+      // wave bits (tid 6..) to the rest.  A boundary controlled phase is predicated on a free local
+      // bit; when that bit spells the WAVE index the predicate is wave-uniform and the kernels skip
+      // the whole micro-op in the waves where it is off (cph_fwd / cph_adj) -- so the bits that this
+      // round's predicates use most become its wave bits, the highest free bits fill up.
+      const int wave_bits = std::max(0, K_ - R_ - 6);
       int free_pos[16], nf = 0;
       for (int b = 0; b < K_; ++b) if (!(reg >> b & 1)) free_pos[nf++] = b;
+      uint32_t wmask = 0;
+      if (plan_->cph_wave_bits && wave_bits > 0) {
+        int uses[16] = {0};
+        for (const Placed& pl : placed) if (pl.kind == 5 && !(pl.pred >> 8)) ++uses[pl.pred & 15u];
+        for (int taken = 0; taken < wave_bits; ++taken) {
+          int best = -1;
+          for (int j = nf - 1; j >= 0; --j) {
+            const int b = free_pos[j];
+            if (wmask >> b & 1u) continue;
+            if (uses[b] > 0 && (best < 0 || uses[b] > uses[best])) best = b;
+          }
+          if (best < 0) break;
+          wmask |= 1u << best;
+        }
+      }
+      for (int j = nf - 1, taken = popc(wmask); j >= 0 && taken < wave_bits; --j)
+        if (!(wmask >> free_pos[j] & 1u)) { wmask |= 1u << free_pos[j]; ++taken; }
+      int order[16], no = 0;  // free local bits in tid-bit order
+      for (int j = 0; j < nf; ++j) if (!(wmask >> free_pos[j] & 1u)) order[no++] = free_pos[j];
+      for (int j = 0; j < nf; ++j) if (wmask >> free_pos[j] & 1u) order[no++] = free_pos[j];
       for (uint32_t tid = 0; tid < (1u << (K_ - R_)); ++tid) {
         uint32_t tl = 0;
-        for (int j = 0; j < nf; ++j) if (tid >> j & 1) tl |= 1u << free_pos[j];
+        for (int j = 0; j < nf; ++j) if (tid >> j & 1) tl |= 1u << order[j];
         p->round_tl.push_back(tl);
       }
+      p->round_wavemasks.push_back(wmask);
     }
     p->round_regmasks.push_back(reg);
     ++p->n_rounds;
@@ -464,9 +483,10 @@ class Builder {
 }  // namespace
 
 bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Plan* plan, std::string* err,
-                int full_threshold, int meas_tile_bits) {
+                int full_threshold, int meas_tile_bits, bool cph_wave_bits) {
   *plan = Plan();
   plan->full_threshold = full_threshold;
+  plan->cph_wave_bits = cph_wave_bits;
   if (m.n < 1 || m.n > kMaxQubits - 1) { *err = "n_qubits must be in [1, 31]"; return false; }
   const int n_eff = std::max(m.n, kMinTileBits);
   const int k_cap = adjoint ? kMaxTileBits - 1 : kMaxTileBits;

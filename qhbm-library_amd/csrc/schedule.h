@@ -61,6 +61,7 @@ struct Pass {
   // statistics (DESIGN.md / bench roofline accounting)
   int n_mat_ops = 0, n_diag_terms = 0, n_rounds = 0, n_instances = 0;
   std::vector<uint32_t> round_regmasks;  // register-bit set of every OP_ROUND (introspection)
+  std::vector<uint32_t> round_wavemasks; // local bits that spell the WAVE index in that round (the rest are lane bits)
   std::vector<uint32_t> round_words;     // index in `prog` of every OP_ROUND's first word
   int n_meas_groups = 0, n_meas_terms = 0;
   int slot_base = 0, n_slots = 0;
@@ -76,6 +77,7 @@ struct Plan {
   std::vector<uint32_t> coef_init;  // static words of the coefficient buffer (records)
   std::vector<uint32_t> record_offsets;  // word offset of every instance record
   int full_threshold = 60;  // per-term cost above which an instance uses the FULL diagonal table
+  bool cph_wave_bits = true;  // map the partner bits of boundary controlled phases to wave bits (schedule.cpp emit_round)
   // forward: indices (into Model::terms) of the Pauli terms whose X-mask does not fit a tile; they
   // are measured on the final state in HBM by the strided-gather kernel
   std::vector<int> global_terms;
@@ -99,7 +101,7 @@ struct Model {
 // selects automatically.  Returns false and fills `err` on failure.
 // `meas_tile_bits`: tile size of measurement-only passes (0 = the largest the forward kernel has).
 bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Plan* out,
-                std::string* err, int full_threshold = 60, int meas_tile_bits = 0);
+                std::string* err, int full_threshold = 60, int meas_tile_bits = 0, bool cph_wave_bits = true);
 
 std::string describe_plan(const Plan& p);
 

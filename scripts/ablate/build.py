@@ -42,6 +42,9 @@ VARIANTS = {
                                             "  const bool on = (((pred >> 8) ? tile_base >> (pred & 0xffu) : (threadIdx.x >> 6))) & 1u;\n  if (__builtin_amdgcn_ballot_w64(on) == 0) return 0.f;\n  const float g = on ? sum_w1<R, J>(p, l) : 0.f;")
                                    .replace("  const bool on = (((pred >> 8) ? tile_base : tl) >> (pred & 0xffu)) & 1u;\n  apply_ph1_v<R, J>(a, v2f{on ? cs.x : 1.f, on ? cs.y : 0.f});",
                                             "  const bool on = (((pred >> 8) ? tile_base >> (pred & 0xffu) : (threadIdx.x >> 6))) & 1u;\n  if (__builtin_amdgcn_ballot_w64(on) == 0) return;\n  apply_ph1_v<R, J>(a, v2f{on ? cs.x : 1.f, on ? cs.y : 0.f});"),
+    # record coefficients as compile-time constants (only the two header words are loaded): what the
+    # scalar-load latency of the record fields costs
+    "const_coefs": lambda t: once(t, "  if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];", "  if constexpr (W >= 2) return 0x3f19999au; else if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];"),
     "no_x_inner": lambda t: in_instance(t, "g[J] = im_lam_x_psi<R, J>(p, l);", "g[J] = p[0].x;"),
     "no_x_on_lambda": lambda t: in_instance(t, "          apply_x<R, J>(l, cs);\n", ""),
     "no_x_at_all": lambda t: in_instance(in_instance(in_instance(t, "          apply_x<R, J>(l, cs);\n", ""), "          apply_x<R, J>(p, cs);\n", ""),
