@@ -37,11 +37,6 @@ VARIANTS = {
                                 "  if (sv == 0x12345u) return;\n  if (true) return;\n  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2"),
     "no_butterfly": lambda t: once(t, "  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2",
                                    "  if (lane >= 0) { const float vv = ((g0 + g1) + (g2 + g3)) + ((g4 + g5) + (g6 + g7)); if (((lane >> 2) & 3) == (G8 & 3) && (lane >> 5) == (G8 >> 2) && sv != 0xffffffffu) cells[sv * NW + wave] = vv; return; }\n  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2"),
-    # potential of wave-uniform CPH predicates (wrong results): predicate := a wave bit, skipped per wave when off
-    "cph_wave_uniform": lambda t: t.replace("  const bool on = (((pred >> 8) ? tile_base : tl) >> (pred & 0xffu)) & 1u;\n  const float g = on ? sum_w1<R, J>(p, l) : 0.f;",
-                                            "  const bool on = (((pred >> 8) ? tile_base >> (pred & 0xffu) : (threadIdx.x >> 6))) & 1u;\n  if (__builtin_amdgcn_ballot_w64(on) == 0) return 0.f;\n  const float g = on ? sum_w1<R, J>(p, l) : 0.f;")
-                                   .replace("  const bool on = (((pred >> 8) ? tile_base : tl) >> (pred & 0xffu)) & 1u;\n  apply_ph1_v<R, J>(a, v2f{on ? cs.x : 1.f, on ? cs.y : 0.f});",
-                                            "  const bool on = (((pred >> 8) ? tile_base >> (pred & 0xffu) : (threadIdx.x >> 6))) & 1u;\n  if (__builtin_amdgcn_ballot_w64(on) == 0) return;\n  apply_ph1_v<R, J>(a, v2f{on ? cs.x : 1.f, on ? cs.y : 0.f});"),
     # record coefficients as compile-time constants (only the two header words are loaded): what the
     # scalar-load latency of the record fields costs
     "const_coefs": lambda t: once(t, "  if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];", "  if constexpr (W >= 2) return 0x3f19999au; else if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];"),
@@ -91,6 +86,14 @@ VARIANTS.update({
     "fwd_no_x": lambda t: in_fwd_instance(t, "if ((h0 >> J) & 1u) apply_x<R, J>(a, rec_cs<L.x(J)>(rv));", "if (((h0 >> J) & 1u) && lane == 77) apply_x<R, J>(a, rec_cs<L.x(J)>(rv));"),
     "fwd_no_full": lambda t: in_fwd_instance(t, "if (h1 & kFullDiagFlag) apply_full<NV>(a, rv, false);", "if ((h1 & kFullDiagFlag) && lane == 77) apply_full<NV>(a, rv, false);"),
     "fwd_no_cph": lambda t: in_fwd_instance(t, "  if (h1 & 0xffu) {", "  if ((h1 & 0xffu) && lane == 77) {"),
+    # forward without its HBM traffic (tile neither loaded nor stored): what the memory phase adds to the compute
+    "fwd_no_tile_io": lambda t: once(once(t, "    TileRegs r;\n    prefetch_tile<K, NT>(r, st, t, tid);\n    commit_tile<K, NT>(tile, r, tid);\n  }\n  for (int i = tid; i < kMaxOps; i += NT) red[i] = 0ull;",
+                                          "  }\n  for (int i = tid; i < kMaxOps; i += NT) red[i] = 0ull;"),
+                                     "  if (a.flags & PASS_STORE) store_tile<K, NT>(tile, st, t, tid);\n}\n", "  if ((a.flags & PASS_STORE) && tid == 1000) store_tile<K, NT>(tile, st, t, tid);\n}\n"),
+    "fwd_const_no_trips": lambda t: VARIANTS["const_coefs"](VARIANTS["fwd_no_round_trips"](t)),
+    # stagger the first generation of forward workgroups (by hardware wave slot) to break lock step
+    "fwd_stagger": lambda t: once(t, "    TileRegs r;\n    prefetch_tile<K, NT>(r, st, t, tid);\n    commit_tile<K, NT>(tile, r, tid);\n  }\n  for (int i = tid; i < kMaxOps; i += NT) red[i] = 0ull;",
+                                  "    if (blockIdx.x < 1024u) { const uint32_t slot = __builtin_amdgcn_s_getreg(0x1804) & 3u; for (uint32_t i = 0; i < slot * 2u; ++i) __builtin_amdgcn_s_sleep(127); }\n    TileRegs r;\n    prefetch_tile<K, NT>(r, st, t, tid);\n    commit_tile<K, NT>(tile, r, tid);\n  }\n  for (int i = tid; i < kMaxOps; i += NT) red[i] = 0ull;"),
     "fwd_no_barriers": lambda t: once(t, "      if (!(w0 & kRoundNoBarrier)) __syncthreads();  // else the next round's waves read only their own writes\n      pc += 3;\n    } else if (opc == OP_GATE2) {",
                                       "      pc += 3;\n    } else if (opc == OP_GATE2) {"),
     "fwd_no_round_trips": lambda t: once(once(t, "      round_load<R>(tile, T, DB, amp);\n      for (uint32_t i = 0; i < n_inst; ++i) {", "      if (pc == 0) round_load<R>(tile, T, DB, amp);\n      for (uint32_t i = 0; i < n_inst; ++i) {"),
