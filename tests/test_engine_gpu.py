@@ -437,3 +437,29 @@ def test_a_compute_call_is_asynchronous_and_graph_capturable():
   assert torch.equal(g_vals, vals) and torch.equal(g_grad, grad)
   want = O.expectation(n, gates, new_params.cpu().numpy().astype(np.float64), bits.cpu().numpy(), ops)
   np.testing.assert_allclose(vals.cpu().numpy(), want, atol=1e-4)
+
+
+def test_x_exponents_far_outside_one_period():
+  """X**t is applied as three shears of the exponent reduced to one period (kernels.hip x_pair4,
+  prep_coefs_kernel): values, Jacobian and the exported state (global phase included) must not
+  notice the reduction, at the period boundaries either."""
+  n, P = 12, 5
+  rng = np.random.default_rng(77)
+  gates = []
+  for q in range(n):
+    gates.append((E.GATE_XPOW, q, -1, q % P, float(rng.uniform(-3, 3)), float(rng.uniform(-9, 9))))
+    gates.append((E.GATE_ZPOW, q, -1, (q + 1) % P, 0.7, 0.1 * q))
+  for q in range(n - 1):
+    gates.append((E.GATE_CZPOW, q, q + 1, (q + 2) % P, 1.3, -0.2))
+  for q, t in zip(range(n), [1.0, -1.0, 2.0, 3.0, -3.0, 0.5, -0.5, 1.5, 4.0, 0.0, 5.0, -7.0]):
+    gates.append((E.GATE_XPOW, q, -1, -1, 0.0, t))   # constants on / next to the period boundaries
+  for q in range(n):
+    gates.append((E.GATE_XPOW, q, -1, (q + 3) % P, -2.5, 6.0))
+  params = rng.uniform(-2, 2, P)
+  bits = _random_bits(rng, 3, n)
+  ops = [O.xxz_chain_op(n), O.random_pauli_op(n, 12, 5)]
+  eng = _engine(n, gates, P, ops)
+  check_values(eng, n, gates, params, bits, ops, rel=2e-5)
+  check_jacobian(eng, n, gates, params, bits[:2], ops, rel=2e-4)
+  sv = eng.statevector(bits[:1], params).cpu().numpy()[0]
+  np.testing.assert_allclose(sv, O.simulate(n, gates, params, list(bits[0])).ravel(), atol=3e-6)
