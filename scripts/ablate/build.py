@@ -40,6 +40,15 @@ VARIANTS = {
     # record coefficients as compile-time constants (only the two header words are loaded): what the
     # scalar-load latency of the record fields costs
     "const_coefs": lambda t: once(t, "  if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];", "  if constexpr (W >= 2) return 0x3f19999au; else if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];"),
+    # wave priority: instances at high priority, exchanges / tile I/O at low
+    "setprio": lambda t: once(once(t, "      instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n      rec_off += L.words();\n      cur[0] = nxt[0];",
+                                      "      __builtin_amdgcn_s_setprio(3);\n      instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n      __builtin_amdgcn_s_setprio(0);\n      rec_off += L.words();\n      cur[0] = nxt[0];"),
+                              "        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);",
+                              "        __builtin_amdgcn_s_setprio(3);\n        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);\n        __builtin_amdgcn_s_setprio(0);"),
+    "setprio_inv": lambda t: once(once(t, "      instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n      rec_off += L.words();\n      cur[0] = nxt[0];",
+                                      "      __builtin_amdgcn_s_setprio(0);\n      instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n      __builtin_amdgcn_s_setprio(3);\n      rec_off += L.words();\n      cur[0] = nxt[0];"),
+                              "        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);",
+                              "        __builtin_amdgcn_s_setprio(0);\n        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);\n        __builtin_amdgcn_s_setprio(3);"),
     "no_x_inner": lambda t: in_instance(t, "g[J] = im_lam_x_psi<R, J>(p, l);", "g[J] = p[0].x;"),
     "no_x_on_lambda": lambda t: in_instance(t, "          apply_x<R, J>(l, cs);\n", ""),
     "no_x_at_all": lambda t: in_instance(in_instance(in_instance(t, "          apply_x<R, J>(l, cs);\n", ""), "          apply_x<R, J>(p, cs);\n", ""),
