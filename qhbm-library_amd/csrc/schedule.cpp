@@ -91,22 +91,26 @@ std::vector<int> absorb(const std::vector<LoweredOp>& ops, const std::vector<int
                         const std::vector<char>& done, uint32_t S, uint32_t all_bits,
                         int* n_mat) {
   std::vector<int> out;
-  uint32_t blocked = 0;
+  // Per-bit order is kept between ops that do not commute.  Diagonal ops commute with each other:
+  // a diagonal op only waits for a pending NON-diagonal op on one of its bits (blocked_mat), a
+  // non-diagonal op for any pending op (blocked_any).  (Treating every pending op as a barrier shrinks
+  // the light cone of a chain circuit by two qubits per layer instead of one.)
+  uint32_t blocked_any = 0, blocked_mat = 0;
   *n_mat = 0;
   for (int oi : order) {
     if (done[oi]) continue;
     const LoweredOp& op = ops[oi];
+    const bool diag = op.type == LOW_DIAG;
     bool ok = false;
-    if (!(op.bits & blocked)) {
-      ok = op.type == LOW_DIAG ? (op.bits & S) != 0 : (op.bits & ~S) == 0;
-    }
+    if (!(op.bits & (diag ? blocked_mat : blocked_any))) ok = diag ? (op.bits & S) != 0 : (op.bits & ~S) == 0;
     if (ok) {
       out.push_back(oi);
-      if (op.type != LOW_DIAG) ++*n_mat;
+      if (!diag) ++*n_mat;
     } else {
-      blocked |= op.bits;
+      blocked_any |= op.bits;
+      if (!diag) blocked_mat |= op.bits;
     }
-    if ((blocked & all_bits) == all_bits) break;
+    if ((blocked_mat & all_bits) == all_bits) break;
   }
   return out;
 }
@@ -172,23 +176,29 @@ class Builder {
     while (left) {
       const size_t before = left;
       // ---- one round: light-cone over up to R register bits -------------------
-      uint32_t reg = 0, blocked = 0;
+      uint32_t reg = 0, blocked = 0, blocked_mat = 0;  // (see absorb(): diagonal ops pass pending diagonal ops)
       std::vector<size_t> seq;
       for (size_t i = 0; i < absorbed.size(); ++i) {
         if (emitted[i]) continue;
         const LoweredOp& op = ops[absorbed[i]];
-        if (op.bits & blocked) { blocked |= op.bits; continue; }
+        const bool diag = op.type == LOW_DIAG;
+        if (op.bits & (diag ? blocked_mat : blocked)) {
+          blocked |= op.bits;
+          if (!diag) blocked_mat |= op.bits;
+          continue;
+        }
         if (op.type == LOW_MAT1) {
           const uint32_t lb = to_local(*p, op.bits);
           if ((reg & lb) || popc(reg) < R_) { reg |= lb; seq.push_back(i); }
-          else blocked |= op.bits;
-        } else if (op.type == LOW_DIAG) {
+          else { blocked |= op.bits; blocked_mat |= op.bits; }
+        } else if (diag) {
           const uint32_t ll = to_local(*p, op.bits & S);
           if (ll & reg) seq.push_back(i);
           else if (popc(reg) < R_) { reg |= ll & (0u - ll); seq.push_back(i); }
           else blocked |= op.bits;
         } else {
           blocked |= op.bits;
+          blocked_mat |= op.bits;
         }
       }
       if (!seq.empty() && K_ > R_) {
@@ -204,15 +214,23 @@ class Builder {
         auto best = score(seq);
         for (int w = 0; w + R_ <= K_; ++w) {
           const uint32_t fixed = ((1u << R_) - 1u) << w;
-          uint32_t blk = 0;
+          uint32_t blk = 0, blk_mat = 0;
           std::vector<size_t> cand;
           for (size_t i = 0; i < absorbed.size(); ++i) {
             if (emitted[i]) continue;
             const LoweredOp& op = ops[absorbed[i]];
-            if (op.bits & blk) { blk |= op.bits; continue; }
+            const bool diag = op.type == LOW_DIAG;
+            if (op.bits & (diag ? blk_mat : blk)) {
+              blk |= op.bits;
+              if (!diag) blk_mat |= op.bits;
+              continue;
+            }
             if (op.type == LOW_MAT1 && (to_local(*p, op.bits) & fixed)) cand.push_back(i);
-            else if (op.type == LOW_DIAG && (to_local(*p, op.bits & S) & fixed)) cand.push_back(i);
-            else blk |= op.bits;
+            else if (diag && (to_local(*p, op.bits & S) & fixed)) cand.push_back(i);
+            else {
+              blk |= op.bits;
+              if (!diag) blk_mat |= op.bits;
+            }
           }
           const auto sc = score(cand);
           if (sc > best) { best = sc; seq.swap(cand); reg = fixed; }

@@ -49,6 +49,30 @@ VARIANTS = {
                                       "      __builtin_amdgcn_s_setprio(0);\n      instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n      __builtin_amdgcn_s_setprio(3);\n      rec_off += L.words();\n      cur[0] = nxt[0];"),
                               "        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);",
                               "        __builtin_amdgcn_s_setprio(0);\n        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);\n        __builtin_amdgcn_s_setprio(3);"),
+    # adjoint without the LDS staging of the tile pair at the start and the end of a pass (registers filled
+    # from / stored to HBM in the prefetch layout -- wrong amplitudes, same traffic): the upper bound of
+    # loading and storing in the first / last round's geometry directly
+    "adj_no_staging": lambda t: once(once(once(t,
+        "template <int K>\n__global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_kernel(",
+        """__device__ __forceinline__ void regs_from_tile(v2f (&a)[16], const TileRegs& r) {
+  a[0] = v2f{r.p0.x, r.p0.y}; a[1] = v2f{r.p0.z, r.p0.w}; a[2] = v2f{r.p1.x, r.p1.y}; a[3] = v2f{r.p1.z, r.p1.w};
+  a[4] = v2f{r.p2.x, r.p2.y}; a[5] = v2f{r.p2.z, r.p2.w}; a[6] = v2f{r.p3.x, r.p3.y}; a[7] = v2f{r.p3.z, r.p3.w};
+  a[8] = v2f{r.p4.x, r.p4.y}; a[9] = v2f{r.p4.z, r.p4.w}; a[10] = v2f{r.p5.x, r.p5.y}; a[11] = v2f{r.p5.z, r.p5.w};
+  a[12] = v2f{r.p6.x, r.p6.y}; a[13] = v2f{r.p6.z, r.p6.w}; a[14] = v2f{r.p7.x, r.p7.y}; a[15] = v2f{r.p7.z, r.p7.w};
+}
+template <int K, int NT>
+__device__ __forceinline__ void regs_to_global(const v2f (&a)[16], float2* __restrict__ st, const TileCtx& t, int tid) {
+  const uint32_t g0 = tile_offset(t, 2u * uint32_t(tid));
+#define QHBM_RG(I) { float2* sb = st + (t.tile_base | uni(tile_offset(t, uint32_t(I) << (K - 3)))); *reinterpret_cast<float4*>(sb + g0) = make_float4(a[2 * I].x, a[2 * I].y, a[2 * I + 1].x, a[2 * I + 1].y); }
+  QHBM_RG(0) QHBM_RG(1) QHBM_RG(2) QHBM_RG(3) QHBM_RG(4) QHBM_RG(5) QHBM_RG(6) QHBM_RG(7)
+#undef QHBM_RG
+}
+template <int K>
+__global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_kernel("""),
+        "  commit_tile<K, NT>(xt, rp, tid);\n  __syncthreads();\n  round_load<R>(xt, T, DB, p);\n  __syncthreads();\n  commit_tile<K, NT>(xt, rl, tid);\n  __syncthreads();\n  round_load<R>(xt, T, DB, l);\n",
+        "  regs_from_tile(p, rp);\n  regs_from_tile(l, rl);\n  __syncthreads();\n"),
+        "    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT>(xt, sp, t, tid);\n    __syncthreads();\n    round_store<R>(xt, T, DB, l);\n    __syncthreads();\n    store_tile<K, NT>(xt, sl, t, tid);\n",
+        "    regs_to_global<K, NT>(p, sp, t, tid);\n    regs_to_global<K, NT>(l, sl, t, tid);\n    __syncthreads();\n"),
     "no_x_inner": lambda t: in_instance(t, "g[J] = im_lam_x_psi<R, J>(p, l);", "g[J] = p[0].x;"),
     "no_x_on_lambda": lambda t: in_instance(t, "          apply_x<R, J>(l, cs);\n", ""),
     "no_x_at_all": lambda t: in_instance(in_instance(in_instance(t, "          apply_x<R, J>(l, cs);\n", ""), "          apply_x<R, J>(p, cs);\n", ""),
