@@ -790,11 +790,13 @@ std::string describe_plan(const Plan& p) {
   {  // micro-op census over all instance records (cost model input)
     const RecordLayout L(p.R, p.adjoint);
     int n_inst = 0, n_full = 0, x = 0, ph1 = 0, ph2 = 0, fph1 = 0, fph2 = 0, cph = 0, cph_tile = 0, groups = 0;
+    int x_hist[5] = {0, 0, 0, 0, 0};
     auto pc = [](uint32_t v) { return __builtin_popcount(v); };
     for (uint32_t off : p.record_offsets) {
       const uint32_t h0 = p.coef_init[off], h1 = p.coef_init[off + 1];
       ++n_inst;
       x += pc(h0 & 0xfu);
+      ++x_hist[pc(h0 & 0xfu)];
       cph += pc(h1 & 0xffu);
       for (int k = 0; k < 8; ++k)
         if ((h1 >> k & 1u) && (p.coef_init[off + L.pred(k)] >> 8)) ++cph_tile;  // predicate on a tile bit: workgroup-uniform
@@ -811,7 +813,8 @@ std::string describe_plan(const Plan& p) {
       }
     }
     os << "  census: instances=" << n_inst << " (FULL " << n_full << ") X=" << x << " PH1=" << ph1 << " PH2=" << ph2
-       << " FULL-PH1=" << fph1 << " FULL-PH2=" << fph2 << " CPH=" << cph << " (tile predicate " << cph_tile << ") slot-groups=" << groups << "\n";
+       << " FULL-PH1=" << fph1 << " FULL-PH2=" << fph2 << " CPH=" << cph << " (tile predicate " << cph_tile << ") slot-groups=" << groups << " instances by X count 0..4: " << x_hist[0] << "/" << x_hist[1] << "/"
+       << x_hist[2] << "/" << x_hist[3] << "/" << x_hist[4] << "\n";
   }
   for (size_t i = 0; i < p.passes.size(); ++i) {
     const Pass& q = p.passes[i];
