@@ -32,8 +32,11 @@ struct DevBuf {
     p = nullptr;
     n = 0;
   }
-  hipError_t reserve(size_t count) {
+  // Growing an existing buffer adds an eighth on top (per-batch buffers follow the number of unique
+  // bitstrings, which wanders from step to step); the first allocation is exact.
+  hipError_t reserve(size_t count, bool slack = true) {
     if (count <= n) return hipSuccess;
+    if (n && slack) count += count / 8;
     release();
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
     if (e == hipSuccess) n = count;
@@ -364,10 +367,18 @@ int values_end(qhbm_engine* h, int U, float* d_out, hipStream_t stream) {
   return 0;
 }
 
+// The state buffers grow with headroom: the number of unique bitstrings of a sampled batch changes
+// from step to step, and every new maximum would otherwise free and re-allocate tens of GiB (seconds).
 int ensure_state_buffers(qhbm_engine* h, uint32_t cs, bool with_lam) {
-  const size_t amps = size_t(cs) << h->fwd.plan.n_eff;
-  HIPCHK(h->psi.reserve(amps));
-  if (with_lam) HIPCHK(h->lam.reserve(amps));
+  const size_t have = std::min(h->psi.n, with_lam ? h->lam.n : h->psi.n) >> h->fwd.plan.n_eff;
+  size_t want = cs;
+  if (want > have) {
+    const size_t cap = std::max<size_t>(cs, budget_bytes(h) / ((with_lam ? 2 : 1) * state_bytes(h)));
+    want = std::min(cap, want + std::max<size_t>(want / 8, 1));
+  }
+  const size_t amps = want << h->fwd.plan.n_eff;
+  HIPCHK(h->psi.reserve(amps, false));
+  if (with_lam) HIPCHK(h->lam.reserve(amps, false));
   return 0;
 }
 
