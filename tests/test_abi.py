@@ -61,15 +61,28 @@ def test_planning_without_device_and_loud_compute_failure():
     eng.expectation(np.zeros((1, 4), np.int8), np.zeros(22, np.float32))
 
 
-@pytest.mark.parametrize("n,layers,max_fwd", [(12, 8, 1), (20, 16, 12), (24, 16, 16), (28, 32, 40)])
-def test_baseline_configs_schedule(n, layers, max_fwd):
-  """Light-cone scheduling: far fewer HBM passes than gates (944 gates at n=20)."""
+@pytest.mark.parametrize("n,layers,max_fwd,max_bwd", [(12, 8, 1, 1), (20, 16, 7, 7), (24, 16, 10, 10), (28, 32, 16, 21)])
+def test_baseline_configs_schedule(n, layers, max_fwd, max_bwd):
+  """Light-cone scheduling: far fewer HBM passes than gates (944 gates at n=20).  The bounds are the
+  pass counts of the scheduler whose diagonal terms wait only for non-diagonal gates (they commute
+  with each other): with every pending op a barrier the chain's cone shrinks twice as fast and config
+  3 needs 10 + 11 passes instead of 7 + 7."""
   op = O.xxz_chain_op(n) if n == 20 else O.tfim_ring_op(n)
   eng = _planner(n, layers, op)
   fwd, bwd = eng.num_passes()
   assert 1 <= fwd <= max_fwd
-  assert 1 <= bwd <= 2 * max_fwd
+  assert 1 <= bwd <= max_bwd
   assert eng.workspace_bytes(8) >= 8 * 8 * 2**n or n > 24
+
+
+def test_first_tile_of_a_chain_absorbs_the_whole_triangle():
+  """12 local qubits at the end of a nearest-neighbour chain: 12 + 11 + ... + 1 = 78 one-qubit gates
+  are inside the light cone of the first adjoint pass."""
+  eng = _planner(20, 16, O.xxz_chain_op(20))
+  text = eng.describe_schedule()
+  adjoint = text[text.index("adjoint plan"):]
+  first = [line for line in adjoint.splitlines() if line.strip().startswith("pass 0:")][0]
+  assert "mat_ops=78" in first, first
 
 
 def test_schedule_options_and_errors():
