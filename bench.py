@@ -362,7 +362,12 @@ def main():
                                 "achieved = bytes_per_launch / avg_launch_ms (HIP events on the launch stream)",
             "unfused_bytes_per_launch": unfused / per_step_launches,
             "fusion_factor": unfused / model if model > 0 else None,
+            "gates_per_launch": n_gate / per_step_launches,
             "valu": valu,
+            "note": ("the pass kernels are bound by fp32 VALU issue (valu.valu_active_frac), not by HBM: "
+                     "frac is the HBM rate of a launch that applies gates_per_launch gates per tile round "
+                     "trip, and it FALLS when the scheduler fuses more gates into a launch while the step "
+                     "gets faster (DESIGN.md section 5)"),
         },
     }
     if args.verify:
