@@ -1047,10 +1047,11 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   const uint32_t* prog = prog_base + a.prog_off;
   uint32_t w0 = uni(prog[0]);
   bool skip = (w0 & 0xffu) != OP_ROUND;  // (an empty program: nothing to un-apply)
-  if (a.zero_mask) {  // tail of the sweep: psi is identically zero on this tile (engine.cpp fill_args)
-    const uint32_t idx = uni(basis_index(bits + size_t(state0 + s_local) * n_user, n_user));
-    skip |= ((idx ^ t.tile_base) & a.zero_mask) != 0;
-  }
+  const uint32_t idx = uni(basis_index(bits + size_t(state0 + s_local) * n_user, n_user));
+  // tail of the sweep: psi is identically zero on this tile (engine.cpp fill_args)
+  if (a.zero_mask) skip |= ((idx ^ t.tile_base) & a.zero_mask) != 0;
+  uint32_t in_local = 0;  // the input bitstring on the tile's local bits (OP_ROUND word 4: dead waves)
+  for (int i = 0; i < K; ++i) in_local |= ((idx >> a.local_pos[i]) & 1u) << i;
   if (skip) {
     for (uint32_t i = tid; i < a.n_slots; i += NT) grow[i] = 0.f;
     return;
@@ -1081,13 +1082,23 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   round_load<R>(xt, T, DB, l);
   for (;;) {
     const uint32_t n_inst = (w0 & ~kRoundNoBarrier) >> 8;
-    for (uint32_t inst = 0; inst < n_inst; ++inst) {
-      rec_load<1>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
-      rec_load<1>(recs, rec_off + L.words() + L.slot0(), lane, svn);
-      instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);
-      rec_off += L.words();
-      cur[0] = nxt[0];
-      sv[0] = svn[0];
+    // A wave whose (wave-index) bits differ from the input bitstring on a bit that no non-diagonal gate
+    // will touch any more holds zeros of psi: nothing it could add to a gradient, nothing a later
+    // round reads from it but zeros -- it skips the instances and only takes part in the exchange.
+    const bool dead = uni((TL ^ in_local) & uni(prog[pc + 4])) != 0;
+    if (dead) {
+      rec_off += n_inst * L.words();
+      rec_load<1>(recs, rec_off, lane, cur);
+      rec_load<1>(recs, rec_off + L.slot0(), lane, sv);
+    } else {
+      for (uint32_t inst = 0; inst < n_inst; ++inst) {
+        rec_load<1>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
+        rec_load<1>(recs, rec_off + L.words() + L.slot0(), lane, svn);
+        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);
+        rec_off += L.words();
+        cur[0] = nxt[0];
+        sv[0] = svn[0];
+      }
     }
     pc += kRoundWords;
     const uint32_t w1 = uni(prog[pc]);

@@ -55,13 +55,15 @@ enum : uint32_t {
   // the coefficient buffer (see RecordLayout) drive the round; tl_table = offset (in the pass's part
   // of the tables buffer, PassArgs::tl_off) of the round's thread -> local-index table TL[tid]: the
   // bits of tid deposited on the non-register local bits, computed once by the scheduler instead of
-  // ~50 VALU per thread and round.
+  // ~50 VALU per thread and round.  Word 4 (adjoint): local index bits that (a) spell the WAVE index in
+  // this round and (b) have no non-diagonal gate left to un-apply -- psi is zero wherever such a bit
+  // differs from the input bitstring, so a wave whose bits differ skips the round's instances.
   OP_ROUND = 1,
   OP_MEASURE = 3,  // [op | n_groups<<8] then groups x {[xl] [n_terms] terms x {[zl] [zn] [coef bits] [op_idx | ny<<24]}}
   OP_GATE2 = 4,    // [op | kind<<8] [pos_q0 | pos_q1<<8 (local bits)] [coef_off] [slot]
 };
 constexpr uint32_t kRoundNoBarrier = 1u << 31;  // OP_ROUND word 0: the next op is a round whose waves own the same amplitudes
-constexpr int kRoundWords = 4;
+constexpr int kRoundWords = 5;  // [op | n_instances<<8 | flags] [register-bit mask] [first record] [tl_table] [dead mask]
 constexpr int kGate2Words = 4;
 constexpr int kMeasTermWords = 4;
 

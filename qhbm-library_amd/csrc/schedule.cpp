@@ -238,6 +238,12 @@ class Builder {
       }
       if (!seq.empty()) {
         for (int i = K_ - 1; i >= 0 && popc(reg) < R_; --i) if (!(reg >> i & 1)) reg |= 1u << i;
+        // local bits without a pending non-diagonal op at the START of this round (adjoint: psi is
+        // back to the input bit there)
+        uint32_t pending = pending_mat_outside_;
+        for (size_t i = 0; i < absorbed.size(); ++i)
+          if (!emitted[i] && ops[absorbed[i]].type != LOW_DIAG) pending |= ops[absorbed[i]].bits;
+        round_finished_local_ = adjoint_ ? to_local(*p, ~pending & S) : 0u;
         emit_round(p, ops, absorbed, seq, reg, S);
         for (size_t i : seq) { emitted[i] = 1; --left; }
       }
@@ -279,6 +285,10 @@ class Builder {
     ++p->n_slots;
     return slot - p->slot_base;
   }
+
+  // set by build_plan / emit_ops for the round being emitted
+  uint32_t pending_mat_outside_ = 0;   // index bits of non-diagonal ops that are neither done nor in this pass
+  uint32_t round_finished_local_ = 0;  // adjoint: local bits with no non-diagonal op left at the round's start
 
   CoefJob base_job(const LoweredOp& op) {
     const Gate& G = m_.gates[op.gate];
@@ -412,6 +422,8 @@ class Builder {
     p->prog.push_back(reg);
     p->prog.push_back(first);
     p->prog.push_back(uint32_t(p->round_tl.size()));
+    const size_t dead_word = p->prog.size();
+    p->prog.push_back(0u);  // dead mask, set below
     {  // TL[tid]: the thread's local index.  Lane bits (tid 0..5) go to the lowest free local bits,
       // wave bits (tid 6..) to the rest.  A boundary controlled phase is predicated on a free local
       // bit; when that bit spells the WAVE index the predicate is wave-uniform and the kernels skip
@@ -422,9 +434,12 @@ class Builder {
       for (int b = 0; b < K_; ++b) if (!(reg >> b & 1)) free_pos[nf++] = b;
       uint32_t wmask = 0;
       if (plan_->cph_wave_bits && wave_bits > 0) {
+        // first choice: finished bits (half the waves skip the WHOLE round per such bit)
+        for (int j = nf - 1, taken = 0; j >= 0 && taken < wave_bits; --j)
+          if (round_finished_local_ >> free_pos[j] & 1u) { wmask |= 1u << free_pos[j]; ++taken; }
         int uses[16] = {0};
         for (const Placed& pl : placed) if (pl.kind == 5 && !(pl.pred >> 8)) ++uses[pl.pred & 15u];
-        for (int taken = 0; taken < wave_bits; ++taken) {
+        for (int taken = popc(wmask); taken < wave_bits; ++taken) {
           int best = -1;
           for (int j = nf - 1; j >= 0; --j) {
             const int b = free_pos[j];
@@ -446,6 +461,7 @@ class Builder {
         p->round_tl.push_back(tl);
       }
       p->round_wavemasks.push_back(wmask);
+      p->prog[dead_word] = wmask & round_finished_local_;
     }
     p->round_regmasks.push_back(reg);
     ++p->n_rounds;
@@ -670,6 +686,14 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     }
     Pass p = b.begin_pass(best_S);
     p.slot_base = int(plan->slot_gate.size());
+    {
+      std::vector<char> here(ops.size(), 0);
+      for (int oi : best_list) here[size_t(oi)] = 1;
+      uint32_t pend = 0;
+      for (size_t oi = 0; oi < ops.size(); ++oi)
+        if (!done[oi] && !here[oi] && ops[oi].type != LOW_DIAG) pend |= ops[oi].bits;
+      b.pending_mat_outside_ = pend;
+    }
     if (!b.emit_ops(&p, ops, best_list, err)) return false;
     for (int oi : best_list) { done[oi] = 1; op_pass[oi] = int(plan->passes.size()); ++n_done; }
     plan->passes.push_back(std::move(p));
@@ -825,6 +849,10 @@ std::string describe_plan(const Plan& p) {
        << " meas_terms=" << q.n_meas_terms << " slots=" << q.n_slots
        << (q.is_measure_only ? " [measure-only]" : "") << " words=" << q.prog.size() << " regs=";
     for (size_t r = 0; r < q.round_regmasks.size(); ++r) os << (r ? "," : "") << std::hex << q.round_regmasks[r] << std::dec;
+    if (p.adjoint) {
+      os << " dead=";
+      for (size_t r = 0; r < q.round_words.size(); ++r) os << (r ? "," : "") << std::hex << q.prog[q.round_words[r] + 4] << std::dec;
+    }
     os << "\n";
   }
   return os.str();
