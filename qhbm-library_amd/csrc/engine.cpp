@@ -176,15 +176,17 @@ void fill_args(const Plan& plan, const Model& m, std::vector<PassArgs>* args, st
     // psi is (the circuit's FIRST ops, those of passes p..last) applied to the basis state, and no
     // bit that is non-local in all of those passes has been acted on other than diagonally: psi is
     // zero wherever such a bit differs from the input bitstring, so those tiles add nothing to any
-    // gradient, and lambda there is only ever paired with zero psi in later passes (the masks are
-    // nested).  The kernel skips them outright.
-    uint32_t common = ~0u;
+    // gradient, and lambda there is only ever paired with zero psi in later passes.  The kernel
+    // skips them outright.
+    // "Acted on" means by a non-diagonal op of pass p or later; a bit that is local in a later pass
+    // without a gate there (the low bits every tile holds, padding) is as good: the tiles skipped now
+    // are read again then, but hold zeros of psi (to rounding) next to a stale lambda.
+    uint32_t later_mat = 0;
     for (size_t i = args->size(); i-- > 0;) {
       uint32_t nl = 0;
       for (uint32_t k = 0; k < (*args)[i].n_nonlocal; ++k) nl |= 1u << (*args)[i].nonlocal_pos[k];
-      common &= nl;
-      (*args)[i].zero_mask = common;
-      if (!common) break;
+      later_mat |= plan.passes[i].mat_bits;
+      (*args)[i].zero_mask = nl & ~later_mat;
     }
   }
 }
@@ -966,7 +968,9 @@ int qhbm_traffic_model(qhbm_engine* h, int U, int with_vjp, double* fwd_bytes, d
     std::vector<uint32_t> prog, tables;
     fill_args(h->adj.plan, h->model, &args, &prog, &tables);
     for (size_t i = 0; i < args.size(); ++i) {
-      const double live = 1.0 / double(1ull << __builtin_popcount(args[i].zero_mask));  // tiles not skipped
+      double live = 1.0 / double(1ull << __builtin_popcount(args[i].zero_mask));  // tiles not skipped
+      // a tile without the low index bits moves whole 128-byte lines for 8 << c contiguous bytes
+      if (args[i].c < 4) live = std::min(1.0, live * double(1u << (4 - args[i].c)));
       b += live * tile_all * 2.0 * ((h->adj.plan.passes[i].flags & PASS_STORE) ? 2.0 : 1.0);
     }
   }

@@ -354,12 +354,26 @@ __device__ __forceinline__ uint32_t tile_offset(const TileCtx& t, uint32_t l) {
 }
 __device__ __forceinline__ uint32_t global_index(const TileCtx& t, uint32_t l) { return t.tile_base | tile_offset(t, l); }
 
-template <int K, int NT>
+// (C0: the pass may have no index bit 0 among its local bits -- adjoint tail passes only)
+template <int K, int NT, bool C0 = false>
 __device__ __forceinline__ void store_tile(const float2* __restrict__ tile, float2* __restrict__ st,
                                            const TileCtx& t, int tid) {
   static_assert((1 << (K - 1)) / NT == 8, "a thread owns eight float4 of its tile");
   const uint32_t g0 = tile_offset(t, 2u * uint32_t(tid));
   const uint32_t s0 = swz(2u * uint32_t(tid));
+  if (C0 && t.c == 0) {  // index bit 0 is not local (tail passes of the adjoint sweep): two 8-byte stores
+    const uint32_t g1 = g0 | tile_offset(t, 1u);
+#define QHBM_ST(I)                                                                                     \
+  {                                                                                                    \
+    float2* sb = st + (t.tile_base | uni(tile_offset(t, uint32_t(I) << (K - 3))));                     \
+    const uint32_t s = s0 ^ swz(uint32_t(I) << (K - 3));                                               \
+    sb[g0] = tile[s];                                                                                  \
+    sb[g1] = tile[s ^ 1u];                                                                             \
+  }
+    QHBM_ST(0) QHBM_ST(1) QHBM_ST(2) QHBM_ST(3) QHBM_ST(4) QHBM_ST(5) QHBM_ST(6) QHBM_ST(7)
+#undef QHBM_ST
+    return;
+  }
 #define QHBM_ST(I)                                                                                     \
   {                                                                                                    \
     float2* sb = st + (t.tile_base | uni(tile_offset(t, uint32_t(I) << (K - 3))));                     \
@@ -377,10 +391,22 @@ __device__ __forceinline__ void store_tile(const float2* __restrict__ tile, floa
 struct TileRegs {
   float4 p0, p1, p2, p3, p4, p5, p6, p7;
 };
-template <int K, int NT>
+template <int K, int NT, bool C0 = false>
 __device__ __forceinline__ void prefetch_tile(TileRegs& r, const float2* __restrict__ st, const TileCtx& t, int tid) {
   static_assert((1 << (K - 1)) / NT == 8, "a thread owns eight float4 of its tile");
   const uint32_t g0 = tile_offset(t, 2u * uint32_t(tid));
+  if (C0 && t.c == 0) {  // index bit 0 is not local: the two amplitudes of a float4 are 8-byte loads
+    const uint32_t g1 = g0 | tile_offset(t, 1u);
+#define QHBM_PF(I)                                                                                       \
+  {                                                                                                      \
+    const float2* sb = st + (t.tile_base | uni(tile_offset(t, uint32_t(I) << (K - 3))));                 \
+    const float2 a = sb[g0], b = sb[g1];                                                                 \
+    r.p##I = make_float4(a.x, a.y, b.x, b.y);                                                            \
+  }
+    QHBM_PF(0) QHBM_PF(1) QHBM_PF(2) QHBM_PF(3) QHBM_PF(4) QHBM_PF(5) QHBM_PF(6) QHBM_PF(7)
+#undef QHBM_PF
+    return;
+  }
 #define QHBM_PF(I)                                                                                       \
   {                                                                                                      \
     const float2* sb = st + (t.tile_base | uni(tile_offset(t, uint32_t(I) << (K - 3))));                 \
@@ -1059,8 +1085,8 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   float2* sp = psi + (size_t(s_local) << a.n);
   float2* sl = lam + (size_t(s_local) << a.n);
   TileRegs rp, rl;
-  prefetch_tile<K, NT>(rp, sp, t, tid);
-  prefetch_tile<K, NT>(rl, sl, t, tid);
+  prefetch_tile<K, NT, true>(rp, sp, t, tid);
+  prefetch_tile<K, NT, true>(rl, sl, t, tid);
   for (uint32_t i = tid; i < a.n_slots * NW; i += NT) cells[i] = 0.f;
 
   constexpr RecordLayout L(R, true);
@@ -1130,11 +1156,11 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   if (a.flags & PASS_STORE) {
     round_store<R>(xt, T, DB, p);
     __syncthreads();
-    store_tile<K, NT>(xt, sp, t, tid);
+    store_tile<K, NT, true>(xt, sp, t, tid);
     __syncthreads();
     round_store<R>(xt, T, DB, l);
     __syncthreads();
-    store_tile<K, NT>(xt, sl, t, tid);
+    store_tile<K, NT, true>(xt, sl, t, tid);
   } else {
     __syncthreads();  // the cells of every wave are complete
   }
@@ -1176,8 +1202,8 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
   float2* sl = lam + (size_t(s_local) << a.n);
   {
     TileRegs rp, rl;
-    prefetch_tile<K, NT>(rp, sp, t, tid);
-    prefetch_tile<K, NT>(rl, sl, t, tid);
+    prefetch_tile<K, NT, true>(rp, sp, t, tid);
+    prefetch_tile<K, NT, true>(rl, sl, t, tid);
     commit_tile<K, NT>(tp, rp, tid);
     commit_tile<K, NT>(tl, rl, tid);
   }
@@ -1254,8 +1280,8 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
   __syncthreads();
   flush_cells<NT, NW>(cells, grow, a.n_slots, tid);
   if (a.flags & PASS_STORE) {
-    store_tile<K, NT>(tp, sp, t, tid);
-    store_tile<K, NT>(tl, sl, t, tid);
+    store_tile<K, NT, true>(tp, sp, t, tid);
+    store_tile<K, NT, true>(tl, sl, t, tid);
   }
 }
 

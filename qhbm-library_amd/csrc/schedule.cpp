@@ -521,6 +521,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   *plan = Plan();
   plan->full_threshold = full_threshold;
   plan->cph_wave_bits = cph_wave_bits;
+  plan->tail_tiles = cph_wave_bits;  // (one developer switch for the scheduler's round-2 layout choices)
   if (m.n < 1 || m.n > kMaxQubits - 1) { *err = "n_qubits must be in [1, 31]"; return false; }
   const int n_eff = std::max(m.n, kMinTileBits);
   const int k_cap = adjoint ? kMaxTileBits - 1 : kMaxTileBits;
@@ -600,6 +601,23 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
       const uint32_t low = (1u << c_min) - 1;
       const int h = K - c_min;
       for (int p = c_min; p + h <= n_eff; ++p) cands.push_back(low | (((1u << h) - 1) << p));
+      // Adjoint tail: once no non-diagonal op is left on the low c_min bits, psi is zero wherever they
+      // differ from the input bitstring, and a tile that still holds them spends 2^c_min times the work
+      // on zeros.  Tiles over the bits that still have gates (8-byte HBM accesses, kernels.hip
+      // prefetch_tile / store_tile with c == 0) touch the same lines for a sixteenth of the work.
+      if (adjoint && plan->tail_tiles) {
+        uint32_t pending_mat = 0;
+        for (size_t oi = 0; oi < ops.size(); ++oi) if (!done[oi] && ops[oi].type != LOW_DIAG) pending_mat |= ops[oi].bits;
+        if (!(pending_mat & low)) {
+          std::vector<int> ub;
+          for (int bit = 0; bit < n_eff; ++bit) if (pending_mat >> bit & 1u) ub.push_back(bit);
+          for (size_t p0 = 0; p0 + size_t(K) <= ub.size(); ++p0) {
+            uint32_t S = 0;
+            for (int k = 0; k < K; ++k) S |= 1u << ub[p0 + size_t(k)];
+            cands.push_back(S);
+          }
+        }
+      }
       // demand-driven: bits of the earliest ready ops (non-diagonal first)
       for (int with_diag = 0; with_diag < 2; ++with_diag) {
         uint32_t S = low, blocked = 0;

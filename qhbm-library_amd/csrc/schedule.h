@@ -77,6 +77,7 @@ struct Plan {
   std::vector<uint32_t> coef_init;  // static words of the coefficient buffer (records)
   std::vector<uint32_t> record_offsets;  // word offset of every instance record
   int full_threshold = 60;  // per-term cost above which an instance uses the FULL diagonal table
+  bool tail_tiles = true;     // adjoint tail passes may drop the low index bits once they have no gate left (schedule.cpp)
   bool cph_wave_bits = true;  // map the partner bits of boundary controlled phases to wave bits (schedule.cpp emit_round)
   // forward: indices (into Model::terms) of the Pauli terms whose X-mask does not fit a tile; they
   // are measured on the final state in HBM by the strided-gather kernel
