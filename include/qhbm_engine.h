@@ -118,8 +118,10 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
  * (tile of measurement-only passes, 0 = largest), "adjoint_exchange" (1 = register-resident tile
  * pair with one LDS exchange buffer, 0 = both tiles in LDS), "full_diag_threshold" /
  * "adjoint_full_diag_threshold", "round_qubits" (must be 4), "force_general_kernels",
- * "cph_wave_bits" (1 = the scheduler maps the partner bits of boundary controlled phases to wave
- * bits, so their predicates are wave-uniform and half the waves skip them).
+ * "cph_wave_bits" (1 = the scheduler's layout choices of round 2: the partner bits of boundary
+ * controlled phases and the bits with no gate left become wave bits, so that whole waves skip work
+ * on predicates that are off / on zeros of psi, and adjoint tail passes use tiles without the low
+ * index bits; 0 = the plain layout, for A/B measurements).
  */
 int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value);
 
