@@ -463,3 +463,37 @@ def test_x_exponents_far_outside_one_period():
   check_jacobian(eng, n, gates, params, bits[:2], ops, rel=2e-4)
   sv = eng.statevector(bits[:1], params).cpu().numpy()[0]
   np.testing.assert_allclose(sv, O.simulate(n, gates, params, list(bits[0])).ravel(), atol=3e-6)
+
+
+@pytest.mark.parametrize("tile", [10, 11])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_deep_chain_with_and_without_the_scheduler_layout_choices(layout, tile):
+  """A circuit deep enough for the adjoint tail -- bits with no gate left: dead waves (tile 11: one wave
+  bit), tiles without the low index bits (tile 10), pruning on every finished non-local bit -- against
+  the oracle, with the scheduler's layout choices on (default) and off (`cph_wave_bits` = 0, the plain
+  layout kept for A/B measurements); the two engines must also agree with each other far inside the
+  oracle tolerance."""
+  n, layers = 15, 10
+  rng = np.random.default_rng(4242)
+  gates, names = O.hea_gates(n, layers, "deep")
+  params = rng.uniform(-1, 1, len(names))
+  ops = [O.xxz_chain_op(n)]
+  bits = _random_bits(rng, 2, n)
+  opts = dict(tile_qubits=tile, adjoint_tile_qubits=tile)
+  eng = _engine(n, gates, len(names), ops, cph_wave_bits=layout, **opts)
+  fwd, bwd = eng.num_passes()
+  assert fwd >= 4 and bwd >= 4
+  if layout:
+    adjoint = eng.describe_schedule()
+    adjoint = adjoint[adjoint.index("adjoint plan"):]
+    dead = [tok for line in adjoint.splitlines() if "dead=" in line for tok in line.split("dead=")[1].split(",")]
+    if tile == 10:
+      assert " c=0 " in adjoint            # a tail pass without the low index bits
+    else:
+      assert any(tok != "0" for tok in dead)  # rounds in which some waves hold zeros only
+  check_values(eng, n, gates, params, bits, ops, rel=3e-5)
+  want_jac = check_jacobian(eng, n, gates, params, bits[:1], ops, rel=3e-4)
+  other = _engine(n, gates, len(names), ops, cph_wave_bits=1 - layout, **opts)
+  _, jac = other.expectation_jacobian(bits[:1], params)
+  _, mine = eng.expectation_jacobian(bits[:1], params)
+  np.testing.assert_allclose(mine.cpu().numpy(), jac.cpu().numpy(), atol=2e-5 * max(1.0, np.abs(want_jac).max()), rtol=0)
