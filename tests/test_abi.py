@@ -61,7 +61,7 @@ def test_planning_without_device_and_loud_compute_failure():
     eng.expectation(np.zeros((1, 4), np.int8), np.zeros(22, np.float32))
 
 
-@pytest.mark.parametrize("n,layers,max_fwd,max_bwd", [(12, 8, 1, 1), (20, 16, 7, 6), (24, 16, 10, 10), (28, 32, 16, 21)])
+@pytest.mark.parametrize("n,layers,max_fwd,max_bwd", [(12, 8, 1, 1), (20, 16, 7, 6), (24, 16, 10, 9), (28, 32, 16, 21)])
 def test_baseline_configs_schedule(n, layers, max_fwd, max_bwd):
   """Light-cone scheduling: far fewer HBM passes than gates (944 gates at n=20).  The bounds are the
   pass counts of the scheduler whose diagonal terms wait only for non-diagonal gates (they commute
@@ -77,12 +77,28 @@ def test_baseline_configs_schedule(n, layers, max_fwd, max_bwd):
 
 def test_first_tile_of_a_chain_absorbs_the_whole_triangle():
   """12 local qubits at the end of a nearest-neighbour chain: 12 + 11 + ... + 1 = 78 one-qubit gates
-  are inside the light cone of the first adjoint pass."""
-  eng = _planner(20, 16, O.xxz_chain_op(20))
+  are inside the light cone of a first pass (the forward plan's second pass adds them to the 30 of its
+  first: 110 with the next layers; the plain adjoint layout starts with exactly the 78)."""
+  eng = _planner(20, 16, O.xxz_chain_op(20), cph_wave_bits=0)
   text = eng.describe_schedule()
   adjoint = text[text.index("adjoint plan"):]
   first = [line for line in adjoint.splitlines() if line.strip().startswith("pass 0:")][0]
   assert "mat_ops=78" in first, first
+
+
+def test_adjoint_pass_order_is_searched_for_early_finished_bits():
+  """The adjoint plan orders its passes so that the low index bits run out of gates early (smaller
+  passes that build the staircase they need), then covers the rest with pruned tail tiles: config 3 puts
+  184 of its 320 one-qubit gates into unpruned passes instead of the greedy order's 220."""
+  import re
+  eng = _planner(20, 16, O.xxz_chain_op(20))
+  text = eng.describe_schedule()
+  adjoint = text[text.index("adjoint plan"):]
+  mats = [int(x) for x in re.findall(r"mat_ops=(\d+)", adjoint)]
+  cs = [int(x) for x in re.findall(r" c=(\d+) ", adjoint)]
+  assert sum(mats) == 320 and len(mats) == 6
+  tail = cs.index(0)
+  assert sum(mats[:tail]) <= 184 and mats[tail] >= 100
 
 
 def test_schedule_options_and_errors():
