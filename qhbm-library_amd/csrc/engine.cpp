@@ -969,8 +969,12 @@ int qhbm_traffic_model(qhbm_engine* h, int U, int with_vjp, double* fwd_bytes, d
     fill_args(h->adj.plan, h->model, &args, &prog, &tables);
     for (size_t i = 0; i < args.size(); ++i) {
       double live = 1.0 / double(1ull << __builtin_popcount(args[i].zero_mask));  // tiles not skipped
-      // a tile without the low index bits moves whole 128-byte lines for 8 << c contiguous bytes
-      if (args[i].c < 4) live = std::min(1.0, live * double(1u << (4 - args[i].c)));
+      // a tile without some of the four low index bits still moves whole 128-byte lines
+      {
+        int low_missing = 0;
+        for (uint32_t k = 0; k < args[i].n_nonlocal; ++k) low_missing += args[i].nonlocal_pos[k] < 4;
+        live = std::min(1.0, live * double(1u << low_missing));
+      }
       b += live * tile_all * 2.0 * ((h->adj.plan.passes[i].flags & PASS_STORE) ? 2.0 : 1.0);
     }
   }

@@ -602,19 +602,22 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
       const uint32_t low = (1u << c_min) - 1;
       const int h = K - c_min;
       for (int p = c_min; p + h <= n_eff; ++p) cands.push_back(low | (((1u << h) - 1) << p));
-      // Adjoint tail: once no non-diagonal op is left on the low c_min bits, psi is zero wherever they
-      // differ from the input bitstring, and a tile that still holds them spends 2^c_min times the work
-      // on zeros.  Tiles over the bits that still have gates (8-byte HBM accesses, kernels.hip
-      // prefetch_tile / store_tile with c == 0) touch the same lines for a sixteenth of the work.
+      // Adjoint tail: once no non-diagonal op is left on one of the low c_min bits, psi is zero wherever
+      // it differs from the input bitstring, and a tile that still holds it spends twice the work on
+      // zeros.  Tiles over the bits that still have gates (8-byte HBM accesses when index bit 0 is
+      // gone: kernels.hip prefetch_tile / store_tile with c == 0) touch the same lines for a half, a
+      // quarter, ... a sixteenth of the work.
       if (adjoint && plan->tail_tiles) {
         uint32_t pending_mat = 0;
         for (size_t oi = 0; oi < ops.size(); ++oi) if (!dn[oi] && ops[oi].type != LOW_DIAG) pending_mat |= ops[oi].bits;
-        if (!(pending_mat & low)) {
+        const uint32_t low_live = low & pending_mat;  // the low bits that still have gates stay in every tile
+        if (low_live != low) {
+          const int h2 = K - popc(low_live);
           std::vector<int> ub;
-          for (int bit = 0; bit < n_eff; ++bit) if (pending_mat >> bit & 1u) ub.push_back(bit);
-          for (size_t p0 = 0; p0 + size_t(K) <= ub.size(); ++p0) {
-            uint32_t S = 0;
-            for (int k = 0; k < K; ++k) S |= 1u << ub[p0 + size_t(k)];
+          for (int bit = c_min; bit < n_eff; ++bit) if (pending_mat >> bit & 1u) ub.push_back(bit);
+          for (size_t p0 = 0; p0 + size_t(h2) <= ub.size(); ++p0) {
+            uint32_t S = low_live;
+            for (int k = 0; k < h2; ++k) S |= 1u << ub[p0 + size_t(k)];
             cands.push_back(S);
           }
         }
@@ -653,15 +656,15 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   };
 
   // Adjoint plans: the ORDER of the passes is searched, not grown greedily.  A pass costs about
-  // (fixed + gates) x (share of its tiles that is not pruned), and tiles are pruned on every finished
-  // bit outside the tile (engine.cpp zero_mask, tail tiles): getting the first bits finished early
+  // (fixed + gates) x (share of its tiles that is not pruned), at least the HBM time of the lines it
+  // touches, and tiles are pruned on every finished bit outside the tile (engine.cpp zero_mask, tail tiles): getting the first bits finished early
   // -- by smaller passes that build the staircase the low bits need -- makes every later gate several
   // times cheaper.  Beam search over pass sequences on that model (config 3: the first four, unpruned
   // passes carry 184 gates instead of 220).
   std::vector<uint32_t> planned;  // local sets of the passes, in order (empty: greedy)
   if (adjoint && K < n_eff && plan->tail_tiles) {
     struct Node { std::vector<char> dn; size_t n_done; double cost; std::vector<uint32_t> sets; };
-    const double kFixed = 10.0;
+    const double kFixed = 10.0, kMemory = 17.0;  // per pass, in units of one unpruned gate (config 3: 14 ms and 24.6 ms against 1.4)
     const size_t kBeam = 16;
     auto finished_bits = [&](const std::vector<char>& dn) {
       uint32_t pend = 0;
@@ -688,7 +691,11 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
           c.dn = nd.dn;
           for (int oi : lst) c.dn[size_t(oi)] = 1;
           c.n_done = nd.n_done + lst.size();
-          c.cost = nd.cost + (kFixed + double(n_mat)) / double(1u << std::min(20, popc(fin & ~S)));
+          // (fixed + gates) on the tiles that are not pruned, but never less than the HBM time of the
+          // 128-byte lines those tiles touch: a tile without k of the four low index bits uses 2^-k of a line
+          const double alive = 1.0 / double(1u << std::min(20, popc(fin & ~S)));
+          const double lines = std::min(1.0, alive * double(1u << popc(((1u << c_min) - 1u) & ~S)));
+          c.cost = nd.cost + std::max(kMemory * lines, alive * (kFixed + double(n_mat)));
           c.sets = nd.sets;
           c.sets.push_back(S);
           if (c.n_done == ops.size()) {
@@ -717,8 +724,8 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   }
   if (!planned.empty()) {
     // The model knows nothing of how well a pass packs into rounds and instances: a searched order with
-    // MORE passes than the greedy one (deep circuits on many qubits, where no bit finishes early
-    // anyway: config 5, 24 against 21) measured slower, so the greedy order stands there.
+    // clearly MORE passes than the greedy one (deep circuits on many qubits, where no bit finishes
+    // early anyway: config 5, 24 against 21) measured slower, so the greedy order stands there.
     std::vector<char> dn(done);
     size_t left = ops.size() - n_done, greedy_passes = 0;
     while (left) {
@@ -735,7 +742,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
       left -= best.size();
       ++greedy_passes;
     }
-    if (left == 0 && planned.size() > greedy_passes) planned.clear();
+    if (left == 0 && planned.size() > greedy_passes + 1) planned.clear();
   }
   size_t planned_i = 0;
 
