@@ -664,7 +664,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   std::vector<uint32_t> planned;  // local sets of the passes, in order (empty: greedy)
   if (adjoint && K < n_eff && plan->tail_tiles) {
     struct Node { std::vector<char> dn; size_t n_done; double cost; std::vector<uint32_t> sets; };
-    const double kFixed = 10.0, kMemory = 17.0;  // per pass, in units of one unpruned gate (config 3: 14 ms and 24.6 ms against 1.4)
+    const double kFixed = 6.0, kMemory = 17.0;  // per pass, in units of one unpruned gate (config 3: 24.6 ms of tile I/O against 1.4 ms per gate; the fixed part 3, 5 and 7 measured alike, 10 and 16 worse)
     const size_t kBeam = ops.size() <= 4000 ? 16 : (ops.size() <= 12000 ? 8 : 4);  // planning time stays ~ a second
     auto finished_bits = [&](const std::vector<char>& dn) {
       uint32_t pend = 0;

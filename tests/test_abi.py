@@ -87,21 +87,20 @@ def test_first_tile_of_a_chain_absorbs_the_whole_triangle():
 
 
 def test_adjoint_pass_order_is_searched_for_early_finished_bits():
-  """The adjoint plan orders its passes so that the low index bits run out of gates early (the first two
-  passes are exactly the 136-gate triangle that finishes the first qubit of the chain), drops every
-  finished low bit from the tiles after that (c = 0) and covers the rest with pruned tail tiles: config 3
-  puts 184 of its 320 one-qubit gates into passes that hold all four low bits or none pruned -- the greedy
-  order needs 220."""
+  """The adjoint plan orders its passes so that the low index bits run out of gates early (the 136-gate
+  triangle 16 + 15 + ... + 1 finishes the first qubit of the chain), then drops every finished low bit
+  from its tiles (c = 0) and prunes on it: config 3 runs at most 150 of its 320 one-qubit gates before
+  the first pruned pass -- the greedy order needs 220."""
   import re
   eng = _planner(20, 16, O.xxz_chain_op(20))
   text = eng.describe_schedule()
   adjoint = text[text.index("adjoint plan"):]
   mats = [int(x) for x in re.findall(r"mat_ops=(\d+)", adjoint)]
   cs = [int(x) for x in re.findall(r" c=(\d+) ", adjoint)]
-  assert sum(mats) == 320 and len(mats) == 6
+  assert sum(mats) == 320 and len(mats) <= 7
   first_c0 = cs.index(0)
-  assert sum(mats[:first_c0]) == 136          # 16 + 15 + ... + 1: the first qubit is finished
-  assert sum(mats[:4]) <= 184 and max(mats[first_c0:]) >= 100
+  assert 136 <= sum(mats[:first_c0]) <= 150
+  assert sum(m for m, c in zip(mats, cs) if c == 0) >= 150
 
 
 def test_schedule_options_and_errors():
