@@ -74,6 +74,8 @@ struct qhbm_engine {
   int opt_tile = 0, opt_adj_tile = 0, opt_profile = 0, opt_round = 0;
   int opt_full_fwd = 60, opt_full_adj = 60, opt_force_general = 0;
   int opt_meas_tile = 0;     // tile qubits of measurement-only passes (0 = largest)
+  int opt_values_from_obs = 1;  // single observable: <psi|O|psi> from lambda = O psi, no measurement in the forward sweep
+  bool retained_mu = false;     // the retained batch also holds the unweighted lambda = O psi
   int opt_cph_wave_bits = 1; // boundary controlled-phase predicates on wave bits (schedule.h Plan::cph_wave_bits)
   int opt_adj_exchange = 1;  // lean adjoint passes: register-resident tile pair + one LDS exchange buffer
   int retained_U = 0;  // final states of the last qhbm_expectation_retain still sit in psi
@@ -330,24 +332,33 @@ hipEvent_t* timer_begin(qhbm_engine* h, int kind, hipStream_t s) {
 void timer_end(hipEvent_t* e, hipStream_t s) { if (e) (void)hipEventRecord(*e, s); }
 
 // Forward passes for one chunk.
+// One observable: lambda = O psi gives <psi|O|psi> for free (apply_observable_kernel<A, true>), so the
+// paths that compute lambda anyway (value + VJP, and the retained forward of an autograd caller) skip
+// every measurement of the forward sweep.
+bool value_mode(const qhbm_engine* h) { return h->opt_values_from_obs != 0 && h->model.n_ops == 1; }
+
+// `skip_measure`: the caller takes the values from lambda = O psi (value_mode): measurement groups
+// are ignored, measurement-only passes and the wide-term kernel are not launched.
 int run_forward_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_t cs, bool keep_state,
-                      hipStream_t stream) {
+                      hipStream_t stream, bool skip_measure = false) {
   DevicePlan& d = h->fwd;
   const size_t np = d.plan.passes.size();
   bool measure_only_after = !d.plan.global_terms.empty();  // they read the final state from HBM
   for (const Pass& p : d.plan.passes) measure_only_after |= p.is_measure_only;
   for (size_t i = 0; i < np; ++i) {
     const Pass& p = d.plan.passes[i];
+    if (skip_measure && p.is_measure_only) continue;
     PassArgs a = d.args[i];
     a.flags = p.flags & (PASS_INIT_BASIS | PASS_GENERAL);
     if (h->opt_force_general) a.flags |= PASS_GENERAL;
+    if (skip_measure) a.flags |= PASS_SKIP_MEASURE;
     if (!p.is_measure_only && (!p.completes_circuit || keep_state || measure_only_after)) a.flags |= PASS_STORE;
     hipEvent_t* ev = timer_begin(h, 0, stream);
     HIPCHK(launch_pass_fwd(p.K, d.plan.R, a, cs, h->psi.p, d_bits, h->model.n, d.prog.p, d.tables.p, d.coef.p,
                            h->op_scale.p, h->vals64.p, s0, stream));
     timer_end(ev, stream);
   }
-  if (!d.plan.global_terms.empty())
+  if (!d.plan.global_terms.empty() && !skip_measure)
     HIPCHK(launch_measure_global(h->psi.p, uint32_t(d.plan.n_eff), cs, h->global_terms.p,
                                  uint32_t(d.plan.global_terms.size()), h->op_scale.p, h->vals64.p,
                                  uint32_t(h->model.n_ops), s0, stream));
@@ -402,17 +413,22 @@ int forward(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, 
 }
 
 // lambda = O psi and the backward passes for one chunk whose final states sit in psi.
-int run_adjoint_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_t c, const float* d_upstream,
-                      hipStream_t stream) {
+// lambda = O psi for the chunk in the workspace.  value_mode (a single observable): unweighted, and
+// <psi|O|psi> goes to the fixed-point value accumulators -- the forward sweep measured nothing.
+int run_observable_chunk(qhbm_engine* h, uint32_t s0, uint32_t c, const float* d_upstream, bool value_mode,
+                         hipStream_t stream) {
+  hipEvent_t* ev = timer_begin(h, 2, stream);
+  HIPCHK(launch_apply_observable(h->psi.p, h->lam.p, uint32_t(h->fwd.plan.n_eff), c, h->terms.p,
+                                 uint32_t(h->model.terms.size()), h->obs_groups.p, h->n_obs_groups, d_upstream,
+                                 uint32_t(h->model.n_ops), s0, h->op_scale.p, value_mode ? h->vals64.p : nullptr, stream));
+  timer_end(ev, stream);
+  return 0;
+}
+
+// The backward passes of a chunk whose (psi, lambda) pair is in the workspace.
+int run_adjoint_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_t c, hipStream_t stream) {
   DevicePlan& b = h->adj;
   const uint32_t n_slots = uint32_t(b.plan.slot_gate.size());
-  {
-    hipEvent_t* ev = timer_begin(h, 2, stream);
-    HIPCHK(launch_apply_observable(h->psi.p, h->lam.p, uint32_t(h->fwd.plan.n_eff), c, h->terms.p,
-                                   uint32_t(h->model.terms.size()), h->obs_groups.p, h->n_obs_groups, d_upstream,
-                                   uint32_t(h->model.n_ops), s0, stream));
-    timer_end(ev, stream);
-  }
   size_t rows = 0;  // tile_grad: one row of the pass's slots per workgroup
   for (const PassArgs& ba : b.args)
     rows = std::max(rows, ((size_t(c) << ba.n_nonlocal) + reduce_tiles_scratch_rows(c, size_t(1) << ba.n_nonlocal)) *
@@ -457,11 +473,15 @@ int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_pa
   HIPCHK(hipMemsetAsync(h->state_grad.p, 0, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), stream));
   const uint32_t cs = adjoint_chunk_states(h, U);
   if (int rc = ensure_state_buffers(h, cs, true)) return rc;
+  const bool vm = value_mode(h);
   for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += cs) {
     const uint32_t c = std::min<uint32_t>(cs, uint32_t(U) - s0);
-    if (int rc = run_forward_chunk(h, d_bits, s0, c, true, stream)) return rc;
-    if (int rc = run_adjoint_chunk(h, d_bits, s0, c, d_upstream, stream)) return rc;
+    if (int rc = run_forward_chunk(h, d_bits, s0, c, true, stream, vm)) return rc;
+    if (int rc = run_observable_chunk(h, s0, c, d_upstream, vm, stream)) return rc;
+    if (int rc = run_adjoint_chunk(h, d_bits, s0, c, stream)) return rc;
   }
+  // value mode ran the sweep on the unweighted lambda: the upstream weight goes onto the gradient rows
+  if (vm) HIPCHK(launch_scale_rows(h->state_grad.p, uint32_t(U), std::max<uint32_t>(n_slots, 1), d_upstream, stream));
   return values_end(h, U, d_out_vals, stream);
 }
 
@@ -584,6 +604,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "adjoint_tile_qubits") { h->opt_adj_tile = int(value); h->plans_valid = false; }
   else if (k == "adjoint_exchange") h->opt_adj_exchange = int(value);
   else if (k == "measure_tile_qubits") { h->opt_meas_tile = int(value); h->plans_valid = false; }
+  else if (k == "values_from_observable") h->opt_values_from_obs = int(value);
   else if (k == "cph_wave_bits") { h->opt_cph_wave_bits = int(value); h->plans_valid = false; }
   else if (k == "chunk_states") h->opt_chunk = value;
   else if (k == "workspace_budget_mb") h->opt_budget_mb = std::max<int64_t>(0, value);  // 0 = default
@@ -643,9 +664,14 @@ int qhbm_expectation_retain(qhbm_engine* h, const int8_t* d_bits, int U, const f
   HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), 1u, 0u, s));
   if (int rc = values_begin(h, U, s)) return rc;
   if (int rc = ensure_state_buffers(h, uint32_t(U), true)) return rc;  // psi AND lambda, so psi is not moved later
-  if (int rc = run_forward_chunk(h, d_bits, 0, uint32_t(U), true, s)) return rc;
+  const bool vm = value_mode(h);
+  if (int rc = run_forward_chunk(h, d_bits, 0, uint32_t(U), true, s, vm)) return rc;
+  if (vm) {
+    if (int rc = run_observable_chunk(h, 0, uint32_t(U), nullptr, true, s)) return rc;
+  }
   if (int rc = values_end(h, U, d_out, s)) return rc;
   h->retained_U = U;
+  h->retained_mu = vm;
   return 0;
 }
 
@@ -662,7 +688,13 @@ int qhbm_expectation_vjp_retained(qhbm_engine* h, const int8_t* d_bits, int U, c
   HIPCHK(launch_combine_diag(b.coef.p, b.rec_offsets.p, int(b.plan.record_offsets.size()), 1u, 0u, s));
   HIPCHK(h->state_grad.reserve(size_t(U) * std::max<uint32_t>(n_slots, 1)));
   HIPCHK(hipMemsetAsync(h->state_grad.p, 0, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), s));
-  if (int rc = run_adjoint_chunk(h, d_bits, 0, uint32_t(U), d_upstream, s)) return rc;
+  if (h->retained_mu) {  // lambda = O psi (unweighted) was computed with the values: weight the rows instead
+    if (int rc = run_adjoint_chunk(h, d_bits, 0, uint32_t(U), s)) return rc;
+    HIPCHK(launch_scale_rows(h->state_grad.p, uint32_t(U), std::max<uint32_t>(n_slots, 1), d_upstream, s));
+  } else {
+    if (int rc = run_observable_chunk(h, 0, uint32_t(U), d_upstream, false, s)) return rc;
+    if (int rc = run_adjoint_chunk(h, d_bits, 0, uint32_t(U), s)) return rc;
+  }
   HIPCHK(launch_reduce_grad(h->state_grad.p, uint32_t(U), n_slots, h->param_slot_begin.p, h->param_slots.p,
                             h->slot_factor.p, d_grad, h->model.n_params, 0, s));
   h->state_grad_U = U;
@@ -957,6 +989,7 @@ int qhbm_traffic_model(qhbm_engine* h, int U, int with_vjp, double* fwd_bytes, d
     fill_args(h->fwd.plan, h->model, &fargs, &fprog, &ftables);
     for (size_t i = 0; i < fargs.size(); ++i) {
       const Pass& p = h->fwd.plan.passes[i];
+      if (with_vjp && value_mode(h) && p.is_measure_only) continue;  // the values come from lambda = O psi
       const double live = 1.0 / double(1ull << __builtin_popcount(fargs[i].zero_mask));  // tiles not skipped
       if (!(p.flags & PASS_INIT_BASIS)) f += live * tile_all;  // the first pass writes the basis state, reads nothing
       if (!p.is_measure_only && (!p.completes_circuit || with_vjp || measure_only_after)) f += live * tile_all;

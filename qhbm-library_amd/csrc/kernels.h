@@ -51,7 +51,7 @@ hipError_t launch_reduce_tiles(float* tile_grad, uint32_t n_states, uint32_t n_t
 hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
-                                   hipStream_t stream);
+                                   const float* op_scale, unsigned long long* out64, hipStream_t stream);
 // Terms measured on the final state in HBM (X-mask wider than a tile); accumulates into out64.
 hipError_t launch_measure_global(const float2* psi, uint32_t n, uint32_t n_states, const DevTerm* terms,
                                  uint32_t n_terms, const float* op_scale, unsigned long long* out64, uint32_t n_ops,
@@ -85,6 +85,7 @@ hipError_t launch_reduce_grad(const float* state_grad, uint32_t U, uint32_t n_sl
                               const int* param_slot_begin, const int* param_slots,
                               const float* slot_factor, float* grad, int n_params, int accumulate,
                               hipStream_t stream);
+hipError_t launch_scale_rows(float* rows, uint32_t U, uint32_t width, const float* w, hipStream_t stream);
 hipError_t launch_scatter_jac(const float* state_grad, uint32_t U, uint32_t n_slots,
                               const int* param_slot_begin, const int* param_slots,
                               const float* slot_factor, float* jac, uint32_t n_ops, uint32_t op,

@@ -869,6 +869,10 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
     } else {  // OP_MEASURE
       const uint32_t n_groups = w0 >> 8;
       pc += 1;
+      if (a.flags & PASS_SKIP_MEASURE) {  // the values come from lambda = O psi (engine.cpp): walk over the groups
+        for (uint32_t g = 0; g < n_groups; ++g) pc += 2u + uni(prog[pc + 1]) * kMeasTermWords;
+        continue;
+      }
       float acc = 0.f;
       uint32_t cur_op = 0xffffffffu;
       for (uint32_t g = 0; g < n_groups; ++g) {
@@ -1333,11 +1337,16 @@ template <int A> struct ObsStage {
   float flip[kObsTermChunk / 2][A];   // real weight, pre-signed for amplitude a    (real-weight path)
 };
 constexpr uint32_t kObsChunk = kObsTermChunk / 2;  // terms staged in LDS at a time
-template <int A>
+// VALUE (a single observable): the weights are the bare coefficients, lambda = O psi unweighted, and
+// <psi|O|psi> = sum_j Re(conj(psi_j) lambda_j) leaves as a by-product in the fixed-point accumulator
+// out64[state] -- the forward sweep then needs no measurement at all, and the caller applies the
+// upstream weight to the state's gradient row (the adjoint sweep is linear in lambda).
+template <int A, bool VALUE>
 __global__ __launch_bounds__(256) void apply_observable_kernel(
     const float2* __restrict__ psi, float2* __restrict__ lam, uint32_t n, const DevTerm* __restrict__ terms,
     uint32_t n_terms, const ObsGroup* __restrict__ groups, uint32_t n_groups,
-    const float* __restrict__ upstream, uint32_t n_ops, uint32_t state0) {
+    const float* __restrict__ upstream, uint32_t n_ops, uint32_t state0, const float* __restrict__ op_scale,
+    unsigned long long* __restrict__ out64) {
   __shared__ ObsStage<A> st;
   const uint32_t s_local = blockIdx.y;
   // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give XCD k the k-th
@@ -1348,7 +1357,7 @@ __global__ __launch_bounds__(256) void apply_observable_kernel(
   const uint32_t jb = bx * (256u * A);                   // block bits of j
   const uint32_t j0 = jb + threadIdx.x;
   const float2* ps = psi + (size_t(s_local) << n);
-  const float* up = upstream + size_t(state0 + s_local) * n_ops;
+  const float* up = VALUE ? nullptr : upstream + size_t(state0 + s_local) * n_ops;
   // The kernel is bound by L2 -> L1 traffic (one gather of the state per mask, no reuse in L1): the
   // block's own amplitudes are staged in LDS once and every mask that stays inside the block reads
   // them there (XXZ at 20 qubits: 11 of the 20 gathers).
@@ -1364,7 +1373,7 @@ __global__ __launch_bounds__(256) void apply_observable_kernel(
     if (k0) __syncthreads();
     for (uint32_t k = k0 + threadIdx.x; k < k1; k += 256u) {
       const DevTerm tm = terms[k];
-      const float w = up[tm.op] * tm.coeff;
+      const float w = VALUE ? tm.coeff : up[tm.op] * tm.coeff;
       const float m = (tm.ny & 2u) ? -w : w;
       // parity of the workgroup-constant part: block bits of j and the x & z overlap (= ny)
       const uint32_t base = (uint32_t(__popc(jb & tm.z)) + tm.ny) & 1u;
@@ -1442,6 +1451,20 @@ __global__ __launch_bounds__(256) void apply_observable_kernel(
   }
 #pragma unroll
   for (int a = 0; a < A; ++a) lam[(size_t(s_local) << n) + j0 + 256u * a] = make_float2(acc[a].x, acc[a].y);
+  if constexpr (VALUE) {
+    float e = 0.f;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      const v2f p = own[threadIdx.x + 256u * a];
+      e += p.x * acc[a].x + p.y * acc[a].y;
+    }
+    e = wave_sum(e);
+    __shared__ float wave_part[4];
+    if ((threadIdx.x & 63u) == 0) wave_part[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0)  // the four waves in a fixed order, the blocks through integer adds: bit-reproducible
+      atomicAdd(&out64[state0 + s_local], to_fixed((wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3]), op_scale[0]));
+  }
 }
 
 // ================================================================================
@@ -1667,6 +1690,12 @@ __global__ __launch_bounds__(256) void reduce_grad_kernel(
     __syncthreads();
   }
   if (threadIdx.x == 0) grad[p] = (accumulate ? grad[p] : 0.f) + float(part[0]);
+}
+
+// rows[s, :] *= w[s]   (the upstream weight of a single observable onto its per-state gradient slots)
+__global__ void scale_rows_kernel(float* __restrict__ rows, uint32_t U, uint32_t width, const float* __restrict__ w) {
+  const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < size_t(U) * width) rows[i] *= w[i / width];
 }
 
 // jac[s, k, p] = sum_slot(p) factor * state_grad[s, slot]   for a fixed op k
@@ -2096,14 +2125,17 @@ hipError_t launch_parity_energy_vjp(const int8_t* bits, int64_t n_rows, int n, c
 hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
-                                   hipStream_t stream) {
+                                   const float* op_scale, unsigned long long* out64, hipStream_t stream) {
+  const bool value = out64 != nullptr;  // single observable: unweighted lambda + <psi|O|psi> (see the kernel)
+#define QHBM_OBS(A_, V_)                                                                                          \
+  hipLaunchKernelGGL((apply_observable_kernel<A_, V_>), dim3((1u << n) / (256u * A_), n_states), dim3(256), 0, stream, \
+                     psi, lam, n, terms, n_terms, groups, n_groups, upstream, n_ops, state0, op_scale, out64)
   if (n >= 11) {
-    hipLaunchKernelGGL(apply_observable_kernel<8>, dim3((1u << n) / 2048u, n_states), dim3(256), 0, stream, psi, lam,
-                       n, terms, n_terms, groups, n_groups, upstream, n_ops, state0);
+    if (value) QHBM_OBS(8, true); else QHBM_OBS(8, false);
   } else {
-    hipLaunchKernelGGL(apply_observable_kernel<4>, dim3((1u << n) / 1024u, n_states), dim3(256), 0, stream, psi, lam,
-                       n, terms, n_terms, groups, n_groups, upstream, n_ops, state0);
+    if (value) QHBM_OBS(4, true); else QHBM_OBS(4, false);
   }
+#undef QHBM_OBS
   return hipGetLastError();
 }
 
@@ -2197,6 +2229,13 @@ hipError_t launch_reduce_grad(const float* state_grad, uint32_t U, uint32_t n_sl
   if (n_params == 0) return hipSuccess;
   hipLaunchKernelGGL(reduce_grad_kernel, dim3(n_params), dim3(256), 0, stream, state_grad, U, n_slots,
                      param_slot_begin, param_slots, slot_factor, grad, accumulate);
+  return hipGetLastError();
+}
+
+hipError_t launch_scale_rows(float* rows, uint32_t U, uint32_t width, const float* w, hipStream_t stream) {
+  const size_t total = size_t(U) * width;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, stream, rows, U, width, w);
   return hipGetLastError();
 }
 

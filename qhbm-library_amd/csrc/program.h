@@ -46,6 +46,7 @@ enum : uint32_t {
   PASS_STORE = 1u << 1,       // write the tile back at the end
   PASS_ADJOINT = 1u << 2,     // tile pair (psi, lambda), program is a backward program
   PASS_GENERAL = 1u << 3,     // the program uses Y / dense 2x2 / dense two-qubit ops (rare-path kernel variant)
+  PASS_SKIP_MEASURE = 1u << 4,  // forward: ignore the measurement groups (the values come from lambda = O psi)
 };
 
 // ---- opcodes (low 8 bits of an instruction's first word) --------------------
