@@ -88,6 +88,7 @@ struct qhbm_engine {
   DevicePlan fwd, adj;
   DevBuf<DevTerm> terms, global_terms;  // global_terms: measured on the final state in HBM (too wide for a tile)
   DevBuf<ObsGroup> obs_groups;
+  DevBuf<float> value_part;  // value mode: one partial of <psi|O|psi> per workgroup of apply_observable_kernel
   uint32_t n_obs_groups = 0;
   DevBuf<float2> psi, lam;
   DevBuf<float> state_grad, slot_factor, vals_tmp, upstream_tmp, phase_cs;
@@ -417,10 +418,12 @@ int forward(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, 
 // <psi|O|psi> goes to the fixed-point value accumulators -- the forward sweep measured nothing.
 int run_observable_chunk(qhbm_engine* h, uint32_t s0, uint32_t c, const float* d_upstream, bool value_mode,
                          hipStream_t stream) {
+  if (value_mode) HIPCHK(h->value_part.reserve(observable_value_parts(uint32_t(h->fwd.plan.n_eff), c)));
   hipEvent_t* ev = timer_begin(h, 2, stream);
   HIPCHK(launch_apply_observable(h->psi.p, h->lam.p, uint32_t(h->fwd.plan.n_eff), c, h->terms.p,
                                  uint32_t(h->model.terms.size()), h->obs_groups.p, h->n_obs_groups, d_upstream,
-                                 uint32_t(h->model.n_ops), s0, h->op_scale.p, value_mode ? h->vals64.p : nullptr, stream));
+                                 uint32_t(h->model.n_ops), s0, h->op_scale.p, value_mode ? h->vals64.p : nullptr,
+                                 h->value_part.p, stream));
   timer_end(ev, stream);
   return 0;
 }

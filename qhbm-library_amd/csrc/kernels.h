@@ -48,10 +48,13 @@ size_t reduce_tiles_scratch_rows(size_t n_states, size_t n_tiles);
 hipError_t launch_reduce_tiles(float* tile_grad, uint32_t n_states, uint32_t n_tiles, uint32_t n_slots,
                                float* state_grad, uint32_t n_slots_total, uint32_t slot_base, uint32_t state0,
                                hipStream_t stream);
+// (value mode, out64 != null: `value_part` holds observable_value_parts(n, n_states) floats of scratch)
+size_t observable_value_parts(uint32_t n, uint32_t n_states);
 hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
-                                   const float* op_scale, unsigned long long* out64, hipStream_t stream);
+                                   const float* op_scale, unsigned long long* out64, float* value_part,
+                                   hipStream_t stream);
 // Terms measured on the final state in HBM (X-mask wider than a tile); accumulates into out64.
 hipError_t launch_measure_global(const float2* psi, uint32_t n, uint32_t n_states, const DevTerm* terms,
                                  uint32_t n_terms, const float* op_scale, unsigned long long* out64, uint32_t n_ops,

@@ -1339,14 +1339,13 @@ template <int A> struct ObsStage {
 constexpr uint32_t kObsChunk = kObsTermChunk / 2;  // terms staged in LDS at a time
 // VALUE (a single observable): the weights are the bare coefficients, lambda = O psi unweighted, and
 // <psi|O|psi> = sum_j Re(conj(psi_j) lambda_j) leaves as a by-product in the fixed-point accumulator
-// out64[state] -- the forward sweep then needs no measurement at all, and the caller applies the
+// value_part[state, workgroup] (value_parts_kernel) -- the forward sweep then needs no measurement at all, and the caller applies the
 // upstream weight to the state's gradient row (the adjoint sweep is linear in lambda).
 template <int A, bool VALUE>
 __global__ __launch_bounds__(256) void apply_observable_kernel(
     const float2* __restrict__ psi, float2* __restrict__ lam, uint32_t n, const DevTerm* __restrict__ terms,
     uint32_t n_terms, const ObsGroup* __restrict__ groups, uint32_t n_groups,
-    const float* __restrict__ upstream, uint32_t n_ops, uint32_t state0, const float* __restrict__ op_scale,
-    unsigned long long* __restrict__ out64) {
+    const float* __restrict__ upstream, uint32_t n_ops, uint32_t state0, float* __restrict__ value_part) {
   __shared__ ObsStage<A> st;
   const uint32_t s_local = blockIdx.y;
   // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give XCD k the k-th
@@ -1459,12 +1458,35 @@ __global__ __launch_bounds__(256) void apply_observable_kernel(
       e += p.x * acc[a].x + p.y * acc[a].y;
     }
     e = wave_sum(e);
-    __shared__ float wave_part[4];
+    // (the staging area is free now; a separate array of 16 bytes would take the kernel from four
+    // workgroups per CU to three)
+    __syncthreads();
+    float* wave_part = reinterpret_cast<float*>(&st.term[0]);
     if ((threadIdx.x & 63u) == 0) wave_part[threadIdx.x >> 6] = e;
     __syncthreads();
-    if (threadIdx.x == 0)  // the four waves in a fixed order, the blocks through integer adds: bit-reproducible
-      atomicAdd(&out64[state0 + s_local], to_fixed((wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3]), op_scale[0]));
+    // one partial per workgroup (512 atomics per state on ONE address cost a quarter of the kernel);
+    // value_parts_kernel adds a state's partials in block order
+    if (threadIdx.x == 0)
+      value_part[size_t(s_local) * gridDim.x + blockIdx.x] = (wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3]);
   }
+}
+
+// <psi|O|psi> of state s = sum of its workgroups' partials, in block order (bit-reproducible), into the
+// fixed-point value accumulator.
+__global__ __launch_bounds__(256) void value_parts_kernel(const float* __restrict__ value_part, uint32_t n_blocks,
+                                                          const float* __restrict__ op_scale,
+                                                          unsigned long long* __restrict__ out64, uint32_t state0) {
+  __shared__ double part[256];
+  const uint32_t s = blockIdx.x;
+  double acc = 0.0;
+  for (uint32_t b = threadIdx.x; b < n_blocks; b += 256u) acc += double(value_part[size_t(s) * n_blocks + b]);
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (int(threadIdx.x) < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out64[state0 + s] += to_fixed(float(part[0]), op_scale[0]);
 }
 
 // ================================================================================
@@ -2122,20 +2144,26 @@ hipError_t launch_parity_energy_vjp(const int8_t* bits, int64_t n_rows, int n, c
   return hipGetLastError();
 }
 
+size_t observable_value_parts(uint32_t n, uint32_t n_states) { return size_t(n_states) * ((1u << n) / (256u * (n >= 11 ? 8u : 4u))); }
+
 hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
-                                   const float* op_scale, unsigned long long* out64, hipStream_t stream) {
+                                   const float* op_scale, unsigned long long* out64, float* value_part,
+                                   hipStream_t stream) {
   const bool value = out64 != nullptr;  // single observable: unweighted lambda + <psi|O|psi> (see the kernel)
 #define QHBM_OBS(A_, V_)                                                                                          \
   hipLaunchKernelGGL((apply_observable_kernel<A_, V_>), dim3((1u << n) / (256u * A_), n_states), dim3(256), 0, stream, \
-                     psi, lam, n, terms, n_terms, groups, n_groups, upstream, n_ops, state0, op_scale, out64)
+                     psi, lam, n, terms, n_terms, groups, n_groups, upstream, n_ops, state0, value_part)
   if (n >= 11) {
     if (value) QHBM_OBS(8, true); else QHBM_OBS(8, false);
   } else {
     if (value) QHBM_OBS(4, true); else QHBM_OBS(4, false);
   }
 #undef QHBM_OBS
+  if (value && n_states)
+    hipLaunchKernelGGL(value_parts_kernel, dim3(n_states), dim3(256), 0, stream, value_part,
+                       (1u << n) / (256u * (n >= 11 ? 8u : 4u)), op_scale, out64, state0);
   return hipGetLastError();
 }
 
