@@ -121,7 +121,9 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
  * "cph_wave_bits" (1 = the scheduler's layout choices of round 2: the partner bits of boundary
  * controlled phases and the bits with no gate left become wave bits, so that whole waves skip work
  * on predicates that are off / on zeros of psi, and adjoint tail passes use tiles without the low
- * index bits; 0 = the plain layout, for A/B measurements).
+ * index bits; 0 = the plain layout, for A/B measurements), "values_from_observable" (1 = with a single
+ * observable the expectation value is taken from lambda = O psi in the calls that compute lambda
+ * anyway, and the forward sweep measures nothing; 0 = always measure in the forward sweep).
  */
 int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value);
 
