@@ -497,3 +497,35 @@ def test_deep_chain_with_and_without_the_scheduler_layout_choices(layout, tile):
   _, jac = other.expectation_jacobian(bits[:1], params)
   _, mine = eng.expectation_jacobian(bits[:1], params)
   np.testing.assert_allclose(mine.cpu().numpy(), jac.cpu().numpy(), atol=2e-5 * max(1.0, np.abs(want_jac).max()), rtol=0)
+
+
+@pytest.mark.parametrize("n,tile", [(11, 0), (14, 11)])
+def test_single_observable_values_from_lambda_match_the_measured_ones(n, tile):
+  """With one observable the fused value + VJP call and the retained forward take <psi|O|psi> from
+  lambda = O psi and measure nothing in the forward sweep (`values_from_observable`, default on).  Values
+  and gradients must equal those of the measuring path and the oracle -- with zero and negative upstream
+  weights too (lambda is computed unweighted, the weight goes onto the gradient row)."""
+  rng = np.random.default_rng(900 + n)
+  gates, names = O.hea_gates(n, 3, "vm")
+  params = rng.uniform(-1, 1, len(names))
+  op = O.random_pauli_op(n, 20, 3) + O.xxz_chain_op(n)
+  bits = _random_bits(rng, 4, n)
+  up = np.array([[0.7], [0.0], [-1.3], [2.0]], np.float32)
+  opts = dict(tile_qubits=tile, adjoint_tile_qubits=max(tile - 1, 0)) if tile else {}
+  want_vals, want_jac = O.expectation_jacobian(n, gates, params, bits, [op])
+  want_grad = np.einsum("bt,btp->p", up, want_jac)
+  results = []
+  for flag in (1, 0):
+    eng = _engine(n, gates, len(names), [op], values_from_observable=flag, **opts)
+    vals, grad = eng.expectation_vjp(bits, params, up)
+    np.testing.assert_allclose(vals.cpu().numpy(), want_vals, atol=2e-5 * _op_norm([op]).max(), rtol=0)
+    np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=2e-4 * max(1.0, np.abs(want_grad).max()), rtol=0)
+    # retained forward, then the backward from the kept (psi, O psi) pair
+    rv = eng.expectation(bits, params, retain=True)
+    assert eng.retained is not None
+    np.testing.assert_allclose(rv.cpu().numpy(), want_vals, atol=2e-5 * _op_norm([op]).max(), rtol=0)
+    rg = eng.expectation_vjp_retained(bits, params, up)
+    np.testing.assert_allclose(rg.cpu().numpy(), want_grad, atol=2e-4 * max(1.0, np.abs(want_grad).max()), rtol=0)
+    results.append((vals.cpu().numpy(), grad.cpu().numpy()))
+  np.testing.assert_allclose(results[0][0], results[1][0], atol=5e-6 * _op_norm([op]).max(), rtol=0)
+  np.testing.assert_allclose(results[0][1], results[1][1], atol=5e-5 * max(1.0, np.abs(want_grad).max()), rtol=0)
