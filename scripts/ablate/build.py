@@ -41,12 +41,12 @@ VARIANTS = {
     # scalar-load latency of the record fields costs
     "const_coefs": lambda t: once(t, "  if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];", "  if constexpr (W >= 2) return 0x3f19999au; else if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];"),
     # wave priority: instances at high priority, exchanges / tile I/O at low
-    "setprio": lambda t: once(once(t, "      instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n      rec_off += L.words();\n      cur[0] = nxt[0];",
-                                      "      __builtin_amdgcn_s_setprio(3);\n      instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n      __builtin_amdgcn_s_setprio(0);\n      rec_off += L.words();\n      cur[0] = nxt[0];"),
+    "setprio": lambda t: once(once(t, "        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n        rec_off += L.words();\n        cur[0] = nxt[0];",
+                                      "        __builtin_amdgcn_s_setprio(3);\n        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n        __builtin_amdgcn_s_setprio(0);\n        rec_off += L.words();\n        cur[0] = nxt[0];"),
                               "        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);",
                               "        __builtin_amdgcn_s_setprio(3);\n        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);\n        __builtin_amdgcn_s_setprio(0);"),
-    "setprio_inv": lambda t: once(once(t, "      instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n      rec_off += L.words();\n      cur[0] = nxt[0];",
-                                      "      __builtin_amdgcn_s_setprio(0);\n      instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n      __builtin_amdgcn_s_setprio(3);\n      rec_off += L.words();\n      cur[0] = nxt[0];"),
+    "setprio_inv": lambda t: once(once(t, "        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n        rec_off += L.words();\n        cur[0] = nxt[0];",
+                                      "        __builtin_amdgcn_s_setprio(0);\n        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n        __builtin_amdgcn_s_setprio(3);\n        rec_off += L.words();\n        cur[0] = nxt[0];"),
                               "        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);",
                               "        __builtin_amdgcn_s_setprio(0);\n        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);\n        __builtin_amdgcn_s_setprio(3);"),
     # adjoint without the LDS staging of the tile pair at the start and the end of a pass (registers filled
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
     round_store<R>(xt, T, DB, l);
     round_load<R>(xt, Tn, DBn, l);
 """),
-    "no_instances": lambda t: once(t, "      instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n      rec_off += L.words();\n      cur[0] = nxt[0];",
-                                   "      if (lane == 77) instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n      rec_off += L.words();\n      cur[0] = nxt[0];"),
+    "no_instances": lambda t: once(t, "        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n        rec_off += L.words();\n        cur[0] = nxt[0];",
+                                   "        if (lane == 77) instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n        rec_off += L.words();\n        cur[0] = nxt[0];"),
 }
 
 def in_fwd_instance(text, old, new, count=-1):
