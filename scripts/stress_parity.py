@@ -14,6 +14,7 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):
     P=8; gates=random_circuit(rng,n,70,P)
   params=rng.uniform(-1,1,P)
   ops=[O.random_pauli_op(n,10,seed,p_identity=0.7), O.xxz_chain_op(n)]
+  if seed%2==1: ops=[ops[0]+ops[1]]   # one observable: the values come out of lambda = O psi in the VJP calls
   bits=rng.integers(0,2,size=(2,n)).astype(np.int8)
   for tile,adj in ((12,12),(11,11),(13,12),(10,10),(12,13)):
     eng=_engine(n,gates,P,ops,tile_qubits=min(tile,n),adjoint_tile_qubits=min(adj,n-1), adjoint_exchange=seed%4!=3)
