@@ -110,36 +110,87 @@ def distinct_bitstrings(n, count, seed):
   return bits
 
 
-def cpu_baseline(n, gates, n_params, op, params, sample_states, mode):
-  """The oracle's C restatement (oracle/qhbm_cpu.c) timed on this host's cores on
-  a bounded sample of the same workload -- a reported baseline, never the product."""
+def cpu_baseline(n, gates, n_params, op, params, bits, upstream_value, mode):
+  """The oracle's C restatement (oracle/qhbm_cpu.c) timed on this host's cores on a bounded sample
+  of the TIMED batch itself (its first K bitstrings, same parameters, same upstream weight) -- a
+  reported baseline, never the product.  Returns the record plus the oracle's values [K, 1] and
+  [P] VJP of those K states, which `parity_check` compares with what the engine produced."""
   from oracle import qhbm_cpu as C
   if not os.path.exists(C.LIB_PATH):
-    return None
+    return None, None, None
   cores = min(C.max_threads(), os.cpu_count() or 1)
-  states = max(1, min(sample_states, cores))
-  bits = distinct_bitstrings(n, states, 999)
-  up = np.full((states, 1), 1.0 / states, np.float32)
+  states = bits.shape[0]
+  up = np.full((states, 1), upstream_value, np.float32)
   t0 = time.perf_counter()
   if mode == "forward":
-    C.expectation(n, gates, params, bits, [op], n_threads=cores)
+    vals, grad = C.expectation(n, gates, params, bits, [op], n_threads=cores), None
   else:
-    C.expectation_vjp(n, gates, params, bits, [op], up, n_threads=cores)
+    vals, grad = C.expectation_vjp(n, gates, params, bits, [op], up, n_threads=cores)
   dt = time.perf_counter() - t0
   return {
       "value": states * len(op) / dt, "unit": "evals/s", "cores": int(min(cores, states)),
       "kind": "port",
-      "sample": f"{states} states of the same workload ({mode} step), one state per thread, "
-                f"{dt:.2f} s wall",
-  }
+      "sample": f"the first {states} states of the timed batch ({mode} step, same parameters), one state "
+                f"per thread, {dt:.2f} s wall",
+  }, vals, grad
+
+
+def parity_check(eng, E, mode, op, bits_k, params, timed_vals_k, oracle_vals, oracle_grad):
+  """The timed workload against the oracle (reference pattern: simulate, compare, assert --
+  tests/inference/qnn_test.py:183-264 of the reference).  Values: rows of the LAST TIMED step.
+  Gradient: the engine's VJP of exactly these K states (a second call outside the timed region, same
+  kernels and plans) with upstream 1/K on both sides -- the timed upstream 1/states_total rescaled,
+  the VJP is linear in it -- so that the tolerance 1e-4 * max(1, |grad|_inf) bites."""
+  k = bits_k.shape[0]
+  sum_abs = float(sum(abs(c) for c, _, _ in op))
+  tol_v = 5e-5 * sum_abs
+  err_v = float(np.abs(timed_vals_k - oracle_vals).max())
+  out = {"states": k, "max_err_values": err_v, "tol_values": tol_v,
+         "values_from": "rows of the last timed step vs oracle/qhbm_cpu.c on the same bitstrings and parameters"}
+  ok = err_v <= tol_v
+  if oracle_grad is not None:
+    up = torch.full((k, 1), 1.0 / k, device="cuda")
+    method = E.GRAD_PARAMETER_SHIFT if mode == "shift" else E.GRAD_ADJOINT
+    _, g = eng.expectation_vjp(torch.from_numpy(bits_k).cuda(), params, up, method=method)
+    g = g.double().cpu().numpy()
+    torch.cuda.synchronize()
+    want = oracle_grad.astype(np.float64)
+    gnorm = float(np.abs(want).max())
+    tol_g = 1e-4 * max(1.0, gnorm)
+    err_g = float(np.abs(g - want).max())
+    out.update({"max_err_grad": err_g, "tol_grad": tol_g, "grad_inf_norm": gnorm,
+                "grad_from": "engine VJP of these K states (call outside the timed region, upstream 1/K) vs the "
+                             "oracle's adjoint VJP with the same upstream"})
+    ok = ok and err_g <= tol_g
+  out["ok"] = bool(ok)
+  return out
+
+
+def gpus_visible_without_hip():
+  """GPU count read from the KFD topology (sysfs), narrowed by HIP_/ROCR_VISIBLE_DEVICES -- no HIP or HSA
+  call, so the launching process holds no GPU context.  None when sysfs cannot tell."""
+  base = "/sys/class/kfd/kfd/topology/nodes"
+  try:
+    count = 0
+    for node in os.listdir(base):
+      with open(os.path.join(base, node, "properties")) as f:
+        props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+      if int(props.get("simd_count", "0")) > 0:
+        count += 1
+  except (OSError, ValueError):
+    return None
+  for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+    if os.environ.get(var) is not None:
+      count = min(count, len([x for x in os.environ[var].split(",") if x.strip()]))
+  return count
 
 
 def self_launch(args):
   """`bench.py --gpus N` outside torchrun: run the N ranks as a child torch.distributed.run (never an
-  exec, and before this process has touched a GPU) and exit with its code."""
-  import torch  # pylint: disable=import-outside-toplevel,redefined-outer-name
-  visible = torch.cuda.device_count()  # counting devices does not initialise the GPU
-  if visible < args.gpus and os.environ.get("QHBM_BENCH_SHARE_DEVICE") != "1":
+  exec) and exit with its code.  This parent makes no HIP call: the early refusal below counts GPUs
+  through sysfs, and every rank checks again with its own runtime (main)."""
+  visible = gpus_visible_without_hip()
+  if visible is not None and visible < args.gpus and os.environ.get("QHBM_BENCH_SHARE_DEVICE") != "1":
     raise SystemExit(f"bench.py --gpus {args.gpus}: only {visible} GPU(s) visible -- refusing to report a "
                      f"{args.gpus}-GPU number from fewer devices")
   with socket.socket() as sock:
@@ -180,6 +231,10 @@ def main():
   ap.add_argument("--adjoint-tile-qubits", type=int, default=0)
   ap.add_argument("--engine-option", action="append", default=[], metavar="NAME=VALUE",
                   help="qhbm_set_option knob for experiments (repeatable), e.g. adjoint_exchange=0")
+  ap.add_argument("--reduction", choices=["allreduce", "ordered"], default="allreduce",
+                  help="N > 1 gradient exchange: all-reduce of the [P] gradient (engine level), or the host "
+                       "mirror's default -- all-gather of the per-state rows [U, P], added in global state order "
+                       "(bit-identical for any N; AnalyticQuantumInference(ordered_reduction=True))")
   ap.add_argument("--cpu-sample-states", type=int, default=64)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--verify", action="store_true",
@@ -202,6 +257,9 @@ def main():
   # every rank on cuda:0 and QHBM_BENCH_BACKEND=gloo carries the collectives through the host.
   if os.environ.get("QHBM_BENCH_SHARE_DEVICE") == "1":
     local_rank = 0
+  elif torch.cuda.device_count() < world:
+    raise SystemExit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} GPU(s) visible -- refusing to "
+                     f"report a {world}-GPU number from fewer devices")
   backend = os.environ.get("QHBM_BENCH_BACKEND", "nccl")
   torch.cuda.set_device(local_rank)
   dist = None
@@ -249,7 +307,11 @@ def main():
       vals, grad = eng.expectation_vjp(bits, params, upstream,
                                        method=E.GRAD_PARAMETER_SHIFT if args.mode == "shift" else E.GRAD_ADJOINT)
     if world > 1:
-      if grad is not None:
+      if grad is not None and args.reduction == "ordered" and args.mode == "vqt":
+        rows = eng.state_gradients(spg) if spg else grad.new_zeros((0, grad.numel()))
+        rows = parallel.all_gather_rows(rows, blocks)
+        grad = rows.to(torch.float64).sum(0).to(torch.float32)
+      elif grad is not None:
         parallel.all_reduce_sum(grad)
       vals = parallel.all_gather_rows(vals, blocks)
     return vals, grad
@@ -275,6 +337,15 @@ def main():
     dt = float(tt.item())
   kt = eng.kernel_time_ms(reset=True)
 
+  # which physical device each rank ran on (PCI bus id), as the ranks themselves report it
+  prop = torch.cuda.get_device_properties(local_rank)
+  my_dev = f"{local_rank}:{getattr(prop, 'pci_bus_id', 0):02x}:{getattr(prop, 'pci_device_id', 0):02x}"
+  device_ids = [my_dev]
+  if world > 1:
+    device_ids = [None] * world
+    dist.all_gather_object(device_ids, my_dev)
+
+  parity_failed = False
   if rank == 0:
     n_terms = len(op)
     evals_per_step = total_states * n_terms
@@ -346,6 +417,11 @@ def main():
             "n_qubits": n, "layers": layers, "states_total": total_states, "states_per_gpu": spg,
             "pauli_terms": n_terms, "hamiltonian": args.hamiltonian,
             "mode": args.mode, "parallelism": f"batch-sharded x{world}",
+            # what the collective backend itself reports: a SCALE record shows that RCCL saw N ranks
+            "backend": dist.get_backend() if world > 1 else None,
+            "backend_world_size": dist.get_world_size() if world > 1 else 1,
+            "devices": sorted(set(device_ids)),
+            "reduction": (args.reduction if args.mode == "vqt" else "allreduce") if world > 1 else None,
             "forward_passes": fwd_passes, "adjoint_passes": bwd_passes,
             "bench_py_sha16": bench_sha, "engine_options": args.engine_option,
         },
@@ -386,13 +462,33 @@ def main():
                         "ok": bool(err_v < 1e-4 * len(op) and err_g < 1e-4)}
     if not args.no_cpu_baseline:
       try:
-        line["cpu_baseline"] = cpu_baseline(n, gates, n_params, op, params_np, args.cpu_sample_states, args.mode)
+        from oracle import qhbm_cpu as C  # pylint: disable=import-outside-toplevel
+        k = max(1, min(args.cpu_sample_states, spg, C.max_threads(), os.cpu_count() or 1))
+        bits_k = all_bits[lo:lo + k]
+        # upstream 1/K: see parity_check; the rate does not depend on the weight
+        oracle_params = params_np
+        if os.environ.get("QHBM_BENCH_CORRUPT_PARITY") == "1":   # test hook: the check must be able to fail
+          oracle_params = params_np + np.float32(0.05)
+        rec, o_vals, o_grad = cpu_baseline(n, gates, n_params, op, oracle_params, bits_k, 1.0 / k, args.mode)
+        line["cpu_baseline"] = rec
+        if rec is not None:
+          timed_rows = vals[:k].float().cpu().numpy()   # global rows lo..lo+k are rank 0's own block
+          line["parity_check"] = parity_check(eng, E, args.mode, op, bits_k, params, timed_rows, o_vals, o_grad)
+          parity_failed = not line["parity_check"]["ok"]
       except Exception as exc:  # pylint: disable=broad-except
         line["cpu_baseline"] = {"error": str(exc)}
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)
+    if parity_failed:
+      print("bench.py: parity_check FAILED: the timed workload disagrees with the oracle: "
+            f"{line['parity_check']}", file=sys.stderr)
+  flag = torch.tensor([1 if (rank == 0 and parity_failed) else 0], dtype=torch.int32,
+                      device="cpu" if backend == "gloo" or world == 1 else "cuda")
   if world > 1:
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
     dist.barrier()
     dist.destroy_process_group()
+  if int(flag.item()):
+    raise SystemExit(3)
 
 
 if __name__ == "__main__":

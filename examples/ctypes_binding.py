@@ -19,7 +19,8 @@ _H2D, _D2H = 1, 2  # hipMemcpyHostToDevice, hipMemcpyDeviceToHost
 
 class Gate(ctypes.Structure):  # struct qhbm_gate
   _fields_ = [("kind", ctypes.c_int32), ("q0", ctypes.c_int32), ("q1", ctypes.c_int32),
-              ("param_idx", ctypes.c_int32), ("scalar", ctypes.c_float), ("offset", ctypes.c_float)]
+              ("param_idx", ctypes.c_int32), ("scalar", ctypes.c_float), ("offset", ctypes.c_float),
+              ("global_shift", ctypes.c_float)]  # ABI v3: cirq's EigenGate global_shift (0 when omitted)
 
 
 def load():
@@ -79,7 +80,7 @@ def check(lib, handle, rc):
 
 
 def make_engine(lib, n_qubits, gates, n_params, ops, device=0):
-  """gates: [(kind, q0, q1, param_idx, scalar, offset)]; ops: [[(coeff, x_mask, z_mask)]]."""
+  """gates: [(kind, q0, q1, param_idx, scalar, offset[, global_shift])]; ops: [[(coeff, x_mask, z_mask)]]."""
   handle = ctypes.c_void_p()
   check(lib, None, lib.qhbm_create(device, ctypes.byref(handle)))
   arr = (Gate * max(1, len(gates)))(*[Gate(*g) for g in gates])

@@ -41,15 +41,19 @@
 extern "C" {
 #endif
 
-#define QHBM_ABI_VERSION 2
+#define QHBM_ABI_VERSION 3
 
 /* Gate kinds: the one-parameter "power gate" families of cirq 0.14.1 that
  * tensorflow-quantum 0.6.1 serialises.  A gate is
  * G**t with the cirq matrix convention
  *     G**t = sum_k exp(i*pi*t*e_k) P_k      (eigen-exponents e_k, projectors P_k)
- * Global phases exp(i*pi*t*global_shift) never change an expectation value and
- * are not represented.  rx/ry/rz(theta) are XPOW/YPOW/ZPOW with scalar = 1/pi.
- * PhasedXPow, FSim and PhasedISwapPow are lowered by the host to products of
+ * times cirq's global phase exp(i*pi*t*global_shift) (qhbm_gate::global_shift; 0 for the
+ * plain power gates).  rx/ry/rz(theta) are XPOW/YPOW/ZPOW with scalar = 1/pi and
+ * global_shift = -0.5.  The phase never changes an expectation value, a gradient or a
+ * sample, so the hot path ignores it; qhbm_statevector applies the product of all gates'
+ * phases to the exported states, which therefore equal cirq's final_state_vector -- and the
+ * matrix tfq.layers.Unitary returns (qhbmlib/inference/qnn_utils.py:23-33) -- exactly, not up
+ * to a phase.  PhasedXPow, FSim and PhasedISwapPow are lowered by the host to products of
  * these kinds. */
 enum qhbm_gate_kind {
   QHBM_GATE_I = 0,
@@ -74,6 +78,9 @@ typedef struct qhbm_gate {
   int32_t param_idx; /* index into params[], -1 = constant exponent */
   float scalar;      /* exponent = scalar * params[param_idx] + offset */
   float offset;
+  float global_shift; /* cirq EigenGate global_shift: the gate is exp(i*pi*t*global_shift) * G**t
+                         (ABI v3; cirq.rx/ry/rz and tfq.util.exponential's
+                         rotations -- qhbmlib/models/circuit.py:268-272 -- carry -0.5) */
 } qhbm_gate;
 
 /* Gradient method for qhbm_expectation_vjp. */
@@ -187,7 +194,8 @@ int qhbm_expectation_jacobian(qhbm_engine* h, const int8_t* d_bits, int U,
  * qhbm_utils.py:24-116 `density_matrix` / `fidelity`).
  *   d_out_states [U, 2^n_qubits] complex64 as interleaved (re, im) floats (device);
  *   amplitude index = the bitstring read as a big-endian binary number (qubit 0 is
- *   the most significant bit, as cirq orders `final_state_vector`).
+ *   the most significant bit, as cirq orders `final_state_vector`), global phase included
+ *   (every gate's exp(i*pi*t*global_shift) and the e^{i*pi*t/2} of cirq's X**t / Y**t).
  * Observables need not be installed. */
 int qhbm_statevector(qhbm_engine* h, const int8_t* d_bits, int U,
                      const float* d_params, void* d_out_states, void* stream);

@@ -30,7 +30,8 @@ def max_threads():
 
 def _pack(n, gates, params, bits, ops):
   arr = (_Gate * max(len(gates), 1))()
-  for i, (kind, q0, q1, pidx, scalar, offset) in enumerate(gates):
+  for i, g in enumerate(gates):   # a 7th entry (cirq global_shift) never changes an expectation value
+    kind, q0, q1, pidx, scalar, offset = g[:6]
     arr[i] = _Gate(int(kind), int(q0), int(q1), int(pidx), float(scalar), float(offset))
   offsets, coeffs, xs, zs = [0], [], [], []
   for op in ops:

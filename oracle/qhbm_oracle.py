@@ -141,10 +141,17 @@ def gate_matrix_derivative(kind, t, global_shift=0.0):
 
 
 # ---------------------------------------------------------------------------
-# Flat circuits: list of (kind, q0, q1, param_idx, scalar, offset).
+# Flat circuits: list of (kind, q0, q1, param_idx, scalar, offset[, global_shift]).
+# global_shift is cirq's EigenGate shift (rx/ry/rz: -0.5): the gate is
+# exp(i pi t global_shift) * G**t.  It never changes an expectation value; the
+# state and the unitary carry it (qnn_utils.py:23-33).
 # ---------------------------------------------------------------------------
+def gate_global_shift(gate):
+  return float(gate[6]) if len(gate) > 6 else 0.0
+
+
 def gate_exponent(gate, params):
-  _, _, _, pidx, scalar, offset = gate
+  pidx, scalar, offset = gate[3], gate[4], gate[5]
   if pidx < 0:
     return float(offset)
   return float(scalar) * float(params[pidx]) + float(offset)
@@ -152,7 +159,7 @@ def gate_exponent(gate, params):
 
 def inverse_gates(gates):
   """circuit.py:164-176: reversed order, exponent negated, same variables."""
-  return [(k, q0, q1, p, -s, -o) for (k, q0, q1, p, s, o) in reversed(gates)]
+  return [(g[0], g[1], g[2], g[3], -g[4], -g[5]) + tuple(g[6:]) for g in reversed(gates)]
 
 
 def _apply_matrix(state, mat, qubits):
@@ -204,7 +211,7 @@ def simulate(n, gates, params, bits):
     kind, q0, q1 = g[0], g[1], g[2]
     t = gate_exponent(g, params)
     qs = (q0,) if gate_num_qubits(kind) == 1 else (q0, q1)
-    state = _apply_matrix(state, gate_matrix(kind, t), qs)
+    state = _apply_matrix(state, gate_matrix(kind, t, gate_global_shift(g)), qs)
   return state
 
 
@@ -321,13 +328,14 @@ def expectation_jacobian(n, gates, params, bitstrings, ops,
       vals[b, k] = float(np.real(np.vdot(psi_final.ravel(), lam.ravel())))
       psi = psi_final
       for g in reversed(gates):
-        kind, q0, q1, pidx, scalar, _ = g
+        kind, q0, q1, pidx, scalar = g[:5]
+        shift = gate_global_shift(g)
         t = gate_exponent(g, params)
         qs = (q0,) if gate_num_qubits(kind) == 1 else (q0, q1)
-        u_dag = gate_matrix(kind, t).conj().T
+        u_dag = gate_matrix(kind, t, shift).conj().T
         psi = _apply_matrix(psi, u_dag, qs)  # psi_{g-1}
         if pidx >= 0:
-          dpsi = _apply_matrix(psi, gate_matrix_derivative(kind, t), qs)
+          dpsi = _apply_matrix(psi, gate_matrix_derivative(kind, t, shift), qs)
           jac[b, k, pidx] += scalar * 2.0 * float(
               np.real(np.vdot(lam.ravel(), dpsi.ravel())))
         lam = _apply_matrix(lam, u_dag, qs)
@@ -343,14 +351,14 @@ def expectation_parameter_shift(n, gates, params, bitstrings, ops):
   bitstrings = np.asarray(bitstrings)
   jac = np.zeros((bitstrings.shape[0], len(ops), len(params)))
   for gi, g in enumerate(gates):
-    kind, q0, q1, pidx, scalar, offset = g
+    kind, q0, q1, pidx, scalar, offset = g[:6]
     if pidx < 0:
       continue
     if kind == GATE_ISWAPPOW:
       raise ValueError("two-term shift rule does not apply to ISWAPPOW")
     for sign in (+1.0, -1.0):
       shifted = list(gates)
-      shifted[gi] = (kind, q0, q1, pidx, scalar, offset + sign * 0.5)
+      shifted[gi] = (kind, q0, q1, pidx, scalar, offset + sign * 0.5) + tuple(g[6:])
       e = expectation(n, shifted, params, bitstrings, ops)
       jac[:, :, pidx] += sign * (math.pi * scalar / 2.0) * e
   return jac

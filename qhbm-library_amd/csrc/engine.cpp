@@ -92,6 +92,8 @@ struct qhbm_engine {
   uint32_t n_obs_groups = 0;
   DevBuf<float2> psi, lam;
   DevBuf<float> state_grad, slot_factor, vals_tmp, upstream_tmp, phase_cs;
+  DevBuf<ShiftPhase> shift_phases;  // gates with a cirq global_shift (qhbm_statevector restores their phases)
+  int n_shift_phases = 0;
   // parameter-shift batches: per-program coefficient buffers, shift tables, accumulators
   DevBuf<float> coef_batch, shift_vals, shift_weight, vals_batch;
   DevBuf<int> shift_gates, shift_param;
@@ -290,6 +292,14 @@ int upload_model(qhbm_engine* h) {
   HIPCHK(h->param_slot_begin.upload(begin));
   HIPCHK(h->param_slots.upload(slots));
   HIPCHK(h->slot_factor.upload(ap.slot_factor));
+  {
+    std::vector<ShiftPhase> sp;
+    for (const Gate& G : h->model.gates)
+      if (G.global_shift != 0.f && G.kind != QHBM_GATE_I)
+        sp.push_back(ShiftPhase{G.param_idx, G.param_idx >= 0 ? G.scalar : 0.f, G.offset, G.global_shift});
+    HIPCHK(h->shift_phases.upload(sp));
+    h->n_shift_phases = int(sp.size());
+  }
   h->model_uploaded = true;
   return 0;
 }
@@ -541,6 +551,8 @@ int qhbm_set_circuit(qhbm_engine* h, int n_qubits, int n_gates, const qhbm_gate*
   m.n_params = n_params;
   m.gates.resize(size_t(n_gates));
   if (n_gates) std::memcpy(m.gates.data(), gates, size_t(n_gates) * sizeof(Gate));
+  for (const Gate& G : m.gates)
+    if (!std::isfinite(G.global_shift)) return fail(h, "gate with a non-finite global_shift");
   Plan probe;
   std::string err;
   Model no_obs = m;
@@ -739,9 +751,11 @@ int qhbm_statevector(qhbm_engine* h, const int8_t* d_bits, int U, const float* d
     HIPCHK(hipMemcpy2DAsync(static_cast<char*>(d_out_states) + size_t(s0) * row, row, h->psi.p, pitch, row, c,
                             hipMemcpyDeviceToDevice, s));
   }
-  // restore the global phase the X**t / Y**t kernels leave out (cirq's e^{i pi t / 2} per gate)
+  // restore the global phase the kernels leave out: cirq's e^{i pi t / 2} per X**t / Y**t and every
+  // gate's exp(i pi t global_shift)
   HIPCHK(h->phase_cs.reserve(2));
-  HIPCHK(launch_global_phase(d.jobs.p, int(d.plan.jobs.size()), d_params, h->phase_cs.p, s));
+  HIPCHK(launch_global_phase(d.jobs.p, int(d.plan.jobs.size()), h->shift_phases.p, h->n_shift_phases, d_params,
+                             h->phase_cs.p, s));
   HIPCHK(launch_scale_states(static_cast<float2*>(d_out_states), size_t(U) << h->model.n, h->phase_cs.p, s));
   return 0;
 }

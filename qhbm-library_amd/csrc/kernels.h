@@ -66,8 +66,13 @@ hipError_t launch_parity_energy_vjp(const int8_t* bits, int64_t n_rows, int n, c
 // block_cum: n_states * 2^n / 1024 doubles of scratch.
 hipError_t launch_sample(const float2* psi, uint32_t n, int n_user, uint32_t n_states, double* block_cum,
                          uint32_t n_shots, uint64_t seed, uint32_t state0, int8_t* out, hipStream_t stream);
-hipError_t launch_global_phase(const CoefJob* jobs, int n_jobs, const float* params, float* out_cs,
-                               hipStream_t stream);
+// One gate with a non-zero cirq global_shift: phase exp(i pi shift (scalar * params[param_idx] + offset)).
+struct ShiftPhase {
+  int32_t param_idx;
+  float scalar, offset, shift;
+};
+hipError_t launch_global_phase(const CoefJob* jobs, int n_jobs, const ShiftPhase* shifts, int n_shifts,
+                               const float* params, float* out_cs, hipStream_t stream);
 hipError_t launch_scale_states(float2* st, size_t count, const float* cs, hipStream_t stream);
 hipError_t launch_prep_coefs(const CoefJob* jobs, int n_jobs, const float* params, float* coef,
                              int shift_gate, double shift, hipStream_t stream);

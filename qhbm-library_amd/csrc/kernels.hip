@@ -1878,10 +1878,12 @@ hipError_t launch_reduce_tiles(float* tile_grad, uint32_t n_states, uint32_t n_t
 
 // ================================================================================
 // qhbm_statevector only: X**t and Y**t are applied as c*I - i*s*G, i.e. without cirq's global
-// phase e^{i pi t / 2} (expectation values never see it).  The exported state restores the
-// product of those phases so that it equals cirq's final_state_vector, not just its ray.
+// phase e^{i pi t / 2} (expectation values never see it), and no kernel applies a gate's
+// exp(i pi t global_shift) (qhbm_gate::global_shift: -0.5 for rx / ry / rz).  The exported state
+// restores the product of those phases so that it equals cirq's final_state_vector, not just its ray.
 // ================================================================================
 __global__ void global_phase_kernel(const CoefJob* __restrict__ jobs, int n_jobs,
+                                    const ShiftPhase* __restrict__ shifts, int n_shifts,
                                     const float* __restrict__ params, float* __restrict__ out_cs) {
   __shared__ double part[256];
   double acc = 0.0;
@@ -1892,6 +1894,12 @@ __global__ void global_phase_kernel(const CoefJob* __restrict__ jobs, int n_jobs
     if (jb.param_idx >= 0) t += double(jb.scalar) * double(params[jb.param_idx]);
     if (jb.mop == MOP_X) t -= 2.0 * rint(0.5 * t);  // the reduced exponent prep_coefs_kernel applies
     acc += 0.5 * t;
+  }
+  for (int j = threadIdx.x; j < n_shifts; j += 256) {
+    const ShiftPhase sp = shifts[j];
+    double t = double(sp.offset);
+    if (sp.param_idx >= 0) t += double(sp.scalar) * double(params[sp.param_idx]);
+    acc += double(sp.shift) * t;
   }
   part[threadIdx.x] = acc;
   __syncthreads();
@@ -1916,9 +1924,10 @@ __global__ __launch_bounds__(256) void scale_states_kernel(float2* __restrict__ 
   }
 }
 
-hipError_t launch_global_phase(const CoefJob* jobs, int n_jobs, const float* params, float* out_cs,
-                               hipStream_t stream) {
-  hipLaunchKernelGGL(global_phase_kernel, dim3(1), dim3(256), 0, stream, jobs, n_jobs, params, out_cs);
+hipError_t launch_global_phase(const CoefJob* jobs, int n_jobs, const ShiftPhase* shifts, int n_shifts,
+                               const float* params, float* out_cs, hipStream_t stream) {
+  hipLaunchKernelGGL(global_phase_kernel, dim3(1), dim3(256), 0, stream, jobs, n_jobs, shifts, n_shifts, params,
+                     out_cs);
   return hipGetLastError();
 }
 

@@ -17,6 +17,7 @@ namespace qhbm {
 struct Gate {  // layout-compatible with the C ABI's qhbm_gate
   int32_t kind, q0, q1, param_idx;
   float scalar, offset;
+  float global_shift;  // cirq's EigenGate shift: a global phase exp(i pi t shift), seen by qhbm_statevector only
 };
 
 struct PauliTerm {

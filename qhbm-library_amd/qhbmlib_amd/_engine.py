@@ -44,7 +44,8 @@ ABI_SYMBOLS = (
 class QhbmGate(ctypes.Structure):
   _fields_ = [("kind", ctypes.c_int32), ("q0", ctypes.c_int32),
               ("q1", ctypes.c_int32), ("param_idx", ctypes.c_int32),
-              ("scalar", ctypes.c_float), ("offset", ctypes.c_float)]
+              ("scalar", ctypes.c_float), ("offset", ctypes.c_float),
+              ("global_shift", ctypes.c_float)]
 
 
 class EngineError(RuntimeError):
@@ -178,12 +179,13 @@ class Engine:
 
   # ---- model -------------------------------------------------------------
   def set_circuit(self, n_qubits, gates, n_params):
-    """gates: iterable of (kind, q0, q1, param_idx, scalar, offset)."""
+    """gates: iterable of (kind, q0, q1, param_idx, scalar, offset[, global_shift])."""
     gates = list(gates)
     arr = (QhbmGate * max(len(gates), 1))()
-    for i, (kind, q0, q1, pidx, scalar, offset) in enumerate(gates):
+    for i, g in enumerate(gates):
+      kind, q0, q1, pidx, scalar, offset = g[:6]
       arr[i] = QhbmGate(int(kind), int(q0), int(q1), int(pidx), float(scalar),
-                        float(offset))
+                        float(offset), float(g[6]) if len(g) > 6 else 0.0)
     self._check(
         self._lib.qhbm_set_circuit(self._h, int(n_qubits), len(gates), arr,
                                    int(n_params)))

@@ -17,6 +17,7 @@ from qhbmlib_amd import _engine
 from qhbmlib_amd import ir
 from qhbmlib_amd import parallel
 from qhbmlib_amd import utils
+from qhbmlib_amd.inference import ebm
 from qhbmlib_amd.models import circuit  # noqa: F401
 from qhbmlib_amd.models import energy
 from qhbmlib_amd.models import hamiltonian
@@ -31,7 +32,8 @@ class _ExpectationFunction(torch.autograd.Function):
   With a process group the unique rows are dealt out in contiguous blocks
   (`parallel.partition`): every rank simulates its block, the values are all-gathered and the
   [P] gradient is all-reduced, so `vqt()` / `qmhl()` scale over the GPUs of a node without user
-  code.  Every rank must pass the same bitstrings."""
+  code (SURVEY.md 8e).  Every rank must pass the same bitstrings and parameters;
+  `AnalyticQuantumInference._expectation` verifies that before the call (`check_consistency`)."""
 
   @staticmethod
   def forward(ctx, symbol_values, engine, bits, method, group, ordered):
@@ -200,18 +202,23 @@ class AnalyticQuantumInference(QuantumInference):
   unique bitstrings are sharded, one process per GPU; None (default) runs on this process's GPU
   only.  `ordered_reduction` (default True) gathers per-state gradient rows and adds them in global
   state order, so losses and gradients are bit-identical for 1, 2, 4 or 8 ranks; False all-reduces
-  the [P] gradient instead (a few hundred floats instead of [U, P], not order-stable)."""
+  the [P] gradient instead (a few hundred floats instead of [U, P], not order-stable).
+  `check_consistency` (default True): before a sharded call the ranks compare a fingerprint of the
+  unique bitstrings and the symbol values (8 bytes each) and raise `parallel.ShardMismatchError` if
+  they differ -- differently seeded samplers would otherwise shard different sets, silently."""
 
   MAX_OPS_PER_CALL = 1024  # kMaxOps of the engine (csrc/program.h)
 
   def __init__(self, input_circuit: circuit.QuantumCircuit, name: Union[None, str] = None,
                device: Union[None, int] = None, gradient_method: int = _engine.GRAD_ADJOINT,
-               process_group=None, max_cached_engines: int = 4, ordered_reduction: bool = True):
+               process_group=None, max_cached_engines: int = 4, ordered_reduction: bool = True,
+               check_consistency: bool = True):
     super().__init__(input_circuit, name)
     self._device = device
     self.gradient_method = gradient_method
     self._process_group = process_group
     self.ordered_reduction = ordered_reduction
+    self.check_consistency = check_consistency
     self._engines = _EngineCache(max_cached_engines)
 
   def _group(self):
@@ -255,6 +262,8 @@ class AnalyticQuantumInference(QuantumInference):
     values = _row_of_tiled(symbol_values, total_circuit).to(torch.float32)
     flat_gates = total_circuit.pqc.flat_gates(qubits, list(symbol_names))
     group = self._group()
+    if group is not None and self.check_consistency:
+      parallel.assert_same_on_all_ranks("the unique bitstrings or the symbol values", bits, values, group=group)
     # one engine call measures at most MAX_OPS_PER_CALL observables (its LDS accumulators);
     # longer lists -- e.g. the 1350 shards of a third-order KOBE on 20 qubits -- go in slices
     parts = []
@@ -304,7 +313,7 @@ class SampledQuantumInference(QuantumInference):
     self._expectation_samples = int(expectation_samples)
     self._device = device
     self._engines = {}
-    self._seed = int(torch.seed() if initial_seed is None else initial_seed) & (2**63 - 1)
+    self._seed = int(ebm.fresh_seed() if initial_seed is None else initial_seed) & (2**63 - 1)
 
   def _next_seed(self):
     self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & (2**63 - 1)

@@ -120,27 +120,31 @@ _KIND_NAMES = {
 
 @dataclasses.dataclass(frozen=True)
 class Gate:
-  """kind ** exponent on `qubits` (cirq EigenGate convention, no global shift:
-  global phases never change an expectation value)."""
+  """exp(i pi t global_shift) * kind ** t on `qubits`, t = `exponent` (cirq EigenGate convention).
+  The global phase never changes an expectation value, a gradient or a sample; the exported
+  statevector and `inference.unitary` carry it (cirq.rx/ry/rz: global_shift = -0.5)."""
   kind: int
   qubits: Tuple[GridQubit, ...]
   exponent: Exponent = Exponent(None, 0.0, 1.0)
+  global_shift: float = 0.0
 
   def __pow__(self, power):
     if isinstance(power, (Symbol, Exponent)):
       base = self.exponent
       if base.symbol is not None:
         raise ValueError("cannot raise a symbolic gate to a symbolic power")
-      return Gate(self.kind, self.qubits, _as_exponent(power) * base.offset)
-    return Gate(self.kind, self.qubits, self.exponent * float(power))
+      return Gate(self.kind, self.qubits, _as_exponent(power) * base.offset, self.global_shift)
+    return Gate(self.kind, self.qubits, self.exponent * float(power), self.global_shift)
 
   def inverse(self) -> "Gate":
-    return Gate(self.kind, self.qubits, -self.exponent)
+    # (e^{i pi t g} G^t)^-1 = e^{i pi (-t) g} G^{-t}: the exponent changes sign, the shift stays
+    return Gate(self.kind, self.qubits, -self.exponent, self.global_shift)
 
   def __repr__(self):
     e = self.exponent
     ex = (f"{e.scalar:g}*{e.symbol}" if e.symbol else "") + (f"{e.offset:+g}" if e.offset or not e.symbol else "")
-    return f"{_KIND_NAMES[self.kind]}{list(self.qubits)}**({ex})"
+    gs = f", global_shift={self.global_shift:g}" if self.global_shift else ""
+    return f"{_KIND_NAMES[self.kind]}{list(self.qubits)}**({ex}{gs})"
 
 
 def _g1(kind):
@@ -170,17 +174,23 @@ def CZPowGate(exponent):  # pylint: disable=invalid-name
   return lambda q0, q1: CZ(q0, q1)**exponent
 
 
+def _rotation(kind, theta):
+  return lambda q: Gate(kind, (q,), _as_exponent(theta) * (1.0 / math.pi), -0.5)
+
+
 def rx(theta):
-  """cirq.rx(theta) = XPowGate(exponent=theta/pi, global_shift=-0.5)."""
-  return lambda q: X(q)**(_as_exponent(theta) * (1.0 / math.pi))
+  """cirq.rx(theta) = XPowGate(exponent=theta/pi, global_shift=-0.5) = exp(-i theta X / 2)."""
+  return _rotation(E.GATE_XPOW, theta)
 
 
 def ry(theta):
-  return lambda q: Y(q)**(_as_exponent(theta) * (1.0 / math.pi))
+  """cirq.ry(theta) = YPowGate(exponent=theta/pi, global_shift=-0.5) = exp(-i theta Y / 2)."""
+  return _rotation(E.GATE_YPOW, theta)
 
 
 def rz(theta):
-  return lambda q: Z(q)**(_as_exponent(theta) * (1.0 / math.pi))
+  """cirq.rz(theta) = ZPowGate(exponent=theta/pi, global_shift=-0.5) = exp(-i theta Z / 2)."""
+  return _rotation(E.GATE_ZPOW, theta)
 
 
 def phased_x_pow(q, phase_exponent, exponent):
@@ -248,7 +258,8 @@ class Circuit:
     return "Circuit(" + ", ".join(map(repr, self.gates)) + ")"
 
   def flat_gates(self, qubits: Sequence[GridQubit], symbol_names: Sequence[str]):
-    """Lowers to the C ABI's gate list: (kind, q0, q1, param_idx, scalar, offset).
+    """Lowers to the C ABI's gate list: (kind, q0, q1, param_idx, scalar, offset[, global_shift]) --
+    the seventh entry only for gates that have a global shift (rx / ry / rz).
     `qubits` fixes the qubit index (sorted qubit j = engine qubit j);
     `symbol_names[i]` is the symbol whose value sits at params[i]."""
     qindex = {q: i for i, q in enumerate(qubits)}
@@ -261,7 +272,8 @@ class Circuit:
       q0 = qindex[g.qubits[0]]
       q1 = qindex[g.qubits[1]] if len(g.qubits) > 1 else -1
       out.append((g.kind, q0, q1, pindex[e.symbol] if e.symbol is not None else -1,
-                  e.scalar if e.symbol is not None else 0.0, e.offset))
+                  e.scalar if e.symbol is not None else 0.0, e.offset) +
+                 ((float(g.global_shift),) if g.global_shift else ()))
     return out
 
 
@@ -396,7 +408,8 @@ def _strings_commute(a: PauliString, b: PauliString) -> bool:
 
 def _exponential_of_string(theta, string: PauliString) -> List[Gate]:
   """exp(-i theta c P): Clifford basis change to Z...Z (X: H, Y: rx(pi/2)), CNOT ladder onto the
-  last qubit, rz(2 theta c) there, and everything undone."""
+  last qubit, rz(2 theta c) there, and everything undone.  rx / rz carry cirq's global_shift = -0.5,
+  so the circuit IS exp(-i theta c P), not just up to a phase."""
   qubits = sorted(string.paulis)
   if not qubits:
     return []  # identity string: a global phase

@@ -7,10 +7,16 @@ never split.  One exchange per call: an all-gather of the per-state expectation
 values and an all-reduce (sum) of the [P] gradient -- KiB-sized messages over
 RCCL/xGMI (latency-bound), nothing else crosses GPUs.
 """
+import hashlib
 from typing import Callable, List, Tuple
 
+import numpy as np
 import torch
 import torch.distributed as dist
+
+
+class ShardMismatchError(RuntimeError):
+  """The ranks of a process group were handed different inputs for one sharded call."""
 
 
 def partition(num_rows: int, world_size: int) -> List[Tuple[int, int]]:
@@ -57,6 +63,59 @@ def all_gather_rows(local: torch.Tensor, blocks: List[Tuple[int, int]], group=No
   dist.all_gather(gathered, padded, group=group)
   out = torch.cat([g[:h - l] for g, (l, h) in zip(gathered, blocks)], 0)
   return out.to(local.device) if host else out
+
+
+def default_group_size() -> int:
+  """World size of the default process group, 1 when torch.distributed is not in use."""
+  return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def agreed_seed(seed: int, group=None) -> int:
+  """Rank 0's `seed` on every rank of `group` (the default group when None; the identity without
+  torch.distributed).  The sharded expectation deals ONE set of unique bitstrings out over the
+  ranks (reference: one sample set, dedup, then the hot path -- qhbmlib/inference/ebm.py:271-280),
+  so every rank's sampler must draw the same samples: samplers created with `initial_seed=None`
+  route their fresh seed through here."""
+  if default_group_size() == 1:
+    return int(seed)
+  box = torch.tensor([int(seed)], dtype=torch.int64)
+  if not _via_host(group):
+    box = box.cuda()
+  dist.broadcast(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+  return int(box.item())
+
+
+def fingerprint(*arrays) -> int:
+  """63-bit content hash (blake2b) of the given tensors / arrays: shapes, dtypes and bytes."""
+  h = hashlib.blake2b(digest_size=8)
+  for a in arrays:
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    a = np.ascontiguousarray(a)
+    h.update(str((a.shape, a.dtype.str)).encode())
+    h.update(a.tobytes())
+  return int.from_bytes(h.digest(), "little") & (2**63 - 1)
+
+
+def assert_same_on_all_ranks(what: str, *arrays, group=None) -> None:
+  """Raises ShardMismatchError (on EVERY rank) unless all ranks of the group hold the same
+  `arrays`.  One all-gather of 8 bytes per rank.  Without this check ranks that sampled different
+  bitstrings -- differently seeded samplers -- or hold different parameters would partition different
+  unique sets and all-gather rows that do not belong together, silently."""
+  world = dist.get_world_size(group)
+  if world == 1:
+    return
+  mine = torch.tensor([fingerprint(*arrays)], dtype=torch.int64)
+  if not _via_host(group):
+    mine = mine.cuda()
+  every = [torch.empty_like(mine) for _ in range(world)]
+  dist.all_gather(every, mine, group=group)
+  prints = [int(t.item()) for t in every]
+  if any(p != prints[0] for p in prints):
+    raise ShardMismatchError(
+        f"sharded expectation: {what} differ between the ranks of the process group (fingerprints "
+        f"{[hex(p) for p in prints]}).  Every rank must pass the same bitstrings and hold the same parameters: "
+        "give the EBM samplers one seed (initial_seed=None is agreed over the default group automatically; an "
+        "explicit initial_seed must be the same on all ranks) and initialise the model identically.")
 
 
 class ShardedExpectation:

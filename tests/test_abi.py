@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported():
   lib = ctypes.CDLL(E.LIB_PATH)
   for sym in declared:
     assert hasattr(lib, sym), sym
-  assert lib.qhbm_abi_version() == 2
+  assert lib.qhbm_abi_version() == 3
 
 
 def test_gate_kind_enum_matches_host_and_oracle():
@@ -40,7 +40,10 @@ def test_gate_kind_enum_matches_host_and_oracle():
       continue
     assert getattr(E, f"GATE_{name}") == int(value)
     assert getattr(O, f"GATE_{name}") == int(value)
-  assert ctypes.sizeof(E.QhbmGate) == 24
+  # struct qhbm_gate, ABI v3: four int32, scalar, offset, global_shift
+  assert ctypes.sizeof(E.QhbmGate) == 28
+  fields = re.search(r"typedef struct qhbm_gate \{(.*?)\} qhbm_gate;", text, re.S).group(1)
+  assert re.findall(r"(?:int32_t|float) (\w+);", fields) == [f[0] for f in E.QhbmGate._fields_]
 
 
 def _planner(n, layers, op, **opts):

@@ -36,22 +36,55 @@ def test_bench_single_process_line():
   assert "12-qubit TFIM ring" in line["config"]["workload"] and line["config"]["states_total"] == 16
   assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
   assert line["verify"]["ok"], line["verify"]
+  pc = line["parity_check"]
+  assert pc["ok"] and pc["states"] == 2 and pc["max_err_values"] <= pc["tol_values"]
+  assert pc["max_err_grad"] <= pc["tol_grad"]
 
 
-def test_bench_two_ranks_as_the_driver_launches_it():
+def test_bench_config3_timed_batch_against_the_oracle():
+  """BASELINE configs[2]'s circuit with bench.py's own seeds (parameters 1234, bitstrings 4321): rows of
+  the timed step and the VJP of the same states against the C oracle, inside the bench run itself
+  (reference pattern simulate / compare / assert, tests/inference/qnn_test.py:183-264)."""
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--states-total", "96", "--steps", "1",
+                        "--warmup", "1", "--cpu-sample-states", "8"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert out.returncode == 0, out.stderr[-2000:]
+  line = _line(out.stdout)
+  assert (line["config"]["n_qubits"], line["config"]["layers"], line["config"]["pauli_terms"]) == (20, 16, 57)
+  pc = line["parity_check"]
+  assert pc["ok"] and pc["states"] == 8, pc
+  assert pc["max_err_values"] <= pc["tol_values"] == pytest.approx(5e-5 * 47.5)
+  assert pc["max_err_grad"] <= pc["tol_grad"] and pc["grad_inf_norm"] > 1e-2
+
+
+def test_bench_exits_non_zero_when_the_oracle_disagrees():
+  """A corrupted workload (QHBM_BENCH_CORRUPT_PARITY=1 perturbs the oracle's parameters) must fail the run."""
+  env = dict(os.environ, QHBM_BENCH_CORRUPT_PARITY="1")
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--cpu-sample-states", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+  assert out.returncode != 0 and "parity_check FAILED" in out.stderr
+  assert not _line(out.stdout)["parity_check"]["ok"]
+
+
+@pytest.mark.parametrize("reduction", ["allreduce", "ordered"])
+def test_bench_two_ranks_as_the_driver_launches_it(reduction):
   with socket.socket() as s:
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
   env = dict(os.environ, QHBM_BENCH_SHARE_DEVICE="1", QHBM_BENCH_BACKEND="gloo")
   cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-         "--gpus", "2", "--no-cpu-baseline"] + SMALL
+         "--gpus", "2", "--cpu-sample-states", "2", "--reduction", reduction] + SMALL
   out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
   assert out.returncode == 0, out.stderr[-3000:]
   line = _line(out.stdout)
   assert line["n_gpus"] == 2
   assert line["config"]["parallelism"] == "batch-sharded x2"
+  # what the collective backend reports, and the exchange that ran (ordered = the host mirror's default)
+  assert line["config"]["backend"] == "gloo" and line["config"]["backend_world_size"] == 2
+  assert line["config"]["reduction"] == reduction and len(line["config"]["devices"]) >= 1
   assert line["verify"]["ok"], line["verify"]
+  assert line["parity_check"]["ok"], line["parity_check"]
 
 
 def test_bench_gpus_flag_starts_its_own_ranks_and_shards_a_fixed_total():
