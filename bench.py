@@ -41,6 +41,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+# fp32 peak: the vector rate (v_pk_fma_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz), which is also the
+# dense f32-input MFMA peak on gfx950 (same guide, "Peak FP32 (vector)" / "(matrix)": 157.3 TFLOP/s)
+FP32_PEAK_TFLOPS = 157.3
 
 
 def hea_gates(n, layers, name="b"):
@@ -362,16 +365,25 @@ def main():
     fwd_unfused = spg * (16.0 * n_gate + 8.0 * n_terms + 8.0) * amp * shift_factor
     bwd_unfused = spg * 48.0 * n_gate * amp
     tm = eng.traffic_model(spg, with_vjp=args.mode == "vqt")
+    fm = eng.flop_model(spg, with_vjp=args.mode == "vqt")
     use_bwd = args.mode == "vqt" and kt["bwd_ms"] >= kt["fwd_ms"]
     if use_bwd:
-      launches, ms, unfused, name, model = kt["bwd_launches"], kt["bwd_ms"], bwd_unfused, "pass_adj_kernel", tm["bwd_bytes"]
+      launches, ms, unfused, name, model, flops = (kt["bwd_launches"], kt["bwd_ms"], bwd_unfused, "pass_adj_kernel",
+                                                   tm["bwd_bytes"], fm["bwd_flops"])
     else:
-      launches, ms, unfused, name, model = (kt["fwd_launches"], kt["fwd_ms"], fwd_unfused, "pass_fwd_kernel",
-                                            tm["fwd_bytes"] * shift_factor)
+      launches, ms, unfused, name, model, flops = (kt["fwd_launches"], kt["fwd_ms"], fwd_unfused, "pass_fwd_kernel",
+                                                   tm["fwd_bytes"] * shift_factor, fm["fwd_flops"] * shift_factor)
     per_step_launches = max(1, launches // max(1, args.steps))
     avg_ms = ms / max(1, launches)
     bytes_per_launch = model / per_step_launches
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # compute roofline of the same kernel: the fp32 operations its gate arithmetic executes
+    # (qhbm_flop_model: counted from the plan's instance records, FMA = 2; reductions and address
+    # arithmetic not counted) over the same HIP-event launch time, against the fp32 vector peak
+    flops_per_launch = flops / per_step_launches
+    achieved_tfs = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    hbm_frac, compute_frac = achieved / HBM_PEAK_GBPS, achieved_tfs / FP32_PEAK_TFLOPS
+    compute_bound = compute_frac > hbm_frac
     # PMC traffic and VALU utilisation come from committed rocprofv3 runs of THIS command
     # (scripts/profile_bench.sh -> profiles/): stored values, not measured in this run.
     traffic, traffic_src, valu = None, None, None
@@ -429,8 +441,26 @@ def main():
         "kernel_ms_per_step": {"forward": kt["fwd_ms"] / args.steps, "adjoint": kt["bwd_ms"] / args.steps,
                                "apply_observable": kt["obs_ms"] / args.steps},
         "roofline": {
-            "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            # the bound is whichever ceiling the dominant kernel sits closer to; achieved / peak / unit /
+            # frac are those of that ceiling, and both are spelled out in "hbm" and "compute"
+            "bound": "fp32_valu" if compute_bound else "hbm", "kernel": name,
+            "achieved": achieved_tfs if compute_bound else achieved,
+            "peak": FP32_PEAK_TFLOPS if compute_bound else HBM_PEAK_GBPS,
+            "unit": "TFLOP/s" if compute_bound else "GB/s",
+            "frac": compute_frac if compute_bound else hbm_frac,
+            "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_frac},
+            "compute": {"flops_per_launch": flops_per_launch, "achieved_TFs": achieved_tfs, "peak": FP32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": compute_frac,
+                        "flops_definition": "fp32 operations of the gate arithmetic (FMA = 2) from the plan's instance "
+                                            "records (qhbm_flop_model), skipped tiles and dead waves excluded; peak = "
+                                            "fp32 vector rate = dense f32 MFMA rate on gfx950",
+                        "flops_per_step": {"forward": fm["fwd_flops"] * shift_factor, "apply_observable": fm["obs_flops"],
+                                           "adjoint": fm["bwd_flops"]},
+                        "achieved_TFs_by_kernel": {
+                            k: (f / (kt[t] / args.steps * 1e-3) / 1e12 if kt[t] > 0 else None)
+                            for k, f, t in (("forward", fm["fwd_flops"] * shift_factor, "fwd_ms"),
+                                            ("apply_observable", fm["obs_flops"], "obs_ms"),
+                                            ("adjoint", fm["bwd_flops"], "bwd_ms"))}},
             "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_ms": avg_ms, "launches_per_step": per_step_launches,
             "bytes_per_launch": bytes_per_launch,
@@ -441,9 +471,10 @@ def main():
             "gates_per_launch": n_gate / per_step_launches,
             "valu": valu,
             "note": ("the pass kernels are bound by fp32 VALU issue (valu.valu_active_frac), not by HBM: "
-                     "frac is the HBM rate of a launch that applies gates_per_launch gates per tile round "
+                     "hbm.frac is the HBM rate of a launch that applies gates_per_launch gates per tile round "
                      "trip, and it FALLS when the scheduler fuses more gates into a launch while the step "
-                     "gets faster (DESIGN.md section 5)"),
+                     "gets faster; compute.frac is the share of the fp32 peak the gate arithmetic reaches "
+                     "(DESIGN.md section 5)"),
         },
     }
     if args.verify:

@@ -246,6 +246,16 @@ int qhbm_kernel_time_ms(qhbm_engine* h, int reset, double* fwd_ms,
  * is the byte count bench.py's roofline divides by the measured kernel time. */
 int qhbm_traffic_model(qhbm_engine* h, int U, int with_vjp, double* fwd_bytes,
                        double* obs_bytes, double* bwd_bytes);
+/* fp32 operations (one FMA = 2) the gate arithmetic of one call on U states executes under the
+ * installed schedule, counted from the plan's instance records with the per-micro-op costs of the
+ * kernels' packed-fp32 sequences (X**t as three shears: 6 per amplitude forward, 16 in the adjoint
+ * incl. lambda and the inner product; phases, FULL tables, boundary phases on the share of waves that
+ * run them; tiles and waves the kernels skip as identically zero excluded; wave reductions, address
+ * arithmetic and record decoding NOT counted): forward passes, lambda = O psi, adjoint passes.
+ * bench.py divides it by the measured kernel time for a compute roofline against the fp32 vector
+ * peak (157.3 TFLOP/s). */
+int qhbm_flop_model(qhbm_engine* h, int U, int with_vjp, double* fwd_flops,
+                    double* obs_flops, double* bwd_flops);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,7 @@ struct qhbm_engine {
   int state_grad_U = 0;  // rows of state_grad the last adjoint VJP filled (qhbm_state_gradients)
   int64_t opt_chunk = 0;
   int64_t opt_budget_mb = 0;  // 0: a third of the device's memory, resolved at first use (budget_bytes)
+  size_t resolved_budget = 0; // the default budget of THIS engine once a device query has succeeded
   // plans
   bool plans_valid = false;
   bool model_uploaded = false;  // everything upload_model copies to the device is current
@@ -124,6 +125,22 @@ int fail(qhbm_engine* h, const std::string& msg) {
     if (_e != hipSuccess)                                                              \
       return fail(h, std::string(#expr) + ": " + hipGetErrorString(_e));               \
   } while (0)
+
+template <typename T> size_t buf_bytes(const DevBuf<T>& b) { return b.n * sizeof(T); }
+size_t plan_bytes(const DevicePlan& d) {
+  return buf_bytes(d.prog) + buf_bytes(d.tables) + buf_bytes(d.rec_offsets) + buf_bytes(d.jobs) + buf_bytes(d.coef);
+}
+// Every byte of device memory the engine holds (qhbm_allocated_bytes; a host-side engine cache bounds
+// its footprint with it).
+size_t own_bytes(const qhbm_engine* h) {
+  return buf_bytes(h->psi) + buf_bytes(h->lam) + buf_bytes(h->state_grad) + buf_bytes(h->tile_grad) +
+         buf_bytes(h->vals64) + buf_bytes(h->block_cum) + buf_bytes(h->coef_batch) + buf_bytes(h->vals_batch) +
+         buf_bytes(h->value_part) + buf_bytes(h->upstream_tmp) + buf_bytes(h->vals_tmp) + buf_bytes(h->prog_acc) +
+         buf_bytes(h->shift_vals) + buf_bytes(h->shift_weight) + buf_bytes(h->shift_gates) + buf_bytes(h->shift_param) +
+         buf_bytes(h->slot_factor) + buf_bytes(h->phase_cs) + buf_bytes(h->shift_phases) + buf_bytes(h->terms) +
+         buf_bytes(h->global_terms) + buf_bytes(h->obs_groups) + buf_bytes(h->op_scale) + buf_bytes(h->op_inv_scale) +
+         buf_bytes(h->param_slot_begin) + buf_bytes(h->param_slots) + plan_bytes(h->fwd) + plan_bytes(h->adj);
+}
 
 int need_device(qhbm_engine* h) {
   if (h->device < 0)
@@ -306,23 +323,25 @@ int upload_model(qhbm_engine* h) {
 
 size_t state_bytes(const qhbm_engine* h) { return size_t(8) << h->fwd.plan.n_eff; }
 
-// Workspace budget in bytes.  Default: a third of the device's memory (96 GB of the MI355X's 288 GB,
-// so BASELINE config 3's 4096 states x (psi, lambda) x 8 MiB = 64 GiB stay resident in one chunk).
-size_t budget_bytes(const qhbm_engine* h) {
+// Workspace budget in bytes (statevector workspace: psi, or psi + lambda).  Default: a third of the
+// device's memory (96 GB of the MI355X's 288 GB, so BASELINE config 3's 4096 states x (psi, lambda) x
+// 8 MiB = 64 GiB stay resident in one chunk) -- but never more than 45 % of what is FREE when the engine
+// first needs it plus what it already holds, so that a second engine, another inference object or
+// another rank sharing the GPU sizes itself to what is left instead of to the whole device.  Resolved
+// once per engine (never process-wide: a planning-only engine or a failed query must not leave its
+// 16 GiB reporting figure behind for a real engine on the same device index).
+size_t budget_bytes(qhbm_engine* h) {
   if (h->opt_budget_mb > 0) return size_t(h->opt_budget_mb) << 20;
-  static size_t device_third[64] = {0};
-  const int d = h->device >= 0 && h->device < 64 ? h->device : 0;
-  if (!device_third[d]) {
-    size_t free_b = 0, total_b = 0;
-    if (h->device >= 0 && hipSetDevice(h->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
-        total_b)
-      device_third[d] = total_b / 3;
-    else device_third[d] = size_t(16) << 30;  // planning-only engine: the figure is only reported
-  }
-  return device_third[d];
+  if (h->resolved_budget) return h->resolved_budget;
+  size_t free_b = 0, total_b = 0;
+  if (h->device < 0 || hipSetDevice(h->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess || !total_b)
+    return size_t(16) << 30;  // planning-only engine / failed query: the figure is only reported, not cached
+  const size_t share = size_t(0.45 * double(free_b + own_bytes(h)));
+  h->resolved_budget = std::max<size_t>(std::min(total_b / 3, share), size_t(64) << 20);
+  return h->resolved_budget;
 }
 
-uint32_t chunk_states(const qhbm_engine* h, int U) {
+uint32_t chunk_states(qhbm_engine* h, int U) {
   // (a chunk is also a grid dimension of the per-state kernels: at most 65535)
   if (h->opt_chunk > 0) return uint32_t(std::min<int64_t>(std::min<int64_t>(h->opt_chunk, U), 65535));
   const size_t budget = budget_bytes(h);
@@ -401,6 +420,12 @@ int ensure_state_buffers(qhbm_engine* h, uint32_t cs, bool with_lam) {
     want = std::min(cap, want + std::max<size_t>(want / 8, 1));
   }
   const size_t amps = want << h->fwd.plan.n_eff;
+  if (with_lam && !h->lam.p) {
+    // a forward-only call may have grown psi to the whole budget: with lambda beside it the pair must
+    // fit the budget again, so psi goes back to its half before lambda is allocated
+    const size_t half = std::max<size_t>(amps, (budget_bytes(h) / (2 * state_bytes(h))) << h->fwd.plan.n_eff);
+    if (h->psi.n > half) h->psi.release();
+  }
   HIPCHK(h->psi.reserve(amps, false));
   if (with_lam) HIPCHK(h->lam.reserve(amps, false));
   return 0;
@@ -461,7 +486,7 @@ int run_adjoint_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_
   return 0;
 }
 
-uint32_t adjoint_chunk_states(const qhbm_engine* h, int U) {
+uint32_t adjoint_chunk_states(qhbm_engine* h, int U) {
   uint32_t cs = chunk_states(h, U);
   if (h->opt_chunk <= 0)  // two buffers per state
     cs = uint32_t(std::min<size_t>(std::min<size_t>(size_t(U), 65535),
@@ -648,8 +673,7 @@ int qhbm_workspace_bytes(qhbm_engine* h, int U, int with_vjp, size_t* out) {
 
 int qhbm_allocated_bytes(qhbm_engine* h, size_t* out) {
   if (!h || !out) return 1;
-  *out = h->psi.n * sizeof(float2) + h->lam.n * sizeof(float2) + h->state_grad.n * sizeof(float) +
-         h->tile_grad.n * sizeof(float) + h->vals64.n * sizeof(unsigned long long) + h->block_cum.n * sizeof(double);
+  *out = own_bytes(h);
   return 0;
 }
 
@@ -991,6 +1015,121 @@ int qhbm_kernel_time_ms(qhbm_engine* h, int reset, double* fwd_ms, int64_t* fwd_
   }
   return 0;
 }
+
+}  // extern "C"
+
+namespace {
+
+// fp32 operations (FMA = 2) the gate arithmetic of one pass kernel executes per AMPLITUDE of a tile it
+// does not skip, from the plan's instance records -- the counts are those of the inline-asm sequences
+// in kernels.hip (v_pk_fma_f32 = 4, v_pk_mul_f32 / v_pk_add_f32 = 2 per amplitude pair of lanes):
+//   forward   X**t three shears 6 | PH1 3 (half the amplitudes x (mul + fma)) | PH2 1.5 | FULL table 5.625
+//             | boundary CPH 3 x (share of waves whose predicate is on) | Y 6 | dense 2x2 14 | dense 4x4 32
+//   adjoint   X 16 (psi 6 + lambda 6 + inner product 4) | PH1 8 | PH2 4 | FULL 17.25 (partials 6 + two
+//             tables) | CPH 8 x share | Y 16 | dense 2x2 44 | dense 4x4 on (psi, lambda) + generator 96
+// Rounds whose waves are dead (OP_ROUND word 4) run on 2^-popc(dead mask) of the waves.  Wave
+// reductions, address arithmetic and record decoding are NOT counted: this is the arithmetic the gate
+// set requires of this kernel design, the numerator of a compute roofline against the fp32 vector peak.
+double pass_flops_per_amplitude(const Plan& plan, const Pass& p) {
+  const RecordLayout L(plan.R, plan.adjoint);
+  const bool adj = plan.adjoint;
+  double total = 0.0;
+  size_t round_i = 0;
+  for (size_t pc = 0; pc < p.prog.size();) {
+    const uint32_t w0 = p.prog[pc], opc = w0 & 0xffu;
+    if (opc == OP_END) break;
+    if (opc == OP_ROUND) {
+      const uint32_t n_inst = (w0 & ~kRoundNoBarrier) >> 8, first = p.prog[pc + 2], dead = p.prog[pc + 4];
+      const uint32_t wmask = round_i < p.round_wavemasks.size() ? p.round_wavemasks[round_i] : 0u;
+      const double alive = adj ? 1.0 / double(1u << __builtin_popcount(dead)) : 1.0;
+      double f = 0.0;
+      for (uint32_t i = 0; i < n_inst; ++i) {
+        const uint32_t* rec = &plan.coef_init[first + size_t(i) * size_t(L.words())];
+        const uint32_t h0 = rec[0], h1 = rec[1];
+        const bool full = (h1 & kFullDiagFlag) != 0;
+        f += (adj ? 16.0 : 6.0) * __builtin_popcount(h0 & 0xfu);
+        if (full) f += adj ? 17.25 : 5.625;
+        else f += (adj ? 8.0 : 3.0) * __builtin_popcount((h0 >> 8) & 0xfu) + (adj ? 4.0 : 1.5) * __builtin_popcount((h0 >> 16) & 0x3fu);
+        for (int k = 0; k < 8; ++k) {
+          if (!(h1 >> k & 1u)) continue;
+          const uint32_t pred = rec[L.pred(k)];
+          const bool uniform = (pred >> 8) != 0 || (wmask >> (pred & 0xffu) & 1u);  // tile bit or wave bit: half skip
+          f += (adj ? 8.0 : 3.0) * (uniform ? 0.5 : 1.0);
+        }
+        f += (adj ? 16.0 : 6.0) * __builtin_popcount((h1 >> 16) & 0xfu) + (adj ? 44.0 : 14.0) * __builtin_popcount((h1 >> 24) & 0xfu);
+      }
+      total += alive * f;
+      ++round_i;
+      pc += kRoundWords;
+    } else if (opc == OP_GATE2) {
+      total += adj ? 96.0 : 32.0;
+      pc += kGate2Words;
+    } else {  // OP_MEASURE: [op | n_groups << 8] then groups x {[xl] [n_terms] terms x 4 words}
+      const uint32_t n_groups = w0 >> 8;
+      ++pc;
+      for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint32_t n_terms = p.prog[pc + 1];
+        total += 6.0 + double(n_terms);  // conj(psi[l ^ x]) psi[l] (3 FMA) + one signed add per term (upper bound)
+        pc += 2 + size_t(n_terms) * kMeasTermWords;
+      }
+    }
+  }
+  return total;
+}
+
+}  // namespace
+
+extern "C" int qhbm_flop_model(qhbm_engine* h, int U, int with_vjp, double* fwd_flops, double* obs_flops,
+                               double* bwd_flops) {
+  if (!h) return 1;
+  if (int rc = build_plans(h)) return rc;
+  const double amps = double(size_t(1) << h->fwd.plan.n_eff) * double(U);
+  double f = 0.0, o = 0.0, b = 0.0;
+  {
+    std::vector<PassArgs> args;
+    std::vector<uint32_t> prog, tables;
+    fill_args(h->fwd.plan, h->model, &args, &prog, &tables);
+    for (size_t i = 0; i < args.size(); ++i) {
+      const Pass& p = h->fwd.plan.passes[i];
+      if (with_vjp && value_mode(h) && p.is_measure_only) continue;
+      const double live = 1.0 / double(1ull << __builtin_popcount(args[i].zero_mask));
+      // the first pass computes on ONE tile per state (the others write zeros and return)
+      const double share = (p.flags & PASS_INIT_BASIS) ? 1.0 / double(1ull << p.nonlocal_pos.size()) : live;
+      Pass q = p;
+      if (with_vjp && value_mode(h)) {  // PASS_SKIP_MEASURE: cut the program at its first measurement
+        for (size_t pc = 0; pc < q.prog.size();) {
+          const uint32_t opc = q.prog[pc] & 0xffu;
+          if (opc == OP_END) break;
+          if (opc == OP_MEASURE) { q.prog[pc] = OP_END; break; }
+          pc += opc == OP_ROUND ? size_t(kRoundWords) : size_t(kGate2Words);
+        }
+      }
+      f += share * amps * pass_flops_per_amplitude(h->fwd.plan, q);
+    }
+  }
+  if (with_vjp) {
+    // lambda = O psi: one packed FMA per amplitude and X-mask group (4), one add per term whose sign varies
+    // inside a thread's amplitudes (upper bound: every term), <psi|O|psi> 4 in value mode
+    std::vector<uint32_t> xs;
+    for (const PauliTerm& t : h->model.terms) xs.push_back(t.x);
+    std::sort(xs.begin(), xs.end());
+    const double groups = double(std::unique(xs.begin(), xs.end()) - xs.begin());
+    o = amps * (4.0 * groups + double(h->model.terms.size()) + (value_mode(h) ? 4.0 : 0.0));
+    std::vector<PassArgs> args;
+    std::vector<uint32_t> prog, tables;
+    fill_args(h->adj.plan, h->model, &args, &prog, &tables);
+    for (size_t i = 0; i < args.size(); ++i) {
+      const double live = 1.0 / double(1ull << __builtin_popcount(args[i].zero_mask));
+      b += live * amps * pass_flops_per_amplitude(h->adj.plan, h->adj.plan.passes[i]);
+    }
+  }
+  if (fwd_flops) *fwd_flops = f;
+  if (obs_flops) *obs_flops = o;
+  if (bwd_flops) *bwd_flops = b;
+  return 0;
+}
+
+extern "C" {
 
 int qhbm_traffic_model(qhbm_engine* h, int U, int with_vjp, double* fwd_bytes, double* obs_bytes,
                        double* bwd_bytes) {

@@ -821,6 +821,15 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
       b.pending_mat_outside_ = pend;
     }
     if (!b.emit_ops(&p, ops, best_list, err)) return false;
+    {
+      // The zero-tile / dead-wave pruning (engine.cpp fill_args, emit_round's dead masks) is sound only
+      // if Pass::mat_bits lists EVERY index bit a non-diagonal op of the pass acts on: a new lowered op
+      // kind that mixes the two halves of a bit without reporting it would be pruned wrongly.
+      uint32_t mixed = 0;
+      for (int oi : best_list) if (ops[size_t(oi)].type != LOW_DIAG) mixed |= ops[size_t(oi)].bits;
+      static_assert(LOW_MAT2 == 3, "a new LoweredType must be classified here: diagonal, or reported in mat_bits");
+      if (mixed != p.mat_bits) { *err = "internal: a non-diagonal op of the pass is missing from mat_bits"; return false; }
+    }
     for (int oi : best_list) { done[oi] = 1; op_pass[oi] = int(plan->passes.size()); ++n_done; }
     plan->passes.push_back(std::move(p));
   }

@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "qhbm_expectation_retain", "qhbm_expectation_vjp_retained", "qhbm_retained_states", "qhbm_state_gradients",
     "qhbm_expectation_jacobian", "qhbm_statevector", "qhbm_sample", "qhbm_parity_energy", "qhbm_parity_energy_vjp",
     "qhbm_num_passes", "qhbm_describe_schedule",
-    "qhbm_kernel_time_ms", "qhbm_traffic_model",
+    "qhbm_kernel_time_ms", "qhbm_traffic_model", "qhbm_flop_model",
 )
 
 
@@ -97,6 +97,7 @@ def load_library():
       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64),
       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
   lib.qhbm_traffic_model.argtypes = [vp, i32, i32] + [ctypes.POINTER(ctypes.c_double)] * 3
+  lib.qhbm_flop_model.argtypes = [vp, i32, i32] + [ctypes.POINTER(ctypes.c_double)] * 3
   _lib = lib
   return lib
 
@@ -264,6 +265,14 @@ class Engine:
     self._check(self._lib.qhbm_traffic_model(self._h, int(num_states), int(with_vjp), ctypes.byref(f),
                                              ctypes.byref(o), ctypes.byref(b)))
     return {"fwd_bytes": f.value, "obs_bytes": o.value, "bwd_bytes": b.value}
+
+  def flop_model(self, num_states, with_vjp=True):
+    """fp32 operations (FMA = 2) of the gate arithmetic of one call: dict of forward / lambda = O psi /
+    adjoint flops (include/qhbm_engine.h qhbm_flop_model)."""
+    f, o, b = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    self._check(self._lib.qhbm_flop_model(self._h, int(num_states), int(with_vjp), ctypes.byref(f),
+                                          ctypes.byref(o), ctypes.byref(b)))
+    return {"fwd_flops": f.value, "obs_flops": o.value, "bwd_flops": b.value}
 
   # ---- hot path --------------------------------------------------------------
   def _prep(self, bits, params):

@@ -10,7 +10,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "qhbm-library_amd", "csrc")
 OUT = os.path.dirname(os.path.abspath(__file__))
-src = open(os.path.join(CSRC, "kernels.hip")).read()
+
+
+def kernel_source():
+  with open(os.path.join(CSRC, "kernels.hip")) as f:
+    return f.read()
 
 
 def once(text, old, new):
@@ -71,7 +75,7 @@ template <int K>
 __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_kernel("""),
         "  commit_tile<K, NT>(xt, rp, tid);\n  __syncthreads();\n  round_load<R>(xt, T, DB, p);\n  __syncthreads();\n  commit_tile<K, NT>(xt, rl, tid);\n  __syncthreads();\n  round_load<R>(xt, T, DB, l);\n",
         "  regs_from_tile(p, rp);\n  regs_from_tile(l, rl);\n  __syncthreads();\n"),
-        "    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT>(xt, sp, t, tid);\n    __syncthreads();\n    round_store<R>(xt, T, DB, l);\n    __syncthreads();\n    store_tile<K, NT>(xt, sl, t, tid);\n",
+        "    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT, true>(xt, sp, t, tid);\n    __syncthreads();\n    round_store<R>(xt, T, DB, l);\n    __syncthreads();\n    store_tile<K, NT, true>(xt, sl, t, tid);\n",
         "    regs_to_global<K, NT>(p, sp, t, tid);\n    regs_to_global<K, NT>(l, sl, t, tid);\n    __syncthreads();\n"),
     "no_x_inner": lambda t: in_instance(t, "g[J] = im_lam_x_psi<R, J>(p, l);", "g[J] = p[0].x;"),
     "no_x_on_lambda": lambda t: in_instance(t, "          apply_x<R, J>(l, cs);\n", ""),
@@ -116,8 +120,8 @@ def in_fwd_instance(text, old, new, count=-1):
 VARIANTS.update({
     "fwd_no_instances": lambda t: once(t, "        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);",
                                        "        if (lane == 77) instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);"),
-    "fwd_no_x": lambda t: in_fwd_instance(t, "if ((h0 >> J) & 1u) apply_x<R, J>(a, rec_cs<L.x(J)>(rv));", "if (((h0 >> J) & 1u) && lane == 77) apply_x<R, J>(a, rec_cs<L.x(J)>(rv));"),
-    "fwd_no_full": lambda t: in_fwd_instance(t, "if (h1 & kFullDiagFlag) apply_full<NV>(a, rv, false);", "if ((h1 & kFullDiagFlag) && lane == 77) apply_full<NV>(a, rv, false);"),
+    "fwd_no_x": lambda t: in_fwd_instance(t, "if ((h0 >> J) & 1u) apply_x<R, J>(a, rec_cs<L.x(J)>(rv, rb));", "if (((h0 >> J) & 1u) && lane == 77) apply_x<R, J>(a, rec_cs<L.x(J)>(rv, rb));"),
+    "fwd_no_full": lambda t: in_fwd_instance(t, "if (h1 & kFullDiagFlag) apply_full<NV>(a, rv, rb, false);", "if ((h1 & kFullDiagFlag) && lane == 77) apply_full<NV>(a, rv, rb, false);"),
     "fwd_no_cph": lambda t: in_fwd_instance(t, "  if (h1 & 0xffu) {", "  if ((h1 & 0xffu) && lane == 77) {"),
     # forward without its HBM traffic (tile neither loaded nor stored): what the memory phase adds to the compute
     "fwd_no_tile_io": lambda t: once(once(t, "    TileRegs r;\n    prefetch_tile<K, NT>(r, st, t, tid);\n    commit_tile<K, NT>(tile, r, tid);\n  }\n  for (int i = tid; i < kMaxOps; i += NT) red[i] = 0ull;",
@@ -127,25 +131,56 @@ VARIANTS.update({
     # stagger the first generation of forward workgroups (by hardware wave slot) to break lock step
     "fwd_stagger": lambda t: once(t, "    TileRegs r;\n    prefetch_tile<K, NT>(r, st, t, tid);\n    commit_tile<K, NT>(tile, r, tid);\n  }\n  for (int i = tid; i < kMaxOps; i += NT) red[i] = 0ull;",
                                   "    if (blockIdx.x < 1024u) { const uint32_t slot = __builtin_amdgcn_s_getreg(0x1804) & 3u; for (uint32_t i = 0; i < slot * 2u; ++i) __builtin_amdgcn_s_sleep(127); }\n    TileRegs r;\n    prefetch_tile<K, NT>(r, st, t, tid);\n    commit_tile<K, NT>(tile, r, tid);\n  }\n  for (int i = tid; i < kMaxOps; i += NT) red[i] = 0ull;"),
-    "fwd_no_barriers": lambda t: once(t, "      if (!(w0 & kRoundNoBarrier)) __syncthreads();  // else the next round's waves read only their own writes\n      pc += 3;\n    } else if (opc == OP_GATE2) {",
-                                      "      pc += 3;\n    } else if (opc == OP_GATE2) {"),
+    "fwd_no_barriers": lambda t: once(t, "      if (!(w0 & kRoundNoBarrier)) __syncthreads();  // else the next round's waves read only their own writes\n      pc += kRoundWords;\n    } else if (opc == OP_GATE2) {",
+                                      "      pc += kRoundWords;\n    } else if (opc == OP_GATE2) {"),
     "fwd_no_round_trips": lambda t: once(once(t, "      round_load<R>(tile, T, DB, amp);\n      for (uint32_t i = 0; i < n_inst; ++i) {", "      if (pc == 0) round_load<R>(tile, T, DB, amp);\n      for (uint32_t i = 0; i < n_inst; ++i) {"),
                                          "      round_store<R>(tile, T, DB, amp);\n      if (!(w0 & kRoundNoBarrier)) __syncthreads();", "      if (lane == 77) round_store<R>(tile, T, DB, amp);\n      if (!(w0 & kRoundNoBarrier)) __syncthreads();"),
 })
 
-which = sys.argv[1:] or list(VARIANTS)
-for name in which:
-  text = VARIANTS[name](src)
-  path = os.path.join(CSRC, f"_ablate_{name}.hip")
-  with open(path, "w") as f:
-    f.write(text)
-  obj = os.path.join(OUT, f"{name}.o")
-  flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-mllvm", "-disable-promote-alloca-to-vector=1",
-           "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
-  subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-c", path, "-o", obj], cwd=CSRC)
-  subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", obj,
-                         os.path.join(CSRC, "engine.o"), os.path.join(CSRC, "schedule.o"), "-o",
-                         os.path.join(OUT, f"lib_{name}.so")], cwd=CSRC)
-  os.remove(path)
-  os.remove(obj)
-  print("built", name, flush=True)
+def check_variants(names=None):
+  """Applies every variant's edit to kernels.hip WITHOUT compiling: {name: error message} of the variants
+  whose anchors no longer match the kernel source (tests/test_scripts_cpu.py keeps this empty)."""
+  src = kernel_source()
+  stale = {}
+  for name in names or list(VARIANTS):
+    try:
+      assert VARIANTS[name](src) != src or name == "base", "the edit changed nothing"
+    except (AssertionError, ValueError) as exc:
+      stale[name] = f"anchor not found: {str(exc)[:120]!r}"
+  return stale
+
+
+def main(which):
+  src = kernel_source()
+  failed = {}
+  for name in which:
+    try:
+      text = VARIANTS[name](src)
+    except (AssertionError, ValueError) as exc:   # a stale anchor must not stop the other variants
+      failed[name] = str(exc)[:200]
+      print(f"SKIPPED {name}: its anchor no longer matches kernels.hip: {failed[name]!r}", flush=True)
+      continue
+    path = os.path.join(CSRC, f"_ablate_{name}.hip")
+    with open(path, "w") as f:
+      f.write(text)
+    obj = os.path.join(OUT, f"{name}.o")
+    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-mllvm", "-disable-promote-alloca-to-vector=1",
+             "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+    try:
+      subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-c", path, "-o", obj], cwd=CSRC)
+      subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", obj,
+                             os.path.join(CSRC, "engine.o"), os.path.join(CSRC, "schedule.o"), "-o",
+                             os.path.join(OUT, f"lib_{name}.so")], cwd=CSRC)
+      print("built", name, flush=True)
+    except subprocess.CalledProcessError as exc:
+      failed[name] = f"compile failed: {exc}"
+      print(f"FAILED {name}: {exc}", flush=True)
+    finally:
+      for tmp in (path, obj):
+        if os.path.exists(tmp):
+          os.remove(tmp)
+  return failed
+
+
+if __name__ == "__main__":
+  sys.exit(1 if main(sys.argv[1:] or list(VARIANTS)) else 0)

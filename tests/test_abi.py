@@ -132,3 +132,25 @@ def test_schedule_options_and_errors():
   eng.set_circuit(12, gates, 3)
   eng.set_observables([O.tfim_ring_op(12)])
   assert eng.num_passes()[0] >= 1
+
+
+def test_flop_model_counts_the_gate_arithmetic_of_the_plan():
+  """qhbm_flop_model on a planning-only engine: a 12-qubit depth-1 HEA runs in one tile and one pass, so
+  the count can be written down: per amplitude 6 flop per X**t (three packed shears), and the 12 Z**t +
+  11 CZ**t phases at between 1.5 (PH2) and 5.625 (one FULL table for several) each."""
+  n = 12
+  eng = _planner(n, 1, O.tfim_ring_op(n))
+  fm = eng.flop_model(10, with_vjp=False)
+  per_amp = fm["fwd_flops"] / (10 * 2**n)
+  meas = sum(6.0 + 1.0 * k for k in (n,) + (1,) * n)    # the ZZ group (x = 0, n terms) and n single-X groups: upper bound
+  assert 6.0 * n + 1.5 * 23 * 0.5 <= per_amp <= 6.0 * n + 5.625 * 23 + meas
+  assert fm["obs_flops"] == 0.0 and fm["bwd_flops"] == 0.0
+  both = eng.flop_model(10, with_vjp=True)
+  # (adjoint rounds late in the pass run on the waves that are not dead only: a loose lower bound)
+  assert 16.0 * n * 10 * 2**n / 4 <= both["bwd_flops"] <= (16.0 * n + 17.25 * 23) * 10 * 2**n and both["obs_flops"] > 0
+  # linear in the batch
+  assert eng.flop_model(20, with_vjp=True)["bwd_flops"] == pytest.approx(2 * both["bwd_flops"])
+  # config 3: zero tiles and dead waves are excluded -- well below the unpruned count, above the X gates alone / 4
+  eng3 = _planner(20, 16, O.xxz_chain_op(20))
+  f3 = eng3.flop_model(1, with_vjp=True)
+  assert 16.0 * 320 * 2**20 / 4 < f3["bwd_flops"] < (16.0 * 320 + 17.25 * 400) * 2**20

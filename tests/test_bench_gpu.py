@@ -33,6 +33,12 @@ def test_bench_single_process_line():
   assert line["n_gpus"] == 1 and line["steps"] == 2 and line["scaling"] == "weak"
   assert line["value"] > 0 and 0 < line["roofline"]["frac"] <= 1.0   # a fraction of the HBM peak, not a fusion factor
   assert line["roofline"]["achieved"] == pytest.approx(line["roofline"]["frac"] * line["roofline"]["peak"])
+  # both ceilings are spelled out and the bound is the larger fraction (never hard-coded)
+  hbm, comp = line["roofline"]["hbm"], line["roofline"]["compute"]
+  assert 0 < hbm["frac"] <= 1.0 and hbm["peak"] == 8000.0 and 0 < comp["frac"] <= 1.0 and comp["peak"] == 157.3
+  assert comp["achieved_TFs"] == pytest.approx(comp["frac"] * 157.3) and comp["flops_per_launch"] > 0
+  assert line["roofline"]["bound"] == ("fp32_valu" if comp["frac"] > hbm["frac"] else "hbm")
+  assert line["roofline"]["frac"] == pytest.approx(max(hbm["frac"], comp["frac"]))
   assert "12-qubit TFIM ring" in line["config"]["workload"] and line["config"]["states_total"] == 16
   assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
   assert line["verify"]["ok"], line["verify"]

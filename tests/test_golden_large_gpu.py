@@ -34,11 +34,16 @@ def c3():
 
 
 @pytest.mark.parametrize("opts", [{}, {"chunk_states": 3}, {"tile_qubits": 12, "adjoint_tile_qubits": 11},
-                                  {"tile_qubits": 14, "adjoint_tile_qubits": 13}],
-                         ids=["default-plan", "chunked", "small-tiles", "large-tiles"])
+                                  {"tile_qubits": 14, "adjoint_tile_qubits": 13}, {"cph_wave_bits": 0},
+                                  {"values_from_observable": 0}],
+                         ids=["default-plan", "chunked", "small-tiles", "large-tiles", "unpruned-layout",
+                              "measured-values"])
 def test_c3_values_and_vjp_against_oracle(c3, opts):
   """BASELINE config 3's circuit (20 qubits, depth 16, 944 parameters, XXZ): default 9 / 11-pass
-  plans, a chunked batch and two other tile geometries, on |0..0>, |1..1> and two random states."""
+  plans, a chunked batch and two other tile geometries, on |0..0>, |1..1> and two random states; the
+  plain layout without dead waves, tail tiles and the searched pass order ("unpruned-layout": the
+  pruned default must not differ from it beyond the tolerance -- a single observable, so the values
+  come from lambda = O psi and the rows are scaled afterwards) and values measured in the forward sweep."""
   n, gates, ops = int(c3["n"]), G.gates_of(c3["gates"]), G.ops_of(c3["ops"])
   norm = sum(abs(c) for c, _, _ in ops[0])
   eng = _engine(n, gates, len(c3["params"]), ops, **opts)
@@ -109,3 +114,108 @@ def test_c5_28_qubit_forward_against_oracle():
   eng = _engine(n, gates, len(g["params"]), [op])
   total = float(eng.expectation(g["bits"], g["params"])[0, 0])
   assert abs(total - g["term_values"].sum()) <= 5e-5 * 56
+
+
+def test_c4_qmhl_loss_through_the_host_mirror_with_parameter_shift_gradients():
+  """BASELINE config 4 as stated -- "QMHL loss, parameter-shift grads" -- at 24 qubits, depth 4 + 4:
+  `inference.qmhl(data, qhbm)` (qmhl_loss.py:33-34) through the host mirror with
+  `gradient_method=GRAD_PARAMETER_SHIFT` (1136 shifted programs per state, batched by the engine), against
+  the C oracle's fixture (tests/golden/make_golden_large.py c4qmhl): loss, d/dtheta, d/dphi.  The adjoint
+  method must give the same numbers.  Tolerances: loss 5e-5 * sum|theta|; gradients 1e-4 * max(1, |g|_inf)."""
+  from qhbmlib_amd import data, inference, ir, models
+  from tests.test_host_api import hea_circuit
+  g = G.load("c4_qmhl_n24_d4.npz")
+  n, layers = int(g["n"]), int(g["layers"])
+  qubits = ir.GridQubit.rect(1, n)
+
+  class FixedData(data.QuantumData):
+    """Data given as bitstring samples through a fixed circuit (qmhl_loss_test.py:206-215's pattern)."""
+
+    def __init__(self, samples, q_infer):
+      self.samples, self.q_infer = samples, q_infer
+
+    def expectation(self, observable):
+      return torch.mean(self.q_infer.expectation(self.samples, observable))
+
+  def run(method):
+    energy = models.BernoulliEnergy(list(range(n)))
+    with torch.no_grad():
+      energy.post_process[0].kernel.copy_(torch.as_tensor(g["thetas"], dtype=torch.float32))
+    model_circuit = models.DirectQuantumCircuit(hea_circuit(qubits, layers, "m"))
+    data_circuit = models.DirectQuantumCircuit(hea_circuit(qubits, layers, "d"))
+    with torch.no_grad():
+      model_circuit.trainable_variables[0].copy_(torch.as_tensor(g["model_params"], dtype=torch.float32))
+      data_circuit.trainable_variables[0].copy_(torch.as_tensor(g["data_params"], dtype=torch.float32))
+    # the oracle's circuits are these circuits (same sorted-symbol parameter layout)
+    assert model_circuit.pqc.flat_gates(qubits, model_circuit.symbol_names) == G.gates_of(g["model_gates"])
+    assert data_circuit.pqc.flat_gates(qubits, data_circuit.symbol_names) == G.gates_of(g["data_gates"])
+    qhbm = inference.QHBM(inference.BernoulliEnergyInference(energy, 16, initial_seed=1),
+                          inference.AnalyticQuantumInference(model_circuit))
+    data_q = inference.AnalyticQuantumInference(data_circuit, gradient_method=method)
+    loss = inference.qmhl(FixedData(torch.from_numpy(g["samples"]), data_q), qhbm)
+    g_theta, g_phi = torch.autograd.grad(loss, (energy.trainable_variables[0], model_circuit.trainable_variables[0]))
+    return float(loss), g_theta.cpu().numpy(), g_phi.cpu().numpy()
+
+  norm = float(np.abs(g["thetas"]).sum())
+  for method in (E.GRAD_PARAMETER_SHIFT, E.GRAD_ADJOINT):
+    loss, g_theta, g_phi = run(method)
+    assert abs(loss - float(g["loss"])) <= 5e-5 * norm, (method, loss, float(g["loss"]))
+    np.testing.assert_allclose(g_theta, g["grad_thetas"], atol=1e-4, rtol=0)
+    tol = 1e-4 * max(1.0, np.abs(g["grad_model_params"]).max())
+    assert np.abs(g_phi - g["grad_model_params"]).max() <= tol, (method, np.abs(g_phi - g["grad_model_params"]).max())
+  assert np.abs(g["grad_model_params"]).max() > 1e-2
+
+
+def test_c4_depth16_parameter_shift_equals_adjoint_on_every_parameter():
+  """24 qubits at config 4's full depth 16: the engine's parameter-shift VJP (2 x 1136 shifted programs,
+  batched) against its adjoint VJP on ALL 1136 parameters, two states, XXZ + the first 24 terms of the
+  random Pauli sum (the adjoint itself is pinned to the oracle at this width in
+  test_c4_all_512_terms_at_24_qubits_against_oracle and by the QMHL fixture above)."""
+  import bench
+  n, layers = 24, 16
+  gates, n_params = bench.hea_gates(n, layers)
+  ops = [bench.xxz_op(n), bench.random_pauli_op(n, 512, 24)[:24]]
+  params = np.random.default_rng(2416).uniform(-1, 1, n_params).astype(np.float32)
+  bits = bench.distinct_bitstrings(n, 2, 44)
+  eng = _engine(n, gates, n_params, ops)
+  up = np.array([[0.8, -0.3], [-0.5, 0.6]], np.float32)
+  vals_a, g_adj = eng.expectation_vjp(bits, params, up)
+  vals_s, g_shift = eng.expectation_vjp(bits, params, up, method=E.GRAD_PARAMETER_SHIFT)
+  g_adj, g_shift = g_adj.cpu().numpy(), g_shift.cpu().numpy()
+  np.testing.assert_allclose(vals_s.cpu().numpy(), vals_a.cpu().numpy(), atol=5e-5 * 60)
+  assert g_adj.shape == (1136,) and np.abs(g_adj).max() > 1e-2
+  assert np.abs(g_shift - g_adj).max() <= 1e-4 * max(1.0, np.abs(g_adj).max()), np.abs(g_shift - g_adj).max()
+
+
+def test_c5_streamed_batch_of_three_28_qubit_states_values_and_vjp_against_oracle():
+  """Config 5's point is streaming (2 GiB per state, "256 samples, 32 per GPU streamed"): with
+  chunk_states = 1 the three states of the fixture go through the workspace one after the other --
+  forward (all 56 TFIM terms), and values + adjoint VJP with per-state weights -- and must match the C
+  oracle (tests/golden/make_golden_large.py c5vjp) and the unchunked run bit for bit."""
+  free, _ = torch.cuda.mem_get_info()
+  if free < 24 << 30:
+    pytest.skip("needs 24 GiB of free HBM")
+  g = G.load("c5_n28_d2_vjp.npz")
+  n, gates, (op,) = int(g["n"]), G.gates_of(g["gates"]), G.ops_of(g["ops"])
+  bits, params, up = g["bits"], g["params"], g["upstream"].astype(np.float32)
+  assert bits.shape == (3, 28)
+  eng = _engine(n, gates, len(params), [[t] for t in op], chunk_states=1)
+  assert eng.workspace_bytes(3) < 3 * (8 << 28)            # one 2 GiB state at a time
+  vals = eng.expectation(bits, params).cpu().numpy()
+  assert np.abs(vals - g["term_values"]).max() <= 5e-5, np.abs(vals - g["term_values"]).max()
+  del eng
+  torch.cuda.empty_cache()
+  want_total = g["term_values"].sum(1)
+  tol_g = 1e-4 * max(1.0, np.abs(g["grad"]).max())
+  results = []
+  for chunk in (1, 0):
+    eng = _engine(n, gates, len(params), [op], **({"chunk_states": chunk} if chunk else {}))
+    total, grad = eng.expectation_vjp(bits, params, up)
+    total, grad = total.cpu().numpy()[:, 0], grad.cpu().numpy()
+    assert np.abs(total - want_total).max() <= 5e-5 * 56, np.abs(total - want_total).max()
+    assert np.abs(grad - g["grad"]).max() <= tol_g, np.abs(grad - g["grad"]).max()
+    results.append((total, grad))
+    del eng
+    torch.cuda.empty_cache()
+  np.testing.assert_array_equal(results[0][0], results[1][0])      # streaming changes no bit
+  np.testing.assert_array_equal(results[0][1], results[1][1])

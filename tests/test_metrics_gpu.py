@@ -71,6 +71,44 @@ def test_unitary_matches_oracle():
   np.testing.assert_allclose(got.conj().T @ got, np.eye(2**n), atol=1e-5)
 
 
+def test_unitary_of_rotation_and_qaia_circuits_includes_the_global_phase():
+  """qnn_utils.py:23-33 returns cirq's unitary, global phase included; circuits built from cirq.rx /
+  ry / rz and from tfq.util.exponential (the QAIA ansatz, circuit.py:268-272) have gates with
+  global_shift = -0.5.  ABI v3 carries it: `unitary` equals the oracle's
+  prod gate_matrix(kind, t, global_shift) -- and the closed forms exp(-i theta P / 2) -- exactly
+  (complex64: 2e-6), not up to a phase."""
+  import scipy.linalg
+  qs = ir.GridQubit.rect(1, 3)
+  a, b, c = ir.symbols("a b c")
+  raw = ir.Circuit(ir.rx(a)(qs[0]), ir.ry(b * 0.5)(qs[1]), ir.rz(c + 0.3)(qs[2]), ir.CNOT(qs[0], qs[1]),
+                   ir.rz(-1.1)(qs[0]), ir.X(qs[2])**0.4, ir.ry(0.9)(qs[2]))
+  circ = models.DirectQuantumCircuit(raw)
+  values = np.array([0.7, -1.9, 2.4])
+  _set(circ.trainable_variables[0], values)
+  flat = raw.flat_gates(circ.qubits, circ.symbol_names)
+  assert sum(len(g) == 7 for g in flat) == 5
+  got = inference.unitary(circ).cpu().numpy()
+  np.testing.assert_allclose(got, O.unitary(3, flat, values), atol=2e-6)
+  # closed forms of the rotations alone
+  px, py, pz = np.array([[0, 1], [1, 0]]), np.array([[0, -1j], [1j, 0]]), np.diag([1.0, -1.0])
+  rots = models.DirectQuantumCircuit(ir.Circuit(ir.rx(a)(qs[0]), ir.ry(b)(qs[1]), ir.rz(c)(qs[2])))
+  _set(rots.trainable_variables[0], values)
+  want = np.kron(np.kron(scipy.linalg.expm(-0.5j * values[0] * px), scipy.linalg.expm(-0.5j * values[1] * py)),
+                 scipy.linalg.expm(-0.5j * values[2] * pz))
+  np.testing.assert_allclose(inference.unitary(rots).cpu().numpy(), want, atol=2e-6)
+  # the QAIA ansatz: exp(-i eta_k H_k) exp(-i gamma_k sum X) layers (tfq.util.exponential circuits)
+  n = 3
+  h_terms = [ir.PZ(qs[0]) * ir.PZ(qs[1]) + ir.PZ(qs[1]) * ir.PZ(qs[2]), ir.PX(qs[0]) + ir.PX(qs[1]) + ir.PX(qs[2])]
+  qaia = models.QAIA(h_terms, [ir.PZ(q) for q in qs] + [ir.PZ(qs[0]) * ir.PZ(qs[2])], 2)
+  rng = np.random.default_rng(9)
+  for v in qaia.value_layers_inputs[0]:
+    _set(v, rng.uniform(-1, 1, tuple(v.shape)))
+  flat_q = qaia.pqc.flat_gates(qaia.qubits, qaia.symbol_names)
+  assert any(len(g) == 7 for g in flat_q)
+  np.testing.assert_allclose(inference.unitary(qaia).cpu().numpy(),
+                             O.unitary(n, flat_q, qaia.symbol_values.detach().cpu().numpy()), atol=2e-6)
+
+
 def test_density_matrix_bell_state():
   """qhbm_utils_test.py:28-51."""
   qubits = ir.GridQubit.rect(1, 2)

@@ -29,8 +29,9 @@ def _dense(op, qubits):
 
 
 def _equal_up_to_phase(u, want, atol=1e-10):
-  k = np.unravel_index(np.argmax(np.abs(want)), want.shape)
-  np.testing.assert_allclose(u * (want[k] / u[k]), want, atol=atol)
+  """EXACT equality since ABI v3: rx / rz carry cirq's global_shift = -0.5 (ir.py), so the circuit of
+  `exponential` is exp(-i c P) itself, as tfq.util.exponential's is -- no phase is divided out."""
+  np.testing.assert_allclose(u, want, atol=atol)
 
 
 def test_exponential_of_pauli_strings_is_the_matrix_exponential():
@@ -49,6 +50,36 @@ def test_exponential_of_pauli_strings_is_the_matrix_exponential():
   _equal_up_to_phase(O.unitary(3, both.flat_gates(qs, []), []), want)
   one = ir.exponential([strings[2]])
   _equal_up_to_phase(O.unitary(3, one.flat_gates(qs, []), []), scipy.linalg.expm(-1j * _dense(strings[2], qs)))
+
+
+def test_rotations_carry_cirqs_global_shift():
+  """cirq.rx/ry/rz(theta) = exp(-i theta P / 2) exactly (XPowGate(exponent=theta/pi, global_shift=-0.5)):
+  the flat gate has a seventh entry, the inverse keeps it, a plain power gate has none."""
+  q = ir.GridQubit(0, 0)
+  theta = 0.83
+  for make, pauli, kind in ((ir.rx, "X", O.GATE_XPOW), (ir.ry, "Y", O.GATE_YPOW), (ir.rz, "Z", O.GATE_ZPOW)):
+    gate = make(theta)(q)
+    (flat,) = ir.Circuit(gate).flat_gates([q], [])
+    assert flat == (kind, 0, -1, -1, 0.0, pytest.approx(theta / np.pi), -0.5)
+    want = scipy.linalg.expm(-0.5j * theta * _P[pauli])
+    np.testing.assert_allclose(O.unitary(1, [flat], []), want, atol=1e-12)
+    np.testing.assert_allclose(O.gate_matrix(kind, theta / np.pi, -0.5), want, atol=1e-12)
+    (inv,) = (ir.Circuit(gate)**-1).flat_gates([q], [])
+    assert inv[6] == -0.5
+    np.testing.assert_allclose(O.unitary(1, [inv], []), want.conj().T, atol=1e-12)
+    sym = make(ir.Symbol("a") * 2.0)(q)                       # symbolic angle: exponent 2 a / pi
+    (fs,) = ir.Circuit(sym).flat_gates([q], ["a"])
+    np.testing.assert_allclose(O.unitary(1, [fs], [0.4]), scipy.linalg.expm(-0.4j * _P[pauli]), atol=1e-12)
+  assert len(ir.Circuit(ir.X(q)**0.3).flat_gates([q], [])[0]) == 6
+  # the phase never reaches an expectation value or a gradient
+  gates6 = [(O.GATE_XPOW, 0, -1, 0, 1.0 / np.pi, 0.0)]
+  gates7 = [gates6[0] + (-0.5,)]
+  bits = np.array([[0], [1]], np.int8)
+  op = [O.pauli_term(1.0, [(0, "Z")]), O.pauli_term(0.5, [(0, "Y")])]
+  v6, j6 = O.expectation_jacobian(1, gates6, [0.7], bits, [op])
+  v7, j7 = O.expectation_jacobian(1, gates7, [0.7], bits, [op])
+  np.testing.assert_allclose(v7, v6, atol=1e-12)
+  np.testing.assert_allclose(j7, j6, atol=1e-12)
 
 
 def test_exponential_of_commuting_sum_and_errors():
