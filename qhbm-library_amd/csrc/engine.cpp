@@ -77,6 +77,7 @@ struct qhbm_engine {
   int opt_values_from_obs = 1;  // single observable: <psi|O|psi> from lambda = O psi, no measurement in the forward sweep
   bool retained_mu = false;     // the retained batch also holds the unweighted lambda = O psi
   int opt_cph_wave_bits = 1; // boundary controlled-phase predicates on wave bits (schedule.h Plan::cph_wave_bits)
+  int opt_obs_xcd_states = 1;  // lambda = O psi: one state per XCD at a time (kernels.hip apply_observable_kernel)
   int opt_adj_exchange = 1;  // lean adjoint passes: register-resident tile pair + one LDS exchange buffer
   int retained_U = 0;  // final states of the last qhbm_expectation_retain still sit in psi
   int state_grad_U = 0;  // rows of state_grad the last adjoint VJP filled (qhbm_state_gradients)
@@ -270,8 +271,8 @@ int upload_model(qhbm_engine* h) {
       groups.back().has_imag |= t[k].ny & 1u;
     }
     {  // order the terms of every real-weight group by sign class (kernels.h ObsGroup)
-      const uint32_t amask = (obs_amps_per_thread(uint32_t(h->fwd.plan.n_eff)) - 1u) << 8;
-      auto cls = [&](const DevTerm& d) { return (d.z & 0xffu) == 0 ? 0 : ((d.z & amask) == 0 ? 1 : 2); };
+      const uint32_t smask = obs_slot_mask(uint32_t(h->fwd.plan.n_eff));
+      auto cls = [&](const DevTerm& d) { return (d.z & kObsThreadMask) == 0 ? 0 : ((d.z & smask) == 0 ? 1 : 2); };
       size_t begin = 0;
       for (ObsGroup& g : groups) {
         if (!g.has_imag) {
@@ -458,7 +459,7 @@ int run_observable_chunk(qhbm_engine* h, uint32_t s0, uint32_t c, const float* d
   HIPCHK(launch_apply_observable(h->psi.p, h->lam.p, uint32_t(h->fwd.plan.n_eff), c, h->terms.p,
                                  uint32_t(h->model.terms.size()), h->obs_groups.p, h->n_obs_groups, d_upstream,
                                  uint32_t(h->model.n_ops), s0, h->op_scale.p, value_mode ? h->vals64.p : nullptr,
-                                 h->value_part.p, stream));
+                                 h->value_part.p, h->opt_obs_xcd_states != 0, stream));
   timer_end(ev, stream);
   return 0;
 }
@@ -643,6 +644,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "adjoint_full_diag_threshold") { h->opt_full_adj = int(value); h->plans_valid = false; }
   else if (k == "adjoint_tile_qubits") { h->opt_adj_tile = int(value); h->plans_valid = false; }
   else if (k == "adjoint_exchange") h->opt_adj_exchange = int(value);
+  else if (k == "observable_xcd_states") h->opt_obs_xcd_states = int(value);
   else if (k == "measure_tile_qubits") { h->opt_meas_tile = int(value); h->plans_valid = false; }
   else if (k == "values_from_observable") h->opt_values_from_obs = int(value);
   else if (k == "cph_wave_bits") { h->opt_cph_wave_bits = int(value); h->plans_valid = false; }

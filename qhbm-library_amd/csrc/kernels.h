@@ -18,16 +18,19 @@ struct DevTerm {  // one Pauli term, amplitude-index bit space
 // Terms of equal x mask, consecutive in the x-sorted term array: [previous end, end).  A group
 // never straddles a multiple of kObsTermChunk / 2 (the kernel stages that many terms in LDS at a time).
 // Within a group of real weights the terms are ordered by how their sign (-1)^{popc(j & z)} varies
-// inside a workgroup of apply_observable_kernel (j = block | a << 8 | tid): first the n_h terms whose z
-// misses the thread bits (one pre-summed weight per amplitude slot a), then the n_l terms whose z
-// misses the `a` bits (one signed sum per thread), then the rest (per amplitude).
+// inside a workgroup of apply_observable_kernel (j = block | slot bits | tid << 1: a thread owns A / 2
+// adjacent pairs, slot s = index bit 0 and the bits from 9 up): first the n_h terms whose z misses the
+// thread bits (one pre-summed weight per slot), then the n_l terms whose z misses the slot bits (one
+// signed sum per thread), then the rest (per amplitude).
 struct ObsGroup {
   uint32_t x, end;
   uint32_t has_imag;  // some term of the group has an odd number of Y factors (imaginary weight)
   uint32_t n_h, n_l;
 };
 constexpr uint32_t obs_amps_per_thread(uint32_t n) { return n >= 11 ? 8u : 4u; }  // A of apply_observable_kernel<A>
-constexpr uint32_t kObsTermChunk = 1024;
+constexpr uint32_t kObsThreadMask = 0x1feu;                                        // index bits 1..8 = the thread
+constexpr uint32_t obs_slot_mask(uint32_t n) { return 1u | ((obs_amps_per_thread(n) / 2u - 1u) << 9); }  // bit 0 and 9 (, 10)
+constexpr uint32_t kObsTermChunk = 512;  // 2 x the terms staged in LDS at a time (12 KiB: five workgroups per CU)
 
 size_t fwd_lds_bytes(int K);
 size_t adj_lds_bytes(int K, bool exchange);
@@ -54,7 +57,7 @@ hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, u
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
                                    const float* op_scale, unsigned long long* out64, float* value_part,
-                                   hipStream_t stream);
+                                   bool xcd_states, hipStream_t stream);
 // Terms measured on the final state in HBM (X-mask wider than a tile); accumulates into out64.
 hipError_t launch_measure_global(const float2* psi, uint32_t n, uint32_t n_states, const DevTerm* terms,
                                  uint32_t n_terms, const float* op_scale, unsigned long long* out64, uint32_t n_ops,

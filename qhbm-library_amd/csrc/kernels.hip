@@ -1321,22 +1321,113 @@ __global__ __launch_bounds__(1024) void reduce_tiles_kernel(const float* __restr
 // Terms arrive sorted by x mask and cut into GROUPS of equal x: one gather psi[j ^ x] per group
 // serves all of its terms (XXZ: 57 terms, 20 gathers), whose signed weights -- staged once per
 // workgroup in LDS as upstream * coeff * i^ny -- fold into one complex factor per amplitude.
-// A thread owns A amplitudes 256 apart, j = block * 256 * A | a << 8 | tid, so a group issues A
-// independent coalesced loads before any of them is needed.  The sign of a term at j ^ x is
-// (-1)^{popc((j ^ x) & z)}: the part from the block and `a` bits of j and from x & z is the same
-// for the whole workgroup, so it is folded into A pre-signed copies of the weight when the term is
-// staged; a thread evaluates only the parity of tid & z, once per term for all of its amplitudes
-// (3 + 2 A VALU per term instead of 4 per amplitude).  The kernel is VALU-bound on exactly these
-// sums, so the terms of a group come sorted by sign class (kernels.h ObsGroup): the ones whose z
-// misses the thread bits are pre-summed per amplitude slot once per workgroup, the ones whose z
-// misses the `a` bits cost one signed sum per THREAD, only the rest are added per amplitude (XXZ at
-// 20 qubits: 2 of the 57 terms), and lambda accumulates with one packed FMA per amplitude and group.
+//
+// A workgroup owns a block of 256 A consecutive amplitudes; a thread owns A of them as A / 2 ADJACENT
+// PAIRS, local index L(s) = 2 tid + (s & 1) + 512 (s >> 1) for slot s: the partner j ^ x of an adjacent
+// pair is an adjacent pair, so every gather is ONE 16-byte load per pair (half the load instructions
+// of 8-byte gathers, twice the bytes in flight per instruction).  The kernel is bound by the LATENCY of
+// those gathers (round 3: 58 % of wave-cycles in s_waitcnt, HBM at 0.57 of its rate, the fill traffic
+// cut by a quarter without any effect on the time), so the loads of the NEXT group that leaves the
+// block are issued before the current group is consumed, and the staging area is small enough for
+// five workgroups per CU.  Masks inside the block read the block's own amplitudes from LDS.
+// The sign of a term at j ^ x is (-1)^{popc((j ^ x) & z)}: the part from the block and slot bits of j
+// and from x & z is the same for the whole workgroup, so it is folded into A pre-signed copies of the
+// weight when the term is staged; a thread evaluates only the parity of its thread bits & z, once per
+// term for all of its amplitudes.  The terms of a group come sorted by sign class (kernels.h
+// ObsGroup): the ones whose z misses the thread bits are pre-summed per slot once per workgroup, the
+// ones whose z misses the slot bits cost one signed sum per THREAD, only the rest are added per
+// amplitude (XXZ at 20 qubits: 2 of the 57 terms), and lambda accumulates with one packed FMA per
+// amplitude and group.
 // ================================================================================
 template <int A> struct ObsStage {
   float4 term[kObsTermChunk / 2];     // z bits, weight (re), weight (im), --      (general path)
-  float flip[kObsTermChunk / 2][A];   // real weight, pre-signed for amplitude a    (real-weight path)
+  float flip[kObsTermChunk / 2][A];   // real weight, pre-signed for slot s         (real-weight path)
 };
 constexpr uint32_t kObsChunk = kObsTermChunk / 2;  // terms staged in LDS at a time
+// index bits of slot s inside the block (kernels.h obs_slot_mask is their union)
+template <int A> __device__ __forceinline__ constexpr uint32_t obs_slot_bits(int s) { return uint32_t(s & 1) | (uint32_t(s >> 1) << 9); }
+// the partners j ^ x of a thread's A / 2 adjacent pairs: one 16-byte load per pair (x with bit 0 cleared)
+template <int A>
+__device__ __forceinline__ void obs_gather(float4 (&buf)[A / 2], const float2* __restrict__ ps, uint32_t j0, uint32_t x) {
+#pragma unroll
+  for (int p = 0; p < A / 2; ++p) buf[p] = *reinterpret_cast<const float4*>(&ps[(j0 + 512u * p) ^ (x & ~1u)]);
+}
+// One group: acc[s] += (signed weight sum of the group's terms at slot s) * psi[j ^ x].  `buf` holds the
+// gathered partners if the mask leaves the block; a mask inside the block reads the block's LDS copy.
+template <int A>
+__device__ __forceinline__ void obs_consume(const ObsGroup& gr, float4 (&buf)[A / 2], const v2f* own, const ObsStage<A>& st,
+                                            uint32_t& k, uint32_t k0, uint32_t tb, v2f (&acc)[A]) {
+  constexpr int P = A / 2;
+  if (gr.x < 256u * A) {  // the mask permutes the workgroup's own block: served from its LDS copy
+#pragma unroll
+    for (int p = 0; p < P; ++p) buf[p] = *reinterpret_cast<const float4*>(&own[(tb + 512u * p) ^ (gr.x & ~1u)]);
+  }
+  // index bit 0 flipped (odd): the two amplitudes of a pair change places -- the accumulation is written
+  // out for both orders under a scalar branch (a select per register would cost sixteen v_cndmask a group)
+  const bool odd = uni(gr.x) & 1u;
+  if (gr.has_imag) {
+    float cr[A], ci[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) cr[a] = ci[a] = 0.f;
+    for (; k < gr.end; ++k) {
+      const float4 t = st.term[k - k0];
+      const uint32_t z = __float_as_uint(t.x);
+      const uint32_t sg0 = (uint32_t(__popc(tb & z)) << 31) ^ __float_as_uint(t.w);
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        const uint32_t sgn = sg0 ^ (uint32_t(__popc(obs_slot_bits<A>(a) & z)) << 31);
+        cr[a] += __uint_as_float(__float_as_uint(t.y) ^ sgn);
+        ci[a] += __uint_as_float(__float_as_uint(t.z) ^ sgn);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const v2f lo = v2f{buf[p].x, buf[p].y}, hi = v2f{buf[p].z, buf[p].w};
+      const v2f v0 = odd ? hi : lo, v1 = odd ? lo : hi;
+      acc[2 * p] += v2f{cr[2 * p] * v0.x - ci[2 * p] * v0.y, cr[2 * p] * v0.y + ci[2 * p] * v0.x};
+      acc[2 * p + 1] += v2f{cr[2 * p + 1] * v1.x - ci[2 * p + 1] * v1.y, cr[2 * p + 1] * v1.y + ci[2 * p + 1] * v1.x};
+    }
+  } else {  // real weights only (X/Z strings, even Y count): the common case
+    float c[A];
+    float sgl = 0.f;  // terms whose sign depends on the thread only: one signed sum for all A amplitudes
+    const uint32_t kl = k + gr.n_h, km = kl + gr.n_l;
+    for (uint32_t q = kl; q < km; ++q) {
+      const uint32_t z = __float_as_uint(st.term[q - k0].x);
+      sgl += __uint_as_float(__float_as_uint(st.flip[q - k0][0]) ^ (uint32_t(__popc(tb & z)) << 31));
+    }
+    {  // pre-summed weights of the thread-independent terms: ONE vector read of the slot row, no branch per
+      // slot (eight conditional 4-byte reads, each with its own wait, were a chain of LDS latencies per group)
+      const float use_h = gr.n_h ? 1.f : 0.f;  // wave-uniform; the row read is valid memory either way
+#pragma unroll
+      for (int q4 = 0; q4 < A / 4; ++q4) {
+        const float4 r4 = *reinterpret_cast<const float4*>(&st.flip[k - k0][4 * q4]);
+        c[4 * q4] = fmaf(use_h, r4.x, sgl);
+        c[4 * q4 + 1] = fmaf(use_h, r4.y, sgl);
+        c[4 * q4 + 2] = fmaf(use_h, r4.z, sgl);
+        c[4 * q4 + 3] = fmaf(use_h, r4.w, sgl);
+      }
+    }
+    for (k = km; k < gr.end; ++k) {
+      const uint32_t z = __float_as_uint(st.term[k - k0].x);
+      const uint32_t sg0 = uint32_t(__popc(tb & z)) << 31;
+#pragma unroll
+      for (int a = 0; a < A; ++a) c[a] += __uint_as_float(__float_as_uint(st.flip[k - k0][a]) ^ sg0);
+    }
+    if (odd) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {  // one packed FMA per amplitude
+        acc[2 * p] += c[2 * p] * v2f{buf[p].z, buf[p].w};
+        acc[2 * p + 1] += c[2 * p + 1] * v2f{buf[p].x, buf[p].y};
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        acc[2 * p] += c[2 * p] * v2f{buf[p].x, buf[p].y};
+        acc[2 * p + 1] += c[2 * p + 1] * v2f{buf[p].z, buf[p].w};
+      }
+    }
+  }
+}
 // VALUE (a single observable): the weights are the bare coefficients, lambda = O psi unweighted, and
 // <psi|O|psi> = sum_j Re(conj(psi_j) lambda_j) leaves as a by-product in the fixed-point accumulator
 // value_part[state, workgroup] (value_parts_kernel) -- the forward sweep then needs no measurement at all, and the caller applies the
@@ -1345,24 +1436,43 @@ template <int A, bool VALUE>
 __global__ __launch_bounds__(256) void apply_observable_kernel(
     const float2* __restrict__ psi, float2* __restrict__ lam, uint32_t n, const DevTerm* __restrict__ terms,
     uint32_t n_terms, const ObsGroup* __restrict__ groups, uint32_t n_groups,
-    const float* __restrict__ upstream, uint32_t n_ops, uint32_t state0, float* __restrict__ value_part) {
+    const float* __restrict__ upstream, uint32_t n_ops, uint32_t state0, float* __restrict__ value_part,
+    uint32_t nb /* workgroups per state */, uint32_t n_states, uint32_t xcd_states) {
+  constexpr int P = A / 2;  // adjacent pairs per thread
   __shared__ ObsStage<A> st;
-  const uint32_t s_local = blockIdx.y;
-  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give XCD k the k-th
-  // CONTIGUOUS eighth of the state, so that the partner runs j ^ x of every mask below that eighth's
-  // size are fetched (by this or a neighbouring workgroup) into the SAME L2 -- consecutive block ids
-  // would put the partners of masks just above the block size on eight different XCDs.
-  const uint32_t bx = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  // Workgroups are dealt round-robin to the 8 XCDs (linear id mod 8), each with its own L2.
+  //   xcd_states: XCD k works on state 8 g + k, its blocks in index order -- EVERY partner run j ^ x of
+  //   that state is fetched into the same L2, by this workgroup or by the one that owns it (config 3:
+  //   3.7 reads of the state from the fabric instead of 5.1).  The last n_states mod 8 states, and tiny
+  //   states, use the other map:
+  //   XCD k takes the k-th CONTIGUOUS eighth of every state, so that the partners of every mask below
+  //   that eighth's size share an L2; the masks above it are fetched from another XCD's share.
+  uint32_t s_local, bx;
+  {
+    const uint32_t wg = blockIdx.x, per_group = 8u * nb, group = wg / per_group, r = wg - group * per_group;
+    if (xcd_states && (group + 1u) * 8u <= n_states) {
+      s_local = group * 8u + (r & 7u);
+      bx = r >> 3;
+    } else {
+      const uint32_t q = r / nb, b = r - q * nb;
+      s_local = group * 8u + q;
+      bx = (nb & 7u) ? b : (b & 7u) * (nb >> 3) + (b >> 3);
+    }
+  }
   const uint32_t jb = bx * (256u * A);                   // block bits of j
-  const uint32_t j0 = jb + threadIdx.x;
+  const uint32_t tb = threadIdx.x << 1;                  // thread bits of j
   const float2* ps = psi + (size_t(s_local) << n);
+  const uint32_t j0 = jb + tb;                           // the thread's first amplitude
   const float* up = VALUE ? nullptr : upstream + size_t(state0 + s_local) * n_ops;
-  // The kernel is bound by L2 -> L1 traffic (one gather of the state per mask, no reuse in L1): the
-  // block's own amplitudes are staged in LDS once and every mask that stays inside the block reads
-  // them there (XXZ at 20 qubits: 11 of the 20 gathers).
-  __shared__ v2f own[256 * A];
+  __shared__ __attribute__((aligned(16))) v2f own[256 * A];
+  float4 self[P];
 #pragma unroll
-  for (int a = 0; a < A; ++a) own[threadIdx.x + 256u * a] = *reinterpret_cast<const v2f*>(&ps[j0 + 256u * a]);
+  for (int p = 0; p < P; ++p) self[p] = *reinterpret_cast<const float4*>(&ps[j0 + 512u * p]);
+  // gathers of the first group that leaves the block (if the first group does): in flight during the staging
+  ObsGroup gr = n_groups ? groups[0] : ObsGroup{0u, 0u, 0u, 0u, 0u};
+  float4 cur[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) *reinterpret_cast<float4*>(&own[tb + 512u * p]) = self[p];
   v2f acc[A];
 #pragma unroll
   for (int a = 0; a < A; ++a) acc[a] = v2f{0.f, 0.f};
@@ -1380,86 +1490,45 @@ __global__ __launch_bounds__(256) void apply_observable_kernel(
                                     __uint_as_float(base << 31));
 #pragma unroll
       for (int a = 0; a < A; ++a) {
-        const uint32_t par = (base + uint32_t(__popc((uint32_t(a) << 8) & tm.z))) & 1u;
+        const uint32_t par = (base + uint32_t(__popc(obs_slot_bits<A>(a) & tm.z))) & 1u;
         st.flip[k - k0][a] = __uint_as_float(__float_as_uint(m) ^ (par << 31));
       }
     }
     __syncthreads();
-    // one pre-summed weight per amplitude slot for the thread-independent terms of every real group
+    // one pre-summed weight per slot for the thread-independent terms of every real group
     // of the chunk, written over the first of them (flip[begin][a])
     for (uint32_t gi = g + threadIdx.x / uint32_t(A); gi < n_groups; gi += 256u / uint32_t(A)) {
-      const ObsGroup gr = groups[gi];
-      if (gr.end > k1) break;
-      if (gr.n_h > 1u) {
+      const ObsGroup gq = groups[gi];
+      if (gq.end > k1) break;
+      if (gq.n_h > 1u) {
         const uint32_t kb = gi ? groups[gi - 1u].end : 0u, a = threadIdx.x % uint32_t(A);
         float sum = st.flip[kb - k0][a];
-        for (uint32_t k = kb + 1u; k < kb + gr.n_h; ++k) sum += st.flip[k - k0][a];
+        for (uint32_t k = kb + 1u; k < kb + gq.n_h; ++k) sum += st.flip[k - k0][a];
         st.flip[kb - k0][a] = sum;
       }
     }
     __syncthreads();
     uint32_t k = k0;
-    for (; g < n_groups; ++g) {
-      const ObsGroup gr = groups[g];  // wave-uniform
-      if (gr.end > k1) break;
-      v2f v[A];
-      if (gr.x < 256u * A) {  // the mask permutes the workgroup's own block: served from its LDS copy
-#pragma unroll
-        for (int a = 0; a < A; ++a) v[a] = own[(threadIdx.x + 256u * a) ^ gr.x];
-      } else {
-#pragma unroll
-        for (int a = 0; a < A; ++a) v[a] = *reinterpret_cast<const v2f*>(&ps[(j0 + 256u * a) ^ gr.x]);
-      }
-      if (gr.has_imag) {
-        float cr[A], ci[A];
-#pragma unroll
-        for (int a = 0; a < A; ++a) cr[a] = ci[a] = 0.f;
-        for (; k < gr.end; ++k) {
-          const float4 t = st.term[k - k0];
-          const uint32_t z = __float_as_uint(t.x);
-          const uint32_t sg0 = (uint32_t(__popc(threadIdx.x & z)) << 31) ^ __float_as_uint(t.w);
-#pragma unroll
-          for (int a = 0; a < A; ++a) {
-            const uint32_t sgn = sg0 ^ (uint32_t(__popc((uint32_t(a) << 8) & z)) << 31);
-            cr[a] += __uint_as_float(__float_as_uint(t.y) ^ sgn);
-            ci[a] += __uint_as_float(__float_as_uint(t.z) ^ sgn);
-          }
-        }
-#pragma unroll
-        for (int a = 0; a < A; ++a) acc[a] += v2f{cr[a] * v[a].x - ci[a] * v[a].y, cr[a] * v[a].y + ci[a] * v[a].x};
-      } else {  // real weights only (X/Z strings, even Y count): the common case
-        float c[A];
-        float s = 0.f;  // terms whose sign depends on the thread only: one signed sum for all A amplitudes
-        const uint32_t kl = k + gr.n_h, km = kl + gr.n_l;
-        for (uint32_t q = kl; q < km; ++q) {
-          const uint32_t z = __float_as_uint(st.term[q - k0].x);
-          s += __uint_as_float(__float_as_uint(st.flip[q - k0][0]) ^ (uint32_t(__popc(threadIdx.x & z)) << 31));
-        }
-#pragma unroll
-        for (int a = 0; a < A; ++a) c[a] = gr.n_h ? st.flip[k - k0][a] + s : s;
-        for (k = km; k < gr.end; ++k) {
-          const uint32_t z = __float_as_uint(st.term[k - k0].x);
-          const uint32_t sg0 = uint32_t(__popc(threadIdx.x & z)) << 31;
-#pragma unroll
-          for (int a = 0; a < A; ++a) c[a] += __uint_as_float(__float_as_uint(st.flip[k - k0][a]) ^ sg0);
-        }
-#pragma unroll
-        for (int a = 0; a < A; ++a) acc[a] += c[a] * v[a];  // one packed FMA per amplitude
-      }
+    while (g < n_groups && gr.end <= k1) {  // gr = groups[g], wave-uniform
+      if (gr.x >= 256u * A) obs_gather<A>(cur, ps, j0, gr.x);
+      obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);
+      ++g;
+      if (g < n_groups) gr = groups[g];
     }
   }
+  float2* ls = lam + (size_t(s_local) << n) + jb;
 #pragma unroll
-  for (int a = 0; a < A; ++a) lam[(size_t(s_local) << n) + j0 + 256u * a] = make_float2(acc[a].x, acc[a].y);
+  for (int p = 0; p < P; ++p)
+    *reinterpret_cast<float4*>(&ls[tb + 512u * p]) = make_float4(acc[2 * p].x, acc[2 * p].y, acc[2 * p + 1].x, acc[2 * p + 1].y);
   if constexpr (VALUE) {
     float e = 0.f;
 #pragma unroll
-    for (int a = 0; a < A; ++a) {
-      const v2f p = own[threadIdx.x + 256u * a];
-      e += p.x * acc[a].x + p.y * acc[a].y;
+    for (int p = 0; p < P; ++p) {
+      const float4 mine = *reinterpret_cast<const float4*>(&own[tb + 512u * p]);  // (not kept in registers: occupancy)
+      e += (mine.x * acc[2 * p].x + mine.y * acc[2 * p].y) + (mine.z * acc[2 * p + 1].x + mine.w * acc[2 * p + 1].y);
     }
     e = wave_sum(e);
-    // (the staging area is free now; a separate array of 16 bytes would take the kernel from four
-    // workgroups per CU to three)
+    // (the staging area is free now; a separate array of 16 bytes would cost a workgroup per CU)
     __syncthreads();
     float* wave_part = reinterpret_cast<float*>(&st.term[0]);
     if ((threadIdx.x & 63u) == 0) wave_part[threadIdx.x >> 6] = e;
@@ -1467,7 +1536,7 @@ __global__ __launch_bounds__(256) void apply_observable_kernel(
     // one partial per workgroup (512 atomics per state on ONE address cost a quarter of the kernel);
     // value_parts_kernel adds a state's partials in block order
     if (threadIdx.x == 0)
-      value_part[size_t(s_local) * gridDim.x + blockIdx.x] = (wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3]);
+      value_part[size_t(s_local) * nb + bx] = (wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3]);  // logical block: the sum order does not depend on the XCD map
   }
 }
 
@@ -2153,26 +2222,27 @@ hipError_t launch_parity_energy_vjp(const int8_t* bits, int64_t n_rows, int n, c
   return hipGetLastError();
 }
 
-size_t observable_value_parts(uint32_t n, uint32_t n_states) { return size_t(n_states) * ((1u << n) / (256u * (n >= 11 ? 8u : 4u))); }
+size_t observable_value_parts(uint32_t n, uint32_t n_states) { return size_t(n_states) * ((1u << n) / (256u * obs_amps_per_thread(n))); }
 
 hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
                                    const float* op_scale, unsigned long long* out64, float* value_part,
-                                   hipStream_t stream) {
+                                   bool xcd_states, hipStream_t stream) {
   const bool value = out64 != nullptr;  // single observable: unweighted lambda + <psi|O|psi> (see the kernel)
+  const uint32_t nb = (1u << n) / (256u * obs_amps_per_thread(n));
+  const uint32_t xs = xcd_states && nb >= 128u ? 1u : 0u;  // (a state must at least fill an XCD's workgroup slots)
 #define QHBM_OBS(A_, V_)                                                                                          \
-  hipLaunchKernelGGL((apply_observable_kernel<A_, V_>), dim3((1u << n) / (256u * A_), n_states), dim3(256), 0, stream, \
-                     psi, lam, n, terms, n_terms, groups, n_groups, upstream, n_ops, state0, value_part)
-  if (n >= 11) {
+  hipLaunchKernelGGL((apply_observable_kernel<A_, V_>), dim3(nb * n_states), dim3(256), 0, stream, psi, lam, n, terms, \
+                     n_terms, groups, n_groups, upstream, n_ops, state0, value_part, nb, n_states, xs)
+  if (obs_amps_per_thread(n) == 8u) {
     if (value) QHBM_OBS(8, true); else QHBM_OBS(8, false);
   } else {
     if (value) QHBM_OBS(4, true); else QHBM_OBS(4, false);
   }
 #undef QHBM_OBS
   if (value && n_states)
-    hipLaunchKernelGGL(value_parts_kernel, dim3(n_states), dim3(256), 0, stream, value_part,
-                       (1u << n) / (256u * (n >= 11 ? 8u : 4u)), op_scale, out64, state0);
+    hipLaunchKernelGGL(value_parts_kernel, dim3(n_states), dim3(256), 0, stream, value_part, nb, op_scale, out64, state0);
   return hipGetLastError();
 }
 

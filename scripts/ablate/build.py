@@ -137,6 +137,41 @@ VARIANTS.update({
                                          "      round_store<R>(tile, T, DB, amp);\n      if (!(w0 & kRoundNoBarrier)) __syncthreads();", "      if (lane == 77) round_store<R>(tile, T, DB, amp);\n      if (!(w0 & kRoundNoBarrier)) __syncthreads();"),
 })
 
+_ABL_HELPERS = '\n// ---- ablation helpers (scripts/ablate/build.py): 16-byte LDS accesses on slot pairs, MFMA filler ----\ntemplate <int R, int... I>\n__device__ __forceinline__ void round_load_b128_(const char* __restrict__ base, uint32_t addr, const uint32_t (&DB)[R],\n                                                 v2f (&a)[1 << R], std::integer_sequence<int, I...>) {\n  ((addr ^= (I ? DB[1 + (I ? __builtin_ctz(I) : 0)] : 0u),\n    [&] { const float4 v = *reinterpret_cast<const float4*>(base + (addr & ~8u));\n          a[2 * (I ^ (I >> 1))] = v2f{v.x, v.y}; a[2 * (I ^ (I >> 1)) + 1] = v2f{v.z, v.w}; }()), ...);\n}\ntemplate <int R, int... I>\n__device__ __forceinline__ void round_store_b128_(char* __restrict__ base, uint32_t addr, const uint32_t (&DB)[R],\n                                                  const v2f (&a)[1 << R], std::integer_sequence<int, I...>) {\n  ((addr ^= (I ? DB[1 + (I ? __builtin_ctz(I) : 0)] : 0u),\n    *reinterpret_cast<float4*>(base + (addr & ~8u)) =\n        make_float4(a[2 * (I ^ (I >> 1))].x, a[2 * (I ^ (I >> 1))].y, a[2 * (I ^ (I >> 1)) + 1].x, a[2 * (I ^ (I >> 1)) + 1].y)), ...);\n}\ntypedef float v4f_abl __attribute__((ext_vector_type(4)));\n__device__ __forceinline__ void mfma_filler(v4f_abl& acc, float x, int count) {\n  for (int i = 0; i < count; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x, x, acc, 0, 0, 0);\n}\n\n}  // namespace\n\n// ================================================================================\n// Forward pass kernel\n'
+_ABL_ANCHOR = '}  // namespace\n\n// ================================================================================\n// Forward pass kernel\n'
+_FWD_LOAD = '      round_load<R>(tile, T, DB, amp);\n      for (uint32_t i = 0; i < n_inst; ++i) {'
+_FWD_STORE = '      round_store<R>(tile, T, DB, amp);\n      if (!(w0 & kRoundNoBarrier)) __syncthreads();'
+
+
+def _with_helpers(t):
+  return once(t, _ABL_ANCHOR, _ABL_HELPERS)
+
+
+VARIANTS.update({
+    # halve the DS instructions of the forward exchange with 16-byte accesses on slot
+    # pairs (addresses forced even: wrong amplitudes, the access pattern and instruction count of a layout
+    # that keeps a register bit at LDS address bit 0)
+    "fwd_b128_store": lambda t: once(_with_helpers(t), _FWD_STORE,
+        "      round_store_b128_<R>(reinterpret_cast<char*>(tile), T, DB, amp, iseq<8>{});\n      if (!(w0 & kRoundNoBarrier)) __syncthreads();"),
+    "fwd_b128_load": lambda t: once(_with_helpers(t), _FWD_LOAD,
+        "      round_load_b128_<R>(reinterpret_cast<const char*>(tile), T, DB, amp, iseq<8>{});\n      for (uint32_t i = 0; i < n_inst; ++i) {"),
+    "fwd_b128_both": lambda t: once(once(_with_helpers(t), _FWD_STORE,
+        "      round_store_b128_<R>(reinterpret_cast<char*>(tile), T, DB, amp, iseq<8>{});\n      if (!(w0 & kRoundNoBarrier)) __syncthreads();"), _FWD_LOAD,
+        "      round_load_b128_<R>(reinterpret_cast<const char*>(tile), T, DB, amp, iseq<8>{});\n      for (uint32_t i = 0; i < n_inst; ++i) {"),
+    # the matrix pipe BESIDE the VALU.  A dense 16 x 16 complex block per round is 32
+    # v_mfma_f32_32x32x2_f32 = 2048 MFMA-pipe cycles per wave (scripts/micro/mfma_block.hip); the same pipe
+    # time as 64 v_mfma_f32_16x16x4_f32 on ONE 4-register accumulator (the kernel keeps its four waves per
+    # SIMD), issued after the instances of every round.  fwd_mfma: on top of the unchanged VALU work (what
+    # co-issue costs); fwd_no_x_mfma: with the X**t shears compiled out (what the round would cost if the X
+    # layer moved to the matrix pipe for free -- no operand staging, no lane swaps).
+    "fwd_mfma": lambda t: once(_with_helpers(t), _FWD_STORE,
+        "      { v4f_abl macc = {0.f, 0.f, 0.f, 0.f}; mfma_filler(macc, amp[0].x, 64); if (macc.x == 12345.f) amp[0].x += macc.y; }\n" + _FWD_STORE),
+    "fwd_no_x_mfma": lambda t: VARIANTS["fwd_mfma"](VARIANTS["fwd_no_x"](t)),
+    "fwd_mfma16": lambda t: once(_with_helpers(t), _FWD_STORE,
+        "      { v4f_abl macc = {0.f, 0.f, 0.f, 0.f}; mfma_filler(macc, amp[0].x, 16); if (macc.x == 12345.f) amp[0].x += macc.y; }\n" + _FWD_STORE),
+})
+
+
 def check_variants(names=None):
   """Applies every variant's edit to kernels.hip WITHOUT compiling: {name: error message} of the variants
   whose anchors no longer match the kernel source (tests/test_scripts_cpu.py keeps this empty)."""
