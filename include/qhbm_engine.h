@@ -212,6 +212,21 @@ int qhbm_sample(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_para
                 int n_shots, uint64_t seed, int shift_gate, double shift,
                 int8_t* d_out_samples, void* stream);
 
+/* Shot COUNTS of several parameter-shifted programs in one launch set -- what the sampled
+ * estimators reduce their shots to (qnn.py:170-226: tfq.layers.SampledExpectation with the
+ * ParameterShift differentiator samples 2 programs per gate occurrence; a Pauli-string estimate is a
+ * signed sum of the counts, a BitstringEnergy average a weighted one):
+ *   d_out_counts [n_programs, U, 2^n_qubits] int32 (device): how many of the n_shots shots of
+ *   C_q(params)|x_u> gave outcome x (index = the bitstring read big-endian, as qhbm_statevector);
+ *   program q is the installed circuit with `shifts[q]` added to the exponent of gate
+ *   `shift_gates[q]` (HOST arrays of n_programs entries; gate < 0 = the unshifted circuit).
+ * Shot j of (q, u) is drawn with a counter-based generator keyed by (seed, q, u, j): a call is
+ * reproducible and independent of how the engine cuts the (program, state) pairs into launch sets.
+ * n_qubits <= 24 (one counter per outcome); larger registers use qhbm_sample per program. */
+int qhbm_sample_counts(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params,
+                       int n_programs, const int32_t* shift_gates, const float* shifts,
+                       int n_shots, uint64_t seed, int32_t* d_out_counts, void* stream);
+
 /* ---- EBM side -------------------------------------------- */
 /* Spin-parity energies of bitstrings on the current HIP device (no engine handle):
  *   d_energy[i] = sum_k d_thetas[k] * prod_{q in S_k} (1 - 2 x_i[q]),  S_k = set bits of d_masks[k]

@@ -835,6 +835,77 @@ int qhbm_sample(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_para
   return 0;
 }
 
+int qhbm_sample_counts(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, int n_programs,
+                       const int32_t* shift_gates, const float* shifts, int n_shots, uint64_t seed,
+                       int32_t* d_out_counts, void* stream) {
+  if (!h) return 1;
+  if (int rc = need_device(h)) return rc;
+  if (U < 0 || n_shots < 0 || n_programs < 0) return fail(h, "negative batch size, program or shot count");
+  if (n_programs && (!shift_gates || !shifts)) return fail(h, "shift_gates / shifts are NULL");
+  if (h->model.n > 24) return fail(h, "qhbm_sample_counts keeps 2^n counters per (program, state): n_qubits <= 24; use qhbm_sample");
+  for (int q = 0; q < n_programs; ++q)
+    if (shift_gates[q] >= int(h->model.gates.size())) return fail(h, "shift_gates entry out of range");
+  if (int rc = upload_model(h)) return rc;
+  if (U == 0 || n_programs == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DevicePlan& d = h->fwd;
+  h->retained_U = 0;
+  h->state_grad_U = 0;
+  h->shift_ready = false;  // the shift tables below replace those of the parameter-shift VJP
+  {
+    std::vector<int> sg(shift_gates, shift_gates + n_programs);
+    std::vector<float> sv(shifts, shifts + n_programs);
+    HIPCHK(hipStreamSynchronize(s));  // synchronous copies into buffers an earlier call on this stream may still read
+    HIPCHK(h->shift_gates.upload(sg));
+    HIPCHK(h->shift_vals.upload(sv));
+  }
+  const uint32_t n_prog = uint32_t(n_programs), n_eff = uint32_t(d.plan.n_eff);
+  const uint32_t stride = uint32_t((d.plan.coef_init.size() + 64 + 63) / 64 * 64);
+  // launch-set geometry as in the parameter-shift VJP: Uc states x Pc programs per set
+  size_t cap = std::max<size_t>(1, budget_bytes(h) / state_bytes(h));
+  uint32_t max_nl = 0;
+  for (const PassArgs& a : d.args) max_nl = std::max(max_nl, a.n_nonlocal);
+  cap = std::min<size_t>(cap, (size_t(1) << 30) >> max_nl);
+  cap = std::min<size_t>(cap, (size_t(2) << 30) / (size_t(stride) * sizeof(float)));
+  cap = std::min<size_t>(cap, 65535);  // grid.y of the per-element kernels
+  if (h->opt_chunk > 0) cap = std::min<size_t>(cap, size_t(h->opt_chunk));
+  const uint32_t Uc = uint32_t(std::min<size_t>(size_t(U), cap));
+  const uint32_t Pc = uint32_t(std::max<size_t>(1, std::min<size_t>(n_prog, cap / Uc)));
+  if (int rc = ensure_state_buffers(h, Uc * Pc, false)) return rc;
+  HIPCHK(h->block_cum.reserve((size_t(Uc) * Pc) << (n_eff - 10)));
+  if (int rc = values_begin(h, int(Uc * Pc), s)) return rc;  // measurement by-products land in the fixed-point scratch
+  if (h->coef_batch_programs < Pc) {
+    HIPCHK(h->coef_batch.reserve(size_t(Pc) * stride));
+    HIPCHK(launch_replicate(d.coef.p, h->coef_batch.p, uint32_t(d.plan.coef_init.size()), stride, Pc, s));
+    h->coef_batch_programs = Pc;
+  }
+  if (n_eff > uint32_t(kMinTileBits))
+    HIPCHK(hipMemsetAsync(d_out_counts, 0, ((size_t(n_prog) * size_t(U)) << h->model.n) * sizeof(int32_t), s));
+  for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += Uc) {
+    const uint32_t c = std::min<uint32_t>(Uc, uint32_t(U) - s0);
+    for (uint32_t q0 = 0; q0 < n_prog; q0 += Pc) {
+      const uint32_t nq = std::min<uint32_t>(Pc, n_prog - q0);
+      HIPCHK(launch_prep_coefs_batch(d.jobs.p, int(d.plan.jobs.size()), d_params, h->coef_batch.p, h->shift_gates.p + q0,
+                                     h->shift_vals.p + q0, nq, stride, s));
+      HIPCHK(launch_combine_diag(h->coef_batch.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), nq, stride, s));
+      for (size_t i = 0; i < d.plan.passes.size(); ++i) {
+        const Pass& p = d.plan.passes[i];
+        if (p.is_measure_only) continue;
+        PassArgs a = d.args[i];
+        a.flags = (p.flags & (PASS_INIT_BASIS | PASS_GENERAL)) | PASS_STORE | PASS_SKIP_MEASURE;
+        if (h->opt_force_general) a.flags |= PASS_GENERAL;
+        a.prog_states = c;
+        a.coef_stride = stride;
+        HIPCHK(launch_pass_fwd(p.K, d.plan.R, a, nq * c, h->psi.p, d_bits, h->model.n, d.prog.p, d.tables.p,
+                               h->coef_batch.p, h->op_scale.p, h->vals64.p, s0, s));
+      }
+      HIPCHK(launch_sample_counts(h->psi.p, n_eff, h->model.n, nq * c, c, q0, h->block_cum.p, uint32_t(n_shots), seed, s0,
+                                  uint32_t(U), d_out_counts, s));
+    }
+  }
+  return 0;
+}
+
 int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params,
                          const float* d_upstream, float* d_out_vals, float* d_grad, int method,
                          void* stream) {

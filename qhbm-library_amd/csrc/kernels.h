@@ -74,6 +74,12 @@ struct ShiftPhase {
   int32_t param_idx;
   float scalar, offset, shift;
 };
+// Shot counts per outcome for n_elements = programs x prog_states (program, state) elements whose final
+// states sit consecutively in psi (element e = program prog0 + e / prog_states on state state0 + e % prog_states):
+// out [programs, n_states_total, 2^n_user] int32 (zeroed by the caller for n > 10).  block_cum: n_elements * 2^n / 1024 doubles.
+hipError_t launch_sample_counts(const float2* psi, uint32_t n, int n_user, uint32_t n_elements, uint32_t prog_states,
+                                uint32_t prog0, double* block_cum, uint32_t n_shots, uint64_t seed, uint32_t state0,
+                                uint32_t n_states_total, int* out, hipStream_t stream);
 hipError_t launch_global_phase(const CoefJob* jobs, int n_jobs, const ShiftPhase* shifts, int n_shifts,
                                const float* params, float* out_cs, hipStream_t stream);
 hipError_t launch_scale_states(float2* st, size_t count, const float* cs, hipStream_t stream);

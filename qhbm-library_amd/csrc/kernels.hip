@@ -2140,6 +2140,143 @@ hipError_t launch_sample(const float2* psi, uint32_t n, int n_user, uint32_t n_s
 }
 
 // ================================================================================
+// Shot COUNTS per outcome for a batch of (program, state) elements (qhbm_sample_counts): what the
+// sampled estimators of qnn.py:170-226 reduce their shots to -- a Pauli-string estimate is a signed sum
+// of the counts, an energy average a weighted one -- without materialising n_shots bitstrings per
+// element.  Element e = program q = e / prog_states on state state0 + e % prog_states; shot j is drawn
+// with Philox keyed by (seed; j, state, program), so counts are reproducible and independent of how
+// the batch is cut into launch sets.  Integer atomics only: bit-reproducible.
+//   n <= 10 (one 1024-amplitude block per element): one workgroup per element builds the cumulative
+//   distribution in LDS (fp64) and every THREAD draws shots by binary search -- 64 x the shot rate of the
+//   wave-per-shot kernel, which is what a million shots per element need;
+//   n  > 10: the block-mass / prefix / wave-per-shot pipeline of qhbm_sample with a global counter per outcome.
+// ================================================================================
+__global__ __launch_bounds__(256) void sample_counts_small_kernel(const float2* __restrict__ psi, int n_user,
+                                                                  uint32_t prog_states, uint32_t prog0, uint32_t n_shots,
+                                                                  uint64_t seed, uint32_t state0, uint32_t n_states_total,
+                                                                  int* __restrict__ out /*[programs, n_states_total, 2^n_user]*/) {
+  __shared__ double cum[kSampleBlock];
+  __shared__ double part[256];
+  __shared__ int hist[kSampleBlock];
+  const uint32_t e = blockIdx.x, tid = threadIdx.x;
+  const uint32_t q = prog0 + e / prog_states, srow = state0 + e % prog_states;
+  const float2* p = psi + size_t(e) * kSampleBlock;
+  double w[4], mine = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float2 v = p[tid * 4u + uint32_t(i)];
+    w[i] = double(v.x) * double(v.x) + double(v.y) * double(v.y);
+    mine += w[i];
+    hist[tid * 4u + uint32_t(i)] = 0;
+  }
+  part[tid] = mine;
+  __syncthreads();
+  for (int k = 1; k < 256; k <<= 1) {  // Hillis-Steele inclusive scan of the thread sums
+    const double add = int(tid) >= k ? part[tid - k] : 0.0;
+    __syncthreads();
+    part[tid] += add;
+    __syncthreads();
+  }
+  double run = part[tid] - mine;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    run += w[i];
+    cum[tid * 4u + uint32_t(i)] = run;
+  }
+  __syncthreads();
+  const double total = cum[kSampleBlock - 1];
+  for (uint32_t shot = tid; shot < n_shots; shot += 256u) {
+    uint32_t c[4] = {shot, srow, 0x51b0c6a1u, q};
+    philox4x32_10(c, uint32_t(seed), uint32_t(seed >> 32));
+    const double u = (double(c[0]) * 0x1p-32 + double(c[1]) * 0x1p-64) * total;  // [0, total)
+    uint32_t lo = 0, hi = kSampleBlock - 1;  // first outcome whose inclusive prefix exceeds u (it has mass)
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (cum[mid] > u) hi = mid; else lo = mid + 1;
+    }
+    atomicAdd(&hist[lo], 1);
+  }
+  __syncthreads();
+  const uint32_t dim = 1u << n_user;  // idle padding qubits are the high index bits and stay |0>
+  int* o = out + (size_t(q) * n_states_total + srow) * dim;
+  for (uint32_t x = tid; x < dim; x += 256u) o[x] = hist[x];
+}
+
+__global__ __launch_bounds__(64) void draw_counts_kernel(const float2* __restrict__ psi, uint32_t n, int n_user,
+                                                         const double* __restrict__ block_cum, uint32_t prog_states,
+                                                         uint32_t prog0, uint64_t seed, uint32_t state0,
+                                                         uint32_t n_states_total, int* __restrict__ out) {
+  const uint32_t shot = blockIdx.x, e = blockIdx.y, lane = threadIdx.x;
+  const uint32_t q = prog0 + e / prog_states, srow = state0 + e % prog_states;
+  const uint32_t nb = (1u << n) / kSampleBlock;
+  const double* cum = block_cum + size_t(e) * nb;
+  uint32_t c[4] = {shot, srow, 0x51b0c6a1u, q};
+  philox4x32_10(c, uint32_t(seed), uint32_t(seed >> 32));
+  const double total = cum[nb - 1];
+  const double u = (double(c[0]) * 0x1p-32 + double(c[1]) * 0x1p-64) * total;
+  uint32_t lo = 0, hi = nb - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (cum[mid] > u) hi = mid; else lo = mid + 1;
+  }
+  const float r = float(u - (lo ? cum[lo - 1] : 0.0));
+  const float2* p = psi + (size_t(e) << n) + size_t(lo) * kSampleBlock;
+  constexpr int kPer = kSampleBlock / 64;
+  float w[kPer];
+  float mine = 0.f;
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) {
+    const float2 v = p[lane * kPer + i];
+    w[i] = v.x * v.x + v.y * v.y;
+    mine += w[i];
+  }
+  float incl = mine;
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) {
+    const float t = __shfl_up(incl, k);
+    if (int(lane) >= k) incl += t;
+  }
+  const float excl = incl - mine;
+  const bool hit = (r >= excl && r < incl) || (lane == 63 && r >= incl);
+  uint64_t ballot = __ballot(hit && mine > 0.f);
+  if (ballot == 0) ballot = __ballot(mine > 0.f);
+  if (ballot == 0) ballot = 1ull;
+  const int owner = (r >= __shfl(incl, 63)) ? 63 - __builtin_clzll(ballot) : __builtin_ctzll(ballot);
+  if (int(lane) == owner) {
+    float acc = excl;
+    int pick = -1, last_nz = 0;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      if (w[i] > 0.f) last_nz = i;
+      acc += w[i];
+      if (pick < 0 && r < acc && w[i] > 0.f) pick = i;
+    }
+    if (pick < 0) pick = last_nz;
+    const uint32_t idx = lo * kSampleBlock + lane * kPer + uint32_t(pick);
+    atomicAdd(&out[((size_t(q) * n_states_total + srow) << n_user) + (idx & ((1u << n_user) - 1u))], 1);
+  }
+}
+
+hipError_t launch_sample_counts(const float2* psi, uint32_t n, int n_user, uint32_t n_elements, uint32_t prog_states,
+                                uint32_t prog0, double* block_cum, uint32_t n_shots, uint64_t seed, uint32_t state0,
+                                uint32_t n_states_total, int* out, hipStream_t stream) {
+  if (!n_elements) return hipSuccess;
+  if (n == uint32_t(kMinTileBits)) {
+    hipLaunchKernelGGL(sample_counts_small_kernel, dim3(n_elements), dim3(256), 0, stream, psi, n_user, prog_states, prog0,
+                       n_shots, seed, state0, n_states_total, out);
+    return hipGetLastError();
+  }
+  if (n_elements > 65535u) return hipErrorInvalidValue;  // grid.y; the engine cuts its launch sets accordingly
+  const uint32_t nb = (1u << n) / kSampleBlock;  // (the caller zeroed `out`: this path adds to global counters)
+  hipLaunchKernelGGL(block_prob_kernel, dim3(nb, n_elements), dim3(256), 0, stream, psi, n, block_cum);
+  hipLaunchKernelGGL(block_scan_kernel, dim3(n_elements), dim3(256), 0, stream, block_cum, nb);
+  if (n_shots)
+    hipLaunchKernelGGL(draw_counts_kernel, dim3(n_shots, n_elements), dim3(64), 0, stream, psi, n, n_user, block_cum,
+                       prog_states, prog0, seed, state0, n_states_total, out);
+  return hipGetLastError();
+}
+
+// ================================================================================
 // EBM side: spin-parity energies of bitstrings,
 //   E(x) = sum_k theta_k * prod_{q in S_k} (1 - 2 x_q)
 // BernoulliEnergy / KOBE = SpinsFromBitstrings -> Parity -> VariableDot

@@ -971,6 +971,18 @@ std::string describe_plan(const Plan& p) {
         groups += ((h0 >> 16) & 0x3fu) != 0;
       }
     }
+    if (p.adjoint) {  // how full the eight-wide gradient reductions are (kernels.hip add_slots8)
+      int hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (uint32_t off : p.record_offsets)
+        for (int g8 = 0; g8 < 4; ++g8) {
+          int cnt = 0;
+          for (int v = 0; v < 8; ++v) cnt += p.coef_init[off + L.slot_lane8(g8, v)] != 0xffffffffu;
+          if (cnt) ++hist[cnt];
+        }
+      os << "  slots per eight-wide reduction 1..8:";
+      for (int c = 1; c <= 8; ++c) os << " " << hist[c];
+      os << "\n";
+    }
     os << "  census: instances=" << n_inst << " (FULL " << n_full << ") X=" << x << " PH1=" << ph1 << " PH2=" << ph2
        << " FULL-PH1=" << fph1 << " FULL-PH2=" << fph2 << " CPH=" << cph << " (tile predicate " << cph_tile << ") slot-groups=" << groups << " instances by X count 0..4: " << x_hist[0] << "/" << x_hist[1] << "/"
        << x_hist[2] << "/" << x_hist[3] << "/" << x_hist[4] << "\n";

@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "qhbm_set_circuit", "qhbm_set_observables", "qhbm_set_option",
     "qhbm_workspace_bytes", "qhbm_allocated_bytes", "qhbm_expectation", "qhbm_expectation_vjp",
     "qhbm_expectation_retain", "qhbm_expectation_vjp_retained", "qhbm_retained_states", "qhbm_state_gradients",
-    "qhbm_expectation_jacobian", "qhbm_statevector", "qhbm_sample", "qhbm_parity_energy", "qhbm_parity_energy_vjp",
+    "qhbm_expectation_jacobian", "qhbm_statevector", "qhbm_sample", "qhbm_sample_counts", "qhbm_parity_energy", "qhbm_parity_energy_vjp",
     "qhbm_num_passes", "qhbm_describe_schedule",
     "qhbm_kernel_time_ms", "qhbm_traffic_model", "qhbm_flop_model",
 )
@@ -88,6 +88,7 @@ def load_library():
   lib.qhbm_expectation_jacobian.argtypes = [vp, vp, i32, vp, vp, vp, vp]
   lib.qhbm_statevector.argtypes = [vp, vp, i32, vp, vp, vp]
   lib.qhbm_sample.argtypes = [vp, vp, i32, vp, i32, ctypes.c_uint64, i32, ctypes.c_double, vp, vp]
+  lib.qhbm_sample_counts.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, ctypes.c_uint64, vp, vp]
   lib.qhbm_parity_energy.argtypes = [vp, i64, i32, vp, vp, i32, vp, vp]
   lib.qhbm_parity_energy_vjp.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp]
   lib.qhbm_num_passes.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
@@ -380,6 +381,23 @@ class Engine:
           self._lib.qhbm_sample(self._h, bits.data_ptr(), bits.shape[0], params.data_ptr(),
                                 int(n_shots), int(seed) & (2**64 - 1), int(shift_gate),
                                 float(shift), out.data_ptr(), self._stream()))
+    return out
+
+  def sample_counts(self, bits, params, n_shots, seed=0, shift_gates=(-1,), shifts=(0.0,)):
+    """int32 [n_programs, batch, 2^n]: how many of `n_shots` shots of every (shifted program, state)
+    pair gave each outcome -- all programs in one launch set (include/qhbm_engine.h qhbm_sample_counts)."""
+    self.retained = None
+    bits, params = self._prep(bits, params)
+    sg = np.ascontiguousarray(shift_gates, dtype=np.int32)
+    sv = np.ascontiguousarray(shifts, dtype=np.float32)
+    if sg.shape != sv.shape or sg.ndim != 1:
+      raise ValueError("shift_gates and shifts must be 1-D and of equal length")
+    out = torch.empty((len(sg), bits.shape[0], 1 << self.n_qubits), dtype=torch.int32, device=self.device)
+    with torch.cuda.device(self.device):
+      self._check(
+          self._lib.qhbm_sample_counts(self._h, bits.data_ptr(), bits.shape[0], params.data_ptr(), len(sg),
+                                       sg.ctypes.data, sv.ctypes.data, int(n_shots), int(seed) & (2**64 - 1),
+                                       out.data_ptr(), self._stream()))
     return out
 
   def expectation_jacobian(self, bits, params):

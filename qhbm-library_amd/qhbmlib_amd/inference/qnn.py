@@ -278,8 +278,9 @@ class AnalyticQuantumInference(QuantumInference):
 class _ParameterShiftSurrogate(torch.autograd.Function):
   """Zero-valued term whose backward is the two-term parameter-shift rule on SAMPLED estimates
   (tfq.differentiators.ParameterShift as driven at qnn.py:188-226): for every gate occurrence
-  with exponent c*s + o, d/ds = (pi c / 2) [f(o + 1/2) - f(o - 1/2)].  `estimator(g, shift)`
-  returns the no-grad estimate [U, T] with gate g's exponent shifted."""
+  with exponent c*s + o, d/ds = (pi c / 2) [f(o + 1/2) - f(o - 1/2)].  `estimator(shift_gates, shifts)`
+  returns the no-grad estimates [Q, U, T] of Q shifted programs at once: all 2 G programs of a backward
+  run as ONE batched engine call per measurement basis (`qhbm_sample_counts`), not 2 G forwards."""
 
   @staticmethod
   def forward(ctx, symbol_values, estimator, gates, shape):
@@ -291,20 +292,36 @@ class _ParameterShiftSurrogate(torch.autograd.Function):
   def backward(ctx, upstream):
     (symbol_values,) = ctx.saved_tensors
     grad = torch.zeros_like(symbol_values)
-    for g, (kind, _, _, pidx, scalar, _) in enumerate(ctx.gates):
+    shifted = []
+    for g, gate in enumerate(ctx.gates):
+      kind, pidx, scalar = gate[0], gate[3], gate[4]
       if pidx < 0 or kind == _engine.GATE_I:
         continue
       if kind == _engine.GATE_ISWAPPOW:
         raise _engine.EngineError("the two-term parameter-shift rule does not apply to ISWAPPOW")
-      plus, minus = ctx.estimator(g, 0.5), ctx.estimator(g, -0.5)
-      grad[pidx] += (0.5 * math.pi * scalar) * torch.sum(upstream.to(plus.device) * (plus - minus)).to(grad.device)
+      shifted.append((g, pidx, scalar))
+    if not shifted:
+      return grad, None, None, None
+    gates = [g for g, _, _ in shifted for _ in (0, 1)]
+    shifts = [sh for _ in shifted for sh in (0.5, -0.5)]
+    est = ctx.estimator(gates, shifts)                                   # [2 G, U, T]
+    diff = est[0::2] - est[1::2]                                         # f(+1/2) - f(-1/2) per gate
+    per_gate = torch.sum(upstream.to(diff.device).unsqueeze(0) * diff, dim=(1, 2))   # [G]
+    weights = torch.tensor([0.5 * math.pi * scalar for _, _, scalar in shifted], dtype=per_gate.dtype,
+                           device=per_gate.device)
+    index = torch.tensor([pidx for _, pidx, _ in shifted], dtype=torch.long, device=grad.device)
+    grad.index_add_(0, index, (weights * per_gate).to(grad.device, grad.dtype))
     return grad, None, None, None
 
 
 class SampledQuantumInference(QuantumInference):
   """Sampling methods for inference on QuantumCircuit objects (qnn.py:142-292): expectation
-  values are averages over `expectation_samples` computational-basis shots drawn by the engine
-  (`qhbm_sample`), derivatives use the parameter-shift rule on sampled estimates."""
+  values are averages over `expectation_samples` computational-basis shots drawn by the engine,
+  derivatives use the parameter-shift rule on sampled estimates.  Estimates are taken from per-outcome
+  shot COUNTS (`qhbm_sample_counts`: every shifted program of a backward pass in one launch set) up to
+  `MAX_COUNT_QUBITS` qubits, from materialised shots (`qhbm_sample`, one program per call) above."""
+
+  MAX_COUNT_QUBITS = 16   # 2^n counters per (program, state)
 
   def __init__(self, input_circuit: circuit.QuantumCircuit, expectation_samples: int,
                name: Union[None, str] = None, device: Union[None, int] = None,
@@ -334,35 +351,57 @@ class SampledQuantumInference(QuantumInference):
 
   _engine_bits = staticmethod(_engine_bits)
 
+  def _counts(self, eng, bits, values, shift_gates, shifts):
+    """float32 [Q, U, 2^n] shot frequencies of Q shifted programs (one engine call)."""
+    counts = eng.sample_counts(bits, values, self._expectation_samples, self._next_seed(), shift_gates, shifts)
+    return counts.to(torch.float32) / float(self._expectation_samples)
+
   def _pauli_estimator(self, total_circuit, bits, values, strings):
-    """estimator(shift_gate, shift) -> [U, len(strings)] sampled <P> of each Pauli string.
-    Strings are grouped by their X/Y pattern; a group shares one rotated circuit
-    (X: H, Y: rx(pi/2), appended after the circuit) and one batch of shots."""
+    """estimator(shift_gates, shifts) -> [Q, U, len(strings)] sampled <P> of each Pauli string under each
+    of the Q shifted programs.  Strings are grouped by their X/Y pattern; a group shares one rotated
+    circuit (X: H, Y: rx(pi/2), appended after the circuit) and one batch of shots."""
     qubits = total_circuit.qubits
     names = total_circuit.symbol_names
+    n = len(qubits)
     base = total_circuit.pqc.flat_gates(qubits, names)
     qindex = {q: i for i, q in enumerate(qubits)}
     groups = {}
     for k, st in enumerate(strings):
       key = tuple(sorted((qindex[q], p) for q, p in st.paulis.items() if p in ("X", "Y")))
       groups.setdefault(key, []).append(k)
+    use_counts = n <= self.MAX_COUNT_QUBITS
+    outcomes = torch.arange(1 << n, dtype=torch.int64) if use_counts else None
     plans = []
     for key, members in groups.items():
       rot = ir.Circuit([ir.H(qubits[i]) if p == "X" else ir.rx(math.pi / 2)(qubits[i]) for i, p in key])
       eng = self._engine_for(qubits, base + rot.flat_gates(qubits, names), len(names))
-      masks = torch.zeros((len(members), len(qubits)), dtype=torch.float32)
+      masks = torch.zeros((len(members), n), dtype=torch.float32)
       for row, k in enumerate(members):
         for q in strings[k].paulis:
           masks[row, qindex[q]] = 1.0
-      plans.append((eng, members, masks))
+      signs = None
+      if use_counts:   # signs[x, m] = (-1)^{popc(x & string m)}; qubit i is bit n - 1 - i of the outcome index
+        weights = (masks.to(torch.int64) * (1 << torch.arange(n - 1, -1, -1, dtype=torch.int64))).sum(1)   # [members]
+        par = outcomes.unsqueeze(1) & weights.unsqueeze(0)
+        par = par ^ (par >> 32)
+        for sh in (16, 8, 4, 2, 1):
+          par = par ^ (par >> sh)
+        signs = (1.0 - 2.0 * (par & 1).to(torch.float32)).to(bits.device if bits.is_cuda else eng.device)
+      plans.append((eng, members, masks, signs))
 
-    def estimator(shift_gate=-1, shift=0.0):
-      out = torch.ones((bits.shape[0], len(strings)), dtype=torch.float32, device=values.device)
-      for eng, members, masks in plans:
-        shots = eng.sample(bits, values, self._expectation_samples, self._next_seed(), shift_gate, shift)
-        ones = torch.matmul(shots.to(torch.float32), masks.to(shots.device).t())  # [U, shots, members]
-        parity = 1.0 - 2.0 * torch.remainder(ones, 2.0)
-        out[:, members] = parity.mean(1).to(out.device)
+    def estimator(shift_gates=(-1,), shifts=(0.0,)):
+      shift_gates, shifts = list(shift_gates), list(shifts)
+      out = torch.ones((len(shift_gates), bits.shape[0], len(strings)), dtype=torch.float32, device=values.device)
+      for eng, members, masks, signs in plans:
+        if signs is not None:
+          freq = self._counts(eng, bits, values, shift_gates, shifts)               # [Q, U, 2^n]
+          out[:, :, members] = torch.matmul(freq, signs.to(freq.device)).to(out.device)
+        else:                                                                       # wide registers: shots, one program at a time
+          for q, (g, sh) in enumerate(zip(shift_gates, shifts)):
+            shots = eng.sample(bits, values, self._expectation_samples, self._next_seed(), g, sh)
+            ones = torch.matmul(shots.to(torch.float32), masks.to(shots.device).t())   # [U, shots, members]
+            parity = 1.0 - 2.0 * torch.remainder(ones, 2.0)
+            out[q][:, members] = parity.mean(1).to(out.device)
       return out
     return estimator, base
 
@@ -377,33 +416,42 @@ class SampledQuantumInference(QuantumInference):
     values = symbol_values.detach()
     if isinstance(observables, hamiltonian.Hamiltonian) and not isinstance(observables.energy, energy.PauliMixin):
       qubits, names = total_circuit.qubits, total_circuit.symbol_names
+      n = len(qubits)
       base = total_circuit.pqc.flat_gates(qubits, names)
       eng = self._engine_for(qubits, base, len(names))
-
-      def shots(shift_gate=-1, shift=0.0):
-        return eng.sample(bits, values, self._expectation_samples, self._next_seed(), shift_gate, shift)
-
       energy_device = next(iter(observables.energy.parameters()), torch.zeros(())).device
 
-      def mean_energy(samples):
-        """[U, 1] shot average of energy(x): the energy is evaluated once per DISTINCT
-        (state, bitstring) pair, found on the GPU, and weighted by its count."""
-        n_states, n_shots, n = samples.shape
-        weights = (1 << torch.arange(n - 1, -1, -1, device=samples.device, dtype=torch.int64))
-        key = (samples.to(torch.int64) * weights).sum(-1) + (
-            torch.arange(n_states, device=samples.device, dtype=torch.int64).unsqueeze(1) << n)
-        uniq, counts = torch.unique(key, return_counts=True)
-        rows = ((uniq.unsqueeze(1) >> torch.arange(n - 1, -1, -1, device=uniq.device)) & 1).to(torch.int8)
+      def weighted_energy(keys, weights, n_rows):
+        """[n_rows, 1]: sum over the DISTINCT (row, bitstring) pairs `keys` = row << n | outcome of
+        energy(bitstring) * weight -- the energy is evaluated once per pair, on its own device."""
+        rows = ((keys.unsqueeze(1) >> torch.arange(n - 1, -1, -1, device=keys.device)) & 1).to(torch.int8)
         e = observables.energy(rows.to(energy_device))
-        w = (counts.to(torch.float32) / float(n_shots)).to(e.device)
-        out = torch.zeros(n_states, dtype=e.dtype, device=e.device)
-        return out.index_add(0, (uniq >> n).to(e.device), e * w).unsqueeze(1)
+        out = torch.zeros(n_rows, dtype=e.dtype, device=e.device)
+        return out.index_add(0, (keys >> n).to(e.device), e * weights.to(e.device, e.dtype)).unsqueeze(1)
 
-      def estimator(shift_gate, shift):
+      def mean_energy(shift_gates, shifts):
+        """[Q, U, 1] shot average of energy(x) under each of the Q shifted programs."""
+        n_prog, n_states = len(shift_gates), bits.shape[0]
+        if n <= self.MAX_COUNT_QUBITS:
+          freq = self._counts(eng, bits, values, shift_gates, shifts).reshape(n_prog * n_states, 1 << n)
+          nz = torch.nonzero(freq)                                      # the outcomes that occurred
+          keys = (nz[:, 0] << n) | nz[:, 1]
+          return weighted_energy(keys, freq[nz[:, 0], nz[:, 1]], n_prog * n_states).reshape(n_prog, n_states, 1)
+        outs = []
+        for g, sh in zip(shift_gates, shifts):
+          samples = eng.sample(bits, values, self._expectation_samples, self._next_seed(), g, sh)
+          place = (1 << torch.arange(n - 1, -1, -1, device=samples.device, dtype=torch.int64))
+          key = (samples.to(torch.int64) * place).sum(-1) + (
+              torch.arange(n_states, device=samples.device, dtype=torch.int64).unsqueeze(1) << n)
+          uniq, counts = torch.unique(key, return_counts=True)
+          outs.append(weighted_energy(uniq, counts.to(torch.float32) / float(samples.shape[1]), n_states))
+        return torch.stack(outs)
+
+      def estimator(shift_gates, shifts):
         with torch.no_grad():
-          return mean_energy(shots(shift_gate, shift)).to(torch.float32)
+          return mean_energy(list(shift_gates), list(shifts)).to(torch.float32)
 
-      forward_pass = mean_energy(shots())  # differentiable w.r.t. the energy's variables
+      forward_pass = mean_energy([-1], [0.0])[0]  # differentiable w.r.t. the energy's variables
       surrogate = _ParameterShiftSurrogate.apply(symbol_values, estimator, base, tuple(forward_pass.shape))
       return forward_pass + surrogate.to(forward_pass.device)
 
@@ -423,7 +471,7 @@ class SampledQuantumInference(QuantumInference):
       mix[k, t] = c
     estimator, base = self._pauli_estimator(total_circuit, bits, values, strings)
     with torch.no_grad():
-      estimates = estimator()
+      estimates = estimator()[0]
     surrogate = _ParameterShiftSurrogate.apply(symbol_values, estimator, base, tuple(estimates.shape))
     return post_process(torch.matmul(estimates + surrogate.to(estimates.device), mix.to(estimates.device)))
 

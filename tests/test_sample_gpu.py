@@ -97,3 +97,56 @@ def test_shifted_program():
   assert abs(got - p1) <= 5 * np.sqrt(p1 * (1 - p1) / shots) + 1e-4
   with pytest.raises(E.EngineError, match="shift_gate"):
     eng.sample(bits, params, 4, shift_gate=len(gates))
+
+
+@pytest.mark.parametrize("n,tile,shots", [(3, 0, 400000), (10, 0, 200000), (12, 10, 60000)])
+def test_sample_counts_of_shifted_programs_match_the_born_rule(n, tile, shots):
+  """qhbm_sample_counts: per-outcome shot counts of several shifted programs in ONE launch set (the
+  2 G programs of tfq's ParameterShift on sampled estimates, qnn.py:188-226).  n <= 10 takes the
+  thread-per-shot kernel, n = 12 the wave-per-shot one with global counters.  Every count is checked
+  against the oracle's probabilities of the program it belongs to (5 sigma), rows add up to the shot
+  count, and a call is reproducible and independent of how the batch is cut."""
+  rng = np.random.default_rng(300 + n)
+  gates, names = O.hea_gates(n, 2, "c")
+  params = rng.uniform(-1, 1, len(names))
+  bits = rng.integers(0, 2, size=(3, n)).astype(np.int8)
+  opts = {"tile_qubits": tile} if tile else {}
+  eng = _engine(n, gates, len(names), **opts)
+  programs = [(-1, 0.0), (0, 0.5), (0, -0.5), (len(gates) - 1, 0.5), (3, -0.5)]
+  sg, sv = [g for g, _ in programs], [s for _, s in programs]
+  counts = eng.sample_counts(bits, params, shots, seed=77, shift_gates=sg, shifts=sv)
+  assert counts.shape == (5, 3, 2**n) and counts.dtype == torch.int32
+  counts = counts.cpu().numpy()
+  assert (counts.sum(-1) == shots).all() and (counts >= 0).all()
+  for q, (g, sh) in enumerate(programs):
+    shifted = list(gates)
+    if g >= 0:
+      k, q0, q1, p, s, o = shifted[g]
+      shifted[g] = (k, q0, q1, p, s, o + sh)
+    for u in range(3):
+      probs = np.abs(O.simulate(n, shifted, params, list(bits[u])).ravel())**2
+      assert counts[q, u][probs < 1e-12].sum() == 0
+      top = np.argsort(probs)[-12:]
+      err = np.abs(counts[q, u][top] / shots - probs[top])
+      assert (err <= 5 * np.sqrt(probs[top] * (1 - probs[top]) / shots) + 1e-5).all(), (q, u, err.max())
+      coarse = 8 if n >= 3 else 2**n
+      tv = np.abs(probs.reshape(coarse, -1).sum(1) - counts[q, u].reshape(coarse, -1).sum(1) / shots).sum()
+      assert tv < 0.02, (q, u, tv)
+  # the shifted programs really differ from the unshifted one
+  assert np.abs(counts[1, 0] - counts[0, 0]).sum() > 0.02 * shots
+  # reproducible; independent of the batch composition and of the launch-set geometry
+  again = eng.sample_counts(bits, params, shots, seed=77, shift_gates=sg, shifts=sv).cpu().numpy()
+  np.testing.assert_array_equal(again, counts)
+  other = eng.sample_counts(bits, params, shots, seed=78, shift_gates=sg, shifts=sv).cpu().numpy()
+  assert (other != counts).any()
+  # shots are keyed by (seed, program position, state row, shot): the first state alone gives the same counts
+  one = eng.sample_counts(bits[:1], params, shots, seed=77, shift_gates=sg[:2], shifts=sv[:2]).cpu().numpy()
+  np.testing.assert_array_equal(one[:, 0], counts[:2, 0])
+  cut = _engine(n, gates, len(names), chunk_states=2, **opts)
+  np.testing.assert_array_equal(cut.sample_counts(bits, params, shots, seed=77, shift_gates=sg, shifts=sv).cpu().numpy(),
+                                counts)
+  # degenerate calls
+  assert eng.sample_counts(bits[:0], params, 10, shift_gates=sg, shifts=sv).shape == (5, 0, 2**n)
+  assert int(eng.sample_counts(bits, params, 0, shift_gates=[-1], shifts=[0.0]).sum()) == 0
+  with pytest.raises(E.EngineError, match="out of range"):
+    eng.sample_counts(bits, params, 4, shift_gates=[len(gates)], shifts=[0.5])
