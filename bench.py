@@ -269,7 +269,12 @@ def main():
   if world > 1:
     import torch.distributed as dist  # pylint: disable=import-outside-toplevel
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend, rank=rank, world_size=world)
+    if backend == "nccl":
+      # bind the communicator to this rank's GPU up front (eager RCCL init on the right device, no guessing
+      # from the first collective's tensors)
+      dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+      dist.init_process_group(backend, rank=rank, world_size=world)
 
   from qhbmlib_amd import _engine as E  # pylint: disable=import-outside-toplevel
   from qhbmlib_amd import parallel  # pylint: disable=import-outside-toplevel
