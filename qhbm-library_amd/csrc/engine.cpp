@@ -77,6 +77,7 @@ struct qhbm_engine {
   int opt_values_from_obs = 1;  // single observable: <psi|O|psi> from lambda = O psi, no measurement in the forward sweep
   bool retained_mu = false;     // the retained batch also holds the unweighted lambda = O psi
   int opt_cph_wave_bits = 1; // boundary controlled-phase predicates on wave bits (schedule.h Plan::cph_wave_bits)
+  int opt_adj_relabel = 1;     // adjoint plans move finished index bits out of the 128-byte lines (schedule.h Pass)
   int opt_obs_xcd_states = 1;  // lambda = O psi: one state per XCD at a time (kernels.hip apply_observable_kernel)
   int opt_adj_exchange = 1;  // lean adjoint passes: register-resident tile pair + one LDS exchange buffer
   int retained_U = 0;  // final states of the last qhbm_expectation_retain still sit in psi
@@ -165,19 +166,38 @@ void fill_args(const Plan& plan, const Model& m, std::vector<PassArgs>* args, st
     a.prog_off = uint32_t(prog->size());
     a.spread_off = uint32_t(tables->size());
     a.spread_shift = 0;  // K == c: the only entry is 0
-    for (size_t i = size_t(p.c); i < p.local_pos.size(); ++i) {
-      if (i == size_t(p.c)) a.spread_shift = uint32_t(p.local_pos[i]);
-      else if (p.local_pos[i] != p.local_pos[i - 1] + 1) { a.spread_shift = 0xffffffffu; break; }
+    for (size_t i = size_t(p.c); i < p.local_phys.size(); ++i) {
+      if (i == size_t(p.c)) a.spread_shift = uint32_t(p.local_phys[i]);
+      else if (p.local_phys[i] != p.local_phys[i - 1] + 1) { a.spread_shift = 0xffffffffu; break; }
     }
     a.n_ops = uint32_t(m.n_ops);
     a.slot_base = uint32_t(p.slot_base);
     a.n_slots = uint32_t(p.n_slots);
-    for (size_t i = 0; i < p.nonlocal_pos.size(); ++i) a.nonlocal_pos[i] = uint8_t(p.nonlocal_pos[i]);
-    for (size_t i = 0; i < p.local_pos.size(); ++i) a.local_pos[i] = uint8_t(p.local_pos[i]);
+    for (size_t i = 0; i < p.nonlocal_phys.size(); ++i) a.nonlocal_pos[i] = uint8_t(p.nonlocal_phys[i]);
+    for (size_t i = 0; i < p.local_phys.size(); ++i) a.local_pos[i] = uint8_t(p.local_phys[i]);
+    for (size_t bit = 0; bit < 32; ++bit) a.phys_of[bit] = uint8_t(bit < p.phys_of.size() ? p.phys_of[bit] : int(bit));
+    a.frozen_old_local = p.frozen_old_local;
     prog->insert(prog->end(), p.prog.begin(), p.prog.end());
     tables->insert(tables->end(), p.spread.begin(), p.spread.end());
     a.tl_off = uint32_t(tables->size());
     tables->insert(tables->end(), p.round_tl.begin(), p.round_tl.end());
+    if (p.flags & PASS_RELABEL) {
+      a.frozen_new_local = p.frozen_new_local;
+      while (tables->size() % 4) tables->push_back(0u);  // the store reads (l0, off0, l1, off1) as one 16-byte word
+      a.relabel_off = uint32_t(tables->size());
+      tables->insert(tables->end(), p.relabel_tab.begin(), p.relabel_tab.end());
+      // consecutive live out-indices are adjacent amplitudes iff the lowest position the tile owns is address bit 0
+      a.relabel_pairs = (p.local_phys[0] == 0 && !(p.frozen_new_local == ((1u << p.K) - 1u))) ? 1u : 0u;
+      uint32_t n_live = 0;
+      for (int i = 0; i < p.K; ++i) n_live += !(p.frozen_new_local >> i & 1u);
+      if (n_live < 1) a.relabel_pairs = 0;
+      for (int i = 0; i < p.K; ++i)
+        if (p.frozen_new_local >> i & 1u) {
+          a.fz_local_bit[a.n_fz] = uint8_t(i);
+          a.fz_out_pos[a.n_fz] = uint8_t(p.store_local_phys[size_t(i)]);
+          ++a.n_fz;
+        }
+    }
     args->push_back(a);
   }
   if (!plan.adjoint) {
@@ -186,7 +206,7 @@ void fill_args(const Plan& plan, const Model& m, std::vector<PassArgs>* args, st
     // differs from the input on such a bit among its NON-LOCAL bits is identically zero, stays zero
     // under the pass, and already reads as zeros in HBM (the first pass wrote them): the kernel
     // returns at once.  Config 3: half the tiles of the second (and heaviest) forward pass.
-    uint32_t touched = 0;
+    uint32_t touched = 0;  // (forward plans never relabel: logical = physical positions)
     for (size_t i = 0; i < args->size(); ++i) {
       uint32_t nl = 0;
       for (uint32_t k = 0; k < (*args)[i].n_nonlocal; ++k) nl |= 1u << (*args)[i].nonlocal_pos[k];
@@ -204,12 +224,15 @@ void fill_args(const Plan& plan, const Model& m, std::vector<PassArgs>* args, st
     // "Acted on" means by a non-diagonal op of pass p or later; a bit that is local in a later pass
     // without a gate there (the low bits every tile holds, padding) is as good: the tiles skipped now
     // are read again then, but hold zeros of psi (to rounding) next to a stale lambda.
-    uint32_t later_mat = 0;
+    uint32_t later_mat = 0;  // logical bits
     for (size_t i = args->size(); i-- > 0;) {
       uint32_t nl = 0;
       for (uint32_t k = 0; k < (*args)[i].n_nonlocal; ++k) nl |= 1u << (*args)[i].nonlocal_pos[k];
       later_mat |= plan.passes[i].mat_bits;
-      (*args)[i].zero_mask = nl & ~later_mat;
+      uint32_t later_phys = 0;  // ... at the positions they have when pass i loads its tiles
+      for (size_t bit = 0; bit < plan.passes[i].phys_of.size(); ++bit)
+        if (later_mat >> bit & 1u) later_phys |= 1u << plan.passes[i].phys_of[bit];
+      (*args)[i].zero_mask = nl & ~later_phys;
     }
   }
 }
@@ -223,7 +246,8 @@ int build_plans(qhbm_engine* h) {
   if (!build_plan(h->model, h->opt_tile, h->opt_round, false, &h->fwd.plan, &err, h->opt_full_fwd, h->opt_meas_tile,
                   h->opt_cph_wave_bits != 0))
     return fail(h, "forward plan: " + err);
-  if (!build_plan(h->model, h->opt_adj_tile, 0, true, &h->adj.plan, &err, h->opt_full_adj, 0, h->opt_cph_wave_bits != 0))
+  if (!build_plan(h->model, h->opt_adj_tile, 0, true, &h->adj.plan, &err, h->opt_full_adj, 0, h->opt_cph_wave_bits != 0,
+                  h->opt_adj_relabel != 0 && h->opt_adj_exchange != 0))
     return fail(h, "adjoint plan: " + err);
   h->fwd.uploaded = h->adj.uploaded = false;
   h->model_uploaded = false;
@@ -643,7 +667,8 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "full_diag_threshold") { h->opt_full_fwd = int(value); h->plans_valid = false; }
   else if (k == "adjoint_full_diag_threshold") { h->opt_full_adj = int(value); h->plans_valid = false; }
   else if (k == "adjoint_tile_qubits") { h->opt_adj_tile = int(value); h->plans_valid = false; }
-  else if (k == "adjoint_exchange") h->opt_adj_exchange = int(value);
+  else if (k == "adjoint_exchange") { h->opt_adj_exchange = int(value); h->plans_valid = false; }
+  else if (k == "adjoint_relabel") { h->opt_adj_relabel = int(value); h->plans_valid = false; }
   else if (k == "observable_xcd_states") h->opt_obs_xcd_states = int(value);
   else if (k == "measure_tile_qubits") { h->opt_meas_tile = int(value); h->plans_valid = false; }
   else if (k == "values_from_observable") h->opt_values_from_obs = int(value);
@@ -1237,7 +1262,10 @@ int qhbm_traffic_model(qhbm_engine* h, int U, int with_vjp, double* fwd_bytes, d
         for (uint32_t k = 0; k < args[i].n_nonlocal; ++k) low_missing += args[i].nonlocal_pos[k] < 4;
         live = std::min(1.0, live * double(1u << low_missing));
       }
-      b += live * tile_all * 2.0 * ((h->adj.plan.passes[i].flags & PASS_STORE) ? 2.0 : 1.0);
+      const Pass& ap = h->adj.plan.passes[i];
+      double write_share = 1.0;  // a relabeling store writes only the amplitudes whose finished bits equal the input
+      if (ap.flags & PASS_RELABEL) write_share = 1.0 / double(1u << __builtin_popcount(ap.frozen_new_local));
+      b += live * tile_all * 2.0 * (1.0 + ((ap.flags & PASS_STORE) ? write_share : 0.0));
     }
   }
   if (fwd_bytes) *fwd_bytes = f;

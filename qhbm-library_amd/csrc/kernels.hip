@@ -1046,6 +1046,54 @@ __device__ __forceinline__ void flush_cells(const float* cells, float* __restric
   }
 }
 
+// ---- relabeling adjoint plans (schedule.h Pass, program.h PassArgs) ------------------------------------
+// The input bitstring as an index in the layout this pass loads.
+__device__ __forceinline__ uint32_t physical_index(const PassArgs& a, uint32_t idx) {
+  uint32_t out = 0;
+  for (uint32_t bit = 0; bit < a.n; ++bit) out |= ((idx >> bit) & 1u) << a.phys_of[bit];
+  return out;
+}
+// Index bits finished by EARLIER passes that this tile holds as local bits: where they differ from the
+// input the memory holds stale data (the finishing pass stored the live half only) -- psi is zero there
+// and lambda there is never needed again, so the prefetched amplitudes are cleared.
+template <int K>
+__device__ __forceinline__ void clear_stale(TileRegs& r, int tid, uint32_t in_local, uint32_t fz) {
+#define QHBM_CL(I)                                                                   \
+  {                                                                                  \
+    const uint32_t l = 2u * uint32_t(tid) + (uint32_t(I) << (K - 3));                \
+    if ((l ^ in_local) & fz) { r.p##I.x = 0.f; r.p##I.y = 0.f; }                     \
+    if (((l | 1u) ^ in_local) & fz) { r.p##I.z = 0.f; r.p##I.w = 0.f; }              \
+  }
+  QHBM_CL(0) QHBM_CL(1) QHBM_CL(2) QHBM_CL(3) QHBM_CL(4) QHBM_CL(5) QHBM_CL(6) QHBM_CL(7)
+#undef QHBM_CL
+}
+// The relabeling store: only the amplitudes whose newly finished bits equal the input bitstring, in
+// the order of their NEW addresses (finished bits moved to the highest positions the tile owns):
+// whole 128-byte lines of live data, nothing written for the dead half.
+template <int K, int NT>
+__device__ __forceinline__ void store_tile_relabeled(const float2* __restrict__ tile, float2* __restrict__ st,
+                                                     const PassArgs& a, const uint32_t* __restrict__ tables,
+                                                     uint32_t tile_base, uint32_t in_local, int tid) {
+  const uint32_t* tab = tables + a.relabel_off;
+  const uint32_t fz_local = in_local & a.frozen_new_local;  // the finished bits of the live amplitudes, local index space
+  uint32_t fz_addr = 0;                                     // ... and where they go in the address
+  for (uint32_t k = 0; k < a.n_fz; ++k) fz_addr |= ((in_local >> a.fz_local_bit[k]) & 1u) << a.fz_out_pos[k];
+  float2* sb = st + (tile_base | fz_addr);
+  const uint32_t n_live = uint32_t(K) - a.n_fz;
+  if (a.relabel_pairs) {
+    for (uint32_t j = uint32_t(tid); j < (1u << (n_live - 1u)); j += uint32_t(NT)) {
+      const uint4 e = *reinterpret_cast<const uint4*>(tab + 4u * j);  // (l0, off0, l1, off1): off1 = off0 + 1
+      const float2 v0 = tile[swz(e.x | fz_local)], v1 = tile[swz(e.z | fz_local)];
+      *reinterpret_cast<float4*>(sb + e.y) = make_float4(v0.x, v0.y, v1.x, v1.y);
+    }
+  } else {
+    for (uint32_t o = uint32_t(tid); o < (1u << n_live); o += uint32_t(NT)) {
+      const uint2 e = *reinterpret_cast<const uint2*>(tab + 2u * o);
+      sb[e.y] = tile[swz(e.x | fz_local)];
+    }
+  }
+}
+
 // ---- exchange layout (default for passes without Y / dense gates) ---------------------------------
 // The (psi, lambda) tile pair lives in REGISTERS for the whole pass; LDS holds one tile-sized
 // exchange buffer through which psi, then lambda, change geometry between rounds.  Half the LDS
@@ -1077,7 +1125,8 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   const uint32_t* prog = prog_base + a.prog_off;
   uint32_t w0 = uni(prog[0]);
   bool skip = (w0 & 0xffu) != OP_ROUND;  // (an empty program: nothing to un-apply)
-  const uint32_t idx = uni(basis_index(bits + size_t(state0 + s_local) * n_user, n_user));
+  // (the input bitstring in the layout this pass loads: relabeling plans move finished bits)
+  const uint32_t idx = uni(physical_index(a, basis_index(bits + size_t(state0 + s_local) * n_user, n_user)));
   // tail of the sweep: psi is identically zero on this tile (engine.cpp fill_args)
   if (a.zero_mask) skip |= ((idx ^ t.tile_base) & a.zero_mask) != 0;
   uint32_t in_local = 0;  // the input bitstring on the tile's local bits (OP_ROUND word 4: dead waves)
@@ -1091,6 +1140,10 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   TileRegs rp, rl;
   prefetch_tile<K, NT, true>(rp, sp, t, tid);
   prefetch_tile<K, NT, true>(rl, sl, t, tid);
+  if (a.frozen_old_local) {
+    clear_stale<K>(rp, tid, in_local, a.frozen_old_local);
+    clear_stale<K>(rl, tid, in_local, a.frozen_old_local);
+  }
   for (uint32_t i = tid; i < a.n_slots * NW; i += NT) cells[i] = 0.f;
 
   constexpr RecordLayout L(R, true);
@@ -1157,7 +1210,15 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
     TL = TLn;
     w0 = w1;
   }
-  if (a.flags & PASS_STORE) {
+  if (a.flags & PASS_RELABEL) {
+    round_store<R>(xt, T, DB, p);
+    __syncthreads();
+    store_tile_relabeled<K, NT>(xt, sp, a, tables, t.tile_base, in_local, tid);
+    __syncthreads();
+    round_store<R>(xt, T, DB, l);
+    __syncthreads();
+    store_tile_relabeled<K, NT>(xt, sl, a, tables, t.tile_base, in_local, tid);
+  } else if (a.flags & PASS_STORE) {
     round_store<R>(xt, T, DB, p);
     __syncthreads();
     store_tile<K, NT, true>(xt, sp, t, tid);

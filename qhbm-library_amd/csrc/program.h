@@ -47,6 +47,7 @@ enum : uint32_t {
   PASS_ADJOINT = 1u << 2,     // tile pair (psi, lambda), program is a backward program
   PASS_GENERAL = 1u << 3,     // the program uses Y / dense 2x2 / dense two-qubit ops (rare-path kernel variant)
   PASS_SKIP_MEASURE = 1u << 4,  // forward: ignore the measurement groups (the values come from lambda = O psi)
+  PASS_RELABEL = 1u << 5,       // adjoint: the store moves the index bits this pass finished (PassArgs::relabel_*)
 };
 
 // ---- opcodes (low 8 bits of an instruction's first word) --------------------
@@ -158,8 +159,21 @@ struct PassArgs {
   // coef + (e / prog_states) * coef_stride and writes output row e.  0 = one program, rows by state.
   uint32_t prog_states;
   uint32_t coef_stride;    // floats between the coefficient buffers of consecutive programs
-  uint8_t nonlocal_pos[32];  // ascending bit positions of the nonlocal index bits
-  uint8_t local_pos[16];     // ascending bit positions of the K local index bits
+  uint8_t nonlocal_pos[32];  // ascending PHYSICAL bit positions of the nonlocal index bits
+  uint8_t local_pos[16];     // ascending PHYSICAL bit positions of the K local index bits
+  // Adjoint plans that relabel (schedule.h Pass): where logical index bit b (bit n-1-q <-> qubit q, the bit
+  // of the input bitstring) sits in the addresses this pass loads; identity otherwise.
+  uint8_t phys_of[32];
+  uint32_t frozen_old_local;  // local index bits finished by earlier passes: their != input half holds stale data, zeroed at load
+  // PASS_RELABEL: the store writes only the amplitudes whose bits `frozen_new_local` equal the input
+  // bitstring, live out-local index o -> tables[relabel_off + 2 o] = local index (those bits clear),
+  // [.. + 1] = offset in the state; the finished bits land on `fz_out_pos` carrying the input bit.
+  uint32_t frozen_new_local;
+  uint32_t relabel_off;
+  uint32_t relabel_pairs;     // 1: consecutive o are adjacent in HBM (16-byte stores), 0: 8-byte stores
+  uint32_t n_fz;
+  uint8_t fz_local_bit[16];
+  uint8_t fz_out_pos[16];
 };
 
 }  // namespace qhbm

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -137,20 +138,29 @@ class Builder {
   Builder(const Model& m, int K, int R, int n_eff, bool adjoint, Plan* plan)
       : m_(m), K_(K), R_(R), n_eff_(n_eff), adjoint_(adjoint), plan_(plan) {}
 
-  Pass begin_pass(uint32_t S) {
+  // `phys[b]`: physical position of logical index bit b in the layout the pass loads (null: identity).
+  Pass begin_pass(uint32_t S, const std::vector<int>* phys = nullptr) {
     Pass p;
     p.K = K_;
     p.R = R_;
+    std::vector<std::pair<int, int>> loc, non;  // (physical position, logical bit)
+    p.phys_of.resize(size_t(n_eff_));
     for (int b = 0; b < n_eff_; ++b) {
-      if (S >> b & 1) p.local_pos.push_back(b); else p.nonlocal_pos.push_back(b);
+      const int ph = phys ? (*phys)[size_t(b)] : b;
+      p.phys_of[size_t(b)] = ph;
+      (S >> b & 1 ? loc : non).push_back({ph, b});
     }
+    std::sort(loc.begin(), loc.end());
+    std::sort(non.begin(), non.end());
+    for (const auto& e : loc) { p.local_phys.push_back(e.first); p.local_pos.push_back(e.second); }
+    for (const auto& e : non) { p.nonlocal_phys.push_back(e.first); p.nonlocal_pos.push_back(e.second); }
     int c = 0;
-    while (c < K_ && p.local_pos[c] == c) ++c;
+    while (c < K_ && p.local_phys[size_t(c)] == c) ++c;
     p.c = c;
     p.spread.resize(size_t(1) << (K_ - c));
     for (uint32_t j = 0; j < p.spread.size(); ++j) {
       uint32_t v = 0;
-      for (int i = c; i < K_; ++i) if (j >> (i - c) & 1) v |= 1u << p.local_pos[i];
+      for (int i = c; i < K_; ++i) if (j >> (i - c) & 1) v |= 1u << p.local_phys[size_t(i)];
       p.spread[j] = v;
     }
     return p;
@@ -344,7 +354,7 @@ class Builder {
         int j2 = -1;
         if (popc(in_reg) == 2) { pl.kind = 4; j2 = rank_of(in_reg & (in_reg - 1)); }
         else if (other_local) { pl.kind = 5; pl.pred = uint32_t(__builtin_ctz(other_local)); }
-        else if (other_nonlocal) { pl.kind = 5; pl.pred = uint32_t(__builtin_ctz(other_nonlocal)) | (1u << 8); }
+        else if (other_nonlocal) { pl.kind = 5; pl.pred = uint32_t(p->phys_of[size_t(__builtin_ctz(other_nonlocal))]) | (1u << 8); }
         else pl.kind = 3;
         const uint32_t touch = (1u << j) | (j2 >= 0 ? (1u << j2) : 0u);
         auto fits = [&](const Instance& in) {
@@ -517,7 +527,7 @@ class Builder {
 }  // namespace
 
 bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Plan* plan, std::string* err,
-                int full_threshold, int meas_tile_bits, bool cph_wave_bits) {
+                int full_threshold, int meas_tile_bits, bool cph_wave_bits, bool relabel) {
   *plan = Plan();
   plan->full_threshold = full_threshold;
   plan->cph_wave_bits = cph_wave_bits;
@@ -557,6 +567,37 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   const uint32_t all_bits = (1u << n_eff) - 1;
   const int c_min = std::min(K, 4);
   Builder b(m, K, R, n_eff, adjoint, plan);
+  // Relabeling adjoint plans (schedule.h Pass): the physical position of every logical index bit, and the
+  // bits already finished and moved.  A finished bit is moved by the pass that finishes it, within the
+  // positions that pass's tile owns (in place: a workgroup still writes only where it read).
+  plan->relabel = relabel && adjoint && K < n_eff && plan->tail_tiles;
+  uint32_t ever_mat = 0;  // bits some non-diagonal op acts on (the others are idle: exact zeros of psi off the input bit)
+  for (const LoweredOp& op : ops) if (op.type != LOW_DIAG) ever_mat |= op.bits;
+  std::vector<int> phys;
+  for (int i = 0; i < n_eff; ++i) phys.push_back(i);
+  uint32_t frozen = 0;
+  auto pending_mat_of = [&](const std::vector<char>& dn) {
+    uint32_t pend = 0;
+    for (size_t oi = 0; oi < ops.size(); ++oi) if (!dn[oi] && ops[oi].type != LOW_DIAG) pend |= ops[oi].bits;
+    return pend;
+  };
+  // The layout after a pass with local set S has run to the state `dn_after`: the bits of S that have no
+  // non-diagonal op left (and are not moved yet) go to the highest positions the tile owns, the tile's other
+  // bits close up below them in their old order.  Returns the newly moved bits.
+  auto relabel_after = [&](uint32_t S, const std::vector<char>& dn_after, std::vector<int>* ph, uint32_t* frz) {
+    const uint32_t f_new = S & all_bits & ~pending_mat_of(dn_after) & ~*frz & ever_mat;
+    if (!f_new) return 0u;
+    std::vector<std::pair<int, int>> tile;  // (physical position, logical bit)
+    for (int bb = 0; bb < n_eff; ++bb) if (S >> bb & 1u) tile.push_back({(*ph)[size_t(bb)], bb});
+    std::sort(tile.begin(), tile.end());
+    std::vector<int> pos;
+    for (const auto& e : tile) pos.push_back(e.first);
+    size_t next = 0;
+    for (const auto& e : tile) if (!(f_new >> e.second & 1u)) (*ph)[size_t(e.second)] = pos[next++];
+    for (const auto& e : tile) if (f_new >> e.second & 1u) (*ph)[size_t(e.second)] = pos[next++];
+    *frz |= f_new;
+    return f_new;
+  };
   std::vector<char> done(ops.size(), 0);
   std::vector<int> op_pass(ops.size(), 0);  // pass that executes each lowered op
   size_t n_done = 0;
@@ -592,12 +633,60 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     return S;
   };
 
-  // Candidate local sets of the next pass, given the ops already done.
-  auto gen_cands = [&](const std::vector<char>& dn) {
+  // Candidate local sets of the next pass, given the ops already done (and, in relabeling plans, the
+  // physical layout `ph`: the tiles are built from the LIVE bits -- those with a non-diagonal op left --
+  // in the order of their physical positions, the four lowest of which are in every tile).
+  auto gen_cands = [&](const std::vector<char>& dn, const std::vector<int>& ph) {
     // ---- candidate local sets -------------------------------------------------
     std::vector<uint32_t> cands;
     if (K >= n_eff) {
       cands.push_back(all_bits);
+    } else if (plan->relabel) {
+      const uint32_t pending_mat = pending_mat_of(dn);
+      std::vector<int> live, rest;  // by physical position
+      {
+        std::vector<std::pair<int, int>> a, r;
+        for (int bit = 0; bit < n_eff; ++bit) (pending_mat >> bit & 1u ? a : r).push_back({ph[size_t(bit)], bit});
+        std::sort(a.begin(), a.end());
+        std::sort(r.begin(), r.end());
+        for (const auto& e : a) live.push_back(e.second);
+        for (const auto& e : r) rest.push_back(e.second);
+      }
+      auto fill = [&](uint32_t S) {  // live bits first (highest position first, as the plain plans fill), then the others
+        for (size_t i = live.size(); i-- > 0 && popc(S) < K;) S |= 1u << live[i];
+        for (size_t i = 0; i < rest.size() && popc(S) < K; ++i) S |= 1u << rest[i];
+        return S;
+      };
+      uint32_t low = 0;
+      for (size_t i = 0; i < live.size() && int(i) < c_min; ++i) low |= 1u << live[i];
+      if (int(live.size()) <= K) {
+        cands.push_back(fill(0u));
+      } else {
+        const size_t h = size_t(K - c_min);
+        for (size_t p0 = size_t(c_min); p0 + h <= live.size(); ++p0) {
+          uint32_t S = low;
+          for (size_t k = 0; k < h; ++k) S |= 1u << live[p0 + k];
+          cands.push_back(S);
+        }
+      }
+      // demand-driven: bits of the earliest ready ops (non-diagonal first); a diagonal op asks for its live
+      // bits, or for one bit if none of them is live any more
+      for (int with_diag = 0; with_diag < 2; ++with_diag) {
+        uint32_t S = low, blocked = 0;
+        for (int oi : order) {
+          if (dn[oi]) continue;
+          const LoweredOp& op = ops[oi];
+          if (op.bits & blocked) { blocked |= op.bits; continue; }
+          if (op.type == LOW_DIAG && !with_diag) continue;
+          uint32_t need = op.bits;
+          if (op.type == LOW_DIAG) {
+            if (op.bits & S) continue;
+            need = op.bits & pending_mat ? (op.bits & pending_mat) & (0u - (op.bits & pending_mat)) : op.bits & (0u - op.bits);
+          }
+          if (popc(S | need) <= K) S |= need; else blocked |= op.bits;
+        }
+        cands.push_back(fill(S));
+      }
     } else {
       const uint32_t low = (1u << c_min) - 1;
       const int h = K - c_min;
@@ -663,8 +752,10 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   // passes carry 184 gates instead of 220).
   std::vector<uint32_t> planned;  // local sets of the passes, in order (empty: greedy)
   if (adjoint && K < n_eff && plan->tail_tiles) {
-    struct Node { std::vector<char> dn; size_t n_done; double cost; std::vector<uint32_t> sets; };
-    const double kFixed = 6.0, kMemory = 17.0;  // per pass, in units of one unpruned gate (config 3: 24.6 ms of tile I/O against 1.4 ms per gate; the fixed part 3, 5 and 7 measured alike, 10 and 16 worse)
+    struct Node { std::vector<char> dn; size_t n_done; double cost; std::vector<uint32_t> sets; std::vector<int> phys; uint32_t frozen; };
+    double kFixed = 6.0, kMemory = 17.0;
+    if (const char* e = std::getenv("QHBM_PLAN_KFIXED")) kFixed = std::atof(e);    // developer knobs (scripts/plan_constants_probe.sh)
+    if (const char* e = std::getenv("QHBM_PLAN_KMEMORY")) kMemory = std::atof(e);  // per pass, in units of one unpruned gate (config 3: 24.6 ms of tile I/O against 1.4 ms per gate; the fixed part 3, 5 and 7 measured alike, 10 and 16 worse)
     const size_t kBeam = ops.size() <= 4000 ? 16 : (ops.size() <= 12000 ? 8 : 4);  // planning time stays ~ a second
     auto finished_bits = [&](const std::vector<char>& dn) {
       uint32_t pend = 0;
@@ -675,12 +766,14 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     beam[0].dn = done;
     beam[0].n_done = n_done;
     beam[0].cost = 0.0;
+    beam[0].phys = phys;
+    beam[0].frozen = frozen;
     double best_cost = -1.0;
     for (int depth = 0; depth < 256 && !beam.empty(); ++depth) {
       std::vector<Node> next;
       for (const Node& nd : beam) {
         const uint32_t fin = finished_bits(nd.dn);
-        std::vector<uint32_t> cs = gen_cands(nd.dn);
+        std::vector<uint32_t> cs = gen_cands(nd.dn, nd.phys);
         std::sort(cs.begin(), cs.end());
         cs.erase(std::unique(cs.begin(), cs.end()), cs.end());
         for (uint32_t S : cs) {
@@ -694,12 +787,24 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
           // (fixed + gates) on the tiles that are not pruned, but never less than the HBM time of the
           // 128-byte lines those tiles touch: a tile without k of the four low index bits uses 2^-k of a line
           const double alive = 1.0 / double(1u << std::min(20, popc(fin & ~S)));
-          const double lines = std::min(1.0, alive * double(1u << popc(((1u << c_min) - 1u) & ~S)));
+          // (relabeling plans keep finished bits out of the lines: the live tiles are made of whole lines)
+          const double lines = plan->relabel ? alive : std::min(1.0, alive * double(1u << popc(((1u << c_min) - 1u) & ~S)));
           c.cost = nd.cost + std::max(kMemory * lines, alive * (kFixed + double(n_mat)));
           c.sets = nd.sets;
           c.sets.push_back(S);
+          c.phys = nd.phys;
+          c.frozen = nd.frozen;
+          if (plan->relabel && c.n_done < ops.size()) relabel_after(S, c.dn, &c.phys, &c.frozen);
           if (c.n_done == ops.size()) {
-            if (best_cost < 0.0 || c.cost < best_cost) { best_cost = c.cost; planned = c.sets; }
+            if (best_cost < 0.0 || c.cost < best_cost) {
+              best_cost = c.cost;
+              planned = c.sets;
+              if (std::getenv("QHBM_PLAN_DEBUG")) {
+                std::fprintf(stderr, "[plan] complete at depth %d cost %.2f:", depth, c.cost);
+                for (uint32_t st : c.sets) std::fprintf(stderr, " %x", st);
+                std::fprintf(stderr, "\n");
+              }
+            }
             continue;
           }
           bool dup = false;
@@ -715,6 +820,12 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
         return nd.cost + double(mats_left) / double(1 << nfin);
       };
       std::sort(next.begin(), next.end(), [&](const Node& x, const Node& y) { return rank(x) < rank(y); });
+      if (std::getenv("QHBM_PLAN_DEBUG"))
+        for (size_t i = 0; i < next.size() && i < 20; ++i) {
+          std::fprintf(stderr, "[plan] depth %d #%zu cost %.2f rank %.2f done %zu frozen %x:", depth, i, next[i].cost, rank(next[i]), next[i].n_done, next[i].frozen);
+          for (uint32_t st : next[i].sets) std::fprintf(stderr, " %x", st);
+          std::fprintf(stderr, "\n");
+        }
       if (next.size() > kBeam) next.resize(kBeam);
       if (best_cost >= 0.0) {  // drop what cannot beat the best complete sequence
         next.erase(std::remove_if(next.begin(), next.end(), [&](const Node& nd) { return nd.cost >= best_cost; }), next.end());
@@ -727,27 +838,45 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     // clearly MORE passes than the greedy one (deep circuits on many qubits, where no bit finishes
     // early anyway: config 5, 24 against 21) measured slower, so the greedy order stands there.
     std::vector<char> dn(done);
+    std::vector<int> gphys(phys);
+    uint32_t gfrozen = frozen;
     size_t left = ops.size() - n_done, greedy_passes = 0;
     while (left) {
       int best_mat = -1;
       size_t best_total = 0;
+      uint32_t best_set = 0;
       std::vector<int> best;
-      for (uint32_t S : gen_cands(dn)) {
+      for (uint32_t S : gen_cands(dn, gphys)) {
         int n_mat = 0;
         std::vector<int> lst = absorb_capped(dn, S, &n_mat);
-        if (n_mat > best_mat || (n_mat == best_mat && lst.size() > best_total)) { best_mat = n_mat; best_total = lst.size(); best.swap(lst); }
+        if (n_mat > best_mat || (n_mat == best_mat && lst.size() > best_total)) { best_mat = n_mat; best_total = lst.size(); best_set = S; best.swap(lst); }
       }
       if (best.empty()) break;
       for (int oi : best) dn[size_t(oi)] = 1;
       left -= best.size();
       ++greedy_passes;
+      if (plan->relabel && left) relabel_after(best_set, dn, &gphys, &gfrozen);
     }
-    if (left == 0 && planned.size() > greedy_passes + 1) planned.clear();
+    // (relabeling plans: a pruned pass moves only its live lines, so more, smaller tail passes are cheap -- the
+    // searched order stands unless the greedy one has FAR fewer passes)
+    if (left == 0 && planned.size() > greedy_passes + (plan->relabel ? 4 : 1)) planned.clear();
   }
   size_t planned_i = 0;
+  if (adjoint) {  // developer knob: QHBM_ADJ_SETS=hex,hex,... forces the local sets of the first adjoint passes
+    if (const char* env = std::getenv("QHBM_ADJ_SETS")) {
+      planned.clear();
+      for (const char* q = env; *q;) {
+        char* end = nullptr;
+        const unsigned long v = std::strtoul(q, &end, 16);
+        if (end == q) break;
+        planned.push_back(uint32_t(v));
+        q = *end ? end + 1 : end;
+      }
+    }
+  }
 
   while (n_done < ops.size()) {
-    std::vector<uint32_t> cands = planned_i < planned.size() ? std::vector<uint32_t>{planned[planned_i++]} : gen_cands(done);
+    std::vector<uint32_t> cands = planned_i < planned.size() ? std::vector<uint32_t>{planned[planned_i++]} : gen_cands(done, phys);
     if (!adjoint && K < n_eff && !groups.empty()) {
       // If one tile can hold every remaining op, this is the last gate pass: spend its spare local
       // bits on the X-masks of the groups no earlier pass can measure, so that the measurement
@@ -810,7 +939,8 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
       }
     }
     if (best_list.empty()) { *err = "scheduler made no progress"; return false; }
-    Pass p = b.begin_pass(best_S);
+    Pass p = b.begin_pass(best_S, &phys);
+    p.frozen_old_local = Builder::to_local(p, frozen & best_S);
     p.slot_base = int(plan->slot_gate.size());
     {
       std::vector<char> here(ops.size(), 0);
@@ -831,6 +961,28 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
       if (mixed != p.mat_bits) { *err = "internal: a non-diagonal op of the pass is missing from mat_bits"; return false; }
     }
     for (int oi : best_list) { done[oi] = 1; op_pass[oi] = int(plan->passes.size()); ++n_done; }
+    if (plan->relabel && n_done < ops.size()) {  // (the last pass stores nothing)
+      const std::vector<int> before(phys);
+      const uint32_t f_new = relabel_after(best_S, done, &phys, &frozen);
+      if (f_new) {
+        p.flags |= PASS_RELABEL;
+        p.frozen_new_local = Builder::to_local(p, f_new);
+        std::vector<int> live_bits;  // local index bits that stay, in ascending physical (= local) order
+        for (int i = 0; i < K; ++i) {
+          p.store_local_phys.push_back(phys[size_t(p.local_pos[size_t(i)])]);
+          if (!(p.frozen_new_local >> i & 1u)) live_bits.push_back(i);
+        }
+        const uint32_t n_live = uint32_t(live_bits.size());
+        p.relabel_tab.resize(size_t(2) << n_live);
+        for (uint32_t o = 0; o < (1u << n_live); ++o) {
+          uint32_t l = 0, off = 0;
+          for (uint32_t j = 0; j < n_live; ++j)
+            if (o >> j & 1u) { l |= 1u << live_bits[j]; off |= 1u << p.store_local_phys[size_t(live_bits[j])]; }
+          p.relabel_tab[2 * size_t(o)] = l;
+          p.relabel_tab[2 * size_t(o) + 1] = off;
+        }
+      }
+    }
     plan->passes.push_back(std::move(p));
   }
 
@@ -840,6 +992,11 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     plan->n_coef_floats = int(plan->coef_init.size());
   }
   if (adjoint) {
+    if (plan->relabel) {  // the relabeling store exists in the exchange-layout kernel only (lean programs)
+      bool general = false;
+      for (const Pass& p : plan->passes) general |= (p.flags & PASS_GENERAL) != 0;
+      if (general) return build_plan(m, tile_bits, round_bits, adjoint, plan, err, full_threshold, meas_tile_bits, cph_wave_bits, false);
+    }
     for (Pass& p : plan->passes) {
       p.flags |= PASS_ADJOINT | PASS_STORE;
       p.prog.push_back(OP_END);
@@ -941,7 +1098,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
 
 std::string describe_plan(const Plan& p) {
   std::ostringstream os;
-  os << (p.adjoint ? "adjoint" : "forward") << " plan: n=" << p.n << " n_eff=" << p.n_eff
+  os << (p.adjoint ? (p.relabel ? "adjoint (relabeling)" : "adjoint") : "forward") << " plan: n=" << p.n << " n_eff=" << p.n_eff
      << " tile_bits=" << p.K << " round_bits=" << p.R << " passes=" << p.passes.size()
      << " coef_floats=" << p.n_coef_floats;
   if (!p.global_terms.empty()) os << " global_terms=" << p.global_terms.size();
@@ -996,6 +1153,12 @@ std::string describe_plan(const Plan& p) {
        << " meas_terms=" << q.n_meas_terms << " slots=" << q.n_slots
        << (q.is_measure_only ? " [measure-only]" : "") << " words=" << q.prog.size() << " regs=";
     for (size_t r = 0; r < q.round_regmasks.size(); ++r) os << (r ? "," : "") << std::hex << q.round_regmasks[r] << std::dec;
+    if (p.relabel) {
+      os << " at=";
+      for (size_t k = 0; k < q.local_phys.size(); ++k) os << (k ? "," : "") << q.local_phys[k];
+      if (q.flags & PASS_RELABEL) os << " moves-local-bits=" << std::hex << q.frozen_new_local << std::dec;
+      if (q.frozen_old_local) os << " stale-local-bits=" << std::hex << q.frozen_old_local << std::dec;
+    }
     if (p.adjoint) {
       os << " dead=";
       for (size_t r = 0; r < q.round_words.size(); ++r) os << (r ? "," : "") << std::hex << q.prog[q.round_words[r] + 4] << std::dec;

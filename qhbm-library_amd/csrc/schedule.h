@@ -52,8 +52,20 @@ struct CoefJob {
 struct Pass {
   int K = 0, R = 0, c = 0;
   uint32_t flags = 0;
-  std::vector<int> local_pos;     // ascending index-bit positions, size K
-  std::vector<int> nonlocal_pos;  // ascending, size n - K
+  // LOGICAL index bits (bit n-1-q <-> qubit q) of the tile, size K, and of the rest, size n - K, each in
+  // ascending order of their PHYSICAL position (the bit of the amplitude's address in HBM).  Logical and
+  // physical positions coincide except in adjoint plans that relabel (Plan::relabel): there a pass that
+  // finishes an index bit stores its tiles with that bit moved to the highest position the tile owns, so
+  // that in every later pass the live half of the state (finished bit == input bit) is made of WHOLE
+  // 128-byte lines instead of every other amplitude of every line.
+  std::vector<int> local_pos;
+  std::vector<int> nonlocal_pos;
+  std::vector<int> local_phys, nonlocal_phys;  // their physical positions when the pass LOADS its tiles (ascending)
+  std::vector<int> phys_of;                    // logical bit -> physical position at load time, size n_eff
+  std::vector<int> store_local_phys;           // physical position of local index bit i when the pass STORES (empty: unchanged)
+  uint32_t frozen_new_local = 0;  // local index bits this pass finishes and moves: stored only where they equal the input bit
+  uint32_t frozen_old_local = 0;  // local index bits finished and moved by EARLIER passes: stale data where != input, zeroed at load
+  std::vector<uint32_t> relabel_tab;  // relabeling store: per live out-local index o: [2 o] = local index (finished bits clear), [2 o + 1] = out offset
   std::vector<uint32_t> prog;     // instruction words, OP_END terminated
   std::vector<uint32_t> spread;   // spread_hi[2^(K-c)]
   std::vector<uint32_t> round_tl; // TL[tid] tables of the rounds, 2^(K-R) entries each (OP_ROUND word 3)
@@ -79,6 +91,7 @@ struct Plan {
   std::vector<uint32_t> record_offsets;  // word offset of every instance record
   int full_threshold = 60;  // per-term cost above which an instance uses the FULL diagonal table
   bool tail_tiles = true;     // adjoint tail passes may drop the low index bits once they have no gate left (schedule.cpp)
+  bool relabel = false;       // adjoint: finished index bits are moved out of the 128-byte lines (Pass::store_local_phys)
   bool cph_wave_bits = true;  // map the partner bits of boundary controlled phases to wave bits (schedule.cpp emit_round)
   // forward: indices (into Model::terms) of the Pauli terms whose X-mask does not fit a tile; they
   // are measured on the final state in HBM by the strided-gather kernel
@@ -103,7 +116,8 @@ struct Model {
 // selects automatically.  Returns false and fills `err` on failure.
 // `meas_tile_bits`: tile size of measurement-only passes (0 = the largest the forward kernel has).
 bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Plan* out,
-                std::string* err, int full_threshold = 60, int meas_tile_bits = 0, bool cph_wave_bits = true);
+                std::string* err, int full_threshold = 60, int meas_tile_bits = 0, bool cph_wave_bits = true,
+                bool relabel = false);
 
 std::string describe_plan(const Plan& p);
 

@@ -177,10 +177,10 @@ VARIANTS.update({
     # 128-byte lines are moved for a half / quarter / ... of their amplitudes): their loads and stores
     # compiled out -- the time a compacted state layout could approach
     "adj_no_io_pruned": lambda t: once(once(t,
-        "  prefetch_tile<K, NT, true>(rp, sp, t, tid);\n  prefetch_tile<K, NT, true>(rl, sl, t, tid);\n  for (uint32_t i = tid; i < a.n_slots * NW; i += NT) cells[i] = 0.f;\n\n  constexpr RecordLayout L(R, true);",
-        "  if (!a.zero_mask) {\n  prefetch_tile<K, NT, true>(rp, sp, t, tid);\n  prefetch_tile<K, NT, true>(rl, sl, t, tid);\n  } else { rp = TileRegs{}; rl = TileRegs{}; rp.p0.x = 1e-3f; rl.p0.y = 1e-3f; }\n  for (uint32_t i = tid; i < a.n_slots * NW; i += NT) cells[i] = 0.f;\n\n  constexpr RecordLayout L(R, true);"),
-        "  if (a.flags & PASS_STORE) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT, true>(xt, sp, t, tid);",
-        "  if ((a.flags & PASS_STORE) && !a.zero_mask) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT, true>(xt, sp, t, tid);"),
+        "  prefetch_tile<K, NT, true>(rp, sp, t, tid);\n  prefetch_tile<K, NT, true>(rl, sl, t, tid);\n  if (a.frozen_old_local) {",
+        "  if (!a.zero_mask) {\n  prefetch_tile<K, NT, true>(rp, sp, t, tid);\n  prefetch_tile<K, NT, true>(rl, sl, t, tid);\n  } else { rp = TileRegs{}; rl = TileRegs{}; rp.p0.x = 1e-3f; rl.p0.y = 1e-3f; }\n  if (a.frozen_old_local) {"),
+        "  } else if (a.flags & PASS_STORE) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT, true>(xt, sp, t, tid);",
+        "  } else if ((a.flags & PASS_STORE) && !a.zero_mask) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT, true>(xt, sp, t, tid);"),
 })
 
 

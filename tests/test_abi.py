@@ -64,18 +64,22 @@ def test_planning_without_device_and_loud_compute_failure():
     eng.expectation(np.zeros((1, 4), np.int8), np.zeros(22, np.float32))
 
 
-@pytest.mark.parametrize("n,layers,max_fwd,max_bwd", [(12, 8, 1, 1), (20, 16, 7, 6), (24, 16, 10, 9), (28, 32, 16, 19)])
-def test_baseline_configs_schedule(n, layers, max_fwd, max_bwd):
+@pytest.mark.parametrize("n,layers,max_fwd,max_bwd,max_bwd_relabel",
+                         [(12, 8, 1, 1, 1), (20, 16, 7, 6, 9), (24, 16, 10, 9, 10), (28, 32, 16, 19, 20)])
+def test_baseline_configs_schedule(n, layers, max_fwd, max_bwd, max_bwd_relabel):
   """Light-cone scheduling: far fewer HBM passes than gates (944 gates at n=20).  The bounds are the
   pass counts of the scheduler whose diagonal terms wait only for non-diagonal gates (they commute
   with each other): with every pending op a barrier the chain's cone shrinks twice as fast and config
-  3 needs 10 + 11 passes instead of 7 + 6."""
+  3 needs 10 + 11 passes instead of 7 + 6.  The default (relabeling) adjoint plans take a few more,
+  smaller tail passes -- a pruned pass moves only its live lines there."""
   op = O.xxz_chain_op(n) if n == 20 else O.tfim_ring_op(n)
-  eng = _planner(n, layers, op)
+  eng = _planner(n, layers, op, adjoint_relabel=0)
   fwd, bwd = eng.num_passes()
   assert 1 <= fwd <= max_fwd
   assert 1 <= bwd <= max_bwd
   assert eng.workspace_bytes(8) >= 8 * 8 * 2**n or n > 24
+  fwd_r, bwd_r = _planner(n, layers, op).num_passes()
+  assert fwd_r == fwd and 1 <= bwd_r <= max_bwd_relabel
 
 
 def test_first_tile_of_a_chain_absorbs_the_whole_triangle():
@@ -91,11 +95,13 @@ def test_first_tile_of_a_chain_absorbs_the_whole_triangle():
 
 def test_adjoint_pass_order_is_searched_for_early_finished_bits():
   """The adjoint plan orders its passes so that the low index bits run out of gates early (the 136-gate
-  triangle 16 + 15 + ... + 1 finishes the first qubit of the chain), then drops every finished low bit
-  from its tiles (c = 0) and prunes on it: config 3 runs at most 150 of its 320 one-qubit gates before
-  the first pruned pass -- the greedy order needs 220."""
+  triangle 16 + 15 + ... + 1 finishes the first qubit of the chain): config 3 runs at most 150 of its 320
+  one-qubit gates before the first pruned pass -- the greedy order needs 220.  Without relabeling the
+  later tiles drop every finished low bit (c = 0) and prune on it; the default, relabeling plan moves a
+  finished bit out of the 128-byte lines when the finishing pass stores (`moves-local-bits`), keeps every
+  tile made of whole lines (c >= 4), and its byte model is well below the other's."""
   import re
-  eng = _planner(20, 16, O.xxz_chain_op(20))
+  eng = _planner(20, 16, O.xxz_chain_op(20), adjoint_relabel=0)
   text = eng.describe_schedule()
   adjoint = text[text.index("adjoint plan"):]
   mats = [int(x) for x in re.findall(r"mat_ops=(\d+)", adjoint)]
@@ -104,6 +110,16 @@ def test_adjoint_pass_order_is_searched_for_early_finished_bits():
   first_c0 = cs.index(0)
   assert 136 <= sum(mats[:first_c0]) <= 150
   assert sum(m for m, c in zip(mats, cs) if c == 0) >= 150
+  rel = _planner(20, 16, O.xxz_chain_op(20))
+  text = rel.describe_schedule()
+  adjoint = text[text.index("adjoint (relabeling) plan"):]
+  lines = [ln for ln in adjoint.splitlines() if ln.strip().startswith("pass ")]
+  mats = [int(re.search(r"mat_ops=(\d+)", ln).group(1)) for ln in lines]
+  assert sum(mats) == 320 and all(int(re.search(r" c=(\d+) ", ln).group(1)) >= 4 for ln in lines)
+  first_move = next(i for i, ln in enumerate(lines) if "moves-local-bits=" in ln)
+  assert 136 <= sum(mats[:first_move + 1]) <= 150          # the pass that finishes the first bit ends the unpruned part
+  assert rel.traffic_model(64, True)["bwd_bytes"] < 0.7 * eng.traffic_model(64, True)["bwd_bytes"]
+  assert rel.flop_model(64, True)["bwd_flops"] <= 1.02 * eng.flop_model(64, True)["bwd_flops"]
 
 
 def test_schedule_options_and_errors():

@@ -466,13 +466,15 @@ def test_x_exponents_far_outside_one_period():
 
 
 @pytest.mark.parametrize("tile", [10, 11])
-@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("layout", ["plain", "relabel", "tail-tiles"])
 def test_deep_chain_with_and_without_the_scheduler_layout_choices(layout, tile):
-  """A circuit deep enough for the adjoint tail -- bits with no gate left: dead waves (tile 11: one wave
-  bit), tiles without the low index bits (tile 10), pruning on every finished non-local bit -- against
-  the oracle, with the scheduler's layout choices on (default) and off (`cph_wave_bits` = 0, the plain
-  layout kept for A/B measurements); the two engines must also agree with each other far inside the
-  oracle tolerance."""
+  """A circuit deep enough for the adjoint tail -- bits with no gate left -- against the oracle under the
+  three layouts the scheduler has: "relabel" (default: the pass that finishes an index bit stores its
+  tiles with that bit moved out of the 128-byte lines, later passes load whole live lines and clear the
+  stale half where they hold a moved bit), "tail-tiles" (`adjoint_relabel` = 0: dead waves (tile 11: one
+  wave bit), tiles without the low index bits (tile 10), pruning on every finished non-local bit) and
+  "plain" (`cph_wave_bits` = 0, kept for A/B measurements); the engines must also agree with each other
+  far inside the oracle tolerance."""
   n, layers = 15, 10
   rng = np.random.default_rng(4242)
   gates, names = O.hea_gates(n, layers, "deep")
@@ -480,20 +482,27 @@ def test_deep_chain_with_and_without_the_scheduler_layout_choices(layout, tile):
   ops = [O.xxz_chain_op(n)]
   bits = _random_bits(rng, 2, n)
   opts = dict(tile_qubits=tile, adjoint_tile_qubits=tile)
-  eng = _engine(n, gates, len(names), ops, cph_wave_bits=layout, **opts)
+  layout_opts = {"plain": dict(cph_wave_bits=0), "relabel": {}, "tail-tiles": dict(adjoint_relabel=0)}
+  eng = _engine(n, gates, len(names), ops, **layout_opts[layout], **opts)
   fwd, bwd = eng.num_passes()
   assert fwd >= 4 and bwd >= 3
-  if layout:
-    adjoint = eng.describe_schedule()
-    adjoint = adjoint[adjoint.index("adjoint plan"):]
-    dead = [tok for line in adjoint.splitlines() if "dead=" in line for tok in line.split("dead=")[1].split(",")]
+  adjoint = eng.describe_schedule()
+  adjoint = adjoint[adjoint.index("adjoint"):]
+  dead = [tok for line in adjoint.splitlines() if "dead=" in line for tok in line.split("dead=")[1].split(",")]
+  if layout == "relabel":
+    assert adjoint.startswith("adjoint (relabeling) plan") and "moves-local-bits=" in adjoint
+    assert " c=0 " not in adjoint              # every tile is made of whole lines
+  elif layout == "tail-tiles":
+    assert adjoint.startswith("adjoint plan") and "moves-local-bits=" not in adjoint
     if tile == 10:
-      assert " c=0 " in adjoint            # a tail pass without the low index bits
+      assert " c=0 " in adjoint                # a tail pass without the low index bits
     else:
-      assert any(tok != "0" for tok in dead)  # rounds in which some waves hold zeros only
+      assert any(tok != "0" for tok in dead)   # rounds in which some waves hold zeros only
+  else:
+    assert adjoint.startswith("adjoint plan") and "moves-local-bits=" not in adjoint
   check_values(eng, n, gates, params, bits, ops, rel=3e-5)
   want_jac = check_jacobian(eng, n, gates, params, bits[:1], ops, rel=3e-4)
-  other = _engine(n, gates, len(names), ops, cph_wave_bits=1 - layout, **opts)
+  other = _engine(n, gates, len(names), ops, **layout_opts["plain" if layout != "plain" else "tail-tiles"], **opts)
   _, jac = other.expectation_jacobian(bits[:1], params)
   _, mine = eng.expectation_jacobian(bits[:1], params)
   np.testing.assert_allclose(mine.cpu().numpy(), jac.cpu().numpy(), atol=2e-5 * max(1.0, np.abs(want_jac).max()), rtol=0)
