@@ -235,6 +235,14 @@ void fill_args(const Plan& plan, const Model& m, std::vector<PassArgs>* args, st
       (*args)[i].zero_mask = nl & ~later_phys;
     }
   }
+  for (size_t i = 0; i < args->size(); ++i) {
+    PassArgs& a = (*args)[i];
+    // the first forward pass writes ONE tile per state when nothing has to be zero-filled: every tile-id bit
+    // follows the input bitstring
+    if ((a.flags & PASS_INIT_BASIS) && (a.flags & PASS_NO_ZERO_FILL))
+      for (uint32_t k = 0; k < a.n_nonlocal; ++k) a.zero_mask |= 1u << a.nonlocal_pos[k];
+    a.n_free = a.n_nonlocal - uint32_t(__builtin_popcount(a.zero_mask));
+  }
 }
 
 int build_plans(qhbm_engine* h) {
@@ -404,7 +412,7 @@ int run_forward_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_
     const Pass& p = d.plan.passes[i];
     if (skip_measure && p.is_measure_only) continue;
     PassArgs a = d.args[i];
-    a.flags = p.flags & (PASS_INIT_BASIS | PASS_GENERAL);
+    a.flags = p.flags & (PASS_INIT_BASIS | PASS_GENERAL | PASS_NO_ZERO_FILL);
     if (h->opt_force_general) a.flags |= PASS_GENERAL;
     if (skip_measure) a.flags |= PASS_SKIP_MEASURE;
     if (!p.is_measure_only && (!p.completes_circuit || keep_state || measure_only_after)) a.flags |= PASS_STORE;
@@ -494,7 +502,7 @@ int run_adjoint_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_
   const uint32_t n_slots = uint32_t(b.plan.slot_gate.size());
   size_t rows = 0;  // tile_grad: one row of the pass's slots per workgroup
   for (const PassArgs& ba : b.args)
-    rows = std::max(rows, ((size_t(c) << ba.n_nonlocal) + reduce_tiles_scratch_rows(c, size_t(1) << ba.n_nonlocal)) *
+    rows = std::max(rows, ((size_t(c) << ba.n_free) + reduce_tiles_scratch_rows(c, size_t(1) << ba.n_free)) *
                               std::max<uint32_t>(ba.n_slots, 1));
   HIPCHK(h->tile_grad.reserve(rows));
   for (size_t i = 0; i < b.plan.passes.size(); ++i) {
@@ -505,7 +513,7 @@ int run_adjoint_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_
                            b.tables.p, b.coef.p, h->tile_grad.p, s0, stream));
     timer_end(ev, stream);
     // tiles of a state are added in tile order (bit-reproducible, no atomics)
-    HIPCHK(launch_reduce_tiles(h->tile_grad.p, c, 1u << ba.n_nonlocal, ba.n_slots, h->state_grad.p, n_slots, ba.slot_base,
+    HIPCHK(launch_reduce_tiles(h->tile_grad.p, c, 1u << ba.n_free, ba.n_slots, h->state_grad.p, n_slots, ba.slot_base,
                                s0, stream));
   }
   return 0;
@@ -917,7 +925,7 @@ int qhbm_sample_counts(qhbm_engine* h, const int8_t* d_bits, int U, const float*
         const Pass& p = d.plan.passes[i];
         if (p.is_measure_only) continue;
         PassArgs a = d.args[i];
-        a.flags = (p.flags & (PASS_INIT_BASIS | PASS_GENERAL)) | PASS_STORE | PASS_SKIP_MEASURE;
+        a.flags = (p.flags & (PASS_INIT_BASIS | PASS_GENERAL | PASS_NO_ZERO_FILL)) | PASS_STORE | PASS_SKIP_MEASURE;
         if (h->opt_force_general) a.flags |= PASS_GENERAL;
         a.prog_states = c;
         a.coef_stride = stride;
@@ -1023,7 +1031,7 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const floa
       for (size_t i = 0; i < d.plan.passes.size(); ++i) {
         const Pass& p = d.plan.passes[i];
         PassArgs a = d.args[i];
-        a.flags = p.flags & (PASS_INIT_BASIS | PASS_GENERAL);
+        a.flags = p.flags & (PASS_INIT_BASIS | PASS_GENERAL | PASS_NO_ZERO_FILL);
         if (h->opt_force_general) a.flags |= PASS_GENERAL;
         if (!p.is_measure_only && (!p.completes_circuit || measure_only_after)) a.flags |= PASS_STORE;
         a.prog_states = c;

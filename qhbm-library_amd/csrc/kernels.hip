@@ -440,6 +440,22 @@ __device__ __forceinline__ TileCtx make_tile_ctx(const PassArgs& a, const uint32
   return t;
 }
 
+// Only the tiles that can hold a non-zero amplitude are launched (PassArgs::n_free): block b of the grid is
+// tile `b & (2^n_free - 1)` of the LIVE tiles of state `b >> n_free`; the tile-id bits that belong to index
+// bits of `zero_mask` are those of the input bitstring `idx` (given in the layout the pass loads).  Launching
+// the dead tiles only to return cost 3 - 6 ms per pass at 4096 states (a million workgroups to dispatch).
+__device__ __forceinline__ uint32_t launched_tile(const PassArgs& a, uint32_t block, uint32_t idx) {
+  uint32_t live = block & ((1u << a.n_free) - 1u), tile_id = 0;
+  for (uint32_t i = 0; i < a.n_nonlocal; ++i) {
+    const uint32_t pos = a.nonlocal_pos[i];
+    uint32_t bit;
+    if ((a.zero_mask >> pos) & 1u) bit = (idx >> pos) & 1u;
+    else { bit = live & 1u; live >>= 1; }
+    tile_id |= bit << i;
+  }
+  return tile_id;
+}
+
 // Round geometry.  Thread `tid` owns the 2^R amplitudes whose local index has
 // tid's bits deposited on the non-register positions (TL, read from the scheduler's per-round table);
 // register value m adds the bits of m on the register positions.  In swizzled slot space both parts
@@ -748,6 +764,27 @@ __device__ __forceinline__ float meas_sum(const v2f (&w)[1 << R], uint32_t zhi) 
   return meas_sum_<R, IM>(w, zhi, iseq<(1 << R)>{});
 }
 
+// ---- relabeling adjoint plans (schedule.h Pass, program.h PassArgs) ------------------------------------
+// The input bitstring as an index in the layout this pass loads.
+__device__ __forceinline__ uint32_t physical_index(const PassArgs& a, uint32_t idx) {
+  uint32_t out = 0;
+  for (uint32_t bit = 0; bit < a.n; ++bit) out |= ((idx >> bit) & 1u) << a.phys_of[bit];
+  return out;
+}
+// Index bits finished by EARLIER passes that this tile holds as local bits: where they differ from the
+// input the memory holds stale data (the finishing pass stored the live half only) -- psi is zero there
+// and lambda there is never needed again, so the prefetched amplitudes are cleared.
+template <int K>
+__device__ __forceinline__ void clear_stale(TileRegs& r, int tid, uint32_t in_local, uint32_t fz) {
+#define QHBM_CL(I)                                                                   \
+  {                                                                                  \
+    const uint32_t l = 2u * uint32_t(tid) + (uint32_t(I) << (K - 3));                \
+    if ((l ^ in_local) & fz) { r.p##I.x = 0.f; r.p##I.y = 0.f; }                     \
+    if (((l | 1u) ^ in_local) & fz) { r.p##I.z = 0.f; r.p##I.w = 0.f; }              \
+  }
+  QHBM_CL(0) QHBM_CL(1) QHBM_CL(2) QHBM_CL(3) QHBM_CL(4) QHBM_CL(5) QHBM_CL(6) QHBM_CL(7)
+#undef QHBM_CL
+}
 }  // namespace
 
 // ================================================================================
@@ -769,8 +806,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const uint32_t tile_id = blockIdx.x & ((1u << a.n_nonlocal) - 1u);
-  const uint32_t s_local = blockIdx.x >> a.n_nonlocal;
+  const uint32_t s_local = blockIdx.x >> a.n_free;
   uint32_t bits_row = state0 + s_local, out_row = state0 + s_local;
   if (a.prog_states) {  // batched programs (PassArgs::prog_states): own coefficients, shared bitstrings
     const uint32_t q = s_local / a.prog_states;
@@ -779,17 +815,20 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
     coef += size_t(q) * a.coef_stride;
   }
   const uint32_t* recs = reinterpret_cast<const uint32_t*>(coef);
+  uint32_t idx = 0;  // the input bitstring as an index: only the passes that prune or initialise read it (n byte loads)
+  if ((a.flags & PASS_INIT_BASIS) | a.zero_mask | a.frozen_old_local) idx = uni(basis_index(bits + size_t(bits_row) * n_user, n_user));
+  const uint32_t tile_id = launched_tile(a, blockIdx.x, idx);
   const TileCtx t = make_tile_ctx(a, tables, tile_id);
   float2* st = psi + (size_t(s_local) << a.n);
 
   if (a.flags & PASS_INIT_BASIS) {
-    const uint32_t idx = uni(basis_index(bits + size_t(bits_row) * n_user, n_user));
     uint32_t nl_mask = 0;
     for (uint32_t i = 0; i < a.n_nonlocal; ++i) nl_mask |= 1u << a.nonlocal_pos[i];
     if ((idx & nl_mask) != t.tile_base) {
       // The basis amplitude lives in another tile: this one is zero and stays zero under the
       // program (every op is linear), so only its image in HBM has to be written.
-      if (a.flags & PASS_STORE) {
+      // (PASS_NO_ZERO_FILL: nothing is written -- later passes never read these tiles unmasked, see schedule.cpp)
+      if ((a.flags & PASS_STORE) && !(a.flags & PASS_NO_ZERO_FILL)) {
         for (int p = tid; p < (1 << (K - 1)); p += NT)
           *reinterpret_cast<float4*>(st + global_index(t, 2u * p)) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -803,12 +842,14 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
       tile[swz(l)] = make_float2(1.f, 0.f);
     }
   } else {
-    if (a.zero_mask) {  // head of the sweep: psi is identically zero on this tile (engine.cpp fill_args)
-      const uint32_t idx = uni(basis_index(bits + size_t(bits_row) * n_user, n_user));
-      if ((idx ^ t.tile_base) & a.zero_mask) return;
-    }
+    // (head of the sweep: the tiles on which psi is identically zero are not launched -- launched_tile)
     TileRegs r;
     prefetch_tile<K, NT>(r, st, t, tid);
+    if (a.frozen_old_local) {  // local bits nothing has acted on yet: their != input half was never written
+      uint32_t in_local = 0;
+      for (int i = 0; i < K; ++i) in_local |= ((idx >> a.local_pos[i]) & 1u) << i;
+      clear_stale<K>(r, tid, in_local, a.frozen_old_local);
+    }
     commit_tile<K, NT>(tile, r, tid);
   }
   for (int i = tid; i < kMaxOps; i += NT) red[i] = 0ull;
@@ -1046,27 +1087,6 @@ __device__ __forceinline__ void flush_cells(const float* cells, float* __restric
   }
 }
 
-// ---- relabeling adjoint plans (schedule.h Pass, program.h PassArgs) ------------------------------------
-// The input bitstring as an index in the layout this pass loads.
-__device__ __forceinline__ uint32_t physical_index(const PassArgs& a, uint32_t idx) {
-  uint32_t out = 0;
-  for (uint32_t bit = 0; bit < a.n; ++bit) out |= ((idx >> bit) & 1u) << a.phys_of[bit];
-  return out;
-}
-// Index bits finished by EARLIER passes that this tile holds as local bits: where they differ from the
-// input the memory holds stale data (the finishing pass stored the live half only) -- psi is zero there
-// and lambda there is never needed again, so the prefetched amplitudes are cleared.
-template <int K>
-__device__ __forceinline__ void clear_stale(TileRegs& r, int tid, uint32_t in_local, uint32_t fz) {
-#define QHBM_CL(I)                                                                   \
-  {                                                                                  \
-    const uint32_t l = 2u * uint32_t(tid) + (uint32_t(I) << (K - 3));                \
-    if ((l ^ in_local) & fz) { r.p##I.x = 0.f; r.p##I.y = 0.f; }                     \
-    if (((l | 1u) ^ in_local) & fz) { r.p##I.z = 0.f; r.p##I.w = 0.f; }              \
-  }
-  QHBM_CL(0) QHBM_CL(1) QHBM_CL(2) QHBM_CL(3) QHBM_CL(4) QHBM_CL(5) QHBM_CL(6) QHBM_CL(7)
-#undef QHBM_CL
-}
 // The relabeling store: only the amplitudes whose newly finished bits equal the input bitstring, in
 // the order of their NEW addresses (finished bits moved to the highest positions the tile owns):
 // whole 128-byte lines of live data, nothing written for the dead half.
@@ -1118,17 +1138,16 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   const int lane = tid & 63;
   const uint32_t wave = uni(uint32_t(tid) >> 6);
   const uint32_t* recs = reinterpret_cast<const uint32_t*>(coef);
-  const uint32_t tile_id = blockIdx.x & ((1u << a.n_nonlocal) - 1u);
-  const uint32_t s_local = blockIdx.x >> a.n_nonlocal;
+  const uint32_t s_local = blockIdx.x >> a.n_free;
+  // (the input bitstring in the layout this pass loads: relabeling plans move finished bits)
+  const uint32_t idx = uni(physical_index(a, basis_index(bits + size_t(state0 + s_local) * n_user, n_user)));
+  // tail of the sweep: the tiles on which psi is identically zero are not launched (launched_tile)
+  const uint32_t tile_id = launched_tile(a, blockIdx.x, idx);
   const TileCtx t = make_tile_ctx(a, tables, tile_id);
   float* grow = tile_grad + size_t(blockIdx.x) * a.n_slots;
   const uint32_t* prog = prog_base + a.prog_off;
   uint32_t w0 = uni(prog[0]);
-  bool skip = (w0 & 0xffu) != OP_ROUND;  // (an empty program: nothing to un-apply)
-  // (the input bitstring in the layout this pass loads: relabeling plans move finished bits)
-  const uint32_t idx = uni(physical_index(a, basis_index(bits + size_t(state0 + s_local) * n_user, n_user)));
-  // tail of the sweep: psi is identically zero on this tile (engine.cpp fill_args)
-  if (a.zero_mask) skip |= ((idx ^ t.tile_base) & a.zero_mask) != 0;
+  const bool skip = (w0 & 0xffu) != OP_ROUND;  // (an empty program: nothing to un-apply)
   uint32_t in_local = 0;  // the input bitstring on the tile's local bits (OP_ROUND word 4: dead waves)
   for (int i = 0; i < K; ++i) in_local |= ((idx >> a.local_pos[i]) & 1u) << i;
   if (skip) {
@@ -1252,17 +1271,12 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
   const int lane = tid & 63;
   const uint32_t wave = uni(uint32_t(tid) >> 6);
   const uint32_t* recs = reinterpret_cast<const uint32_t*>(coef);
-  const uint32_t tile_id = blockIdx.x & ((1u << a.n_nonlocal) - 1u);
-  const uint32_t s_local = blockIdx.x >> a.n_nonlocal;
+  const uint32_t s_local = blockIdx.x >> a.n_free;
+  // tail of the sweep: the tiles on which psi is identically zero are not launched (launched_tile; these plans
+  // never relabel: logical = physical index bits)
+  const uint32_t tile_id = launched_tile(a, blockIdx.x, uni(basis_index(bits + size_t(state0 + s_local) * n_user, n_user)));
   const TileCtx t = make_tile_ctx(a, tables, tile_id);
   float* grow = tile_grad + size_t(blockIdx.x) * a.n_slots;
-  if (a.zero_mask) {  // tail of the sweep: psi is identically zero on this tile (engine.cpp fill_args)
-    const uint32_t idx = uni(basis_index(bits + size_t(state0 + s_local) * n_user, n_user));
-    if ((idx ^ t.tile_base) & a.zero_mask) {
-      for (uint32_t i = tid; i < a.n_slots; i += NT) grow[i] = 0.f;
-      return;
-    }
-  }
   float2* sp = psi + (size_t(s_local) << a.n);
   float2* sl = lam + (size_t(s_local) << a.n);
   {
@@ -1897,7 +1911,7 @@ static hipError_t launch_fwd_t(const PassArgs& a, uint32_t n_states, float2* psi
   const size_t lds = fwd_lds_bytes(K);
   static bool attr_done[kMaxDevices] = {};
   if (hipError_t e = opt_in_lds(&pass_fwd_kernel<K, R, GEN>, attr_done, lds); e != hipSuccess) return e;
-  const uint32_t grid = n_states << a.n_nonlocal;
+  const uint32_t grid = n_states << a.n_free;
   hipLaunchKernelGGL((pass_fwd_kernel<K, R, GEN>), dim3(grid), dim3(1 << (K - R)), lds, stream, a, psi, bits,
                      n_user, prog, tables, coef, op_scale, out64, state0);
   return hipGetLastError();
@@ -1935,7 +1949,7 @@ static hipError_t launch_adj_t(const PassArgs& a, uint32_t n_states, float2* psi
   const size_t lds = adj_lds_bytes(K, false);
   static bool attr_done[kMaxDevices] = {};
   if (hipError_t e = opt_in_lds(&pass_adj_kernel<K, GEN>, attr_done, lds); e != hipSuccess) return e;
-  const uint32_t grid = n_states << a.n_nonlocal;
+  const uint32_t grid = n_states << a.n_free;
   hipLaunchKernelGGL((pass_adj_kernel<K, GEN>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, lam, bits,
                      n_user, prog, tables, coef, tile_grad, state0);
   return hipGetLastError();
@@ -1948,7 +1962,7 @@ static hipError_t launch_adjx_t(const PassArgs& a, uint32_t n_states, float2* ps
   const size_t lds = adj_lds_bytes(K, true);
   static bool attr_done[kMaxDevices] = {};
   if (hipError_t e = opt_in_lds(&pass_adjx_kernel<K>, attr_done, lds); e != hipSuccess) return e;
-  const uint32_t grid = n_states << a.n_nonlocal;
+  const uint32_t grid = n_states << a.n_free;
   hipLaunchKernelGGL((pass_adjx_kernel<K>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, lam, bits,
                      n_user, prog, tables, coef, tile_grad, state0);
   return hipGetLastError();

@@ -48,6 +48,8 @@ enum : uint32_t {
   PASS_GENERAL = 1u << 3,     // the program uses Y / dense 2x2 / dense two-qubit ops (rare-path kernel variant)
   PASS_SKIP_MEASURE = 1u << 4,  // forward: ignore the measurement groups (the values come from lambda = O psi)
   PASS_RELABEL = 1u << 5,       // adjoint: the store moves the index bits this pass finished (PassArgs::relabel_*)
+  PASS_NO_ZERO_FILL = 1u << 6,  // forward, with PASS_INIT_BASIS: tiles without the basis amplitude write nothing (later
+                                // passes clear what they load of them: PassArgs::frozen_old_local)
 };
 
 // ---- opcodes (low 8 bits of an instruction's first word) --------------------
@@ -146,6 +148,10 @@ struct PassArgs {
   uint32_t n;              // qubits after padding
   uint32_t c;              // low `c` local bits are index bits 0..c-1 (contiguous in HBM)
   uint32_t n_nonlocal;     // n - K
+  // Tiles that differ from the input bitstring on a bit of `zero_mask` are identically zero and are NOT
+  // LAUNCHED: the grid holds 2^n_free tiles per state, the other n_nonlocal - n_free tile-id bits are read
+  // off the input bitstring (kernels.hip launched_tile).
+  uint32_t n_free;
   uint32_t prog_off;       // word offset of this pass's program
   uint32_t spread_off;     // offset of spread_hi[2^(K-c)] in the tables buffer
   uint32_t tl_off;         // offset of this pass's round TL tables in the tables buffer (OP_ROUND word 3)
@@ -164,7 +170,9 @@ struct PassArgs {
   // Adjoint plans that relabel (schedule.h Pass): where logical index bit b (bit n-1-q <-> qubit q, the bit
   // of the input bitstring) sits in the addresses this pass loads; identity otherwise.
   uint8_t phys_of[32];
-  uint32_t frozen_old_local;  // local index bits finished by earlier passes: their != input half holds stale data, zeroed at load
+  // local index bits whose != input half holds STALE data, zeroed at load: adjoint -- bits finished and moved by
+  // earlier passes; forward -- bits no earlier pass has acted on (never written: PASS_NO_ZERO_FILL)
+  uint32_t frozen_old_local;
   // PASS_RELABEL: the store writes only the amplitudes whose bits `frozen_new_local` equal the input
   // bitstring, live out-local index o -> tables[relabel_off + 2 o] = local index (those bits clear),
   // [.. + 1] = offset in the state; the finished bits land on `fz_out_pos` carrying the input bit.

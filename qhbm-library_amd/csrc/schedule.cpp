@@ -1012,6 +1012,20 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   }
   plan->passes.front().flags |= PASS_INIT_BASIS;
   plan->passes.back().completes_circuit = true;
+  // The first pass writes the basis state: ONE tile per state is not zero.  If every index bit is acted on
+  // by some non-diagonal gate, the other tiles need not be written at all: a later pass skips the tiles that
+  // differ from the input on a bit nothing has acted on yet (engine.cpp fill_args: zero_mask), and clears,
+  // when it loads a tile, the amplitudes that differ on such a bit among its LOCAL bits -- the only places
+  // never written before.  (With an idle bit the final state would keep unwritten regions: zeros are filled.)
+  if (plan->passes.size() > 1 && ever_mat == all_bits) {
+    plan->passes.front().flags |= PASS_NO_ZERO_FILL;
+    uint32_t touched = plan->passes.front().mat_bits;
+    for (size_t i = 1; i < plan->passes.size(); ++i) {
+      Pass& q = plan->passes[i];
+      q.frozen_old_local = Builder::to_local(q, pass_set(q) & ~touched);
+      touched |= q.mat_bits;
+    }
+  }
 
   std::vector<char> gdone(groups.size(), 0);
   size_t g_left = groups.size();
