@@ -77,6 +77,7 @@ struct qhbm_engine {
   int opt_values_from_obs = 1;  // single observable: <psi|O|psi> from lambda = O psi, no measurement in the forward sweep
   bool retained_mu = false;     // the retained batch also holds the unweighted lambda = O psi
   int opt_cph_wave_bits = 1; // boundary controlled-phase predicates on wave bits (schedule.h Plan::cph_wave_bits)
+  int opt_fwd_pair = 1;        // dense lean forward passes run on pairs of states, tiles in registers (pass_fwd2_kernel)
   int opt_adj_relabel = 1;     // adjoint plans move finished index bits out of the 128-byte lines (schedule.h Pass)
   int opt_obs_xcd_states = 1;  // lambda = O psi: one state per XCD at a time (kernels.hip apply_observable_kernel)
   int opt_adj_exchange = 1;  // lean adjoint passes: register-resident tile pair + one LDS exchange buffer
@@ -417,8 +418,14 @@ int run_forward_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_
     if (skip_measure) a.flags |= PASS_SKIP_MEASURE;
     if (!p.is_measure_only && (!p.completes_circuit || keep_state || measure_only_after)) a.flags |= PASS_STORE;
     hipEvent_t* ev = timer_begin(h, 0, stream);
-    HIPCHK(launch_pass_fwd(p.K, d.plan.R, a, cs, h->psi.p, d_bits, h->model.n, d.prog.p, d.tables.p, d.coef.p,
-                           h->op_scale.p, h->vals64.p, s0, stream));
+    // dense lean passes without a measurement to take: two states per workgroup, tiles in registers
+    const bool pair = h->opt_fwd_pair && cs >= 2 && !(a.flags & (PASS_INIT_BASIS | PASS_GENERAL)) && a.zero_mask == 0 &&
+                      a.frozen_old_local == 0 && (skip_measure || p.n_meas_groups == 0) && pass_fwd_pair_supported(p.K);
+    if (pair)
+      HIPCHK(launch_pass_fwd_pair(p.K, a, cs, h->psi.p, d.prog.p, d.tables.p, d.coef.p, stream));
+    else
+      HIPCHK(launch_pass_fwd(p.K, d.plan.R, a, cs, h->psi.p, d_bits, h->model.n, d.prog.p, d.tables.p, d.coef.p,
+                             h->op_scale.p, h->vals64.p, s0, stream));
     timer_end(ev, stream);
   }
   if (!d.plan.global_terms.empty() && !skip_measure)
@@ -677,6 +684,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "adjoint_tile_qubits") { h->opt_adj_tile = int(value); h->plans_valid = false; }
   else if (k == "adjoint_exchange") { h->opt_adj_exchange = int(value); h->plans_valid = false; }
   else if (k == "adjoint_relabel") { h->opt_adj_relabel = int(value); h->plans_valid = false; }
+  else if (k == "forward_pairs") h->opt_fwd_pair = int(value);
   else if (k == "observable_xcd_states") h->opt_obs_xcd_states = int(value);
   else if (k == "measure_tile_qubits") { h->opt_meas_tile = int(value); h->plans_valid = false; }
   else if (k == "values_from_observable") h->opt_values_from_obs = int(value);

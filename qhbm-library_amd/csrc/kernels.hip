@@ -968,6 +968,102 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
 }
 
 // ================================================================================
+// Forward pass on a PAIR of states (dense, lean, measurement-free passes): the exchange layout of the
+// adjoint kernel below applied to the forward sweep.  A workgroup holds the same tile of two consecutive
+// states in REGISTERS (16 + 16 amplitudes per thread) and runs every instance on both with one set of
+// scalar record fields; LDS is one tile-sized exchange buffer through which first one state, then the
+// other changes geometry between rounds.  Twice the packed-fp32 work per round trip, barrier, record
+// decode and thread -> index table as pass_fwd_kernel: that kernel sat at 0.70 of the VALU issue rate
+// (its waves wait on the LDS round trip between rounds), the adjoint kernel with this structure at 0.92.
+// Used when nothing distinguishes the two states' tiles: no tile pruned, nothing stale, no measurement
+// in the pass (or the values come from lambda = O psi), one program (engine.cpp run_forward_chunk).
+// ================================================================================
+template <int K>
+__global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_kernel(
+    PassArgs a, float2* __restrict__ psi, const uint32_t* __restrict__ prog_base, const uint32_t* __restrict__ tables,
+    const float* __restrict__ coef, uint32_t n_states) {
+  constexpr int R = 4;
+  constexpr int NT = 1 << (K - R);
+  constexpr int NR = 1 << R;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* xt = reinterpret_cast<float2*>(smem);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const uint32_t* recs = reinterpret_cast<const uint32_t*>(coef);
+  const uint32_t tile_id = blockIdx.x & ((1u << a.n_nonlocal) - 1u);
+  const uint32_t pair = blockIdx.x >> a.n_nonlocal;
+  const uint32_t s_a = 2u * pair, s_b = min(2u * pair + 1u, n_states - 1u);  // (an odd batch: the last state twice)
+  const TileCtx t = make_tile_ctx(a, tables, tile_id);
+  float2* st_a = psi + (size_t(s_a) << a.n);
+  float2* st_b = psi + (size_t(s_b) << a.n);
+  TileRegs ra, rb;
+  prefetch_tile<K, NT>(ra, st_a, t, tid);
+  prefetch_tile<K, NT>(rb, st_b, t, tid);
+  const uint32_t* prog = prog_base + a.prog_off;
+  uint32_t w0 = uni(prog[0]);
+  if ((w0 & 0xffu) != OP_ROUND) return;  // nothing to apply (measurement-only programs never come here)
+  constexpr RecordLayout L(R, false);
+  uint32_t pc = 0;
+  uint32_t cur[1], nxt[1];
+  uint32_t rec_off = uni(prog[2]);
+  rec_load<1>(recs, rec_off, lane, cur);
+  const uint32_t* tlt = tables + a.tl_off + uint32_t(tid);
+  uint32_t DB[R], T, TL = tlt[uni(prog[3])];
+  round_geometry<K, R>(uni(prog[1]), TL, DB, &T);
+  v2f p[NR], q[NR];
+  commit_tile<K, NT>(xt, ra, tid);
+  __syncthreads();
+  round_load<R>(xt, T, DB, p);
+  __syncthreads();
+  commit_tile<K, NT>(xt, rb, tid);
+  __syncthreads();
+  round_load<R>(xt, T, DB, q);
+  for (;;) {
+    const uint32_t n_inst = (w0 & ~kRoundNoBarrier) >> 8;
+    for (uint32_t inst = 0; inst < n_inst; ++inst) {
+      rec_load<1>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
+      instance_fwd<R, 1, false>(cur, recs, rec_off, lane, p, TL, t.tile_base);
+      instance_fwd<R, 1, false>(cur, recs, rec_off, lane, q, TL, t.tile_base);
+      rec_off += L.words();
+      cur[0] = nxt[0];
+    }
+    pc += kRoundWords;
+    const uint32_t w1 = uni(prog[pc]);
+    if ((w1 & 0xffu) != OP_ROUND) break;  // OP_MEASURE (ignored: see above) or OP_END
+    const bool sync = !(w0 & kRoundNoBarrier);  // else the next round's waves own the same amplitudes
+    uint32_t DBn[R], Tn;
+    const uint32_t TLn = tlt[uni(prog[pc + 3])];
+    round_geometry<K, R>(uni(prog[pc + 1]), TLn, DBn, &Tn);
+    const uint32_t next_off = uni(prog[pc + 2]);
+    if (next_off != rec_off) {
+      rec_off = next_off;
+      rec_load<1>(recs, rec_off, lane, cur);
+    }
+    round_store<R>(xt, T, DB, p);
+    if (sync) __syncthreads();
+    round_load<R>(xt, Tn, DBn, p);
+    if (sync) __syncthreads();
+    round_store<R>(xt, T, DB, q);
+    if (sync) __syncthreads();
+    round_load<R>(xt, Tn, DBn, q);
+#pragma unroll
+    for (int j = 0; j < R; ++j) DB[j] = DBn[j];
+    T = Tn;
+    TL = TLn;
+    w0 = w1;
+  }
+  if (a.flags & PASS_STORE) {
+    round_store<R>(xt, T, DB, p);
+    __syncthreads();
+    store_tile<K, NT>(xt, st_a, t, tid);
+    __syncthreads();
+    round_store<R>(xt, T, DB, q);
+    __syncthreads();
+    if (s_b != s_a) store_tile<K, NT>(xt, st_b, t, tid);
+  }
+}
+
+// ================================================================================
 // Adjoint pass kernels: tile pair (psi, lambda); program already in reverse order.
 // For each parametrised gate:  dE/dt = -2*pi * Im <lam| A |psi>  with psi, lam taken
 // AFTER the gate and A = sum_k e_k P_k, then both are multiplied by U^dagger.
@@ -1932,6 +2028,30 @@ hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, f
   QHBM_FWD_CASE(14, 4)
 #undef QHBM_FWD_CASE
   return hipErrorInvalidValue;
+}
+
+template <int K>
+static hipError_t launch_fwd2_t(const PassArgs& a, uint32_t n_states, float2* psi, const uint32_t* prog,
+                                const uint32_t* tables, const float* coef, hipStream_t stream) {
+  const size_t lds = size_t(8) << K;
+  static bool attr_done[kMaxDevices] = {};
+  if (hipError_t e = opt_in_lds(&pass_fwd2_kernel<K>, attr_done, lds); e != hipSuccess) return e;
+  const uint32_t grid = ((n_states + 1u) / 2u) << a.n_nonlocal;
+  hipLaunchKernelGGL((pass_fwd2_kernel<K>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, prog, tables, coef, n_states);
+  return hipGetLastError();
+}
+
+bool pass_fwd_pair_supported(int K) { return K >= 10 && K <= 13; }
+
+hipError_t launch_pass_fwd_pair(int K, const PassArgs& a, uint32_t n_states, float2* psi, const uint32_t* prog,
+                                const uint32_t* tables, const float* coef, hipStream_t stream) {
+  switch (K) {
+    case 10: return launch_fwd2_t<10>(a, n_states, psi, prog, tables, coef, stream);
+    case 11: return launch_fwd2_t<11>(a, n_states, psi, prog, tables, coef, stream);
+    case 12: return launch_fwd2_t<12>(a, n_states, psi, prog, tables, coef, stream);
+    case 13: return launch_fwd2_t<13>(a, n_states, psi, prog, tables, coef, stream);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_values_from_fixed(const unsigned long long* acc, const float* inv_scale, float* out, uint32_t count,
