@@ -420,9 +420,9 @@ int run_forward_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_
     hipEvent_t* ev = timer_begin(h, 0, stream);
     // dense lean passes without a measurement to take: two states per workgroup, tiles in registers
     const bool pair = h->opt_fwd_pair && cs >= 2 && !(a.flags & (PASS_INIT_BASIS | PASS_GENERAL)) && a.zero_mask == 0 &&
-                      a.frozen_old_local == 0 && (skip_measure || p.n_meas_groups == 0) && pass_fwd_pair_supported(p.K);
+                      (skip_measure || p.n_meas_groups == 0) && pass_fwd_pair_supported(p.K);
     if (pair)
-      HIPCHK(launch_pass_fwd_pair(p.K, a, cs, h->psi.p, d.prog.p, d.tables.p, d.coef.p, stream));
+      HIPCHK(launch_pass_fwd_pair(p.K, a, cs, h->psi.p, d_bits, h->model.n, s0, d.prog.p, d.tables.p, d.coef.p, stream));
     else
       HIPCHK(launch_pass_fwd(p.K, d.plan.R, a, cs, h->psi.p, d_bits, h->model.n, d.prog.p, d.tables.p, d.coef.p,
                              h->op_scale.p, h->vals64.p, s0, stream));

@@ -42,8 +42,9 @@ hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, f
 // The same pass on PAIRS of consecutive states, tile pair in registers (kernels.hip pass_fwd2_kernel): only for
 // lean passes that prune nothing, load nothing stale and measure nothing (or whose measurements are ignored).
 bool pass_fwd_pair_supported(int K);
-hipError_t launch_pass_fwd_pair(int K, const PassArgs& a, uint32_t n_states, float2* psi, const uint32_t* prog,
-                                const uint32_t* tables, const float* coef, hipStream_t stream);
+hipError_t launch_pass_fwd_pair(int K, const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits, int n_user,
+                                uint32_t state0, const uint32_t* prog, const uint32_t* tables, const float* coef,
+                                hipStream_t stream);
 hipError_t launch_values_from_fixed(const unsigned long long* acc, const float* inv_scale, float* out, uint32_t count,
                                     uint32_t n_ops, hipStream_t stream);
 // tile_grad [n_states * tiles, a.n_slots]: one gradient row per workgroup.  `exchange` selects the

@@ -980,8 +980,9 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
 // ================================================================================
 template <int K>
 __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_kernel(
-    PassArgs a, float2* __restrict__ psi, const uint32_t* __restrict__ prog_base, const uint32_t* __restrict__ tables,
-    const float* __restrict__ coef, uint32_t n_states) {
+    PassArgs a, float2* __restrict__ psi, const int8_t* __restrict__ bits, int n_user, uint32_t state0,
+    const uint32_t* __restrict__ prog_base, const uint32_t* __restrict__ tables, const float* __restrict__ coef,
+    uint32_t n_states) {
   constexpr int R = 4;
   constexpr int NT = 1 << (K - R);
   constexpr int NR = 1 << R;
@@ -999,6 +1000,17 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_ker
   TileRegs ra, rb;
   prefetch_tile<K, NT>(ra, st_a, t, tid);
   prefetch_tile<K, NT>(rb, st_b, t, tid);
+  if (a.frozen_old_local) {  // local bits nothing has acted on yet: their != input half was never written (per state)
+    const uint32_t idx_a = uni(basis_index(bits + size_t(state0 + s_a) * n_user, n_user));
+    const uint32_t idx_b = uni(basis_index(bits + size_t(state0 + s_b) * n_user, n_user));
+    uint32_t in_a = 0, in_b = 0;
+    for (int i = 0; i < K; ++i) {
+      in_a |= ((idx_a >> a.local_pos[i]) & 1u) << i;
+      in_b |= ((idx_b >> a.local_pos[i]) & 1u) << i;
+    }
+    clear_stale<K>(ra, tid, in_a, a.frozen_old_local);
+    clear_stale<K>(rb, tid, in_b, a.frozen_old_local);
+  }
   const uint32_t* prog = prog_base + a.prog_off;
   uint32_t w0 = uni(prog[0]);
   if ((w0 & 0xffu) != OP_ROUND) return;  // nothing to apply (measurement-only programs never come here)
@@ -2031,25 +2043,28 @@ hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, f
 }
 
 template <int K>
-static hipError_t launch_fwd2_t(const PassArgs& a, uint32_t n_states, float2* psi, const uint32_t* prog,
-                                const uint32_t* tables, const float* coef, hipStream_t stream) {
+static hipError_t launch_fwd2_t(const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits, int n_user,
+                                uint32_t state0, const uint32_t* prog, const uint32_t* tables, const float* coef,
+                                hipStream_t stream) {
   const size_t lds = size_t(8) << K;
   static bool attr_done[kMaxDevices] = {};
   if (hipError_t e = opt_in_lds(&pass_fwd2_kernel<K>, attr_done, lds); e != hipSuccess) return e;
   const uint32_t grid = ((n_states + 1u) / 2u) << a.n_nonlocal;
-  hipLaunchKernelGGL((pass_fwd2_kernel<K>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, prog, tables, coef, n_states);
+  hipLaunchKernelGGL((pass_fwd2_kernel<K>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, bits, n_user, state0, prog,
+                     tables, coef, n_states);
   return hipGetLastError();
 }
 
 bool pass_fwd_pair_supported(int K) { return K >= 10 && K <= 13; }
 
-hipError_t launch_pass_fwd_pair(int K, const PassArgs& a, uint32_t n_states, float2* psi, const uint32_t* prog,
-                                const uint32_t* tables, const float* coef, hipStream_t stream) {
+hipError_t launch_pass_fwd_pair(int K, const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits, int n_user,
+                                uint32_t state0, const uint32_t* prog, const uint32_t* tables, const float* coef,
+                                hipStream_t stream) {
   switch (K) {
-    case 10: return launch_fwd2_t<10>(a, n_states, psi, prog, tables, coef, stream);
-    case 11: return launch_fwd2_t<11>(a, n_states, psi, prog, tables, coef, stream);
-    case 12: return launch_fwd2_t<12>(a, n_states, psi, prog, tables, coef, stream);
-    case 13: return launch_fwd2_t<13>(a, n_states, psi, prog, tables, coef, stream);
+    case 10: return launch_fwd2_t<10>(a, n_states, psi, bits, n_user, state0, prog, tables, coef, stream);
+    case 11: return launch_fwd2_t<11>(a, n_states, psi, bits, n_user, state0, prog, tables, coef, stream);
+    case 12: return launch_fwd2_t<12>(a, n_states, psi, bits, n_user, state0, prog, tables, coef, stream);
+    case 13: return launch_fwd2_t<13>(a, n_states, psi, bits, n_user, state0, prog, tables, coef, stream);
     default: return hipErrorInvalidValue;
   }
 }
