@@ -739,6 +739,44 @@ __device__ __forceinline__ void instance_fwd(const uint32_t (&rv)[NV], const uin
   }
 }
 
+// The same instance on TWO register files (pass_fwd2_kernel: the same tile of two states): every micro-op's
+// scalar predicate, record fields and branch are paid once for both.  Lean programs only.
+template <int R, int J>
+__device__ __forceinline__ void cph_fwd2(v2f (&a)[1 << R], v2f (&b)[1 << R], v2f cs, uint32_t pred, uint32_t tl,
+                                         uint32_t tile_base) {
+  const bool on = (((pred >> 8) ? tile_base : tl) >> (pred & 0xffu)) & 1u;
+  if (__builtin_amdgcn_ballot_w64(on) == 0) return;
+  const v2f c2 = v2f{on ? cs.x : 1.f, on ? cs.y : 0.f};
+  apply_ph1_v<R, J>(a, c2);
+  apply_ph1_v<R, J>(b, c2);
+}
+template <int R, int NV>
+__device__ __forceinline__ void instance_fwd_pair(const uint32_t (&rv)[NV], const uint32_t* __restrict__ recs,
+                                                  uint32_t rec_off, v2f (&a)[1 << R], v2f (&b)[1 << R], uint32_t tl,
+                                                  uint32_t tile_base) {
+  constexpr RecordLayout L(R, false);
+  const RecBase rb{recs + rec_off};
+  const uint32_t h0 = rec_word<0>(rv, rb), h1 = rec_word<1>(rv, rb);
+  QHBM_FOR_RB(R, if ((h0 >> J) & 1u) { const v2f cs = rec_cs<L.x(J)>(rv, rb); apply_x<R, J>(a, cs); apply_x<R, J>(b, cs); })
+  if (h1 & kFullDiagFlag) { apply_full<NV>(a, rv, rb, false); apply_full<NV>(b, rv, rb, false); }
+  QHBM_FOR_RB(R, if ((h0 >> (8 + J)) & 1u) { const v2f cs = rec_cs<L.ph1(J)>(rv, rb); apply_ph1<R, J>(a, cs); apply_ph1<R, J>(b, cs); })
+  if ((h0 >> 16) & 0x3fu) {
+    QHBM_FOR_PAIR(R,
+      if ((h0 >> (16 + pair_index(JA, JB))) & 1u) {
+        const v2f cs = rec_cs<L.ph2(pair_index(JA, JB))>(rv, rb);
+        apply_ph2<R, JA, JB>(a, cs);
+        apply_ph2<R, JA, JB>(b, cs);
+      })
+  }
+  if (h1 & 0xffu) {
+    QHBM_FOR_RB(R,
+      if ((h1 >> (2 * J)) & 1u)
+        cph_fwd2<R, J>(a, b, rec_cs<L.cph(2 * J)>(rv, rb), rec_word<L.pred(2 * J)>(rv, rb), tl, tile_base);
+      if ((h1 >> (2 * J + 1)) & 1u)
+        cph_fwd2<R, J>(a, b, rec_cs<L.cph(2 * J + 1)>(rv, rb), rec_word<L.pred(2 * J + 1)>(rv, rb), tl, tile_base);)
+  }
+}
+
 // Measurement helpers (register file indexed by the high bits of the local index).
 __device__ __forceinline__ v2f meas_w(const float2* __restrict__ tile, uint32_t s, uint32_t xs) {
   const float2 p = tile[s];
@@ -1034,8 +1072,7 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_ker
     const uint32_t n_inst = (w0 & ~kRoundNoBarrier) >> 8;
     for (uint32_t inst = 0; inst < n_inst; ++inst) {
       rec_load<1>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
-      instance_fwd<R, 1, false>(cur, recs, rec_off, lane, p, TL, t.tile_base);
-      instance_fwd<R, 1, false>(cur, recs, rec_off, lane, q, TL, t.tile_base);
+      instance_fwd_pair<R, 1>(cur, recs, rec_off, p, q, TL, t.tile_base);
       rec_off += L.words();
       cur[0] = nxt[0];
     }
