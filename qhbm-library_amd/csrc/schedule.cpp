@@ -1152,6 +1152,15 @@ std::string describe_plan(const Plan& p) {
         }
       os << "  slots per eight-wide reduction 1..8:";
       for (int c = 1; c <= 8; ++c) os << " " << hist[c];
+      int half[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // per slot group: all in values 0..3 / all in 4..7 / both
+      for (uint32_t off : p.record_offsets)
+        for (int g8 = 0; g8 < 4; ++g8) {
+          int lo = 0, hi = 0;
+          for (int v = 0; v < 8; ++v) (v < 4 ? lo : hi) += p.coef_init[off + L.slot_lane8(g8, v)] != 0xffffffffu;
+          if (lo + hi) ++half[g8][lo && hi ? 2 : (lo ? 0 : 1)];
+        }
+      os << "; by group (X+PH1 | PH2 | CPH | Y+dense) low-half only / high-half only / both:";
+      for (int g8 = 0; g8 < 4; ++g8) os << " " << half[g8][0] << "/" << half[g8][1] << "/" << half[g8][2];
       os << "\n";
     }
     os << "  census: instances=" << n_inst << " (FULL " << n_full << ") X=" << x << " PH1=" << ph1 << " PH2=" << ph2

@@ -538,3 +538,63 @@ def test_single_observable_values_from_lambda_match_the_measured_ones(n, tile):
     results.append((vals.cpu().numpy(), grad.cpu().numpy()))
   np.testing.assert_allclose(results[0][0], results[1][0], atol=5e-6 * _op_norm([op]).max(), rtol=0)
   np.testing.assert_allclose(results[0][1], results[1][1], atol=5e-5 * max(1.0, np.abs(want_grad).max()), rtol=0)
+
+
+# ---- round-3 layouts: relabeling adjoint plans, compact grids, paired forward passes ---------------
+@pytest.mark.parametrize("n,layers,tile,states,seed", [(13, 6, 10, 5, 1), (14, 9, 10, 4, 2), (15, 8, 11, 3, 3),
+                                                        (16, 12, 12, 7, 4), (17, 14, 12, 2, 5), (16, 5, 11, 1, 6)])
+def test_lean_chain_circuits_under_every_layout_switch(n, layers, tile, states, seed):
+  """Lean circuits (X / Z / CZ / ZZ powers, constant and parametrised, on a scrambled chain) deep enough
+  for finished bits, with ODD and single-state batches: the default engine -- adjoint plans that relabel
+  finished index bits, grids of live tiles only, dense forward passes on pairs of states, a first forward
+  pass that writes one tile per state -- against the oracle, and against the same engine with each of those
+  switched off (`adjoint_relabel`, `forward_pairs`, `cph_wave_bits`), value + VJP (single observable:
+  values from lambda = O psi) and two observables (measured values), chunked and retained."""
+  rng = np.random.default_rng(9000 + seed)
+  n_params = 7
+  perm = rng.permutation(n)
+  gates = []
+  for layer in range(layers):
+    for q in range(n):
+      if rng.random() < 0.85:
+        gates.append((E.GATE_XPOW, int(perm[q]), -1, int(rng.integers(n_params)) if rng.random() < 0.8 else -1,
+                      float(rng.uniform(-1.2, 1.2)), float(rng.uniform(-0.4, 0.4))))
+      if rng.random() < 0.7:
+        gates.append((E.GATE_ZPOW, int(perm[q]), -1, int(rng.integers(n_params)), float(rng.uniform(-1, 1)), 0.1))
+    for q0 in range(layer % 2, n - 1, 2):
+      kind = E.GATE_CZPOW if rng.random() < 0.75 else E.GATE_ZZPOW
+      gates.append((kind, int(perm[q0]), int(perm[q0 + 1]), int(rng.integers(n_params)) if rng.random() < 0.9 else -1,
+                    float(rng.uniform(-1, 1)), float(rng.uniform(-0.3, 0.3))))
+  params = rng.uniform(-1, 1, n_params)
+  bits = _random_bits(rng, states, n)
+  xxz = O.xxz_chain_op(n)
+  opts = dict(tile_qubits=tile, adjoint_tile_qubits=min(tile, 12))
+  up1 = rng.normal(size=(states, 1)).astype(np.float32)
+  want_v, want_jac = O.expectation_jacobian(n, gates, params, bits[:2], [xxz])
+  results = {}
+  for name, extra in (("default", {}), ("no-relabel", dict(adjoint_relabel=0)), ("no-pairs", dict(forward_pairs=0)),
+                      ("plain", dict(cph_wave_bits=0)), ("chunked", dict(chunk_states=2))):
+    eng = _engine(n, gates, n_params, [xxz], **opts, **extra)
+    vals, grad = eng.expectation_vjp(bits, params, up1)
+    rows = eng.state_gradients(states).cpu().numpy()
+    results[name] = (vals.cpu().numpy(), grad.cpu().numpy(), rows)
+    if name == "default":
+      assert "relabeling" in eng.describe_schedule() or eng.num_passes()[1] == 1
+      np.testing.assert_allclose(vals.cpu().numpy()[:2], want_v, atol=2e-5 * _op_norm([xxz])[0])
+      want_rows = up1[:2] * want_jac[:, 0, :]
+      np.testing.assert_allclose(rows[:2], want_rows, atol=2e-4 * max(1.0, np.abs(want_rows).max()))
+      # forward now, backward later from the retained states
+      eng.expectation(bits, params, retain=True)
+      if eng.retained is not None:
+        np.testing.assert_allclose(eng.expectation_vjp_retained(bits, params, up1).cpu().numpy(), grad.cpu().numpy(),
+                                   atol=1e-6 * max(1.0, float(np.abs(grad.cpu().numpy()).max())))
+  scale = max(1.0, np.abs(results["default"][1]).max())
+  for name, (v, g, r) in results.items():
+    np.testing.assert_allclose(v, results["default"][0], atol=3e-5, err_msg=name)
+    np.testing.assert_allclose(g, results["default"][1], atol=3e-5 * scale, err_msg=name)
+    np.testing.assert_allclose(r, results["default"][2], atol=3e-5 * scale, err_msg=name)
+  # two observables: the forward sweep measures (no paired passes where a pass measures), full Jacobian of two states
+  ops2 = [xxz, O.tfim_ring_op(n)]
+  eng = _engine(n, gates, n_params, ops2, **opts)
+  check_values(eng, n, gates, params, bits, ops2, rel=3e-5)
+  check_jacobian(eng, n, gates, params, bits[:1], ops2, rel=3e-4)
