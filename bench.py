@@ -500,13 +500,15 @@ def main():
       try:
         from oracle import qhbm_cpu as C  # pylint: disable=import-outside-toplevel
         k = max(1, min(args.cpu_sample_states, spg, C.max_threads(), os.cpu_count() or 1))
+        if world > 1:   # the CPU baseline is an N = 1 figure; N > 1 runs keep the parity check on a few states
+          k = min(k, 8)
         bits_k = all_bits[lo:lo + k]
         # upstream 1/K: see parity_check; the rate does not depend on the weight
         oracle_params = params_np
         if os.environ.get("QHBM_BENCH_CORRUPT_PARITY") == "1":   # test hook: the check must be able to fail
           oracle_params = params_np + np.float32(0.05)
         rec, o_vals, o_grad = cpu_baseline(n, gates, n_params, op, oracle_params, bits_k, 1.0 / k, args.mode)
-        line["cpu_baseline"] = rec
+        line["cpu_baseline"] = rec if world == 1 else None
         if rec is not None:
           timed_rows = vals[:k].float().cpu().numpy()   # global rows lo..lo+k are rank 0's own block
           line["parity_check"] = parity_check(eng, E, args.mode, op, bits_k, params, timed_rows, o_vals, o_grad)
