@@ -130,7 +130,12 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
  * on predicates that are off / on zeros of psi, and adjoint tail passes use tiles without the low
  * index bits; 0 = the plain layout, for A/B measurements), "values_from_observable" (1 = with a single
  * observable the expectation value is taken from lambda = O psi in the calls that compute lambda
- * anyway, and the forward sweep measures nothing; 0 = always measure in the forward sweep).
+ * anyway, and the forward sweep measures nothing; 0 = always measure in the forward sweep),
+ * "adjoint_relabel" (1 = adjoint plans move finished index bits out of the 128-byte lines when the finishing
+ * pass stores its tiles), "forward_pairs" (1 = dense lean forward passes run on pairs of states with the
+ * tiles in registers), "wide_last_pass" (-1 = the last forward gate pass may take a tile one or two bits
+ * wider when that saves a pass, unless tile_qubits is set; 0 = never; 1 = always), "observable_xcd_states"
+ * (1 = lambda = O psi works on one state per XCD at a time).
  */
 int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value);
 

@@ -77,6 +77,7 @@ struct qhbm_engine {
   int opt_values_from_obs = 1;  // single observable: <psi|O|psi> from lambda = O psi, no measurement in the forward sweep
   bool retained_mu = false;     // the retained batch also holds the unweighted lambda = O psi
   int opt_cph_wave_bits = 1; // boundary controlled-phase predicates on wave bits (schedule.h Plan::cph_wave_bits)
+  int opt_wide_last = -1;      // forward: the last gate pass may take a tile one or two bits wider (-1: unless tile_qubits is set)
   int opt_fwd_pair = 1;        // dense lean forward passes run on pairs of states, tiles in registers (pass_fwd2_kernel)
   int opt_adj_relabel = 1;     // adjoint plans move finished index bits out of the 128-byte lines (schedule.h Pass)
   int opt_obs_xcd_states = 1;  // lambda = O psi: one state per XCD at a time (kernels.hip apply_observable_kernel)
@@ -253,7 +254,7 @@ int build_plans(qhbm_engine* h) {
   if (h->model.n_ops > kMaxOps) return fail(h, "too many observables (max 1024)");
   std::string err;
   if (!build_plan(h->model, h->opt_tile, h->opt_round, false, &h->fwd.plan, &err, h->opt_full_fwd, h->opt_meas_tile,
-                  h->opt_cph_wave_bits != 0))
+                  h->opt_cph_wave_bits != 0, false, h->opt_wide_last))
     return fail(h, "forward plan: " + err);
   if (!build_plan(h->model, h->opt_adj_tile, 0, true, &h->adj.plan, &err, h->opt_full_adj, 0, h->opt_cph_wave_bits != 0,
                   h->opt_adj_relabel != 0 && h->opt_adj_exchange != 0))
@@ -685,6 +686,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "adjoint_exchange") { h->opt_adj_exchange = int(value); h->plans_valid = false; }
   else if (k == "adjoint_relabel") { h->opt_adj_relabel = int(value); h->plans_valid = false; }
   else if (k == "forward_pairs") h->opt_fwd_pair = int(value);
+  else if (k == "wide_last_pass") { h->opt_wide_last = int(value); h->plans_valid = false; }
   else if (k == "observable_xcd_states") h->opt_obs_xcd_states = int(value);
   else if (k == "measure_tile_qubits") { h->opt_meas_tile = int(value); h->plans_valid = false; }
   else if (k == "values_from_observable") h->opt_values_from_obs = int(value);

@@ -527,7 +527,7 @@ class Builder {
 }  // namespace
 
 bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Plan* plan, std::string* err,
-                int full_threshold, int meas_tile_bits, bool cph_wave_bits, bool relabel) {
+                int full_threshold, int meas_tile_bits, bool cph_wave_bits, bool relabel, int wide_last_pass) {
   *plan = Plan();
   plan->full_threshold = full_threshold;
   plan->cph_wave_bits = cph_wave_bits;
@@ -756,7 +756,8 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     double kFixed = 6.0, kMemory = 17.0;
     if (const char* e = std::getenv("QHBM_PLAN_KFIXED")) kFixed = std::atof(e);    // developer knobs (scripts/plan_constants_probe.sh)
     if (const char* e = std::getenv("QHBM_PLAN_KMEMORY")) kMemory = std::atof(e);  // per pass, in units of one unpruned gate (config 3: 24.6 ms of tile I/O against 1.4 ms per gate; the fixed part 3, 5 and 7 measured alike, 10 and 16 worse)
-    const size_t kBeam = ops.size() <= 4000 ? 16 : (ops.size() <= 12000 ? 8 : 4);  // planning time stays ~ a second
+    size_t kBeam = ops.size() <= 4000 ? 16 : (ops.size() <= 12000 ? 8 : 4);  // planning time stays well below a second
+    if (const char* e = std::getenv("QHBM_PLAN_BEAM")) kBeam = size_t(std::max(1, std::atoi(e)));
     auto finished_bits = [&](const std::vector<char>& dn) {
       uint32_t pend = 0;
       for (size_t oi = 0; oi < ops.size(); ++oi) if (!dn[oi] && ops[oi].type != LOW_DIAG) pend |= ops[oi].bits;
@@ -877,6 +878,27 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
 
   while (n_done < ops.size()) {
     std::vector<uint32_t> cands = planned_i < planned.size() ? std::vector<uint32_t>{planned[planned_i++]} : gen_cands(done, phys);
+    // A WIDER last pass: when everything that is left needs one or two index bits more than a tile has, the
+    // last gate pass takes a tile of 2^(K+1) or 2^(K+2) amplitudes instead of leaving a pass of its own to a
+    // handful of gates (config 3: 33 gates on 13 bits were 32 + 1 in two passes, the second a full read and
+    // write of the state for ONE gate: 14 of the forward sweep's 110 ms).
+    int wide_K = 0;
+    uint32_t wide_S = 0;
+    // (not for the first pass, and not against an explicit tile size unless asked for: wide_last_pass = 1)
+    const bool widen = wide_last_pass > 0 || (wide_last_pass < 0 && tile_bits == 0);
+    if (!adjoint && K < n_eff && plan->tail_tiles && widen && !plan->passes.empty() && !std::getenv("QHBM_NO_WIDE_LAST_PASS")) {
+      uint32_t S = (1u << c_min) - 1;
+      for (int oi : order) {
+        if (done[oi]) continue;
+        const LoweredOp& op = ops[oi];
+        S |= op.type == LOW_DIAG ? (op.bits & S ? 0u : (op.bits & (0u - op.bits))) : op.bits;
+      }
+      const int need = popc(S);
+      if (need > K && need <= std::min(K + 2, std::min(n_eff, 13))) {  // (13: the paired forward kernel's largest tile)
+        wide_K = need;
+        wide_S = S;
+      }
+    }
     if (!adjoint && K < n_eff && !groups.empty()) {
       // If one tile can hold every remaining op, this is the last gate pass: spend its spare local
       // bits on the X-masks of the groups no earlier pass can measure, so that the measurement
@@ -939,7 +961,18 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
       }
     }
     if (best_list.empty()) { *err = "scheduler made no progress"; return false; }
-    Pass p = b.begin_pass(best_S, &phys);
+    Builder wide(m, wide_K ? wide_K : K, R, n_eff, adjoint, plan);
+    Builder* bp = &b;
+    if (wide_K) {  // does the wider tile really take everything that is left?
+      int n_mat = 0;
+      std::vector<int> all_left = absorb(ops, order, done, wide_S, all_bits, &n_mat);
+      if (all_left.size() == ops.size() - n_done) {
+        best_S = wide_S;
+        best_list.swap(all_left);
+        bp = &wide;
+      }
+    }
+    Pass p = bp->begin_pass(best_S, &phys);
     p.frozen_old_local = Builder::to_local(p, frozen & best_S);
     p.slot_base = int(plan->slot_gate.size());
     {
@@ -948,9 +981,9 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
       uint32_t pend = 0;
       for (size_t oi = 0; oi < ops.size(); ++oi)
         if (!done[oi] && !here[oi] && ops[oi].type != LOW_DIAG) pend |= ops[oi].bits;
-      b.pending_mat_outside_ = pend;
+      bp->pending_mat_outside_ = pend;
     }
-    if (!b.emit_ops(&p, ops, best_list, err)) return false;
+    if (!bp->emit_ops(&p, ops, best_list, err)) return false;
     {
       // The zero-tile / dead-wave pruning (engine.cpp fill_args, emit_round's dead masks) is sound only
       // if Pass::mat_bits lists EVERY index bit a non-diagonal op of the pass acts on: a new lowered op
@@ -995,7 +1028,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     if (plan->relabel) {  // the relabeling store exists in the exchange-layout kernel only (lean programs)
       bool general = false;
       for (const Pass& p : plan->passes) general |= (p.flags & PASS_GENERAL) != 0;
-      if (general) return build_plan(m, tile_bits, round_bits, adjoint, plan, err, full_threshold, meas_tile_bits, cph_wave_bits, false);
+      if (general) return build_plan(m, tile_bits, round_bits, adjoint, plan, err, full_threshold, meas_tile_bits, cph_wave_bits, false, wide_last_pass);
     }
     for (Pass& p : plan->passes) {
       p.flags |= PASS_ADJOINT | PASS_STORE;

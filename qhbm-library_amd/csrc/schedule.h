@@ -117,7 +117,7 @@ struct Model {
 // `meas_tile_bits`: tile size of measurement-only passes (0 = the largest the forward kernel has).
 bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Plan* out,
                 std::string* err, int full_threshold = 60, int meas_tile_bits = 0, bool cph_wave_bits = true,
-                bool relabel = false);
+                bool relabel = false, int wide_last_pass = -1);
 
 std::string describe_plan(const Plan& p);
 

@@ -548,7 +548,8 @@ def test_lean_chain_circuits_under_every_layout_switch(n, layers, tile, states, 
   for finished bits, with ODD and single-state batches: the default engine -- adjoint plans that relabel
   finished index bits, grids of live tiles only, dense forward passes on pairs of states, a first forward
   pass that writes one tile per state -- against the oracle, and against the same engine with each of those
-  switched off (`adjoint_relabel`, `forward_pairs`, `cph_wave_bits`), value + VJP (single observable:
+  switched off (`adjoint_relabel`, `forward_pairs`, `cph_wave_bits`) and with the wider last forward pass forced
+  on against the explicit tile size (`wide_last_pass`), value + VJP (single observable:
   values from lambda = O psi) and two observables (measured values), chunked and retained."""
   rng = np.random.default_rng(9000 + seed)
   n_params = 7
@@ -573,7 +574,8 @@ def test_lean_chain_circuits_under_every_layout_switch(n, layers, tile, states, 
   want_v, want_jac = O.expectation_jacobian(n, gates, params, bits[:2], [xxz])
   results = {}
   for name, extra in (("default", {}), ("no-relabel", dict(adjoint_relabel=0)), ("no-pairs", dict(forward_pairs=0)),
-                      ("plain", dict(cph_wave_bits=0)), ("chunked", dict(chunk_states=2))):
+                      ("plain", dict(cph_wave_bits=0)), ("chunked", dict(chunk_states=2)),
+                      ("wide-last-pass", dict(wide_last_pass=1))):
     eng = _engine(n, gates, n_params, [xxz], **opts, **extra)
     vals, grad = eng.expectation_vjp(bits, params, up1)
     rows = eng.state_gradients(states).cpu().numpy()
