@@ -30,7 +30,7 @@ struct ObsGroup {
 constexpr uint32_t obs_amps_per_thread(uint32_t n) { return n >= 11 ? 8u : 4u; }  // A of apply_observable_kernel<A>
 constexpr uint32_t kObsThreadMask = 0x1feu;                                        // index bits 1..8 = the thread
 constexpr uint32_t obs_slot_mask(uint32_t n) { return 1u | ((obs_amps_per_thread(n) / 2u - 1u) << 9); }  // bit 0 and 9 (, 10)
-constexpr uint32_t kObsTermChunk = 512;  // 2 x the terms staged in LDS at a time (12 KiB: five workgroups per CU)
+constexpr uint32_t kObsTermChunk = 512;  // 2 x the terms staged in LDS at a time (13 KiB: five workgroups per CU)
 
 size_t fwd_lds_bytes(int K);
 size_t adj_lds_bytes(int K, bool exchange);

@@ -1562,15 +1562,23 @@ __global__ __launch_bounds__(1024) void reduce_tiles_kernel(const float* __restr
 template <int A> struct ObsStage {
   float4 term[kObsTermChunk / 2];     // z bits, weight (re), weight (im), --      (general path)
   float flip[kObsTermChunk / 2][A];   // real weight, pre-signed for slot s         (real-weight path)
+  uint32_t live[kObsTermChunk / 2];   // [first term of a group] pairs of slots whose weight is not exactly zero
 };
 constexpr uint32_t kObsChunk = kObsTermChunk / 2;  // terms staged in LDS at a time
 // index bits of slot s inside the block (kernels.h obs_slot_mask is their union)
 template <int A> __device__ __forceinline__ constexpr uint32_t obs_slot_bits(int s) { return uint32_t(s & 1) | (uint32_t(s >> 1) << 9); }
 // the partners j ^ x of a thread's A / 2 adjacent pairs: one 16-byte load per pair (x with bit 0 cleared)
+// Only the pairs of `live` are fetched: the terms of a mask often cancel on part of the index space -- XX + YY on a
+// pair of qubits is zero where the two bits are equal --, and where the mask's qubits are block or slot bits the
+// whole workgroup sees weight 0 for those slots (config 3: half of the partner runs).  A pair that is not
+// fetched holds the thread's own amplitudes instead and is multiplied by exactly 0.
 template <int A>
-__device__ __forceinline__ void obs_gather(float4 (&buf)[A / 2], const float2* __restrict__ ps, uint32_t j0, uint32_t x) {
+__device__ __forceinline__ void obs_gather(float4 (&buf)[A / 2], const float2* __restrict__ ps, uint32_t j0, uint32_t x,
+                                           uint32_t live) {
+  if (live == 0) return;
 #pragma unroll
-  for (int p = 0; p < A / 2; ++p) buf[p] = *reinterpret_cast<const float4*>(&ps[(j0 + 512u * p) ^ (x & ~1u)]);
+  for (int p = 0; p < A / 2; ++p)  // (no branch per pair: a dead one re-reads the thread's own pair, a hit in the nearest cache)
+    buf[p] = *reinterpret_cast<const float4*>(&ps[(j0 + 512u * p) ^ ((live >> p) & 1u ? x & ~1u : 0u)]);
 }
 // One group: acc[s] += (signed weight sum of the group's terms at slot s) * psi[j ^ x].  `buf` holds the
 // gathered partners if the mask leaves the block; a mask inside the block reads the block's LDS copy.
@@ -1653,7 +1661,7 @@ __device__ __forceinline__ void obs_consume(const ObsGroup& gr, float4 (&buf)[A 
 // value_part[state, workgroup] (value_parts_kernel) -- the forward sweep then needs no measurement at all, and the caller applies the
 // upstream weight to the state's gradient row (the adjoint sweep is linear in lambda).
 template <int A, bool VALUE>
-__global__ __launch_bounds__(256) void apply_observable_kernel(
+__global__ __launch_bounds__(256, 5) void apply_observable_kernel(
     const float2* __restrict__ psi, float2* __restrict__ lam, uint32_t n, const DevTerm* __restrict__ terms,
     uint32_t n_terms, const ObsGroup* __restrict__ groups, uint32_t n_groups,
     const float* __restrict__ upstream, uint32_t n_ops, uint32_t state0, float* __restrict__ value_part,
@@ -1692,7 +1700,9 @@ __global__ __launch_bounds__(256) void apply_observable_kernel(
   ObsGroup gr = n_groups ? groups[0] : ObsGroup{0u, 0u, 0u, 0u, 0u};
   float4 cur[P];
 #pragma unroll
-  for (int p = 0; p < P; ++p) *reinterpret_cast<float4*>(&own[tb + 512u * p]) = self[p];
+  for (int p = 0; p < P; ++p) {
+    *reinterpret_cast<float4*>(&own[tb + 512u * p]) = self[p];
+  }
   v2f acc[A];
 #pragma unroll
   for (int a = 0; a < A; ++a) acc[a] = v2f{0.f, 0.f};
@@ -1717,21 +1727,33 @@ __global__ __launch_bounds__(256) void apply_observable_kernel(
     __syncthreads();
     // one pre-summed weight per slot for the thread-independent terms of every real group
     // of the chunk, written over the first of them (flip[begin][a])
+    // ... and the pairs of slots the group does not vanish on (obs_gather): all of them unless every term of
+    // the group is thread-independent and the weights of both slots of a pair add up to exactly 0
     for (uint32_t gi = g + threadIdx.x / uint32_t(A); gi < n_groups; gi += 256u / uint32_t(A)) {
       const ObsGroup gq = groups[gi];
       if (gq.end > k1) break;
+      const uint32_t kb = gi ? groups[gi - 1u].end : 0u, a = threadIdx.x % uint32_t(A);
+      float sum = st.flip[kb - k0][a];
       if (gq.n_h > 1u) {
-        const uint32_t kb = gi ? groups[gi - 1u].end : 0u, a = threadIdx.x % uint32_t(A);
-        float sum = st.flip[kb - k0][a];
         for (uint32_t k = kb + 1u; k < kb + gq.n_h; ++k) sum += st.flip[k - k0][a];
         st.flip[kb - k0][a] = sum;
       }
+      // the A lanes of a group are consecutive lanes of one wave
+      const uint32_t nz = uint32_t(__ballot(sum != 0.f) >> ((threadIdx.x & 63u) / uint32_t(A) * uint32_t(A))) & ((1u << A) - 1u);
+      uint32_t pairs = 0;
+#pragma unroll
+      for (int p = 0; p < P; ++p) pairs |= ((nz >> (2 * p)) & 3u) ? 1u << p : 0u;
+      if (a == 0) st.live[kb - k0] = (gq.has_imag || gq.n_h != gq.end - kb) ? (1u << P) - 1u : pairs;
     }
     __syncthreads();
     uint32_t k = k0;
+    uint32_t live_next = st.live[0];  // read one group ahead: the gathers must not wait for it
     while (g < n_groups && gr.end <= k1) {  // gr = groups[g], wave-uniform
-      if (gr.x >= 256u * A) obs_gather<A>(cur, ps, j0, gr.x);
-      obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);
+      const uint32_t live = uni(live_next);
+      if (gr.x >= 256u * A) obs_gather<A>(cur, ps, j0, gr.x, live);
+      live_next = st.live[min(gr.end - k0, kObsChunk - 1u)];  // (past the chunk's last group: unused)
+      if (live) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);  // else: the group vanishes on the whole block
+      else k = gr.end;
       ++g;
       if (g < n_groups) gr = groups[g];
     }

@@ -337,6 +337,44 @@ def test_pauli_terms_wider_than_a_tile():
   np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=1e-4 * max(1.0, np.abs(want_grad).max()))
 
 
+@pytest.mark.parametrize("n,layers", [(9, 2), (16, 2), (20, 1)])
+def test_masks_whose_terms_cancel_on_part_of_the_index_space(n, layers):
+  """lambda = O psi skips the partner runs of a mask on the blocks (and slot pairs) where the weights of its
+  terms add up to exactly zero: XX + YY on two qubits vanishes where their bits are equal.  The skip must not
+  fire when the cancellation is only partial (unequal coefficients, different operators with different
+  upstream weights, a Z factor on a thread bit), and a zero upstream weight kills every mask of its operator.
+  Single observable (values from lambda, unweighted) and several (weighted), against the C oracle."""
+  from oracle import qhbm_cpu as C
+  rng = np.random.default_rng(n)
+  gates, names = O.hea_gates(n, layers, "z")
+  params = rng.uniform(-1, 1, len(names)).astype(np.float32)
+  pairs = [(a, b) for a, b in [(0, 1), (n - 2, n - 1), (n - 1, 0), (n // 2, n - 1), (3, n - 3)] if a != b]
+  flipflop = [t for a, b in pairs for t in (O.pauli_term(1.0, [(a, "X"), (b, "X")]), O.pauli_term(1.0, [(a, "Y"), (b, "Y")]))]
+  unequal = [t for a, b in pairs for t in (O.pauli_term(0.75, [(a, "X"), (b, "X")]), O.pauli_term(-0.5, [(a, "Y"), (b, "Y")]))]
+  dressed = [t for a, b in pairs[1:] for t in (O.pauli_term(1.0, [(a, "X"), (b, "X"), (2, "Z")]),
+                                                O.pauli_term(1.0, [(a, "Y"), (b, "Y"), (2, "Z")]))]
+  xx_only = [O.pauli_term(1.0, [(a, "X"), (b, "X")]) for a, b in pairs]
+  yy_only = [O.pauli_term(1.0, [(a, "Y"), (b, "Y")]) for a, b in pairs]
+  bits = _random_bits(rng, 6, n)
+  for op in (flipflop, unequal, flipflop + dressed + O.xxz_chain_op(n)):          # values from lambda = O psi
+    eng = _engine(n, gates, len(names), [op])
+    up = rng.normal(size=(6, 1)).astype(np.float32)
+    vals, grad = eng.expectation_vjp(bits, params, up)
+    want, want_grad = C.expectation_vjp(n, gates, params, bits, [op], up)
+    np.testing.assert_allclose(vals.cpu().numpy(), want, atol=2e-5 * _op_norm([op])[0])
+    np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=1e-4 * max(1.0, np.abs(want_grad).max()))
+  ops = [flipflop, xx_only, yy_only, dressed]                                       # weighted: XX and YY of ops 1, 2 share masks
+  eng = _engine(n, gates, len(names), ops)
+  for up in (rng.normal(size=(6, 4)).astype(np.float32),
+             np.tile(np.array([[0.0, 1.0, 1.0, 0.0]], np.float32), (6, 1)),           # ops 1 + 2 cancel like op 0 alone
+             np.tile(np.array([[0.0, 1.0, 0.5, 0.0]], np.float32), (6, 1)),
+             np.zeros((6, 4), np.float32)):
+    vals, grad = eng.expectation_vjp(bits, params, up)
+    want, want_grad = C.expectation_vjp(n, gates, params, bits, ops, up)
+    np.testing.assert_allclose(vals.cpu().numpy(), want, atol=2e-5 * _op_norm(ops).max())
+    np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=1e-4 * max(1.0, np.abs(want_grad).max()))
+
+
 def test_results_are_bit_reproducible_and_independent_of_chunking():
   """No floating-point atomics anywhere: expectation values accumulate in 64-bit fixed point,
   gradient partials go wave -> tile -> state in fixed order.  Two runs, and a run cut into chunks
