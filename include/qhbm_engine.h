@@ -131,6 +131,9 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
  * index bits; 0 = the plain layout, for A/B measurements), "values_from_observable" (1 = with a single
  * observable the expectation value is taken from lambda = O psi in the calls that compute lambda
  * anyway, and the forward sweep measures nothing; 0 = always measure in the forward sweep),
+ * "forward_values_from_observable" (forward-only calls with a single observable: -1 = the same kernel, storing
+ * nothing, supplies the value when the plan has more than one pass and some term flips two or more qubits or
+ * needs a measurement-only pass; 0 = measure in the passes; 1 = always),
  * "adjoint_relabel" (1 = adjoint plans move finished index bits out of the 128-byte lines when the finishing
  * pass stores its tiles), "forward_pairs" (1 = dense lean forward passes run on pairs of states with the
  * tiles in registers), "wide_last_pass" (-1 = the last forward gate pass may take a tile one or two bits

@@ -77,6 +77,8 @@ struct qhbm_engine {
   int opt_values_from_obs = 1;  // single observable: <psi|O|psi> from lambda = O psi, no measurement in the forward sweep
   bool retained_mu = false;     // the retained batch also holds the unweighted lambda = O psi
   int opt_cph_wave_bits = 1; // boundary controlled-phase predicates on wave bits (schedule.h Plan::cph_wave_bits)
+  int opt_fwd_values_obs = -1; // forward-only calls, one observable: values from the lambda = O psi kernel (no lambda stored) instead of
+                               // measurements in the passes (-1: when the plan has more than one pass, i.e. the state is in HBM anyway)
   int opt_wide_last = -1;      // forward: the last gate pass may take a tile one or two bits wider (-1: unless tile_qubits is set)
   int opt_fwd_pair = 1;        // dense lean forward passes run on pairs of states, tiles in registers (pass_fwd2_kernel)
   int opt_adj_relabel = 1;     // adjoint plans move finished index bits out of the 128-byte lines (schedule.h Pass)
@@ -402,6 +404,18 @@ void timer_end(hipEvent_t* e, hipStream_t s) { if (e) (void)hipEventRecord(*e, s
 // every measurement of the forward sweep.
 bool value_mode(const qhbm_engine* h) { return h->opt_values_from_obs != 0 && h->model.n_ops == 1; }
 
+// Forward-only calls: whether <psi|O|psi> comes from the lambda = O psi kernel (storing nothing) after lean passes.
+bool forward_values_from_observable(const qhbm_engine* h) {
+  if (!value_mode(h) || h->opt_fwd_values_obs == 0) return false;
+  if (h->opt_fwd_values_obs > 0) return true;
+  // measured (scripts/fwd_values_ab.sh): XXZ at 20 qubits - 17 %, 512 random Pauli strings at 24 qubits - 12 %;
+  // sums of single-flip and diagonal terms (TFIM) are measured in the tiles at no traffic: + 2 % at 28 and at 16 qubits
+  bool wide = false;
+  for (const Pass& p : h->fwd.plan.passes) wide |= p.is_measure_only;
+  for (const auto& t : h->model.terms) wide |= __builtin_popcountll(t.x) >= 2;
+  return wide && h->fwd.plan.passes.size() > 1;
+}
+
 // `skip_measure`: the caller takes the values from lambda = O psi (value_mode): measurement groups
 // are ignored, measurement-only passes and the wide-term kernel are not launched.
 int run_forward_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_t cs, bool keep_state,
@@ -472,6 +486,9 @@ int ensure_state_buffers(qhbm_engine* h, uint32_t cs, bool with_lam) {
   return 0;
 }
 
+int run_observable_chunk(qhbm_engine* h, uint32_t s0, uint32_t c, const float* d_upstream, bool value_mode,
+                         hipStream_t stream, bool store_lambda = true);
+
 int forward(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, float* d_out,
             int shift_gate, double shift, hipStream_t stream) {
   DevicePlan& d = h->fwd;
@@ -482,9 +499,15 @@ int forward(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, 
   if (int rc = values_begin(h, U, stream)) return rc;
   const uint32_t cs = chunk_states(h, U);
   if (int rc = ensure_state_buffers(h, cs, false)) return rc;
+  // One observable and a state that passes through HBM anyway: the lean (paired, measurement-free) passes and one
+  // sweep of the lambda = O psi kernel for <psi|O|psi> -- nothing stored -- beat the measuring passes (config 3:
+  // 148 -> 124 ms per 4096 states).  A single-pass plan measures in its tile and never writes the state.
+  const bool from_obs = forward_values_from_observable(h);
   for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += cs) {
     const uint32_t c = std::min<uint32_t>(cs, uint32_t(U) - s0);
-    if (int rc = run_forward_chunk(h, d_bits, s0, c, false, stream)) return rc;
+    if (int rc = run_forward_chunk(h, d_bits, s0, c, from_obs, stream, from_obs)) return rc;
+    if (from_obs)
+      if (int rc = run_observable_chunk(h, s0, c, nullptr, true, stream, false)) return rc;
   }
   return values_end(h, U, d_out, stream);
 }
@@ -493,10 +516,10 @@ int forward(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, 
 // lambda = O psi for the chunk in the workspace.  value_mode (a single observable): unweighted, and
 // <psi|O|psi> goes to the fixed-point value accumulators -- the forward sweep measured nothing.
 int run_observable_chunk(qhbm_engine* h, uint32_t s0, uint32_t c, const float* d_upstream, bool value_mode,
-                         hipStream_t stream) {
+                         hipStream_t stream, bool store_lambda) {
   if (value_mode) HIPCHK(h->value_part.reserve(observable_value_parts(uint32_t(h->fwd.plan.n_eff), c)));
   hipEvent_t* ev = timer_begin(h, 2, stream);
-  HIPCHK(launch_apply_observable(h->psi.p, h->lam.p, uint32_t(h->fwd.plan.n_eff), c, h->terms.p,
+  HIPCHK(launch_apply_observable(h->psi.p, store_lambda ? h->lam.p : nullptr, uint32_t(h->fwd.plan.n_eff), c, h->terms.p,
                                  uint32_t(h->model.terms.size()), h->obs_groups.p, h->n_obs_groups, d_upstream,
                                  uint32_t(h->model.n_ops), s0, h->op_scale.p, value_mode ? h->vals64.p : nullptr,
                                  h->value_part.p, h->opt_obs_xcd_states != 0, stream));
@@ -686,6 +709,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "adjoint_exchange") { h->opt_adj_exchange = int(value); h->plans_valid = false; }
   else if (k == "adjoint_relabel") { h->opt_adj_relabel = int(value); h->plans_valid = false; }
   else if (k == "forward_pairs") h->opt_fwd_pair = int(value);
+  else if (k == "forward_values_from_observable") h->opt_fwd_values_obs = int(value);
   else if (k == "wide_last_pass") { h->opt_wide_last = int(value); h->plans_valid = false; }
   else if (k == "observable_xcd_states") h->opt_obs_xcd_states = int(value);
   else if (k == "measure_tile_qubits") { h->opt_meas_tile = int(value); h->plans_valid = false; }
@@ -1201,18 +1225,19 @@ extern "C" int qhbm_flop_model(qhbm_engine* h, int U, int with_vjp, double* fwd_
   if (int rc = build_plans(h)) return rc;
   const double amps = double(size_t(1) << h->fwd.plan.n_eff) * double(U);
   double f = 0.0, o = 0.0, b = 0.0;
+  const bool from_obs = with_vjp ? value_mode(h) : forward_values_from_observable(h);  // no measurement in the sweep
   {
     std::vector<PassArgs> args;
     std::vector<uint32_t> prog, tables;
     fill_args(h->fwd.plan, h->model, &args, &prog, &tables);
     for (size_t i = 0; i < args.size(); ++i) {
       const Pass& p = h->fwd.plan.passes[i];
-      if (with_vjp && value_mode(h) && p.is_measure_only) continue;
+      if (from_obs && p.is_measure_only) continue;
       const double live = 1.0 / double(1ull << __builtin_popcount(args[i].zero_mask));
       // the first pass computes on ONE tile per state (the others write zeros and return)
       const double share = (p.flags & PASS_INIT_BASIS) ? 1.0 / double(1ull << p.nonlocal_pos.size()) : live;
       Pass q = p;
-      if (with_vjp && value_mode(h)) {  // PASS_SKIP_MEASURE: cut the program at its first measurement
+      if (from_obs) {  // PASS_SKIP_MEASURE: cut the program at its first measurement
         for (size_t pc = 0; pc < q.prog.size();) {
           const uint32_t opc = q.prog[pc] & 0xffu;
           if (opc == OP_END) break;
@@ -1223,7 +1248,7 @@ extern "C" int qhbm_flop_model(qhbm_engine* h, int U, int with_vjp, double* fwd_
       f += share * amps * pass_flops_per_amplitude(h->fwd.plan, q);
     }
   }
-  if (with_vjp) {
+  if (with_vjp || from_obs) {
     // lambda = O psi: one packed FMA per amplitude and X-mask group (4), one add per term whose sign varies
     // inside a thread's amplitudes (upper bound: every term), <psi|O|psi> 4 in value mode
     std::vector<uint32_t> xs;
@@ -1231,6 +1256,8 @@ extern "C" int qhbm_flop_model(qhbm_engine* h, int U, int with_vjp, double* fwd_
     std::sort(xs.begin(), xs.end());
     const double groups = double(std::unique(xs.begin(), xs.end()) - xs.begin());
     o = amps * (4.0 * groups + double(h->model.terms.size()) + (value_mode(h) ? 4.0 : 0.0));
+  }
+  if (with_vjp) {
     std::vector<PassArgs> args;
     std::vector<uint32_t> prog, tables;
     fill_args(h->adj.plan, h->model, &args, &prog, &tables);
@@ -1255,18 +1282,20 @@ int qhbm_traffic_model(qhbm_engine* h, int U, int with_vjp, double* fwd_bytes, d
   double f = 0.0, o = 0.0, b = 0.0;
   bool measure_only_after = !h->fwd.plan.global_terms.empty();
   for (const Pass& p : h->fwd.plan.passes) measure_only_after |= p.is_measure_only;
+  const bool from_obs = with_vjp ? value_mode(h) : forward_values_from_observable(h);  // no measurement in the sweep
   {
     std::vector<PassArgs> fargs;
     std::vector<uint32_t> fprog, ftables;
     fill_args(h->fwd.plan, h->model, &fargs, &fprog, &ftables);
     for (size_t i = 0; i < fargs.size(); ++i) {
       const Pass& p = h->fwd.plan.passes[i];
-      if (with_vjp && value_mode(h) && p.is_measure_only) continue;  // the values come from lambda = O psi
+      if (from_obs && p.is_measure_only) continue;  // the values come from lambda = O psi
       const double live = 1.0 / double(1ull << __builtin_popcount(fargs[i].zero_mask));  // tiles not skipped
       if (!(p.flags & PASS_INIT_BASIS)) f += live * tile_all;  // the first pass writes the basis state, reads nothing
-      if (!p.is_measure_only && (!p.completes_circuit || with_vjp || measure_only_after)) f += live * tile_all;
+      if (!p.is_measure_only && (!p.completes_circuit || from_obs || with_vjp || measure_only_after)) f += live * tile_all;
     }
   }
+  if (!with_vjp && from_obs) o = tile_all;  // psi read (gathered through L2), nothing written
   if (with_vjp) {
     o = 2.0 * tile_all;  // psi read (gathered through L2), lambda written
     std::vector<PassArgs> args;

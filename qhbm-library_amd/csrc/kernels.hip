@@ -1758,10 +1758,12 @@ __global__ __launch_bounds__(256, 5) void apply_observable_kernel(
       if (g < n_groups) gr = groups[g];
     }
   }
-  float2* ls = lam + (size_t(s_local) << n) + jb;
+  if (lam) {  // (null: a forward-only call that wants <psi|O|psi> alone)
+    float2* ls = lam + (size_t(s_local) << n) + jb;
 #pragma unroll
-  for (int p = 0; p < P; ++p)
-    *reinterpret_cast<float4*>(&ls[tb + 512u * p]) = make_float4(acc[2 * p].x, acc[2 * p].y, acc[2 * p + 1].x, acc[2 * p + 1].y);
+    for (int p = 0; p < P; ++p)
+      *reinterpret_cast<float4*>(&ls[tb + 512u * p]) = make_float4(acc[2 * p].x, acc[2 * p].y, acc[2 * p + 1].x, acc[2 * p + 1].y);
+  }
   if constexpr (VALUE) {
     float e = 0.f;
 #pragma unroll

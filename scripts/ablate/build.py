@@ -184,6 +184,18 @@ VARIANTS.update({
 })
 
 
+_OBS_LOOP = "      if (live) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);  // else: the group vanishes on the whole block"
+VARIANTS.update({
+    # lambda = O psi (wrong lambda): without the masks that leave the block (no gathers: staging + the masks served
+    # from LDS + the block's own read and write), without the masks inside the block, without either
+    "obs_no_far": lambda t: once(t, _OBS_LOOP, "      if (live && gr.x < 256u * A) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);").replace(
+        "      if (gr.x >= 256u * A) obs_gather<A>(cur, ps, j0, gr.x, live);", "", 1),
+    "obs_no_near": lambda t: once(t, _OBS_LOOP, "      if (live && gr.x >= 256u * A) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);"),
+    "obs_no_groups": lambda t: once(t, _OBS_LOOP, "      if (live && gr.x == 0x7fffffffu) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);").replace(
+        "      if (gr.x >= 256u * A) obs_gather<A>(cur, ps, j0, gr.x, live);", "", 1),
+})
+
+
 def check_variants(names=None):
   """Applies every variant's edit to kernels.hip WITHOUT compiling: {name: error message} of the variants
   whose anchors no longer match the kernel source (tests/test_scripts_cpu.py keeps this empty)."""

@@ -578,6 +578,42 @@ def test_single_observable_values_from_lambda_match_the_measured_ones(n, tile):
   np.testing.assert_allclose(results[0][1], results[1][1], atol=5e-5 * max(1.0, np.abs(want_grad).max()), rtol=0)
 
 
+@pytest.mark.parametrize("n,tile", [(12, 10), (15, 11)])
+def test_forward_only_values_from_the_observable_kernel(n, tile):
+  """A forward-only call with one observable on a multi-pass plan takes <psi|O|psi> from the lambda = O psi
+  kernel (nothing stored) when some term flips two or more qubits (`forward_values_from_observable`: auto),
+  and keeps measuring in the tiles for single-flip + diagonal sums (TFIM) and on single-pass plans.  Both
+  routes against the oracle and against each other, chunked too; several observables always measure."""
+  rng = np.random.default_rng(70 + n)
+  gates, names = O.hea_gates(n, 3, "fo")
+  params = rng.uniform(-1, 1, len(names))
+  bits = _random_bits(rng, 5, n)
+  xxz, tfim = O.xxz_chain_op(n), O.tfim_ring_op(n)
+  launches = {}
+  for name, op in (("xxz", xxz), ("tfim", tfim)):
+    want = O.expectation(n, gates, params, bits, [op])
+    got = {}
+    for flag in (-1, 0, 1):
+      eng = _engine(n, gates, len(names), [op], tile_qubits=tile, forward_values_from_observable=flag, profile_events=1)
+      assert eng.num_passes()[0] > 1
+      got[flag] = eng.expectation(bits, params).cpu().numpy()
+      launches[name, flag] = eng.kernel_time_ms()["obs_launches"]
+      np.testing.assert_allclose(got[flag], want, atol=1e-5 * _op_norm([op])[0], rtol=0)
+      eng.set_option("chunk_states", 2)
+      np.testing.assert_array_equal(eng.expectation(bits, params).cpu().numpy(), got[flag])
+    np.testing.assert_allclose(got[0], got[1], atol=3e-6 * _op_norm([op])[0], rtol=0)
+  assert launches["xxz", -1] == 1 and launches["xxz", 0] == 0 and launches["xxz", 1] == 1
+  assert launches["tfim", -1] == 0 and launches["tfim", 1] == 1
+  single = _engine(min(n, 12), *O.hea_gates(min(n, 12), 2, "fo")[:1], len(O.hea_gates(min(n, 12), 2, "fo")[1]), [O.xxz_chain_op(min(n, 12))],
+                   profile_events=1)
+  if single.num_passes()[0] == 1:                      # one tile: the state never reaches HBM
+    single.expectation(_random_bits(rng, 3, min(n, 12)), rng.uniform(-1, 1, len(O.hea_gates(min(n, 12), 2, "fo")[1])))
+    assert single.kernel_time_ms()["obs_launches"] == 0
+  both = _engine(n, gates, len(names), [xxz, tfim], tile_qubits=tile, forward_values_from_observable=1, profile_events=1)
+  check_values(both, n, gates, params, bits, [xxz, tfim])
+  assert both.kernel_time_ms()["obs_launches"] == 0
+
+
 # ---- round-3 layouts: relabeling adjoint plans, compact grids, paired forward passes ---------------
 @pytest.mark.parametrize("n,layers,tile,states,seed", [(13, 6, 10, 5, 1), (14, 9, 10, 4, 2), (15, 8, 11, 3, 3),
                                                         (16, 12, 12, 7, 4), (17, 14, 12, 2, 5), (16, 5, 11, 1, 6)])
