@@ -117,7 +117,8 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
 /* ---- tuning ------------------------------------------------------------ */
 /* Optional knobs (name -> value); unknown names are an error.
  *   "tile_qubits"          log2 amplitudes of one LDS tile (10..14), 0 = auto
- *   "adjoint_tile_qubits"  the same for the backward sweep (10..13), 0 = auto
+ *   "adjoint_tile_qubits"  the same for the backward sweep (10..13), 0 = auto (12, or 13 when that plan has at
+ *                          least 2 % less arithmetic in qhbm_flop_model)
  *   "chunk_states"         states simulated per launch group, 0 = auto
  *   "workspace_budget_mb"  cap on the statevector workspace; 0 = a third of the device's memory
  *   "profile_events"       record HIP events around the pass kernels (qhbm_kernel_time_ms)

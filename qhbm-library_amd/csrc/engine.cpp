@@ -249,6 +249,19 @@ void fill_args(const Plan& plan, const Model& m, std::vector<PassArgs>* args, st
   }
 }
 
+double pass_flops_per_amplitude(const Plan& plan, const Pass& p);
+
+// fp32 operations of the adjoint sweep per state (the numerator of qhbm_flop_model's bwd_flops).
+double adjoint_plan_flops(const Plan& plan, const Model& m) {
+  std::vector<PassArgs> args;
+  std::vector<uint32_t> prog, tables;
+  fill_args(plan, m, &args, &prog, &tables);
+  double f = 0.0;
+  for (size_t i = 0; i < args.size(); ++i)
+    f += pass_flops_per_amplitude(plan, plan.passes[i]) / double(1ull << __builtin_popcount(args[i].zero_mask));
+  return f * double(size_t(1) << plan.n_eff);
+}
+
 int build_plans(qhbm_engine* h) {
   if (h->plans_valid) return 0;
   h->retained_U = 0;
@@ -261,6 +274,19 @@ int build_plans(qhbm_engine* h) {
   if (!build_plan(h->model, h->opt_adj_tile, 0, true, &h->adj.plan, &err, h->opt_full_adj, 0, h->opt_cph_wave_bits != 0,
                   h->opt_adj_relabel != 0 && h->opt_adj_exchange != 0))
     return fail(h, "adjoint plan: " + err);
+  // Tile size of the backward sweep left to the engine: the pass kernel runs at the same fp32 rate with tiles of
+  // 2^12 and of 2^13 amplitudes (65-69 TFLOP/s over 20...28 qubits, scripts/adj_tile_ab.sh), so the plan with
+  // less arithmetic in its flop model is the faster one -- deep circuits whose index bits never finish early
+  // (depth-32 TFIM: - 5...9 %) take the larger tile, chains that prune early keep the smaller.
+  if (h->opt_adj_tile == 0 && h->opt_adj_exchange != 0 && h->adj.plan.K == 12 && h->adj.plan.passes.size() > 1 &&
+      h->adj.plan.n_eff >= 14) {
+    Plan wide;
+    std::string err2;
+    if (build_plan(h->model, 13, 0, true, &wide, &err2, h->opt_full_adj, 0, h->opt_cph_wave_bits != 0,
+                   h->opt_adj_relabel != 0) &&
+        wide.K == 13 && adjoint_plan_flops(wide, h->model) < 0.98 * adjoint_plan_flops(h->adj.plan, h->model))
+      h->adj.plan = std::move(wide);
+  }
   h->fwd.uploaded = h->adj.uploaded = false;
   h->model_uploaded = false;
   h->shift_ready = false;

@@ -122,6 +122,24 @@ def test_adjoint_pass_order_is_searched_for_early_finished_bits():
   assert rel.flop_model(64, True)["bwd_flops"] <= 1.02 * eng.flop_model(64, True)["bwd_flops"]
 
 
+def test_adjoint_tile_is_chosen_by_the_flop_model():
+  """`adjoint_tile_qubits` = 0: the backward plan is built with tiles of 2^12 and 2^13 amplitudes and the one with
+  less arithmetic in the flop model runs (the kernel's fp32 rate is the same for both, scripts/adj_tile_ab.sh):
+  config 3 and the depth-16 chains keep 2^12, depth-32 TFIM circuits (nothing finishes early) take 2^13.  An
+  explicit option is obeyed."""
+  def tile_bits(eng):
+    text = eng.describe_schedule()
+    return int(re.search(r"tile_bits=(\d+)", text[text.index("adjoint"):]).group(1))
+  c3 = _planner(20, 16, O.xxz_chain_op(20))
+  assert tile_bits(c3) == 12
+  deep = _planner(24, 32, O.tfim_ring_op(24))
+  assert tile_bits(deep) == 13
+  forced = _planner(24, 32, O.tfim_ring_op(24), adjoint_tile_qubits=12)
+  assert tile_bits(forced) == 12
+  assert deep.flop_model(1, True)["bwd_flops"] < 0.98 * forced.flop_model(1, True)["bwd_flops"]
+  assert tile_bits(_planner(20, 16, O.xxz_chain_op(20), adjoint_tile_qubits=13)) == 13
+
+
 def test_schedule_options_and_errors():
   eng = _planner(14, 2, O.xxz_chain_op(14), tile_qubits=10, adjoint_tile_qubits=10)
   fwd, bwd = eng.num_passes()
