@@ -117,8 +117,8 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
 /* ---- tuning ------------------------------------------------------------ */
 /* Optional knobs (name -> value); unknown names are an error.
  *   "tile_qubits"          log2 amplitudes of one LDS tile (10..14), 0 = auto
- *   "adjoint_tile_qubits"  the same for the backward sweep (10..13), 0 = auto (12, or 13 when that plan has at
- *                          least 2 % less arithmetic in qhbm_flop_model)
+ *   "adjoint_tile_qubits"  the same for the backward sweep (10..13), 0 = auto (12, or 13 when that plan's
+ *                          modelled time -- arithmetic of qhbm_flop_model, tile traffic -- is at least 2 % lower)
  *   "chunk_states"         states simulated per launch group, 0 = auto
  *   "workspace_budget_mb"  cap on the statevector workspace; 0 = a third of the device's memory
  *   "profile_events"       record HIP events around the pass kernels (qhbm_kernel_time_ms)
@@ -132,6 +132,8 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
  * index bits; 0 = the plain layout, for A/B measurements), "values_from_observable" (1 = with a single
  * observable the expectation value is taken from lambda = O psi in the calls that compute lambda
  * anyway, and the forward sweep measures nothing; 0 = always measure in the forward sweep),
+ * "adjoint_plan_search" (1 = the backward plan is the one with the least modelled time among the pass orders the
+ * scheduler ranked best and the greedy order; 0 = the scheduler's first choice),
  * "forward_values_from_observable" (forward-only calls with a single observable: -1 = the same kernel, storing
  * nothing, supplies the value when the plan has more than one pass and some term flips two or more qubits or
  * needs a measurement-only pass; 0 = measure in the passes; 1 = always),

@@ -79,6 +79,7 @@ struct qhbm_engine {
   int opt_cph_wave_bits = 1; // boundary controlled-phase predicates on wave bits (schedule.h Plan::cph_wave_bits)
   int opt_fwd_values_obs = -1; // forward-only calls, one observable: values from the lambda = O psi kernel (no lambda stored) instead of
                                // measurements in the passes (-1: when the plan has more than one pass, i.e. the state is in HBM anyway)
+  int opt_adj_plan_search = 1; // adjoint: build the scheduler's best few pass orders and keep the one with the fewest model flops
   int opt_wide_last = -1;      // forward: the last gate pass may take a tile one or two bits wider (-1: unless tile_qubits is set)
   int opt_fwd_pair = 1;        // dense lean forward passes run on pairs of states, tiles in registers (pass_fwd2_kernel)
   int opt_adj_relabel = 1;     // adjoint plans move finished index bits out of the 128-byte lines (schedule.h Pass)
@@ -251,15 +252,30 @@ void fill_args(const Plan& plan, const Model& m, std::vector<PassArgs>* args, st
 
 double pass_flops_per_amplitude(const Plan& plan, const Pass& p);
 
-// fp32 operations of the adjoint sweep per state (the numerator of qhbm_flop_model's bwd_flops).
-double adjoint_plan_flops(const Plan& plan, const Model& m) {
+// Modelled time of the adjoint sweep per state, in seconds: per pass the larger of its arithmetic at the rate the
+// pass kernel sustains (67 TFLOP/s of qhbm_flop_model's flops: 65-69 over 20...28 qubits, depths 16 and 32, tiles of
+// 2^12 and 2^13, scripts/adj_tile_ab.sh) and its tile traffic (qhbm_traffic_model's bytes) at 5.5 TB/s, the rate of
+// a pass with nothing to compute (config 3: 24.6 ms per 4096 state pairs read and written).
+double adjoint_plan_seconds(const Plan& plan, const Model& m) {
   std::vector<PassArgs> args;
   std::vector<uint32_t> prog, tables;
   fill_args(plan, m, &args, &prog, &tables);
-  double f = 0.0;
-  for (size_t i = 0; i < args.size(); ++i)
-    f += pass_flops_per_amplitude(plan, plan.passes[i]) / double(1ull << __builtin_popcount(args[i].zero_mask));
-  return f * double(size_t(1) << plan.n_eff);
+  const double amps = double(size_t(1) << plan.n_eff);
+  double t = 0.0;
+  for (size_t i = 0; i < args.size(); ++i) {
+    const Pass& p = plan.passes[i];
+    const double live = 1.0 / double(1ull << __builtin_popcount(args[i].zero_mask));
+    int low_missing = 0;  // a tile without some of the four low index bits still moves whole 128-byte lines
+    for (uint32_t k = 0; k < args[i].n_nonlocal; ++k) low_missing += args[i].nonlocal_pos[k] < 4;
+    const double lines = std::min(1.0, live * double(1u << low_missing));
+    const double write_share = (p.flags & PASS_RELABEL) ? 1.0 / double(1u << __builtin_popcount(p.frozen_new_local)) : 1.0;
+    const double bytes = lines * amps * 8.0 * 2.0 * (1.0 + ((p.flags & PASS_STORE) ? write_share : 0.0));
+    const double flops = live * amps * pass_flops_per_amplitude(plan, p);
+    // (+ a tenth of the traffic time: what the start and the end of a pass -- tiles loading, tiles draining -- add to
+    // a pass bound by arithmetic; fitted on orders with 6...8 passes more than their rivals, scripts/adj_search_ab.sh)
+    t += std::max(flops / 67e12, bytes / 5.5e12) + 0.1 * bytes / 5.5e12;
+  }
+  return t;
 }
 
 int build_plans(qhbm_engine* h) {
@@ -271,20 +287,40 @@ int build_plans(qhbm_engine* h) {
   if (!build_plan(h->model, h->opt_tile, h->opt_round, false, &h->fwd.plan, &err, h->opt_full_fwd, h->opt_meas_tile,
                   h->opt_cph_wave_bits != 0, false, h->opt_wide_last))
     return fail(h, "forward plan: " + err);
-  if (!build_plan(h->model, h->opt_adj_tile, 0, true, &h->adj.plan, &err, h->opt_full_adj, 0, h->opt_cph_wave_bits != 0,
-                  h->opt_adj_relabel != 0 && h->opt_adj_exchange != 0))
-    return fail(h, "adjoint plan: " + err);
-  // Tile size of the backward sweep left to the engine: the pass kernel runs at the same fp32 rate with tiles of
-  // 2^12 and of 2^13 amplitudes (65-69 TFLOP/s over 20...28 qubits, scripts/adj_tile_ab.sh), so the plan with
-  // less arithmetic in its flop model is the faster one -- deep circuits whose index bits never finish early
-  // (depth-32 TFIM: - 5...9 %) take the larger tile, chains that prune early keep the smaller.
+  // The backward plan.  Its pass kernel runs at the same fp32 rate whatever the plan (adjoint_plan_seconds), so the
+  // plan with the least modelled time -- arithmetic, or tile traffic where a pass has little to compute -- is kept:
+  //  * the scheduler's search ranks pass orders by a proxy (gates x live share); the best few complete orders and
+  //    the greedy one are built out and compared;
+  //  * with the tile size left to the engine, the same is done with tiles of 2^13 amplitudes, which win where no
+  //    index bit finishes early and every pass is a full pass (depth-32 TFIM: - 5...9 %), and lose on chains that
+  //    prune early (config 3: + 8 %).
+  const bool relabel = h->opt_adj_relabel != 0 && h->opt_adj_exchange != 0;
+  auto plan_adjoint = [&](int tile, Plan* out, double* seconds, std::string* e) {
+    if (!build_plan(h->model, tile, 0, true, out, e, h->opt_full_adj, 0, h->opt_cph_wave_bits != 0, relabel)) return false;
+    *seconds = adjoint_plan_seconds(*out, h->model);
+    if (!h->opt_adj_plan_search) return true;
+    const std::vector<std::vector<uint32_t>> orders = out->candidate_orders;
+    for (const std::vector<uint32_t>& order : orders) {
+      Plan alt;
+      std::string e2;
+      if (!build_plan(h->model, tile, 0, true, &alt, &e2, h->opt_full_adj, 0, h->opt_cph_wave_bits != 0, relabel, -1, &order))
+        continue;
+      const double f = adjoint_plan_seconds(alt, h->model);
+      if (std::getenv("QHBM_PLAN_DEBUG"))
+        std::fprintf(stderr, "[plan] tile %d candidate with %zu passes: %.4g ms per state (kept so far: %zu passes, %.4g ms)\n", tile,
+                     alt.passes.size(), f * 1e3, out->passes.size(), *seconds * 1e3);
+      if (f < 0.99 * *seconds) { *out = std::move(alt); *seconds = f; }
+    }
+    return true;
+  };
+  double adj_seconds = 0.0;
+  if (!plan_adjoint(h->opt_adj_tile, &h->adj.plan, &adj_seconds, &err)) return fail(h, "adjoint plan: " + err);
   if (h->opt_adj_tile == 0 && h->opt_adj_exchange != 0 && h->adj.plan.K == 12 && h->adj.plan.passes.size() > 1 &&
       h->adj.plan.n_eff >= 14) {
     Plan wide;
     std::string err2;
-    if (build_plan(h->model, 13, 0, true, &wide, &err2, h->opt_full_adj, 0, h->opt_cph_wave_bits != 0,
-                   h->opt_adj_relabel != 0) &&
-        wide.K == 13 && adjoint_plan_flops(wide, h->model) < 0.98 * adjoint_plan_flops(h->adj.plan, h->model))
+    double wide_seconds = 0.0;
+    if (plan_adjoint(13, &wide, &wide_seconds, &err2) && wide.K == 13 && wide_seconds < 0.98 * adj_seconds)
       h->adj.plan = std::move(wide);
   }
   h->fwd.uploaded = h->adj.uploaded = false;
@@ -736,6 +772,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "adjoint_relabel") { h->opt_adj_relabel = int(value); h->plans_valid = false; }
   else if (k == "forward_pairs") h->opt_fwd_pair = int(value);
   else if (k == "forward_values_from_observable") h->opt_fwd_values_obs = int(value);
+  else if (k == "adjoint_plan_search") { h->opt_adj_plan_search = int(value); h->plans_valid = false; }
   else if (k == "wide_last_pass") { h->opt_wide_last = int(value); h->plans_valid = false; }
   else if (k == "observable_xcd_states") h->opt_obs_xcd_states = int(value);
   else if (k == "measure_tile_qubits") { h->opt_meas_tile = int(value); h->plans_valid = false; }

@@ -527,7 +527,8 @@ class Builder {
 }  // namespace
 
 bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Plan* plan, std::string* err,
-                int full_threshold, int meas_tile_bits, bool cph_wave_bits, bool relabel, int wide_last_pass) {
+                int full_threshold, int meas_tile_bits, bool cph_wave_bits, bool relabel, int wide_last_pass,
+                const std::vector<uint32_t>* forced_order) {
   *plan = Plan();
   plan->full_threshold = full_threshold;
   plan->cph_wave_bits = cph_wave_bits;
@@ -751,7 +752,9 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   // times cheaper.  Beam search over pass sequences on that model (config 3: the first four, unpruned
   // passes carry 184 gates instead of 220).
   std::vector<uint32_t> planned;  // local sets of the passes, in order (empty: greedy)
-  if (adjoint && K < n_eff && plan->tail_tiles) {
+  std::vector<std::pair<double, std::vector<uint32_t>>> complete;  // every complete order the search reached
+  if (forced_order) planned = *forced_order;
+  if (adjoint && K < n_eff && plan->tail_tiles && !forced_order) {
     struct Node { std::vector<char> dn; size_t n_done; double cost; std::vector<uint32_t> sets; std::vector<int> phys; uint32_t frozen; };
     double kFixed = 6.0, kMemory = 17.0;
     if (const char* e = std::getenv("QHBM_PLAN_KFIXED")) kFixed = std::atof(e);    // developer knobs (scripts/plan_constants_probe.sh)
@@ -797,6 +800,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
           c.frozen = nd.frozen;
           if (plan->relabel && c.n_done < ops.size()) relabel_after(S, c.dn, &c.phys, &c.frozen);
           if (c.n_done == ops.size()) {
+            complete.emplace_back(c.cost, c.sets);
             if (best_cost < 0.0 || c.cost < best_cost) {
               best_cost = c.cost;
               planned = c.sets;
@@ -834,7 +838,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
       beam.swap(next);
     }
   }
-  if (!planned.empty()) {
+  if (!planned.empty() && !forced_order) {
     // The model knows nothing of how well a pass packs into rounds and instances: a searched order with
     // clearly MORE passes than the greedy one (deep circuits on many qubits, where no bit finishes
     // early anyway: config 5, 24 against 21) measured slower, so the greedy order stands there.
@@ -842,6 +846,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     std::vector<int> gphys(phys);
     uint32_t gfrozen = frozen;
     size_t left = ops.size() - n_done, greedy_passes = 0;
+    std::vector<uint32_t> greedy_sets;
     while (left) {
       int best_mat = -1;
       size_t best_total = 0;
@@ -856,10 +861,18 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
       for (int oi : best) dn[size_t(oi)] = 1;
       left -= best.size();
       ++greedy_passes;
+      greedy_sets.push_back(best_set);
       if (plan->relabel && left) relabel_after(best_set, dn, &gphys, &gfrozen);
     }
     // (relabeling plans: a pruned pass moves only its live lines, so more, smaller tail passes are cheap -- the
     // searched order stands unless the greedy one has FAR fewer passes)
+    // the candidates handed to the caller: the searched orders by proxy cost (the chosen one excluded), the greedy one
+    std::sort(complete.begin(), complete.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+    for (const auto& c : complete) {
+      if (plan->candidate_orders.size() >= 6) break;
+      if (c.second != planned) plan->candidate_orders.push_back(c.second);
+    }
+    if (left == 0) plan->candidate_orders.push_back(greedy_sets);
     if (left == 0 && planned.size() > greedy_passes + (plan->relabel ? 4 : 1)) planned.clear();
   }
   size_t planned_i = 0;

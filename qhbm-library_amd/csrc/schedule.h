@@ -99,6 +99,10 @@ struct Plan {
   // adjoint: gradient slot -> (gate, chain-rule factor to the exponent)
   std::vector<int> slot_gate;
   std::vector<float> slot_factor;
+  // adjoint plans: complete pass orders (local sets, in order) the search ranked best by its proxy cost, and the
+  // greedy order; the caller may rebuild the plan with any of them (`forced_order`) and keep the one whose flop
+  // model is smallest (engine.cpp build_plans)
+  std::vector<std::vector<uint32_t>> candidate_orders;
 };
 
 struct Model {
@@ -117,7 +121,7 @@ struct Model {
 // `meas_tile_bits`: tile size of measurement-only passes (0 = the largest the forward kernel has).
 bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Plan* out,
                 std::string* err, int full_threshold = 60, int meas_tile_bits = 0, bool cph_wave_bits = true,
-                bool relabel = false, int wide_last_pass = -1);
+                bool relabel = false, int wide_last_pass = -1, const std::vector<uint32_t>* forced_order = nullptr);
 
 std::string describe_plan(const Plan& p);
 

@@ -65,13 +65,15 @@ def test_planning_without_device_and_loud_compute_failure():
 
 
 @pytest.mark.parametrize("n,layers,max_fwd,max_bwd,max_bwd_relabel",
-                         [(12, 8, 1, 1, 1), (20, 16, 7, 6, 9), (24, 16, 10, 9, 10), (28, 32, 16, 19, 20)])
+                         [(12, 8, 1, 1, 1), (20, 16, 7, 6, 9), (24, 16, 10, 9, 10), (28, 32, 16, 21, 26)])
 def test_baseline_configs_schedule(n, layers, max_fwd, max_bwd, max_bwd_relabel):
   """Light-cone scheduling: far fewer HBM passes than gates (944 gates at n=20).  The bounds are the
   pass counts of the scheduler whose diagonal terms wait only for non-diagonal gates (they commute
   with each other): with every pending op a barrier the chain's cone shrinks twice as fast and config
   3 needs 10 + 11 passes instead of 7 + 6.  The default (relabeling) adjoint plans take a few more,
-  smaller tail passes -- a pruned pass moves only its live lines there."""
+  smaller tail passes -- a pruned pass moves only its live lines there -- and the engine keeps the candidate order
+  with the least modelled time, which for deep circuits is one with more, better-pruned passes (config 5: 26, or
+  18 with tiles of 2^13 amplitudes -- a tie on the hardware; `adjoint_plan_search` = 0: the scheduler's first choice)."""
   op = O.xxz_chain_op(n) if n == 20 else O.tfim_ring_op(n)
   eng = _planner(n, layers, op, adjoint_relabel=0)
   fwd, bwd = eng.num_passes()
@@ -80,6 +82,7 @@ def test_baseline_configs_schedule(n, layers, max_fwd, max_bwd, max_bwd_relabel)
   assert eng.workspace_bytes(8) >= 8 * 8 * 2**n or n > 24
   fwd_r, bwd_r = _planner(n, layers, op).num_passes()
   assert fwd_r == fwd and 1 <= bwd_r <= max_bwd_relabel
+  assert _planner(n, layers, op, adjoint_plan_search=0).num_passes()[1] <= min(bwd_r, 20)
 
 
 def test_first_tile_of_a_chain_absorbs_the_whole_triangle():
@@ -122,21 +125,27 @@ def test_adjoint_pass_order_is_searched_for_early_finished_bits():
   assert rel.flop_model(64, True)["bwd_flops"] <= 1.02 * eng.flop_model(64, True)["bwd_flops"]
 
 
-def test_adjoint_tile_is_chosen_by_the_flop_model():
-  """`adjoint_tile_qubits` = 0: the backward plan is built with tiles of 2^12 and 2^13 amplitudes and the one with
-  less arithmetic in the flop model runs (the kernel's fp32 rate is the same for both, scripts/adj_tile_ab.sh):
-  config 3 and the depth-16 chains keep 2^12, depth-32 TFIM circuits (nothing finishes early) take 2^13.  An
-  explicit option is obeyed."""
+def test_adjoint_plan_is_chosen_by_the_time_model():
+  """The backward plan is the one with the least modelled time (per pass: arithmetic of the flop model at the rate
+  the kernel sustains, or tile traffic) among the scheduler's best pass orders and the greedy one, with tiles of
+  2^12 and -- `adjoint_tile_qubits` = 0 -- of 2^13 amplitudes (scripts/adj_tile_ab.sh, adj_search_ab.sh): config 3
+  keeps the scheduler's first choice on 2^12, deep TFIM circuits (nothing finishes early) take other orders and
+  / or the larger tile.  Explicit options are obeyed."""
   def tile_bits(eng):
     text = eng.describe_schedule()
     return int(re.search(r"tile_bits=(\d+)", text[text.index("adjoint"):]).group(1))
   c3 = _planner(20, 16, O.xxz_chain_op(20))
-  assert tile_bits(c3) == 12
-  deep = _planner(24, 32, O.tfim_ring_op(24))
-  assert tile_bits(deep) == 13
-  forced = _planner(24, 32, O.tfim_ring_op(24), adjoint_tile_qubits=12)
+  first = _planner(20, 16, O.xxz_chain_op(20), adjoint_plan_search=0)
+  assert tile_bits(c3) == 12 and c3.describe_schedule() == first.describe_schedule()
+  deep_first = _planner(24, 32, O.tfim_ring_op(24), adjoint_plan_search=0)
+  assert tile_bits(deep_first) == 13
+  forced = _planner(24, 32, O.tfim_ring_op(24), adjoint_tile_qubits=12, adjoint_plan_search=0)
   assert tile_bits(forced) == 12
-  assert deep.flop_model(1, True)["bwd_flops"] < 0.98 * forced.flop_model(1, True)["bwd_flops"]
+  assert deep_first.flop_model(1, True)["bwd_flops"] < 0.98 * forced.flop_model(1, True)["bwd_flops"]
+  deep = _planner(24, 32, O.tfim_ring_op(24))              # another order: more passes, less arithmetic
+  assert deep.num_passes()[1] > deep_first.num_passes()[1]
+  assert deep.flop_model(1, True)["bwd_flops"] < 0.97 * deep_first.flop_model(1, True)["bwd_flops"]
+  assert tile_bits(_planner(26, 32, O.tfim_ring_op(26))) == 13
   assert tile_bits(_planner(20, 16, O.xxz_chain_op(20), adjoint_tile_qubits=13)) == 13
 
 

@@ -578,6 +578,32 @@ def test_single_observable_values_from_lambda_match_the_measured_ones(n, tile):
   np.testing.assert_allclose(results[0][1], results[1][1], atol=5e-5 * max(1.0, np.abs(want_grad).max()), rtol=0)
 
 
+@pytest.mark.parametrize("n,layers,adj_tile", [(14, 6, 0), (15, 14, 10), (16, 14, 10), (17, 6, 11), (17, 20, 11), (15, 20, 10)])
+def test_adjoint_plans_rebuilt_from_a_candidate_order(n, layers, adj_tile):
+  """`adjoint_plan_search` (default on) rebuilds the backward plan from the scheduler's candidate pass orders and
+  keeps the one with the least modelled time: on these circuits that is NOT the scheduler's first choice.  Values
+  and the VJP of both plans against the C oracle, and against each other."""
+  from oracle import qhbm_cpu as C
+  rng = np.random.default_rng(31 * n + layers)
+  gates, names = O.hea_gates(n, layers, "ps")
+  params = rng.uniform(-1, 1, len(names)).astype(np.float32)
+  ops = [O.tfim_ring_op(n)]
+  bits = _random_bits(rng, 5, n)
+  up = rng.normal(size=(5, 1)).astype(np.float32)
+  want, want_grad = C.expectation_vjp(n, gates, params, bits, ops, up)
+  plans, grads = [], []
+  for search in (0, 1):
+    eng = _engine(n, gates, len(names), ops, adjoint_tile_qubits=adj_tile, adjoint_plan_search=search)
+    text = eng.describe_schedule()
+    plans.append(text[text.index("adjoint"):])
+    vals, grad = eng.expectation_vjp(bits, params, up)
+    np.testing.assert_allclose(vals.cpu().numpy(), want, atol=2e-5 * _op_norm(ops)[0])
+    np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=1e-4 * max(1.0, np.abs(want_grad).max()))
+    grads.append(grad.cpu().numpy())
+  assert plans[0] != plans[1]
+  np.testing.assert_allclose(grads[0], grads[1], atol=2e-5 * max(1.0, np.abs(want_grad).max()))
+
+
 @pytest.mark.parametrize("n,tile", [(12, 10), (15, 11)])
 def test_forward_only_values_from_the_observable_kernel(n, tile):
   """A forward-only call with one observable on a multi-pass plan takes <psi|O|psi> from the lambda = O psi
