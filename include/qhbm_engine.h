@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define QHBM_ABI_VERSION 3
+#define QHBM_ABI_VERSION 4
 
 /* Gate kinds: the one-parameter "power gate" families of cirq 0.14.1 that
  * tensorflow-quantum 0.6.1 serialises.  A gate is
@@ -107,6 +107,15 @@ const char* qhbm_last_error(const qhbm_engine* h);
 int qhbm_set_circuit(qhbm_engine* h, int n_qubits, int n_gates,
                      const qhbm_gate* gates, int n_params);
 
+/* Which parameters want a gradient (optional; after qhbm_set_circuit, which resets it).  needs_grad[p] == 0 freezes
+ * parameter p: its entries of every gradient the engine returns are 0, its gates get no gradient work (no slot in the
+ * adjoint sweep, no shifted programs under the parameter-shift rule), and the adjoint sweep STOPS at the first gate,
+ * in circuit order, of a parameter that is not frozen -- the leading gates of frozen parameters are never un-applied.
+ * The reference has no such notion (tfq's differentiators return d/d(symbol) for every symbol, qnn.py:75-76, used or
+ * not); the host mirror derives the mask from torch's requires_grad of the circuits that make up the total circuit
+ * (QMHL with a fixed data QHBM: the data circuit's half).  NULL restores "all".  Host pointer, n_params entries. */
+int qhbm_set_gradient_mask(qhbm_engine* h, const uint8_t* needs_grad, int n_params);
+
 /* Installs n_ops observables; op k is sum_{j in [term_offsets[k],
  * term_offsets[k+1])} coeffs[j] * Pauli(x_masks[j], z_masks[j]).
  * Replaces the tiled PauliSum protos of qnn.py:133.  Arrays are copied. */
@@ -132,6 +141,8 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
  * index bits; 0 = the plain layout, for A/B measurements), "values_from_observable" (1 = with a single
  * observable the expectation value is taken from lambda = O psi in the calls that compute lambda
  * anyway, and the forward sweep measures nothing; 0 = always measure in the forward sweep),
+ * "adjoint_stop_early" (with frozen parameters, qhbm_set_gradient_mask: 1 = the backward sweep stops at the first
+ * gate of a live parameter, 0 = it runs to the basis state and prunes its tail, -1 = whichever the time model prefers),
  * "adjoint_plan_search" (1 = the backward plan is the one with the least modelled time among the pass orders the
  * scheduler ranked best and the greedy order; 0 = the scheduler's first choice),
  * "forward_values_from_observable" (forward-only calls with a single observable: -1 = the same kernel, storing

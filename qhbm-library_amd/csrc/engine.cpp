@@ -79,6 +79,7 @@ struct qhbm_engine {
   int opt_cph_wave_bits = 1; // boundary controlled-phase predicates on wave bits (schedule.h Plan::cph_wave_bits)
   int opt_fwd_values_obs = -1; // forward-only calls, one observable: values from the lambda = O psi kernel (no lambda stored) instead of
                                // measurements in the passes (-1: when the plan has more than one pass, i.e. the state is in HBM anyway)
+  int opt_adj_stop_early = -1; // frozen parameters: the backward sweep stops at the first live gate (-1: if the time model says that is cheaper)
   int opt_adj_plan_search = 1; // adjoint: build the scheduler's best few pass orders and keep the one with the fewest model flops
   int opt_wide_last = -1;      // forward: the last gate pass may take a tile one or two bits wider (-1: unless tile_qubits is set)
   int opt_fwd_pair = 1;        // dense lean forward passes run on pairs of states, tiles in registers (pass_fwd2_kernel)
@@ -229,7 +230,7 @@ void fill_args(const Plan& plan, const Model& m, std::vector<PassArgs>* args, st
     // "Acted on" means by a non-diagonal op of pass p or later; a bit that is local in a later pass
     // without a gate there (the low bits every tile holds, padding) is as good: the tiles skipped now
     // are read again then, but hold zeros of psi (to rounding) next to a stale lambda.
-    uint32_t later_mat = 0;  // logical bits
+    uint32_t later_mat = plan.dense_tail ? ~0u : 0u;  // logical bits (dense_tail: the sweep does not end at the basis state)
     for (size_t i = args->size(); i-- > 0;) {
       uint32_t nl = 0;
       for (uint32_t k = 0; k < (*args)[i].n_nonlocal; ++k) nl |= 1u << (*args)[i].nonlocal_pos[k];
@@ -295,21 +296,43 @@ int build_plans(qhbm_engine* h) {
   //    index bit finishes early and every pass is a full pass (depth-32 TFIM: - 5...9 %), and lose on chains that
   //    prune early (config 3: + 8 %).
   const bool relabel = h->opt_adj_relabel != 0 && h->opt_adj_exchange != 0;
-  auto plan_adjoint = [&](int tile, Plan* out, double* seconds, std::string* e) {
-    if (!build_plan(h->model, tile, 0, true, out, e, h->opt_full_adj, 0, h->opt_cph_wave_bits != 0, relabel)) return false;
-    *seconds = adjoint_plan_seconds(*out, h->model);
+  auto plan_adjoint_of = [&](const Model& model, int tile, Plan* out, double* seconds, std::string* e) {
+    if (!build_plan(model, tile, 0, true, out, e, h->opt_full_adj, 0, h->opt_cph_wave_bits != 0, relabel)) return false;
+    *seconds = adjoint_plan_seconds(*out, model);
     if (!h->opt_adj_plan_search) return true;
     const std::vector<std::vector<uint32_t>> orders = out->candidate_orders;
     for (const std::vector<uint32_t>& order : orders) {
       Plan alt;
       std::string e2;
-      if (!build_plan(h->model, tile, 0, true, &alt, &e2, h->opt_full_adj, 0, h->opt_cph_wave_bits != 0, relabel, -1, &order))
+      if (!build_plan(model, tile, 0, true, &alt, &e2, h->opt_full_adj, 0, h->opt_cph_wave_bits != 0, relabel, -1, &order))
         continue;
-      const double f = adjoint_plan_seconds(alt, h->model);
+      const double f = adjoint_plan_seconds(alt, model);
       if (std::getenv("QHBM_PLAN_DEBUG"))
         std::fprintf(stderr, "[plan] tile %d candidate with %zu passes: %.4g ms per state (kept so far: %zu passes, %.4g ms)\n", tile,
                      alt.passes.size(), f * 1e3, out->passes.size(), *seconds * 1e3);
       if (f < 0.99 * *seconds) { *out = std::move(alt); *seconds = f; }
+    }
+    return true;
+  };
+  //  * with frozen parameters (qhbm_set_gradient_mask) the sweep may stop at the first gate of a live parameter --
+  //    but what is left of psi there is no basis state, and nothing can be pruned any more: for a shallow circuit
+  //    the full sweep with its pruned tail is the cheaper one.  Both are planned.
+  auto plan_adjoint = [&](int tile, Plan* out, double* seconds, std::string* e) {
+    bool any_live = false;  // (no live parameter at all: nothing to sweep, whatever the option says)
+    for (const Gate& G : h->model.gates) any_live |= G.param_idx >= 0 && !h->model.frozen(G.param_idx);
+    if (h->opt_adj_stop_early == 0 && !h->model.param_frozen.empty() && any_live) {
+      Model whole = h->model;
+      whole.stop_at_first_live_gate = false;
+      return plan_adjoint_of(whole, tile, out, seconds, e);
+    }
+    if (!plan_adjoint_of(h->model, tile, out, seconds, e)) return false;
+    if (h->opt_adj_stop_early < 0 && !h->model.param_frozen.empty() && out->dense_tail) {
+      Model whole = h->model;
+      whole.stop_at_first_live_gate = false;
+      Plan alt;
+      std::string e2;
+      double f = 0.0;
+      if (plan_adjoint_of(whole, tile, &alt, &f, &e2) && f < *seconds) { *out = std::move(alt); *seconds = f; }
     }
     return true;
   };
@@ -700,6 +723,7 @@ int qhbm_set_circuit(qhbm_engine* h, int n_qubits, int n_gates, const qhbm_gate*
   if (m.n != n_qubits) { m.terms.clear(); m.n_ops = 0; }
   m.n = n_qubits;
   m.n_params = n_params;
+  m.param_frozen.clear();  // (a mask belongs to the circuit it was set for)
   m.gates.resize(size_t(n_gates));
   if (n_gates) std::memcpy(m.gates.data(), gates, size_t(n_gates) * sizeof(Gate));
   for (const Gate& G : m.gates)
@@ -713,6 +737,26 @@ int qhbm_set_circuit(qhbm_engine* h, int n_qubits, int n_gates, const qhbm_gate*
   h->model = std::move(m);
   h->have_circuit = true;
   h->plans_valid = false;
+  return 0;
+}
+
+int qhbm_set_gradient_mask(qhbm_engine* h, const uint8_t* needs_grad, int n_params) {
+  if (!h) return 1;
+  if (!h->have_circuit) return fail(h, "call qhbm_set_circuit first");
+  std::vector<char> frozen;
+  if (needs_grad) {
+    if (n_params != h->model.n_params) return fail(h, "gradient mask: n_params differs from the circuit's");
+    frozen.resize(size_t(n_params));
+    bool any = false;
+    for (int i = 0; i < n_params; ++i) any |= (frozen[size_t(i)] = needs_grad[i] ? 0 : 1) != 0;
+    if (!any) frozen.clear();
+  }
+  if (frozen != h->model.param_frozen) {
+    h->model.param_frozen = std::move(frozen);
+    h->plans_valid = false;  // the backward plan and the shift tables depend on it
+    h->shift_ready = false;
+    h->retained_U = 0;
+  }
   return 0;
 }
 
@@ -772,6 +816,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "adjoint_relabel") { h->opt_adj_relabel = int(value); h->plans_valid = false; }
   else if (k == "forward_pairs") h->opt_fwd_pair = int(value);
   else if (k == "forward_values_from_observable") h->opt_fwd_values_obs = int(value);
+  else if (k == "adjoint_stop_early") { h->opt_adj_stop_early = int(value); h->plans_valid = false; }
   else if (k == "adjoint_plan_search") { h->opt_adj_plan_search = int(value); h->plans_valid = false; }
   else if (k == "wide_last_pass") { h->opt_wide_last = int(value); h->plans_valid = false; }
   else if (k == "observable_xcd_states") h->opt_obs_xcd_states = int(value);
@@ -1069,7 +1114,7 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const floa
     std::vector<float> sv, sw;
     for (size_t g = 0; g < h->model.gates.size(); ++g) {
       const Gate& G = h->model.gates[g];
-      if (G.param_idx < 0 || G.kind == QHBM_GATE_I) continue;
+      if (G.param_idx < 0 || G.kind == QHBM_GATE_I || h->model.frozen(G.param_idx)) continue;
       if (G.kind == QHBM_GATE_ISWAPPOW)
         return fail(h, "the two-term parameter-shift rule does not apply to ISWAPPOW; use the adjoint method");
       sg.push_back(int(g)); sg.push_back(int(g));
@@ -1267,6 +1312,9 @@ double pass_flops_per_amplitude(const Plan& plan, const Pass& p) {
     } else if (opc == OP_GATE2) {
       total += adj ? 96.0 : 32.0;
       pc += kGate2Words;
+    } else if (opc == OP_MEASURE_WHT) {  // |psi|^2, ten butterfly stages, the terms spread over the threads
+      total += 3.0 + 10.0 + 2.0 * double(w0 >> 8) / double(size_t(1) << (plan.K - plan.R));
+      pc += size_t(kWhtHeaderWords) + size_t(w0 >> 8) * kMeasTermWords;
     } else {  // OP_MEASURE: [op | n_groups << 8] then groups x {[xl] [n_terms] terms x 4 words}
       const uint32_t n_groups = w0 >> 8;
       ++pc;
@@ -1304,7 +1352,7 @@ extern "C" int qhbm_flop_model(qhbm_engine* h, int U, int with_vjp, double* fwd_
         for (size_t pc = 0; pc < q.prog.size();) {
           const uint32_t opc = q.prog[pc] & 0xffu;
           if (opc == OP_END) break;
-          if (opc == OP_MEASURE) { q.prog[pc] = OP_END; break; }
+          if (opc == OP_MEASURE || opc == OP_MEASURE_WHT) { q.prog[pc] = OP_END; break; }
           pc += opc == OP_ROUND ? size_t(kRoundWords) : size_t(kGate2Words);
         }
       }

@@ -823,6 +823,73 @@ __device__ __forceinline__ void clear_stale(TileRegs& r, int tid, uint32_t in_lo
   QHBM_CL(0) QHBM_CL(1) QHBM_CL(2) QHBM_CL(3) QHBM_CL(4) QHBM_CL(5) QHBM_CL(6) QHBM_CL(7)
 #undef QHBM_CL
 }
+// The value of lane (l ^ 2^B) of the wave, for the butterflies of measure_diagonal_wht: quad permutes, LDS-crossbar
+// swizzles (no LDS memory involved) and, across the two halves, a bpermute.
+template <int B> __device__ __forceinline__ float lane_xor(float v, int lane) {
+  if constexpr (B == 0) return dpp_get<0xB1>(v);        // quad_perm:[1,0,3,2]
+  else if constexpr (B == 1) return dpp_get<0x4E>(v);   // quad_perm:[2,3,0,1]
+  else if constexpr (B <= 4) return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), ((1 << B) << 10) | 0x1f));
+  else return __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(v)));
+}
+template <int B, int NR> __device__ __forceinline__ void wht_lane_stage(float (&w)[NR], int lane) {
+  const float s = (lane >> B) & 1 ? -1.f : 1.f;  // lane bit clear: w + partner, set: partner - w
+#pragma unroll
+  for (int i = 0; i < NR; ++i) w[i] = fmaf(s, w[i], lane_xor<B>(w[i], lane));
+}
+
+// OP_MEASURE_WHT (program.h): every diagonal term of the group from ONE Walsh-Hadamard transform of the tile's
+// probabilities.  Thread tid holds p[i] = |psi[l]|^2 at l = i NT + tid; after the transform over the register index
+// i (in registers) and the six lane bits (cross-lane), w[c] in lane L is  sum_{i, j} (-1)^{popc(i & c) + popc(j & L)}
+// p over the wave's 64 NR amplitudes: the term with local z mask zl is w[zl >> (K - R)] of lane zl & 63, times the
+// parity of its wave bits and of its tile bits -- one LDS gather per term, the terms dealt to the lanes, every lane
+// adding its term to the (integer) accumulator of the term's operator.  `scr`: 64 floats private to the wave.
+template <int K, int R, int NT>
+__device__ __forceinline__ void measure_diagonal_wht(const float2* __restrict__ tile, int tid, uint32_t tile_base,
+                                                     const uint32_t* __restrict__ class_end,
+                                                     const uint32_t* __restrict__ terms, float* scr,
+                                                     const float* __restrict__ op_scale, unsigned long long* red) {
+  constexpr int NR = 1 << R;
+  const int lane = tid & 63;
+  const uint32_t wave = uint32_t(tid) >> 6;
+  float w[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const float2 v = tile[swz(uint32_t(i) * NT + uint32_t(tid))];
+    w[i] = v.x * v.x + v.y * v.y;
+  }
+#pragma unroll
+  for (int s = 0; s < R; ++s)
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      if (!(i >> s & 1)) {
+        const float x = w[i], y = w[i | (1 << s)];
+        w[i] = x + y;
+        w[i | (1 << s)] = x - y;
+      }
+  wht_lane_stage<0>(w, lane);
+  wht_lane_stage<1>(w, lane);
+  wht_lane_stage<2>(w, lane);
+  wht_lane_stage<3>(w, lane);
+  wht_lane_stage<4>(w, lane);
+  wht_lane_stage<5>(w, lane);
+  uint32_t begin = 0;
+#pragma unroll
+  for (int c = 0; c < NR; ++c) {
+    const uint32_t end = uni(class_end[c]);
+    if (end != begin) {  // (wave-uniform)
+      scr[lane] = w[c];  // the wave's own 64 floats: DS operations of a wave execute in order
+      for (uint32_t k = begin + uint32_t(lane); k < end; k += 64u) {
+        const uint32_t* tw = terms + size_t(k) * kMeasTermWords;  // (the program is only 4-byte aligned)
+        const uint4 t = make_uint4(tw[0], tw[1], tw[2], tw[3]);    // zl, zn, coefficient, operator
+        const uint32_t par = uint32_t(__popc(tile_base & t.y) + __popc(wave & (t.x >> 6))) & 1u;
+        const float v = __uint_as_float(t.z ^ (par << 31)) * scr[t.x & 63u];
+        atomicAdd(&red[t.w], to_fixed(v, op_scale[t.w]));
+      }
+    }
+    begin = end;
+  }
+}
+
 }  // namespace
 
 // ================================================================================
@@ -945,6 +1012,17 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
         __syncthreads();
       }
       pc += kGate2Words;
+    } else if (opc == OP_MEASURE_WHT) {
+      const uint32_t n_terms = w0 >> 8;
+      const uint32_t* class_end = prog + pc + 1;
+      const uint32_t* terms = prog + pc + kWhtHeaderWords;
+      pc += uint32_t(kWhtHeaderWords) + n_terms * uint32_t(kMeasTermWords);
+      if (!(a.flags & PASS_SKIP_MEASURE)) {
+        // (scratch: the top NT floats of the accumulator array -- the scheduler emits this op only if they are free)
+        float* scr = reinterpret_cast<float*>(red + kMaxOps) - NT + (tid & ~63);
+        measure_diagonal_wht<K, R, NT>(tile, tid, t.tile_base, class_end, terms, scr, op_scale, red);
+        __syncthreads();
+      }
     } else {  // OP_MEASURE
       const uint32_t n_groups = w0 >> 8;
       pc += 1;

@@ -65,7 +65,16 @@ enum : uint32_t {
   OP_ROUND = 1,
   OP_MEASURE = 3,  // [op | n_groups<<8] then groups x {[xl] [n_terms] terms x {[zl] [zn] [coef bits] [op_idx | ny<<24]}}
   OP_GATE2 = 4,    // [op | kind<<8] [pos_q0 | pos_q1<<8 (local bits)] [coef_off] [slot]
+  // Many DIAGONAL terms (x = 0: Z strings -- the shards of a modular Hamiltonian, energy.py:165-167 / 200-209) at
+  // once: the tile's |psi|^2 goes through a Walsh-Hadamard transform over the register and lane bits of its local
+  // index, after which term k is ONE coefficient, W[z_k], times the parity of its wave and tile bits -- a few hundred
+  // instructions per wave for any number of terms instead of ~30 per term.
+  // [op | n_terms<<8] [class_end x 16] then terms x {[zl] [zn] [coef bits] [op_idx]} sorted by class = zl >> (K - R),
+  // the register part of the mask (class_end[c] = end of class c in the term list).
+  OP_MEASURE_WHT = 5,
 };
+constexpr int kWhtHeaderWords = 1 + 16;  // (kRoundBits = 4 register bits: 16 classes)
+constexpr uint32_t kWhtMinTerms = 32;  // below: the per-term path (a ZZ chain of one operator is cheaper there)
 constexpr uint32_t kRoundNoBarrier = 1u << 31;  // OP_ROUND word 0: the next op is a round whose waves own the same amplitudes
 constexpr int kRoundWords = 5;  // [op | n_instances<<8 | flags] [register-bit mask] [first record] [tl_table] [dead mask]
 constexpr int kGate2Words = 4;

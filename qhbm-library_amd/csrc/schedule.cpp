@@ -288,7 +288,7 @@ class Builder {
   int new_slot(Pass* p, const LoweredOp& op, float scale) {
     if (!adjoint_) return -1;
     const Gate& G = m_.gates[op.gate];
-    if (G.param_idx < 0) return -1;
+    if (G.param_idx < 0 || m_.frozen(G.param_idx)) return -1;
     const int slot = static_cast<int>(plan_->slot_gate.size());
     plan_->slot_gate.push_back(op.gate);
     plan_->slot_factor.push_back(scale * G.scalar * (op.type == LOW_DIAG ? op.mult : 1.f));
@@ -495,9 +495,40 @@ class Builder {
     ++p->n_rounds;
   }
 
-  void emit_measure(Pass* p, const std::vector<MeasGroup>& groups, const std::vector<int>& which) {
-    if (which.empty()) return;
+  void emit_measure(Pass* p, const std::vector<MeasGroup>& groups, const std::vector<int>& all) {
+    if (all.empty()) return;
     const uint32_t S = local_set_mask(*p);
+    // the diagonal group with many terms goes through the tile's Walsh-Hadamard transform (program.h
+    // OP_MEASURE_WHT); its scratch is the top of the kernel's accumulator array: n_ops * 8 + NT * 4 <= 8 * kMaxOps
+    std::vector<int> which;
+    static_assert(kRoundBits == 4, "OP_MEASURE_WHT has 16 register classes");
+    for (int gi : all) {
+      const MeasGroup& g = groups[gi];
+      const bool wht = g.x == 0 && g.terms.size() >= kWhtMinTerms && R_ == kRoundBits && K_ - R_ >= 6 &&
+                       size_t(m_.n_ops) * 8 + (size_t(4) << (K_ - R_)) <= size_t(8) * kMaxOps && !std::getenv("QHBM_NO_WHT");
+      if (!wht) { which.push_back(gi); continue; }
+      std::vector<std::pair<uint32_t, int>> order;  // (class, term)
+      for (int ti : g.terms) order.push_back({to_local(*p, m_.terms[ti].z & S) >> (K_ - R_), ti});
+      std::stable_sort(order.begin(), order.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+      p->prog.push_back(OP_MEASURE_WHT | (uint32_t(order.size()) << 8));
+      for (uint32_t c = 0; c < 16u; ++c) {
+        uint32_t end = 0;
+        for (const auto& e : order) end += e.first <= c;
+        p->prog.push_back(end);
+      }
+      for (const auto& e : order) {
+        const PauliTerm& t = m_.terms[e.second];
+        uint32_t cb;
+        std::memcpy(&cb, &t.coeff, 4);
+        p->prog.push_back(to_local(*p, t.z & S));
+        p->prog.push_back(t.z & ~S);
+        p->prog.push_back(cb);
+        p->prog.push_back(uint32_t(t.op));
+        ++p->n_meas_terms;
+      }
+      ++p->n_meas_groups;
+    }
+    if (which.empty()) return;
     p->prog.push_back(OP_MEASURE | (uint32_t(which.size()) << 8));
     for (int gi : which) {
       const MeasGroup& g = groups[gi];
@@ -562,6 +593,21 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
 
   std::vector<LoweredOp> ops;
   if (!lower(m, &ops, err)) return false;
+  // Frozen parameters (Model::param_frozen): the backward sweep un-applies the circuit from its end and may stop
+  // at the first gate, in circuit order, whose parameter wants a gradient -- everything before it only moves
+  // (psi, lambda) further back for nobody.  What is left of psi there is not a basis state: every index bit
+  // stays "pending" for good (`always_pending`), so no tile, wave or line is ever pruned.
+  uint32_t always_pending = 0;
+  if (adjoint && !m.param_frozen.empty() && m.stop_at_first_live_gate) {
+    size_t first = 0;
+    while (first < ops.size() && (m.gates[size_t(ops[first].gate)].param_idx < 0 || m.frozen(m.gates[size_t(ops[first].gate)].param_idx))) ++first;
+    bool mixes = false;  // (dropping diagonal gates alone leaves psi a basis state times a phase)
+    for (size_t i = 0; i < first; ++i) mixes |= ops[i].type != LOW_DIAG;
+    if (first > 0) {
+      ops.erase(ops.begin(), ops.begin() + long(first));
+      if (mixes) { always_pending = (1u << std::max(m.n, kMinTileBits)) - 1u; plan->dense_tail = true; }
+    }
+  }
   std::vector<int> order(ops.size());
   for (size_t i = 0; i < ops.size(); ++i) order[i] = adjoint ? int(ops.size() - 1 - i) : int(i);
 
@@ -572,13 +618,13 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   // bits already finished and moved.  A finished bit is moved by the pass that finishes it, within the
   // positions that pass's tile owns (in place: a workgroup still writes only where it read).
   plan->relabel = relabel && adjoint && K < n_eff && plan->tail_tiles;
-  uint32_t ever_mat = 0;  // bits some non-diagonal op acts on (the others are idle: exact zeros of psi off the input bit)
+  uint32_t ever_mat = always_pending;  // bits some non-diagonal op acts on (the others are idle: exact zeros of psi off the input bit)
   for (const LoweredOp& op : ops) if (op.type != LOW_DIAG) ever_mat |= op.bits;
   std::vector<int> phys;
   for (int i = 0; i < n_eff; ++i) phys.push_back(i);
   uint32_t frozen = 0;
   auto pending_mat_of = [&](const std::vector<char>& dn) {
-    uint32_t pend = 0;
+    uint32_t pend = always_pending;
     for (size_t oi = 0; oi < ops.size(); ++oi) if (!dn[oi] && ops[oi].type != LOW_DIAG) pend |= ops[oi].bits;
     return pend;
   };
@@ -698,7 +744,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
       // gone: kernels.hip prefetch_tile / store_tile with c == 0) touch the same lines for a half, a
       // quarter, ... a sixteenth of the work.
       if (adjoint && plan->tail_tiles) {
-        uint32_t pending_mat = 0;
+        uint32_t pending_mat = always_pending;
         for (size_t oi = 0; oi < ops.size(); ++oi) if (!dn[oi] && ops[oi].type != LOW_DIAG) pending_mat |= ops[oi].bits;
         const uint32_t low_live = low & pending_mat;  // the low bits that still have gates stay in every tile
         if (low_live != low) {
@@ -735,7 +781,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
       size_t keep = 0;
       int slots = 0;
       for (; keep < lst.size(); ++keep)
-        if (m.gates[ops[lst[keep]].gate].param_idx >= 0 && ++slots > kMaxSlotsPerPass) break;
+        if (m.gates[ops[lst[keep]].gate].param_idx >= 0 && !m.frozen(m.gates[ops[lst[keep]].gate].param_idx) && ++slots > kMaxSlotsPerPass) break;
       if (keep < lst.size()) {
         lst.resize(keep);
         *n_mat = 0;
@@ -762,7 +808,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     size_t kBeam = ops.size() <= 4000 ? 16 : (ops.size() <= 12000 ? 8 : 4);  // planning time stays well below a second
     if (const char* e = std::getenv("QHBM_PLAN_BEAM")) kBeam = size_t(std::max(1, std::atoi(e)));
     auto finished_bits = [&](const std::vector<char>& dn) {
-      uint32_t pend = 0;
+      uint32_t pend = always_pending;
       for (size_t oi = 0; oi < ops.size(); ++oi) if (!dn[oi] && ops[oi].type != LOW_DIAG) pend |= ops[oi].bits;
       return all_bits & ~pend;
     };
@@ -991,7 +1037,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     {
       std::vector<char> here(ops.size(), 0);
       for (int oi : best_list) here[size_t(oi)] = 1;
-      uint32_t pend = 0;
+      uint32_t pend = always_pending;
       for (size_t oi = 0; oi < ops.size(); ++oi)
         if (!done[oi] && !here[oi] && ops[oi].type != LOW_DIAG) pend |= ops[oi].bits;
       bp->pending_mat_outside_ = pend;

@@ -103,12 +103,20 @@ struct Plan {
   // greedy order; the caller may rebuild the plan with any of them (`forced_order`) and keep the one whose flop
   // model is smallest (engine.cpp build_plans)
   std::vector<std::vector<uint32_t>> candidate_orders;
+  // adjoint plans of a model with frozen leading gates: the sweep ends at an intermediate state of the circuit, not
+  // at the basis state -- no index bit ever "finishes", nothing is pruned (engine.cpp fill_args)
+  bool dense_tail = false;
 };
 
 struct Model {
   int n = 0;
   int n_params = 0;
   std::vector<Gate> gates;
+  // parameters whose gradient nobody asks for (qhbm_set_gradient_mask; empty: none): their gates get no gradient
+  // slot, and the backward sweep stops at the first gate (in circuit order) of a parameter that is not frozen
+  std::vector<char> param_frozen;
+  bool stop_at_first_live_gate = true;  // (engine.cpp plans both ways and keeps the cheaper: stopping early forgoes the pruning)
+  bool frozen(int param_idx) const { return param_idx >= 0 && size_t(param_idx) < param_frozen.size() && param_frozen[size_t(param_idx)]; }
   int n_ops = 0;
   std::vector<PauliTerm> terms;
 };

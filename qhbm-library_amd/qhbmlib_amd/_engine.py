@@ -32,7 +32,7 @@ GRAD_PARAMETER_SHIFT = 1
 
 ABI_SYMBOLS = (
     "qhbm_abi_version", "qhbm_create", "qhbm_destroy", "qhbm_last_error",
-    "qhbm_set_circuit", "qhbm_set_observables", "qhbm_set_option",
+    "qhbm_set_circuit", "qhbm_set_gradient_mask", "qhbm_set_observables", "qhbm_set_option",
     "qhbm_workspace_bytes", "qhbm_allocated_bytes", "qhbm_expectation", "qhbm_expectation_vjp",
     "qhbm_expectation_retain", "qhbm_expectation_vjp_retained", "qhbm_retained_states", "qhbm_state_gradients",
     "qhbm_expectation_jacobian", "qhbm_statevector", "qhbm_sample", "qhbm_sample_counts", "qhbm_parity_energy", "qhbm_parity_energy_vjp",
@@ -74,6 +74,7 @@ def load_library():
   lib.qhbm_last_error.argtypes = [vp]
   lib.qhbm_last_error.restype = ctypes.c_char_p
   lib.qhbm_set_circuit.argtypes = [vp, i32, i32, ctypes.POINTER(QhbmGate), i32]
+  lib.qhbm_set_gradient_mask.argtypes = [vp, vp, i32]
   lib.qhbm_set_observables.argtypes = [vp, i32, vp, vp, vp, vp]
   lib.qhbm_set_option.argtypes = [vp, ctypes.c_char_p, i64]
   lib.qhbm_workspace_bytes.argtypes = [vp, i32, i32,
@@ -194,6 +195,7 @@ class Engine:
     if n_qubits != self.n_qubits:
       self.n_ops = 0
     self.n_qubits, self.n_params = int(n_qubits), int(n_params)
+    self._grad_mask = None  # (qhbm_set_circuit resets the engine's mask)
 
   def set_observables(self, ops):
     """ops: list of ops, each a list of (coeff, x_mask, z_mask), qubit space."""
@@ -214,6 +216,22 @@ class Engine:
                                        cf.ctypes.data, xm.ctypes.data,
                                        zm.ctypes.data))
     self.n_ops = len(ops)
+
+  def set_gradient_mask(self, needs_grad):
+    """needs_grad: one truth value per parameter (None: all).  Frozen parameters get zero gradient entries and no
+    gradient work; the adjoint sweep stops at the first gate of a parameter that is not frozen
+    (include/qhbm_engine.h qhbm_set_gradient_mask).  Reset by set_circuit."""
+    key = None if needs_grad is None else tuple(bool(f) for f in needs_grad)
+    if key == getattr(self, "_grad_mask", None):
+      return
+    if key is None:
+      self._check(self._lib.qhbm_set_gradient_mask(self._h, None, 0))
+    else:
+      mask = np.ascontiguousarray(np.asarray(key, dtype=np.uint8))
+      if mask.shape != (self.n_params,):
+        raise EngineError(f"gradient mask of shape {mask.shape} for {self.n_params} parameters")
+      self._check(self._lib.qhbm_set_gradient_mask(self._h, mask.ctypes.data, self.n_params))
+    self._grad_mask = key
 
   def set_option(self, name, value):
     self._check(self._lib.qhbm_set_option(self._h, name.encode(), int(value)))

@@ -36,9 +36,14 @@ class _ExpectationFunction(torch.autograd.Function):
   `AnalyticQuantumInference._expectation` verifies that before the call (`check_consistency`)."""
 
   @staticmethod
-  def forward(ctx, symbol_values, engine, bits, method, group, ordered):
+  def forward(ctx, symbol_values, engine, bits, method, group, ordered, grad_mask=None):
     ctx.engine, ctx.method, ctx.group, ctx.ordered = engine, method, group, ordered
     ctx.rows = None
+    # symbols nobody wants a gradient of (a fixed data circuit's): no gradient work, and the backward sweep stops
+    # at the first gate that is not theirs (qhbm_set_gradient_mask; a no-op unless the mask changed)
+    ctx.grad_mask = None if grad_mask is None or all(grad_mask) else tuple(bool(f) for f in grad_mask)
+    if ctx.needs_input_grad[0]:
+      engine.set_gradient_mask(ctx.grad_mask)
     if group is not None:
       blocks = parallel.partition(bits.shape[0], dist.get_world_size(group))
       ctx.rows = blocks[dist.get_rank(group)]
@@ -59,6 +64,7 @@ class _ExpectationFunction(torch.autograd.Function):
   def backward(ctx, upstream):
     (symbol_values,) = ctx.saved_tensors
     eng = ctx.engine
+    eng.set_gradient_mask(ctx.grad_mask)  # (another forward on this engine may have set another one: then the plans are rebuilt)
     upstream = upstream.contiguous()
     if ctx.rows is not None:
       upstream = upstream[ctx.rows[0]:ctx.rows[1]].contiguous()
@@ -79,13 +85,15 @@ class _ExpectationFunction(torch.autograd.Function):
         grad = rows.to(torch.float64).sum(0).to(torch.float32)
       else:
         parallel.all_reduce_sum(grad, ctx.group)
-    return grad.to(symbol_values.device), None, None, None, None, None
+    return grad.to(symbol_values.device), None, None, None, None, None, None
 
 
 class ResolvedCircuits(tuple):
   """What `QuantumCircuit.__call__(bitstrings)` hands to `_expectation` where the reference hands
   `[U]` serialized protos (circuit.py:129-136): the unique bitstrings and the circuit they
   initialise.  Unpacks as `(bitstrings, circuit)`."""
+
+  gradient_mask = None  # optional: one bool per symbol, False = nobody wants that gradient (set by `expectation`)
 
   def __new__(cls, bitstrings, circuit):  # pylint: disable=redefined-outer-name
     return super().__new__(cls, (bitstrings, circuit))
@@ -131,6 +139,8 @@ class QuantumInference(torch.nn.Module, abc.ABC):
       total_circuit = self.circuit
     circuits = ResolvedCircuits(*total_circuit(unique_states))
     tiled_values = total_circuit.symbol_values.unsqueeze(0).expand(circuits.num_circuits, -1)
+    if tiled_values.requires_grad:  # which symbols a backward pass will want (e.g. not a fixed data circuit's)
+      circuits.gradient_mask = total_circuit.symbol_requires_grad()
     unique_expectations = self._expectation(circuits, total_circuit.symbol_names, tiled_values, observables)
     return utils.expand_unique_results(unique_expectations, idx)
 
@@ -270,7 +280,11 @@ class AnalyticQuantumInference(QuantumInference):
     for lo in range(0, max(len(ops), 1), self.MAX_OPS_PER_CALL):
       masks = [ir.as_pauli_sum(op).masks(qubits) for op in ops[lo:lo + self.MAX_OPS_PER_CALL]]
       eng = self._engine_for(len(qubits), flat_gates, len(symbol_names), masks)
-      parts.append(_ExpectationFunction.apply(values, eng, bits, self.gradient_method, group, self.ordered_reduction))
+      grad_mask = getattr(circuits, "gradient_mask", None)
+      if grad_mask is not None and len(grad_mask) != len(symbol_names):
+        grad_mask = None
+      parts.append(_ExpectationFunction.apply(values, eng, bits, self.gradient_method, group, self.ordered_reduction,
+                                              grad_mask))
     expectations = parts[0] if len(parts) == 1 else torch.cat(parts, 1)
     return post_process(expectations)
 

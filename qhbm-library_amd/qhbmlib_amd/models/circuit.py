@@ -78,6 +78,17 @@ class QuantumCircuit(torch.nn.Module):
       return torch.zeros((0,), dtype=torch.float32)
     return torch.cat(intermediate, 0)
 
+  def symbol_requires_grad(self):
+    """One bool per symbol: does `symbol_values[i]` depend on a tensor that requires grad?  (The engine does no
+    gradient work for the others -- `qhbm_set_gradient_mask` -- e.g. for the circuit of a fixed data QHBM.)"""
+    flags = []
+    for inputs, layers in zip(self.value_layers_inputs, self.value_layers):
+      x = inputs
+      for layer in layers:
+        x = layer(x)
+      flags += [bool(x.requires_grad)] * int(x.numel())
+    return flags
+
   @property
   def pqc(self):
     return self._pqc

@@ -5,6 +5,7 @@ the oracle in complex128.  Bars (SURVEY.md 8c / BASELINE.md):
   expectations  |d| <= 1e-5 * sum|c_k|  (n <= 12),  5e-5 * sum|c_k| deeper/larger
   gradients     |d| <= 1e-4 * max(1, ||grad||_inf)
 """
+import itertools
 import math
 
 import numpy as np
@@ -602,6 +603,129 @@ def test_adjoint_plans_rebuilt_from_a_candidate_order(n, layers, adj_tile):
     grads.append(grad.cpu().numpy())
   assert plans[0] != plans[1]
   np.testing.assert_allclose(grads[0], grads[1], atol=2e-5 * max(1.0, np.abs(want_grad).max()))
+
+
+@pytest.mark.parametrize("n,layers,adj_tile", [(6, 3, 0), (13, 4, 10), (15, 6, 11), (16, 8, 0)])
+def test_gradient_mask_freezes_parameters_and_shortens_the_backward_sweep(n, layers, adj_tile):
+  """`qhbm_set_gradient_mask`: frozen parameters get zero gradient entries, the others are unchanged -- for the
+  adjoint sweep (which stops at the first gate, in circuit order, of a live parameter and then prunes nothing: what
+  is left of psi is not a basis state) and for the shift rule (no programs for frozen gates).  Masks: the leading
+  half of the circuit (the QMHL case: a fixed data circuit in front of U_model^dagger), leading diagonal gates only,
+  scattered parameters, everything, nothing; against the C oracle's full gradient."""
+  from oracle import qhbm_cpu as C
+  rng = np.random.default_rng(100 * n + layers)
+  hea, names = O.hea_gates(n, layers, "gm")
+  P = len(names) + 4                      # four leading diagonal gates with parameters of their own, then the HEA
+  gates = [(E.GATE_ZPOW, q, -1, len(names) + q, 1.0, 0.1) for q in range(3)] + [(E.GATE_CZPOW, 0, 1, len(names) + 3, -0.5, 0.0)] + hea
+  params = rng.uniform(-1, 1, P).astype(np.float32)
+  ops = [O.xxz_chain_op(n), O.tfim_ring_op(n)]
+  bits = _random_bits(rng, 4, n)
+  up = rng.normal(size=(4, 2)).astype(np.float32)
+  want, want_grad = C.expectation_vjp(n, gates, params, bits, ops, up)
+  tol = 1e-4 * max(1.0, np.abs(want_grad).max())
+  first_half = {g[3] for g in gates[:len(gates) // 2] if g[3] >= 0}
+  first_x_layer = {g[3] for g in gates[:n + 4] if g[3] >= 0}
+  lead_diag = set()
+  for g in gates:                         # the parameters of the gates before the first parametrised X**t, if any are diagonal
+    if g[3] >= 0 and g[0] == E.GATE_XPOW:
+      break
+    if g[3] >= 0:
+      lead_diag.add(g[3])
+  masks = {"leading half": np.array([p not in first_half for p in range(P)]),
+           "first X layer": np.array([p not in first_x_layer for p in range(P)]),
+           "scattered": rng.random(P) < 0.5,
+           "everything frozen": np.zeros(P, bool),
+           "nothing frozen": np.ones(P, bool)}
+  assert len(lead_diag) == 4
+  masks["leading diagonal gates"] = np.array([p not in lead_diag for p in range(P)])
+  for stop_early, (name, mask) in itertools.product((1, 0, -1), masks.items()):
+    eng = _engine(n, gates, P, ops, adjoint_tile_qubits=adj_tile, adjoint_stop_early=stop_early)
+    eng.set_gradient_mask(mask)
+    vals, grad = eng.expectation_vjp(bits, params, up)
+    np.testing.assert_allclose(vals.cpu().numpy(), want, atol=2e-5 * _op_norm(ops).max(), err_msg=name)
+    got = grad.cpu().numpy()
+    assert (got[~mask] == 0).all(), name
+    np.testing.assert_allclose(got[mask], want_grad[mask], atol=tol, err_msg=name)
+    if name == "leading half" and stop_early < 0:  # (stopping early forgoes the pruning of the tail: the cheaper plan is kept)
+      assert eng.flop_model(1, True)["bwd_flops"] <= eng_full_flops(n, gates, P, ops, adj_tile)
+    if name == "leading half" and stop_early == 1 and n > 12:
+      assert "adjoint" in eng.describe_schedule() and eng.num_passes()[1] >= 1
+    if name == "everything frozen":
+      assert eng.num_passes()[1] == 0
+    # retained forward + backward from the kept pair, and per-state rows
+    rv = eng.expectation(bits, params, retain=True)
+    rg = eng.expectation_vjp_retained(bits, params, up).cpu().numpy()
+    np.testing.assert_allclose(rg[mask], want_grad[mask], atol=tol, err_msg=name)
+    assert (rg[~mask] == 0).all()
+    if n <= 13:                                              # the shift rule: 2 forwards per live gate occurrence
+      _, sg = eng.expectation_vjp(bits, params, up, E.GRAD_PARAMETER_SHIFT)
+      sg = sg.cpu().numpy()
+      assert (sg[~mask] == 0).all(), name
+      np.testing.assert_allclose(sg[mask], want_grad[mask], atol=3 * tol, err_msg=name)
+  eng.set_gradient_mask(None)
+  _, grad = eng.expectation_vjp(bits, params, up)
+  np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=tol)
+  with pytest.raises(E.EngineError, match="gradient mask"):
+    eng.set_gradient_mask(np.ones(P + 1, bool))
+  eng.set_circuit(n, gates, P)                               # a new circuit forgets the mask
+  eng.set_observables(ops)
+  _, grad = eng.expectation_vjp(bits, params, up)
+  np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=tol)
+
+
+def eng_full_flops(n, gates, n_params, ops, adj_tile):
+  return _engine(n, gates, n_params, ops, adjoint_tile_qubits=adj_tile).flop_model(1, True)["bwd_flops"]
+
+
+@pytest.mark.parametrize("n,tile,layers", [(10, 0, 2), (12, 0, 2), (13, 10, 3), (15, 11, 3), (16, 12, 2)])
+def test_many_diagonal_terms_through_the_walsh_hadamard_measurement(n, tile, layers, monkeypatch):
+  """Diagonal groups of >= 32 terms -- the Z-string shards of a modular Hamiltonian (energy.py:165-167, 200-209) --
+  are measured through ONE Walsh-Hadamard transform of the tile's |psi|^2 (program.h OP_MEASURE_WHT): every term is
+  a single coefficient of it.  KOBE-2 shards (one term per operator), Z strings of every weight with bits among the
+  register, lane, wave and tile bits, one operator of many diagonal terms next to non-diagonal operators, and more
+  operators than the scratch leaves room for (fallback to the per-term path); against the C oracle and against the
+  per-term path (QHBM_NO_WHT), forward-only, chunked, with gradients, and under the batched shift rule."""
+  from oracle import qhbm_cpu as C
+  rng = np.random.default_rng(17 * n + tile)
+  gates, names = O.hea_gates(n, layers, "wh")
+  params = rng.uniform(-1, 1, len(names)).astype(np.float32)
+  bits = _random_bits(rng, 4, n)
+  opts = dict(tile_qubits=tile) if tile else {}
+  shards = O.kobe_shards(n, 2)
+  strings = [[O.pauli_term(float(rng.normal()), [(int(q), "Z") for q in rng.choice(n, size=int(rng.integers(1, n + 1)), replace=False)])]
+             for _ in range(70)]
+  dense_sum = [t for op in strings[:50] for t in op]
+  cases = {"kobe-2 shards": shards,
+           "z strings of every weight": strings,
+           "one operator of 50 diagonal terms beside XXZ and TFIM": [dense_sum, O.xxz_chain_op(n), O.tfim_ring_op(n)] + shards[:n]}
+  if n <= 13:
+    cases["more operators than the scratch leaves"] = (shards * (900 // len(shards) + 1))[:900]
+  for name, ops in cases.items():
+    up = rng.normal(size=(4, len(ops))).astype(np.float32)
+    want, want_grad = C.expectation_vjp(n, gates, params, bits, ops, up)
+    tol = 3e-5 * np.maximum(_op_norm(ops), 1.0)
+    got = {}
+    for no_wht in ("", "1"):
+      if no_wht:
+        monkeypatch.setenv("QHBM_NO_WHT", "1")
+      else:
+        monkeypatch.delenv("QHBM_NO_WHT", raising=False)
+      eng = _engine(n, gates, len(names), ops, **opts)
+      got[no_wht] = eng.expectation(bits, params).cpu().numpy()
+      assert (np.abs(got[no_wht] - want) <= tol[None, :]).all(), (name, no_wht, np.abs(got[no_wht] - want).max())
+      eng.set_option("chunk_states", 2)
+      np.testing.assert_array_equal(eng.expectation(bits, params).cpu().numpy(), got[no_wht])
+      if not no_wht and len(ops) <= 200:
+        # value + gradient calls measure the same way (several operators: the values come from the passes)
+        eng.set_option("chunk_states", 0)
+        vals, grad = eng.expectation_vjp(bits, params, up)
+        np.testing.assert_array_equal(vals.cpu().numpy(), got[no_wht])
+        np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=1e-4 * max(1.0, np.abs(want_grad).max()))
+        if n <= 12 and name == "kobe-2 shards":                # batched shifted programs share the measurement code
+          _, sg = eng.expectation_vjp(bits, params, up, E.GRAD_PARAMETER_SHIFT)
+          np.testing.assert_allclose(sg.cpu().numpy(), want_grad, atol=3e-4 * max(1.0, np.abs(want_grad).max()))
+    monkeypatch.delenv("QHBM_NO_WHT", raising=False)
+    np.testing.assert_allclose(got[""], got["1"], atol=3e-6 * max(1.0, _op_norm(ops).max()), err_msg=name)
 
 
 @pytest.mark.parametrize("n,tile", [(12, 10), (15, 11)])

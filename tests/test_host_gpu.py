@@ -405,3 +405,50 @@ def test_autograd_through_a_batch_larger_than_one_backward_chunk():
   eng.set_option("chunk_states", 0)
   out = qnn.expectation(states, ops)
   assert eng.retained is not None and eng.retained_states() == states.shape[0]
+
+
+def test_qmhl_with_a_fixed_data_qhbm_skips_its_gradient_work():
+  """QMHL against data from a FIXED QHBM (its circuit's variables do not require grad): the total circuit of
+  `data.expectation(model.modular_hamiltonian)` is U_data then U_model^dagger, and only the second half's symbols
+  want a gradient.  The host derives the engine's gradient mask from requires_grad (`symbol_requires_grad`); the
+  model's gradients must equal those of the unmasked run, the data circuit gets none, and the backward plan is
+  not more expensive than the unmasked one."""
+  qdata = data
+  n, layers = 13, 3
+  qubits = ir.GridQubit.rect(1, n)
+
+  def make(tag, seed):
+    torch.manual_seed(seed)
+    ebm = models.KOBE(list(range(n)), 2)
+    ebm.build([None, n])
+    with torch.no_grad():
+      ebm.trainable_variables[0].uniform_(-0.3, 0.3)
+    circ = models.DirectQuantumCircuit(hea_circuit(qubits, layers, tag))
+    with torch.no_grad():
+      circ.trainable_variables[0].uniform_(-1.0, 1.0)
+    e_inf = inference.AnalyticEnergyInference(ebm, 64, initial_seed=seed)
+    return inference.QHBM(e_inf, inference.AnalyticQuantumInference(circ)), ebm, circ
+
+  target, _, data_circ = make("fd", 3)
+  model, ebm, circ = make("fm", 5)
+  data_params = list(data_circ.trainable_variables)
+  results = []
+  for freeze in (False, True):
+    for p in data_params:
+      p.requires_grad_(not freeze)
+      p.grad = None
+    for p in list(ebm.parameters()) + circ.trainable_variables:
+      p.grad = None
+    loss = inference.qmhl(qdata.QHBMData(target), model)
+    loss.backward()
+    (eng,) = list(target.q_inference._engines._engines.values())
+    results.append((float(loss.detach()), circ.trainable_variables[0].grad.clone(),
+                    [p.grad.clone() for p in ebm.parameters() if p.grad is not None],
+                    eng.flop_model(1, True)["bwd_flops"], data_params[0].grad))
+  (l0, g0, e0, f0, d0), (l1, g1, e1, f1, d1) = results
+  assert d0 is not None and d1 is None
+  assert f1 <= f0
+  assert l0 == l1   # (fixed seeds: the same samples both times)
+  np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), atol=2e-5 * max(1.0, float(g0.abs().max())))
+  for a, b in zip(e0, e1):
+    np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), atol=2e-5 * max(1.0, float(a.abs().max())))

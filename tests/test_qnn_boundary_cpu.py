@@ -86,6 +86,9 @@ class _StubEngine:
   def set_observables(self, ops):
     self.ops = ops
 
+  def set_gradient_mask(self, needs_grad):
+    self.gradient_mask = needs_grad
+
   def allocated_bytes(self):
     return 1 << 20
 
