@@ -328,16 +328,33 @@ class Builder {
     // kind: 0 X, 1 Y, 2 dense, 3 PH1, 4 PH2, 5 CPH
     std::vector<Instance> insts(1);
     std::vector<Placed> placed;
+    // An op goes into the EARLIEST instance it may legally run in, not only the last one: ops on different register
+    // bits commute, and so do diagonal ops among themselves.  Inside an instance the kernels run the one-qubit gates
+    // first and the diagonal terms after them (forward), or the other way round (adjoint), so per register bit:
+    //   a gate must come after the last gate on its bit, and after (forward) / not before (adjoint) the last
+    //   diagonal term that touches it; a diagonal term must come not before (forward) / after (adjoint) the last
+    //   gate on each of its register bits.
+    // An inverted circuit lists a layer as Z_q^-1 X_q^-1 per qubit: in sweep order X_a Z_a X_b Z_b ..., which the
+    // last-instance rule packed as ONE gate per instance (U_model^dagger of a QMHL step: 320 instances for 320 gates).
+    int last_mat[8], last_diag[8];
+    for (int j = 0; j < 8; ++j) last_mat[j] = last_diag[j] = -1;
+    const bool pack = !std::getenv("QHBM_NO_INSTANCE_PACKING");
+    auto instance_at = [&](int idx) -> Instance* {
+      while (int(insts.size()) <= idx) insts.emplace_back();
+      return &insts[size_t(idx)];
+    };
     for (size_t i : seq) {
       const LoweredOp& op = ops[absorbed[i]];
       Placed pl{};
       pl.op = &op;
       if (op.type == LOW_MAT1) {
         const int j = rank_of(to_local(*p, op.bits));
-        Instance* in = &insts.back();
-        const bool conflict = adjoint_ ? bool(in->mat_mask >> j & 1)
-                                       : bool((in->mat_mask >> j & 1) || (in->diag_touch >> j & 1));
-        if (conflict) { insts.emplace_back(); in = &insts.back(); }
+        int at = std::max(last_mat[j] + 1, adjoint_ ? last_diag[j] : last_diag[j] + 1);
+        if (!pack) at = std::max(at, int(insts.size()) - 1);
+        at = std::max(at, 0);
+        Instance* in = instance_at(at);
+        last_mat[j] = at;
+        pl.inst = at;
         in->mat_mask |= 1u << j;
         pl.kind = op.kind == QHBM_GATE_XPOW ? 0 : (op.kind == QHBM_GATE_YPOW ? 1 : 2);
         if (pl.kind != 0) p->flags |= PASS_GENERAL;
@@ -358,13 +375,19 @@ class Builder {
         else pl.kind = 3;
         const uint32_t touch = (1u << j) | (j2 >= 0 ? (1u << j2) : 0u);
         auto fits = [&](const Instance& in) {
-          if (adjoint_ && (in.mat_mask & touch)) return false;  // MAT executes after diagonals there
           if (pl.kind == 3) return !(in.ph1_mask >> j & 1);
           if (pl.kind == 4) return !(in.ph2_mask >> pair_index(j, j2) & 1);
           return ((in.cph_mask >> (2 * j)) & 3u) != 3u;
         };
-        if (!fits(insts.back())) insts.emplace_back();
-        Instance* in = &insts.back();
+        int at = adjoint_ ? last_mat[j] + 1 : last_mat[j];
+        if (j2 >= 0) at = std::max(at, adjoint_ ? last_mat[j2] + 1 : last_mat[j2]);
+        if (!pack) at = std::max(at, int(insts.size()) - 1);
+        at = std::max(at, 0);
+        while (at < int(insts.size()) && !fits(insts[size_t(at)])) ++at;
+        Instance* in = instance_at(at);
+        last_diag[j] = std::max(last_diag[j], at);
+        if (j2 >= 0) last_diag[j2] = std::max(last_diag[j2], at);
+        pl.inst = at;
         in->diag_touch |= touch;
         pl.j = j;
         pl.j2 = j2;
@@ -376,7 +399,6 @@ class Builder {
         }
         ++p->n_diag_terms;
       }
-      pl.inst = int(insts.size()) - 1;
       placed.push_back(pl);
     }
     // ---- fixed-layout records (program.h RecordLayout), consecutive in the coefficient buffer
