@@ -17,6 +17,7 @@
 #include "schedule.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,9 +30,57 @@ namespace {
 
 inline int popc(uint32_t x) { return __builtin_popcount(x); }
 
+// A gate with a constant, odd-integer exponent: CNOT**(+-1) = CNOT and H**(+-1) = H exactly (eigenvalues +-1).
+bool odd_constant(const Gate& G) {
+  if (G.param_idx >= 0) return false;
+  const float t = G.offset;
+  return t == std::nearbyint(t) && (long(std::nearbyint(t)) & 1L);
+}
+
 bool lower(const Model& m, std::vector<LoweredOp>* ops, std::string* err) {
   ops->clear();
+  const bool fuse = !std::getenv("QHBM_NO_SANDWICH_FUSION");
   for (size_t g = 0; g < m.gates.size(); ++g) {
+    // tfq.util.exponential writes exp(-i theta Z_a Z_b / 2) as CNOT(a, b) rz_b(theta) CNOT(a, b) and
+    // exp(-i theta X_q / 2) as H_q rz_q(theta) H_q (circuit.py:268-272: the QAIA ansatz is made of these).  Taken
+    // literally that is two dense two-qubit / one-qubit gates around every rotation; but CNOT Z_b^t CNOT = (Z_a Z_b)^t
+    // and H Z^t H = X^t EXACTLY (global phases included: ZPow(t, shift) becomes ZZPow / XPow(t, shift)), which are
+    // lean ops of the fast kernels.  The fused op keeps the ROTATION's gate index: its parameter, its gradient slot
+    // and its parameter-shift programs are the rotation's.
+    if (fuse && g + 2 < m.gates.size()) {
+      const Gate &A = m.gates[g], &Z = m.gates[g + 1], &B = m.gates[g + 2];
+      const bool in_range = Z.q0 >= 0 && Z.q0 < m.n && A.q0 >= 0 && A.q0 < m.n && Z.param_idx < m.n_params;
+      if (in_range && Z.kind == QHBM_GATE_ZPOW && A.kind == B.kind && A.q0 == B.q0 && A.q1 == B.q1 && odd_constant(A) &&
+          odd_constant(B)) {
+        LoweredOp op;
+        op.gate = static_cast<int>(g + 1);
+        if (A.kind == QHBM_GATE_CNOTPOW && A.q1 == Z.q0 && A.q1 >= 0 && A.q1 < m.n && A.q1 != A.q0) {
+          op.kind = QHBM_GATE_ZZPOW;
+          op.b0 = m.n - 1 - A.q0;
+          op.b1 = m.n - 1 - A.q1;
+          op.bits = (1u << op.b0) | (1u << op.b1);
+          LoweredOp a = op, b = op, c = op;  // e^{i pi t [b0 xor b1]} = e^{i pi t b0} e^{i pi t b1} e^{-2 i pi t b0 b1}
+          a.type = b.type = c.type = LOW_DIAG;
+          a.bits = 1u << op.b0; a.b1 = -1;
+          b.bits = 1u << op.b1; b.b0 = op.b1; b.b1 = -1;
+          c.mult = -2.f;
+          ops->push_back(a);
+          ops->push_back(b);
+          ops->push_back(c);
+          g += 2;
+          continue;
+        }
+        if (A.kind == QHBM_GATE_HPOW && A.q0 == Z.q0) {
+          op.kind = QHBM_GATE_XPOW;
+          op.type = LOW_MAT1;
+          op.b0 = m.n - 1 - Z.q0;
+          op.bits = 1u << op.b0;
+          ops->push_back(op);
+          g += 2;
+          continue;
+        }
+      }
+    }
     const Gate& G = m.gates[g];
     if (G.kind < 0 || G.kind >= QHBM_GATE_KIND_COUNT) {
       *err = "gate " + std::to_string(g) + ": unknown kind " + std::to_string(G.kind);

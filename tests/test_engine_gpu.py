@@ -728,6 +728,67 @@ def test_many_diagonal_terms_through_the_walsh_hadamard_measurement(n, tile, lay
     np.testing.assert_allclose(got[""], got["1"], atol=3e-6 * max(1.0, _op_norm(ops).max()), err_msg=name)
 
 
+@pytest.mark.parametrize("n,tile", [(5, 0), (11, 0), (13, 10), (14, 11)])
+def test_cnot_and_hadamard_sandwiches_are_fused_into_lean_rotations(n, tile, monkeypatch):
+  """tfq.util.exponential writes exp(-i theta Z_a Z_b / 2) as CNOT rz CNOT and exp(-i theta X / 2) as H rz H
+  (circuit.py:268-272).  The scheduler lowers such adjacent triples to ZZ**t / X**t of the ROTATION's gate (exact,
+  global phase included), and leaves look-alikes alone: other qubits, an even or fractional or parametrised outer
+  exponent, a rotation on the control.  Values, adjoint and shift-rule gradients and the exported state (phase!)
+  against the oracle, with the fusion on and off (QHBM_NO_SANDWICH_FUSION)."""
+  rng = np.random.default_rng(50 + n)
+  P = 6
+  gates = []
+  def rz(q, p=None):
+    p = int(rng.integers(P)) if p is None else p
+    return (E.GATE_ZPOW, q, -1, p, float(rng.uniform(0.3, 1.2)), float(rng.uniform(-0.3, 0.3)), -0.5)
+  for layer in range(3):
+    for q in range(n):                                         # mixing layer: H rz H, forward and inverted exponents
+      sign = 1.0 if (q + layer) % 2 else -1.0
+      gates += [(E.GATE_HPOW, q, -1, -1, 0.0, sign), rz(q), (E.GATE_HPOW, q, -1, -1, 0.0, -sign)]
+    for a in range(n):                                         # ZZ ring: CNOT rz CNOT
+      b = (a + 1) % n
+      gates += [(E.GATE_CNOTPOW, a, b, -1, 0.0, 1.0), rz(b), (E.GATE_CNOTPOW, a, b, -1, 0.0, -1.0 if a % 2 else 3.0)]
+    gates.append((E.GATE_XPOW, layer % n, -1, layer, 1.0, 0.1))
+  look_alikes = [
+      [(E.GATE_CNOTPOW, 0, 1, -1, 0.0, 1.0), rz(0, 1), (E.GATE_CNOTPOW, 0, 1, -1, 0.0, 1.0)],          # rotation on the control
+      [(E.GATE_CNOTPOW, 0, 1, -1, 0.0, 1.0), rz(1, 2), (E.GATE_CNOTPOW, 1, 0, -1, 0.0, 1.0)],          # reversed second CNOT
+      [(E.GATE_CNOTPOW, 0, 1, -1, 0.0, 2.0), rz(1, 3), (E.GATE_CNOTPOW, 0, 1, -1, 0.0, 1.0)],          # even exponent
+      [(E.GATE_CNOTPOW, 0, 1, -1, 0.0, 0.5), rz(1, 4), (E.GATE_CNOTPOW, 0, 1, -1, 0.0, -0.5)],         # fractional
+      [(E.GATE_CNOTPOW, 0, 1, 5, 1.0, 0.0), rz(1, 0), (E.GATE_CNOTPOW, 0, 1, 5, -1.0, 0.0)],           # parametrised
+      [(E.GATE_HPOW, 2, -1, -1, 0.0, 1.0), rz(3, 1), (E.GATE_HPOW, 2, -1, -1, 0.0, 1.0)],             # rotation elsewhere
+      [(E.GATE_HPOW, 2, -1, -1, 0.0, 0.5), rz(2, 2), (E.GATE_HPOW, 2, -1, -1, 0.0, -0.5)],            # fractional H
+      [(E.GATE_HPOW, 4, -1, -1, 0.0, 1.0), rz(4, 3), (E.GATE_HPOW, 4, -1, -1, 0.0, 1.0), rz(4, 4), (E.GATE_HPOW, 4, -1, -1, 0.0, 1.0)],  # overlapping triples
+  ]
+  for extra in look_alikes:
+    gates += extra
+  params = rng.uniform(-1, 1, P)
+  ops = [O.xxz_chain_op(n), O.tfim_ring_op(n)]
+  bits = _random_bits(rng, 3, n)
+  opts = dict(tile_qubits=tile, adjoint_tile_qubits=tile) if tile else {}
+  want_vals, want_jac = O.expectation_jacobian(n, gates, params, bits, ops)
+  up = rng.normal(size=(3, 2)).astype(np.float32)
+  want_grad = np.einsum("bt,btp->p", up, want_jac)
+  passes = {}
+  for off in ("", "1"):
+    if off:
+      monkeypatch.setenv("QHBM_NO_SANDWICH_FUSION", "1")
+    else:
+      monkeypatch.delenv("QHBM_NO_SANDWICH_FUSION", raising=False)
+    eng = _engine(n, gates, P, ops, **opts)
+    text = eng.describe_schedule()
+    passes[off] = sum(int(x) for x in __import__("re").findall(r"rounds=(\d+)", text[:text.index("adjoint")]))
+    vals, grad = eng.expectation_vjp(bits, params, up)
+    np.testing.assert_allclose(vals.cpu().numpy(), want_vals, atol=2e-5 * _op_norm(ops).max())
+    np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=2e-4 * max(1.0, np.abs(want_grad).max()))
+    _, sg = eng.expectation_vjp(bits, params, up, E.GRAD_PARAMETER_SHIFT)
+    np.testing.assert_allclose(sg.cpu().numpy(), want_grad, atol=5e-4 * max(1.0, np.abs(want_grad).max()))
+    states = eng.statevector(bits, params).cpu().numpy()
+    for row, b in zip(states, bits):
+      np.testing.assert_allclose(row, O.simulate(n, gates, params, list(b)).ravel(), atol=5e-6)
+  monkeypatch.delenv("QHBM_NO_SANDWICH_FUSION", raising=False)
+  assert passes[""] < passes["1"] / 3        # (rounds of the forward plan: the dense gates took one each)
+
+
 @pytest.mark.parametrize("n,tile", [(12, 10), (15, 11)])
 def test_forward_only_values_from_the_observable_kernel(n, tile):
   """A forward-only call with one observable on a multi-pass plan takes <psi|O|psi> from the lambda = O psi
