@@ -1973,6 +1973,7 @@ __global__ void prep_coefs_kernel(const CoefJob* __restrict__ jobs, int n_jobs,
     return;
   }
   if (jb.mop == MOP_X) {  // X**t has period 2 in t: theta = pi t / 2 in [-pi/2, pi/2], |tan(theta/2)| <= 1
+    t *= double(jb.mult);  // (1 except for the X**(1/2) of a lowered constant Hadamard)
     const double tr = t - 2.0 * rint(0.5 * t);
     double s2, c2;
     sincospi(0.5 * tr, &s2, &c2);
@@ -2310,7 +2311,10 @@ __global__ void global_phase_kernel(const CoefJob* __restrict__ jobs, int n_jobs
     if (jb.mop != MOP_X && jb.mop != MOP_Y) continue;
     double t = double(jb.offset);
     if (jb.param_idx >= 0) t += double(jb.scalar) * double(params[jb.param_idx]);
-    if (jb.mop == MOP_X) t -= 2.0 * rint(0.5 * t);  // the reduced exponent prep_coefs_kernel applies
+    if (jb.mop == MOP_X) {
+      t *= double(jb.mult);
+      t -= 2.0 * rint(0.5 * t);  // the reduced exponent prep_coefs_kernel applies
+    }
     acc += 0.5 * t;
   }
   for (int j = threadIdx.x; j < n_shifts; j += 256) {

@@ -37,9 +37,31 @@ bool odd_constant(const Gate& G) {
   return t == std::nearbyint(t) && (long(std::nearbyint(t)) & 1L);
 }
 
-bool lower(const Model& m, std::vector<LoweredOp>* ops, std::string* err) {
+bool lower(const Model& m, std::vector<LoweredOp>* ops, std::string* err, double* const_phase = nullptr) {
   ops->clear();
+  if (const_phase) *const_phase = 0.0;
   const bool fuse = !std::getenv("QHBM_NO_SANDWICH_FUSION");
+  // A constant Hadamard (H**k, k odd) is  e^{-i pi/4} Z^(1/2) X^(1/2) Z^(1/2): three LEAN ops instead of a dense 2 x 2
+  // that would turn its pass over to the general kernels; a constant CNOT is H_t CZ H_t.  The X**t kernels leave out
+  // cirq's e^{i pi t / 2} (restored for qhbm_statevector from the jobs), so a lowered H owes the exported state
+  // e^{-i pi/4} more: `const_phase`, in units of pi.  Exponents: the ops carry the GATE's exponent k times `mult`.
+  const bool lean_clifford = !std::getenv("QHBM_NO_LEAN_CLIFFORD");
+  auto push_hadamard = [&](int bit, int gate, float k) {
+    LoweredOp z;
+    z.kind = QHBM_GATE_ZPOW;
+    z.type = LOW_DIAG;
+    z.gate = gate;
+    z.b0 = bit;
+    z.bits = 1u << bit;
+    z.mult = 0.5f / k;
+    LoweredOp x = z;
+    x.kind = QHBM_GATE_XPOW;
+    x.type = LOW_MAT1;
+    ops->push_back(z);
+    ops->push_back(x);
+    ops->push_back(z);
+    if (const_phase) *const_phase -= 0.25;
+  };
   for (size_t g = 0; g < m.gates.size(); ++g) {
     // tfq.util.exponential writes exp(-i theta Z_a Z_b / 2) as CNOT(a, b) rz_b(theta) CNOT(a, b) and
     // exp(-i theta X_q / 2) as H_q rz_q(theta) H_q (circuit.py:268-272: the QAIA ansatz is made of these).  Taken
@@ -120,10 +142,27 @@ bool lower(const Model& m, std::vector<LoweredOp>* ops, std::string* err) {
         ops->push_back(c);
         break;
       }
+      case QHBM_GATE_HPOW:
+        if (lean_clifford && odd_constant(G)) { push_hadamard(op.b0, op.gate, G.offset); break; }
+        op.type = LOW_MAT1;
+        ops->push_back(op);
+        break;
       case QHBM_GATE_XPOW:
       case QHBM_GATE_YPOW:
-      case QHBM_GATE_HPOW:
         op.type = LOW_MAT1;
+        ops->push_back(op);
+        break;
+      case QHBM_GATE_CNOTPOW:
+        if (lean_clifford && odd_constant(G)) {  // CNOT = H_t CZ H_t
+          push_hadamard(op.b1, op.gate, G.offset);
+          LoweredOp cz = op;
+          cz.kind = QHBM_GATE_CZPOW;
+          cz.type = LOW_DIAG;  // exp(i pi t) on |11>, t odd: -1
+          ops->push_back(cz);
+          push_hadamard(op.b1, op.gate, G.offset);
+          break;
+        }
+        op.type = LOW_MAT2;
         ops->push_back(op);
         break;
       default:
@@ -491,7 +530,7 @@ class Builder {
           break;
         default: job.mop = MOP_PHASE; lane = L.cph(pl.k); slot_lane = L.slot_cph(pl.k); rec[L.pred(pl.k)] = pl.pred; break;
       }
-      if (job.mop == MOP_PHASE) job.mult = op.mult;
+      if (job.mop == MOP_PHASE || job.mop == MOP_X) job.mult = op.mult;
       job.out_off = int32_t(rb) + lane;
       plan_->jobs.push_back(job);
       const float kPiF = 3.14159265358979323846f;
@@ -663,7 +702,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   plan->adjoint = adjoint;
 
   std::vector<LoweredOp> ops;
-  if (!lower(m, &ops, err)) return false;
+  if (!lower(m, &ops, err, &plan->const_phase)) return false;
   // Frozen parameters (Model::param_frozen): the backward sweep un-applies the circuit from its end and may stop
   // at the first gate, in circuit order, whose parameter wants a gradient -- everything before it only moves
   // (psi, lambda) further back for nobody.  What is left of psi there is not a basis state: every index bit

@@ -33,7 +33,7 @@ struct LoweredOp {
   int gate = -1;        // index into the circuit
   uint32_t bits = 0;    // index bits touched
   int b0 = -1, b1 = -1; // index bit of q0 / q1
-  float mult = 1.f;     // LOW_DIAG: phase = exp(i*pi*mult*t) where all `bits` are 1
+  float mult = 1.f;     // LOW_DIAG: phase = exp(i*pi*mult*t) where all `bits` are 1; X**(mult*t) for an X op
 };
 
 // One entry of the per-call coefficient preparation.
@@ -106,6 +106,9 @@ struct Plan {
   // adjoint plans of a model with frozen leading gates: the sweep ends at an intermediate state of the circuit, not
   // at the basis state -- no index bit ever "finishes", nothing is pruned (engine.cpp fill_args)
   bool dense_tail = false;
+  // constant global phase, in units of pi, that the lowering of constant Hadamards / CNOTs owes the exported state
+  // (schedule.cpp lower(): -1/4 per lowered H)
+  double const_phase = 0.0;
 };
 
 struct Model {

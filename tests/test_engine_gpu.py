@@ -776,7 +776,7 @@ def test_cnot_and_hadamard_sandwiches_are_fused_into_lean_rotations(n, tile, mon
       monkeypatch.delenv("QHBM_NO_SANDWICH_FUSION", raising=False)
     eng = _engine(n, gates, P, ops, **opts)
     text = eng.describe_schedule()
-    passes[off] = sum(int(x) for x in __import__("re").findall(r"rounds=(\d+)", text[:text.index("adjoint")]))
+    passes[off] = sum(int(x) for x in __import__("re").findall(r"mat_ops=(\d+)", text[:text.index("adjoint")]))
     vals, grad = eng.expectation_vjp(bits, params, up)
     np.testing.assert_allclose(vals.cpu().numpy(), want_vals, atol=2e-5 * _op_norm(ops).max())
     np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=2e-4 * max(1.0, np.abs(want_grad).max()))
@@ -786,7 +786,7 @@ def test_cnot_and_hadamard_sandwiches_are_fused_into_lean_rotations(n, tile, mon
     for row, b in zip(states, bits):
       np.testing.assert_allclose(row, O.simulate(n, gates, params, list(b)).ravel(), atol=5e-6)
   monkeypatch.delenv("QHBM_NO_SANDWICH_FUSION", raising=False)
-  assert passes[""] < passes["1"] / 3        # (rounds of the forward plan: the dense gates took one each)
+  assert passes[""] < passes["1"] / 2        # (one-qubit gates of the forward plan: a literal CNOT / H costs X**(1/2)s of its own)
 
 
 @pytest.mark.parametrize("n,tile", [(12, 10), (15, 11)])
@@ -885,3 +885,50 @@ def test_lean_chain_circuits_under_every_layout_switch(n, layers, tile, states, 
   eng = _engine(n, gates, n_params, ops2, **opts)
   check_values(eng, n, gates, params, bits, ops2, rel=3e-5)
   check_jacobian(eng, n, gates, params, bits[:1], ops2, rel=3e-4)
+
+
+@pytest.mark.parametrize("n,tile", [(4, 0), (12, 10), (14, 11)])
+def test_constant_hadamards_and_cnots_run_as_lean_ops(n, tile, monkeypatch):
+  """A constant H**k / CNOT**k (k odd) is lowered to e^{-i pi/4} Z^(1/2) X^(1/2) Z^(1/2) / H_t CZ H_t (schedule.cpp
+  lower()), so Clifford + rotation circuits stay on the lean kernels; parametrised, even or fractional exponents keep
+  the dense path.  Values, gradients (adjoint and shift rule) and the exported state with its global phase against
+  the oracle, with the lowering on and off (QHBM_NO_LEAN_CLIFFORD); the Bell pair of qhbm_utils_test.py:28-51."""
+  rng = np.random.default_rng(9 * n)
+  P = 5
+  gates = []
+  for layer in range(3):
+    for q in range(n):
+      gates.append((E.GATE_HPOW, q, -1, -1, 0.0, float(rng.choice([1.0, -1.0, 3.0]))))
+      gates.append((E.GATE_ZPOW, q, -1, int(rng.integers(P)), float(rng.uniform(0.2, 1.0)), 0.1))
+    for a in range(n - 1):
+      c, t = (a, a + 1) if (a + layer) % 2 else (a + 1, a)
+      gates.append((E.GATE_CNOTPOW, c, t, -1, 0.0, float(rng.choice([1.0, -1.0]))))
+      gates.append((E.GATE_XPOW, t, -1, int(rng.integers(P)), 0.7, -0.2))
+  gates += [(E.GATE_HPOW, 0, -1, -1, 0.0, 2.0), (E.GATE_HPOW, 1, -1, -1, 0.0, 0.5), (E.GATE_HPOW, 2, -1, 0, 1.0, 0.0),
+            (E.GATE_CNOTPOW, 0, 1, -1, 0.0, 0.5), (E.GATE_CNOTPOW, 2, 3, 1, 1.0, 0.0), (E.GATE_CNOTPOW, 3, 2, -1, 0.0, 2.0)]
+  params = rng.uniform(-1, 1, P)
+  ops = [O.xxz_chain_op(n), O.tfim_ring_op(n)]
+  bits = _random_bits(rng, 3, n)
+  opts = dict(tile_qubits=tile, adjoint_tile_qubits=tile) if tile else {}
+  want_vals, want_jac = O.expectation_jacobian(n, gates, params, bits, ops)
+  up = rng.normal(size=(3, 2)).astype(np.float32)
+  want_grad = np.einsum("bt,btp->p", up, want_jac)
+  for off in ("", "1"):
+    if off:
+      monkeypatch.setenv("QHBM_NO_LEAN_CLIFFORD", "1")
+    else:
+      monkeypatch.delenv("QHBM_NO_LEAN_CLIFFORD", raising=False)
+    eng = _engine(n, gates, P, ops, **opts)
+    vals, grad = eng.expectation_vjp(bits, params, up)
+    np.testing.assert_allclose(vals.cpu().numpy(), want_vals, atol=2e-5 * _op_norm(ops).max())
+    np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=2e-4 * max(1.0, np.abs(want_grad).max()))
+    _, sg = eng.expectation_vjp(bits, params, up, E.GRAD_PARAMETER_SHIFT)
+    np.testing.assert_allclose(sg.cpu().numpy(), want_grad, atol=5e-4 * max(1.0, np.abs(want_grad).max()))
+    states = eng.statevector(bits, params).cpu().numpy()
+    for row, b in zip(states, bits):
+      np.testing.assert_allclose(row, O.simulate(n, gates, params, list(b)).ravel(), atol=5e-6)
+    bell = E.Engine(0)
+    bell.set_circuit(2, [(E.GATE_HPOW, 0, -1, -1, 0.0, 1.0), (E.GATE_CNOTPOW, 0, 1, -1, 0.0, 1.0)], 0)
+    got = bell.statevector(np.zeros((1, 2), np.int8), np.zeros(0, np.float32)).cpu().numpy()[0]
+    np.testing.assert_allclose(got, np.array([1, 0, 0, 1]) / np.sqrt(2), atol=1e-6)
+  monkeypatch.delenv("QHBM_NO_LEAN_CLIFFORD", raising=False)
