@@ -147,8 +147,25 @@ bool lower(const Model& m, std::vector<LoweredOp>* ops, std::string* err, double
         op.type = LOW_MAT1;
         ops->push_back(op);
         break;
-      case QHBM_GATE_XPOW:
       case QHBM_GATE_YPOW:
+        if (lean_clifford) {  // Y**t = S X**t S^dagger (S = Z^(1/2)): exact, cirq's phase included; the X op is the gate's
+          LoweredOp s = op;
+          s.kind = QHBM_GATE_ZPOW;
+          s.type = LOW_DIAG;
+          s.fixed = true;
+          s.fixed_t = -0.5f;
+          ops->push_back(s);
+          op.kind = QHBM_GATE_XPOW;
+          op.type = LOW_MAT1;
+          ops->push_back(op);
+          s.fixed_t = 0.5f;
+          ops->push_back(s);
+          break;
+        }
+        op.type = LOW_MAT1;
+        ops->push_back(op);
+        break;
+      case QHBM_GATE_XPOW:
         op.type = LOW_MAT1;
         ops->push_back(op);
         break;
@@ -170,6 +187,35 @@ bool lower(const Model& m, std::vector<LoweredOp>* ops, std::string* err, double
         ops->push_back(op);
         break;
     }
+  }
+  // A fixed one-bit phase next to a Z**t on the same bit (nothing non-diagonal on that bit between them) is that
+  // gate's exponent plus a constant: Z^(1/2) Z**t = Z**(t + 1/2).  In an ansatz of Y**a Z**b layers every S / S^dagger of
+  // the Y decompositions disappears this way.
+  for (size_t i = 0; i < ops->size();) {
+    LoweredOp& f = (*ops)[i];
+    if (!(f.fixed && f.type == LOW_DIAG && popc(f.bits) == 1)) { ++i; continue; }
+    long host = -1;
+    auto usable = [&](const LoweredOp& o) {
+      return o.type == LOW_DIAG && o.bits == f.bits && o.mult == 1.f && o.kind == QHBM_GATE_ZPOW && (o.fixed || true);
+    };
+    for (size_t j = i + 1; j < ops->size(); ++j) {
+      const LoweredOp& o = (*ops)[j];
+      if (!(o.bits & f.bits)) continue;
+      if (o.type != LOW_DIAG) break;
+      if (usable(o)) { host = long(j); break; }
+    }
+    if (host < 0)
+      for (size_t j = i; j-- > 0;) {
+        const LoweredOp& o = (*ops)[j];
+        if (!(o.bits & f.bits)) continue;
+        if (o.type != LOW_DIAG) break;
+        if (usable(o)) { host = long(j); break; }
+      }
+    if (host < 0) { ++i; continue; }
+    LoweredOp& hst = (*ops)[size_t(host)];
+    if (hst.fixed) hst.fixed_t += f.fixed_t;
+    else hst.add_offset += f.fixed_t;
+    ops->erase(ops->begin() + long(i));
   }
   return true;
 }
@@ -376,7 +422,7 @@ class Builder {
   int new_slot(Pass* p, const LoweredOp& op, float scale) {
     if (!adjoint_) return -1;
     const Gate& G = m_.gates[op.gate];
-    if (G.param_idx < 0 || m_.frozen(G.param_idx)) return -1;
+    if (op.fixed || G.param_idx < 0 || m_.frozen(G.param_idx)) return -1;
     const int slot = static_cast<int>(plan_->slot_gate.size());
     plan_->slot_gate.push_back(op.gate);
     plan_->slot_factor.push_back(scale * G.scalar * (op.type == LOW_DIAG ? op.mult : 1.f));
@@ -395,7 +441,13 @@ class Builder {
     job.gate = op.gate;
     job.param_idx = G.param_idx;
     job.scalar = G.scalar;
-    job.offset = G.offset;
+    job.offset = G.offset + op.add_offset;
+    if (op.fixed) {  // a constant of the decomposition: not the gate's exponent, never shifted with it
+      job.gate = -2;
+      job.param_idx = -1;
+      job.scalar = 0.f;
+      job.offset = op.fixed_t;
+    }
     job.out_off = 0;
     job.dagger = adjoint_ ? 1 : 0;
     job.mult = 1.f;

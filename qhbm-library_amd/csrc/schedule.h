@@ -34,6 +34,11 @@ struct LoweredOp {
   uint32_t bits = 0;    // index bits touched
   int b0 = -1, b1 = -1; // index bit of q0 / q1
   float mult = 1.f;     // LOW_DIAG: phase = exp(i*pi*mult*t) where all `bits` are 1; X**(mult*t) for an X op
+  // an op of a gate's DECOMPOSITION with an exponent of its own (Y**t = Z^(1/2) X**t Z^(-1/2): the two phases):
+  // no parameter, no gradient slot, never shifted
+  bool fixed = false;
+  float fixed_t = 0.f;
+  float add_offset = 0.f;  // a neighbouring fixed phase on the same bit folded into this Z**t: exponent t + add_offset
 };
 
 // One entry of the per-call coefficient preparation.

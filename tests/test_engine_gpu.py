@@ -932,3 +932,47 @@ def test_constant_hadamards_and_cnots_run_as_lean_ops(n, tile, monkeypatch):
     got = bell.statevector(np.zeros((1, 2), np.int8), np.zeros(0, np.float32)).cpu().numpy()[0]
     np.testing.assert_allclose(got, np.array([1, 0, 0, 1]) / np.sqrt(2), atol=1e-6)
   monkeypatch.delenv("QHBM_NO_LEAN_CLIFFORD", raising=False)
+
+
+@pytest.mark.parametrize("n,tile", [(3, 0), (12, 10), (14, 11)])
+def test_y_powers_run_as_conjugated_x_powers(n, tile, monkeypatch):
+  """Y**t = S X**t S^dagger exactly (cirq's phase included): the scheduler lowers a Y power -- parametrised or not --
+  to the X power of the same gate between two fixed phases, and folds those into neighbouring Z**t gates on the same
+  qubit (Z^(1/2) Z**t = Z**(t + 1/2)).  ry-style layers, Y next to Y, Y next to H / CNOT, Y at both ends of the circuit;
+  values, adjoint and shift-rule gradients and the exported state against the oracle, lowering on and off."""
+  rng = np.random.default_rng(3 * n + 1)
+  P = 6
+  gates = [(E.GATE_YPOW, 0, -1, 0, 1.0, 0.0), (E.GATE_YPOW, 0, -1, 1, -0.5, 0.3)]           # Y Y on one qubit, at the start
+  for layer in range(3):
+    for q in range(n):
+      gates.append((E.GATE_YPOW, q, -1, int(rng.integers(P)), float(rng.uniform(0.3, 1.0)), float(rng.uniform(-0.2, 0.2))))
+      gates.append((E.GATE_ZPOW, q, -1, int(rng.integers(P)), float(rng.uniform(0.3, 1.0)), 0.0))
+    for a in range(0, n - 1):
+      gates.append((E.GATE_CZPOW, a, a + 1, int(rng.integers(P)), 1.0, 0.0))
+    gates.append((E.GATE_HPOW, layer % n, -1, -1, 0.0, 1.0))
+    gates.append((E.GATE_YPOW, layer % n, -1, -1, 0.0, 0.37))                               # constant Y after an H
+    if n > 1:
+      gates.append((E.GATE_CNOTPOW, 0, 1, -1, 0.0, 1.0))
+  gates.append((E.GATE_YPOW, n - 1, -1, 2, 2.5, -1.7))                                      # far outside one period, at the end
+  params = rng.uniform(-1, 1, P)
+  ops = [O.xxz_chain_op(n), O.tfim_ring_op(n)] if n > 3 else [O.tfim_ring_op(n), [O.pauli_term(1.0, [(0, "Y")])]]
+  bits = _random_bits(rng, 3, n)
+  opts = dict(tile_qubits=tile, adjoint_tile_qubits=tile) if tile else {}
+  want_vals, want_jac = O.expectation_jacobian(n, gates, params, bits, ops)
+  up = rng.normal(size=(3, 2)).astype(np.float32)
+  want_grad = np.einsum("bt,btp->p", up, want_jac)
+  for off in ("", "1"):
+    if off:
+      monkeypatch.setenv("QHBM_NO_LEAN_CLIFFORD", "1")
+    else:
+      monkeypatch.delenv("QHBM_NO_LEAN_CLIFFORD", raising=False)
+    eng = _engine(n, gates, P, ops, **opts)
+    vals, grad = eng.expectation_vjp(bits, params, up)
+    np.testing.assert_allclose(vals.cpu().numpy(), want_vals, atol=2e-5 * _op_norm(ops).max())
+    np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=2e-4 * max(1.0, np.abs(want_grad).max()))
+    _, sg = eng.expectation_vjp(bits, params, up, E.GRAD_PARAMETER_SHIFT)
+    np.testing.assert_allclose(sg.cpu().numpy(), want_grad, atol=5e-4 * max(1.0, np.abs(want_grad).max()))
+    states = eng.statevector(bits, params).cpu().numpy()
+    for row, b in zip(states, bits):
+      np.testing.assert_allclose(row, O.simulate(n, gates, params, list(b)).ravel(), atol=5e-6)
+  monkeypatch.delenv("QHBM_NO_LEAN_CLIFFORD", raising=False)
