@@ -46,7 +46,7 @@ bool lower(const Model& m, std::vector<LoweredOp>* ops, std::string* err, double
   // cirq's e^{i pi t / 2} (restored for qhbm_statevector from the jobs), so a lowered H owes the exported state
   // e^{-i pi/4} more: `const_phase`, in units of pi.  Exponents: the ops carry the GATE's exponent k times `mult`.
   const bool lean_clifford = !std::getenv("QHBM_NO_LEAN_CLIFFORD");
-  auto push_hadamard = [&](int bit, int gate, float k) {
+  auto push_hadamard = [&](int bit, int gate, float k, bool fixed_exponents = false) {
     LoweredOp z;
     z.kind = QHBM_GATE_ZPOW;
     z.type = LOW_DIAG;
@@ -54,6 +54,11 @@ bool lower(const Model& m, std::vector<LoweredOp>* ops, std::string* err, double
     z.b0 = bit;
     z.bits = 1u << bit;
     z.mult = 0.5f / k;
+    if (fixed_exponents) {  // (inside the decomposition of a PARAMETRISED gate: the exponents 1/2 are constants of their own)
+      z.mult = 1.f;
+      z.fixed = true;
+      z.fixed_t = 0.5f;
+    }
     LoweredOp x = z;
     x.kind = QHBM_GATE_XPOW;
     x.type = LOW_MAT1;
@@ -182,6 +187,43 @@ bool lower(const Model& m, std::vector<LoweredOp>* ops, std::string* err, double
         op.type = LOW_MAT2;
         ops->push_back(op);
         break;
+      case QHBM_GATE_XXPOW:
+      case QHBM_GATE_YYPOW:
+        if (lean_clifford) {
+          // XX**t = (H x H) ZZ**t (H x H),  YY**t = (S x S) XX**t (S x S)^dagger: exact (the +1 / -1 eigenspaces map onto
+          // each other); the three phases of the ZZ power are the gate's own ops
+          auto push_s = [&](int bit, float t) {
+            LoweredOp sgt;
+            sgt.kind = QHBM_GATE_ZPOW;
+            sgt.type = LOW_DIAG;
+            sgt.gate = op.gate;
+            sgt.b0 = bit;
+            sgt.bits = 1u << bit;
+            sgt.fixed = true;
+            sgt.fixed_t = t;
+            ops->push_back(sgt);
+          };
+          const bool yy = G.kind == QHBM_GATE_YYPOW;
+          if (yy) { push_s(op.b0, -0.5f); push_s(op.b1, -0.5f); }
+          push_hadamard(op.b0, op.gate, 1.f, true);
+          push_hadamard(op.b1, op.gate, 1.f, true);
+          LoweredOp a = op, b = op, c = op;
+          a.kind = b.kind = c.kind = QHBM_GATE_ZZPOW;
+          a.type = b.type = c.type = LOW_DIAG;
+          a.bits = 1u << op.b0; a.b1 = -1;
+          b.bits = 1u << op.b1; b.b0 = op.b1; b.b1 = -1;
+          c.mult = -2.f;
+          ops->push_back(a);
+          ops->push_back(b);
+          ops->push_back(c);
+          push_hadamard(op.b0, op.gate, 1.f, true);
+          push_hadamard(op.b1, op.gate, 1.f, true);
+          if (yy) { push_s(op.b0, 0.5f); push_s(op.b1, 0.5f); }
+          break;
+        }
+        op.type = LOW_MAT2;
+        ops->push_back(op);
+        break;
       default:
         op.type = LOW_MAT2;
         ops->push_back(op);
@@ -215,7 +257,10 @@ bool lower(const Model& m, std::vector<LoweredOp>* ops, std::string* err, double
     LoweredOp& hst = (*ops)[size_t(host)];
     if (hst.fixed) hst.fixed_t += f.fixed_t;
     else hst.add_offset += f.fixed_t;
-    ops->erase(ops->begin() + long(i));
+    const bool cancelled = hst.fixed && hst.fixed_t == 0.f;  // S^dagger S: nothing left
+    if (cancelled) ops->erase(ops->begin() + host);
+    ops->erase(ops->begin() + long(i) - (cancelled && size_t(host) < i ? 1 : 0));
+    if (cancelled && size_t(host) < i) --i;
   }
   return true;
 }
