@@ -436,6 +436,10 @@ int upload_model(qhbm_engine* h) {
     for (const Gate& G : h->model.gates)
       if (G.global_shift != 0.f && G.kind != QHBM_GATE_I)
         sp.push_back(ShiftPhase{G.param_idx, G.param_idx >= 0 ? G.scalar : 0.f, G.offset, G.global_shift});
+    for (const auto& gp : h->fwd.plan.gate_phases) {  // lowered SWAP / ISWAP powers (schedule.cpp lower())
+      const Gate& G = h->model.gates[size_t(gp.first)];
+      sp.push_back(ShiftPhase{G.param_idx, G.param_idx >= 0 ? G.scalar : 0.f, G.offset, gp.second});
+    }
     if (h->fwd.plan.const_phase != 0.0)  // lowered constant Hadamards (schedule.cpp lower())
       sp.push_back(ShiftPhase{-1, 0.f, 1.f, float(h->fwd.plan.const_phase)});
     HIPCHK(h->shift_phases.upload(sp));

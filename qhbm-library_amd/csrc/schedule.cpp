@@ -37,9 +37,11 @@ bool odd_constant(const Gate& G) {
   return t == std::nearbyint(t) && (long(std::nearbyint(t)) & 1L);
 }
 
-bool lower(const Model& m, std::vector<LoweredOp>* ops, std::string* err, double* const_phase = nullptr) {
+bool lower(const Model& m, std::vector<LoweredOp>* ops, std::string* err, double* const_phase = nullptr,
+           std::vector<std::pair<int, float>>* phases = nullptr) {
   ops->clear();
   if (const_phase) *const_phase = 0.0;
+  if (phases) phases->clear();
   const bool fuse = !std::getenv("QHBM_NO_SANDWICH_FUSION");
   // A constant Hadamard (H**k, k odd) is  e^{-i pi/4} Z^(1/2) X^(1/2) Z^(1/2): three LEAN ops instead of a dense 2 x 2
   // that would turn its pass over to the general kernels; a constant CNOT is H_t CZ H_t.  The X**t kernels leave out
@@ -66,6 +68,35 @@ bool lower(const Model& m, std::vector<LoweredOp>* ops, std::string* err, double
     ops->push_back(x);
     ops->push_back(z);
     if (const_phase) *const_phase -= 0.25;
+  };
+  // (P x P)**(mult t) for P = X (which = 0), Y (1), Z (2) on the two bits of `op`: the ZZ power's three phases carry the
+  // gate's exponent; XX = (H x H) ZZ (H x H), YY = (S x S) XX (S x S)^dagger with constants of their own.
+  auto push_pair_power = [&](const LoweredOp& op, int which, float mult) {
+    auto push_s = [&](int bit, float t) {
+      LoweredOp sgt;
+      sgt.kind = QHBM_GATE_ZPOW;
+      sgt.type = LOW_DIAG;
+      sgt.gate = op.gate;
+      sgt.b0 = bit;
+      sgt.bits = 1u << bit;
+      sgt.fixed = true;
+      sgt.fixed_t = t;
+      ops->push_back(sgt);
+    };
+    if (which == 1) { push_s(op.b0, -0.5f); push_s(op.b1, -0.5f); }
+    if (which <= 1) { push_hadamard(op.b0, op.gate, 1.f, true); push_hadamard(op.b1, op.gate, 1.f, true); }
+    LoweredOp a = op, b = op, c = op;  // e^{i pi t [b0 xor b1]} = e^{i pi t b0} e^{i pi t b1} e^{-2 i pi t b0 b1}
+    a.kind = b.kind = c.kind = QHBM_GATE_ZZPOW;
+    a.type = b.type = c.type = LOW_DIAG;
+    a.bits = 1u << op.b0; a.b1 = -1;
+    b.bits = 1u << op.b1; b.b0 = op.b1; b.b1 = -1;
+    a.mult = b.mult = mult;
+    c.mult = -2.f * mult;
+    ops->push_back(a);
+    ops->push_back(b);
+    ops->push_back(c);
+    if (which <= 1) { push_hadamard(op.b0, op.gate, 1.f, true); push_hadamard(op.b1, op.gate, 1.f, true); }
+    if (which == 1) { push_s(op.b0, 0.5f); push_s(op.b1, 0.5f); }
   };
   for (size_t g = 0; g < m.gates.size(); ++g) {
     // tfq.util.exponential writes exp(-i theta Z_a Z_b / 2) as CNOT(a, b) rz_b(theta) CNOT(a, b) and
@@ -149,6 +180,29 @@ bool lower(const Model& m, std::vector<LoweredOp>* ops, std::string* err, double
       }
       case QHBM_GATE_HPOW:
         if (lean_clifford && odd_constant(G)) { push_hadamard(op.b0, op.gate, G.offset); break; }
+        if (lean_clifford) {
+          // H = Ry(pi/4) Z Ry(-pi/4): H**t = Y^(1/4) Z**t Y^(-1/4) (the phases of the two Y powers cancel), and
+          // Y^a = S X^a S^dagger -- the S, S^dagger next to Z**t cancel in the folding pass below
+          auto push_fixed = [&](int type, int kind, float t) {
+            LoweredOp f = op;
+            f.kind = kind;
+            f.type = type;
+            f.fixed = true;
+            f.fixed_t = t;
+            ops->push_back(f);
+          };
+          push_fixed(LOW_DIAG, QHBM_GATE_ZPOW, -0.5f);
+          push_fixed(LOW_MAT1, QHBM_GATE_XPOW, -0.25f);
+          push_fixed(LOW_DIAG, QHBM_GATE_ZPOW, 0.5f);
+          LoweredOp z = op;
+          z.kind = QHBM_GATE_ZPOW;
+          z.type = LOW_DIAG;
+          ops->push_back(z);
+          push_fixed(LOW_DIAG, QHBM_GATE_ZPOW, -0.5f);
+          push_fixed(LOW_MAT1, QHBM_GATE_XPOW, 0.25f);
+          push_fixed(LOW_DIAG, QHBM_GATE_ZPOW, 0.5f);
+          break;
+        }
         op.type = LOW_MAT1;
         ops->push_back(op);
         break;
@@ -175,50 +229,47 @@ bool lower(const Model& m, std::vector<LoweredOp>* ops, std::string* err, double
         ops->push_back(op);
         break;
       case QHBM_GATE_CNOTPOW:
-        if (lean_clifford && odd_constant(G)) {  // CNOT = H_t CZ H_t
-          push_hadamard(op.b1, op.gate, G.offset);
+        if (lean_clifford) {  // CNOT**t = H_t CZ**t H_t (X**t = H Z**t H): the controlled phase is the gate's op
+          push_hadamard(op.b1, op.gate, 1.f, true);
           LoweredOp cz = op;
           cz.kind = QHBM_GATE_CZPOW;
-          cz.type = LOW_DIAG;  // exp(i pi t) on |11>, t odd: -1
+          cz.type = LOW_DIAG;  // exp(i pi t) on |11>
           ops->push_back(cz);
-          push_hadamard(op.b1, op.gate, G.offset);
+          push_hadamard(op.b1, op.gate, 1.f, true);
           break;
         }
         op.type = LOW_MAT2;
         ops->push_back(op);
         break;
       case QHBM_GATE_XXPOW:
+        if (lean_clifford) { push_pair_power(op, 0, 1.f); break; }
+        op.type = LOW_MAT2;
+        ops->push_back(op);
+        break;
       case QHBM_GATE_YYPOW:
+        if (lean_clifford) { push_pair_power(op, 1, 1.f); break; }
+        op.type = LOW_MAT2;
+        ops->push_back(op);
+        break;
+      case QHBM_GATE_SWAPPOW:
+        // SWAP**t = e^{-i pi t / 2} XX**(t/2) YY**(t/2) ZZ**(t/2): the three commute, and on the triplet exactly one of them
+        // contributes e^{i pi t / 2}, on the singlet all three
         if (lean_clifford) {
-          // XX**t = (H x H) ZZ**t (H x H),  YY**t = (S x S) XX**t (S x S)^dagger: exact (the +1 / -1 eigenspaces map onto
-          // each other); the three phases of the ZZ power are the gate's own ops
-          auto push_s = [&](int bit, float t) {
-            LoweredOp sgt;
-            sgt.kind = QHBM_GATE_ZPOW;
-            sgt.type = LOW_DIAG;
-            sgt.gate = op.gate;
-            sgt.b0 = bit;
-            sgt.bits = 1u << bit;
-            sgt.fixed = true;
-            sgt.fixed_t = t;
-            ops->push_back(sgt);
-          };
-          const bool yy = G.kind == QHBM_GATE_YYPOW;
-          if (yy) { push_s(op.b0, -0.5f); push_s(op.b1, -0.5f); }
-          push_hadamard(op.b0, op.gate, 1.f, true);
-          push_hadamard(op.b1, op.gate, 1.f, true);
-          LoweredOp a = op, b = op, c = op;
-          a.kind = b.kind = c.kind = QHBM_GATE_ZZPOW;
-          a.type = b.type = c.type = LOW_DIAG;
-          a.bits = 1u << op.b0; a.b1 = -1;
-          b.bits = 1u << op.b1; b.b0 = op.b1; b.b1 = -1;
-          c.mult = -2.f;
-          ops->push_back(a);
-          ops->push_back(b);
-          ops->push_back(c);
-          push_hadamard(op.b0, op.gate, 1.f, true);
-          push_hadamard(op.b1, op.gate, 1.f, true);
-          if (yy) { push_s(op.b0, 0.5f); push_s(op.b1, 0.5f); }
+          push_pair_power(op, 0, 0.5f);
+          push_pair_power(op, 1, 0.5f);
+          push_pair_power(op, 2, 0.5f);
+          if (phases) phases->push_back({op.gate, -0.5f});
+          break;
+        }
+        op.type = LOW_MAT2;
+        ops->push_back(op);
+        break;
+      case QHBM_GATE_ISWAPPOW:
+        // ISWAP**t = exp(i pi t (XX + YY) / 4) = e^{i pi t / 2} XX**(-t/2) YY**(-t/2)
+        if (lean_clifford) {
+          push_pair_power(op, 0, -0.5f);
+          push_pair_power(op, 1, -0.5f);
+          if (phases) phases->push_back({op.gate, 0.5f});
           break;
         }
         op.type = LOW_MAT2;
@@ -799,7 +850,7 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   plan->adjoint = adjoint;
 
   std::vector<LoweredOp> ops;
-  if (!lower(m, &ops, err, &plan->const_phase)) return false;
+  if (!lower(m, &ops, err, &plan->const_phase, &plan->gate_phases)) return false;
   // Frozen parameters (Model::param_frozen): the backward sweep un-applies the circuit from its end and may stop
   // at the first gate, in circuit order, whose parameter wants a gradient -- everything before it only moves
   // (psi, lambda) further back for nobody.  What is left of psi there is not a basis state: every index bit

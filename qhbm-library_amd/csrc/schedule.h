@@ -114,6 +114,8 @@ struct Plan {
   // constant global phase, in units of pi, that the lowering of constant Hadamards / CNOTs owes the exported state
   // (schedule.cpp lower(): -1/4 per lowered H)
   double const_phase = 0.0;
+  // ... and per gate: (gate, f) = a factor e^{i pi f t_gate} (SWAP**t = e^{-i pi t / 2} XX**(t/2) YY**(t/2) ZZ**(t/2))
+  std::vector<std::pair<int, float>> gate_phases;
 };
 
 struct Model {
