@@ -197,3 +197,13 @@ def test_flop_model_counts_the_gate_arithmetic_of_the_plan():
   eng3 = _planner(20, 16, O.xxz_chain_op(20))
   f3 = eng3.flop_model(1, with_vjp=True)
   assert 16.0 * 320 * 2**20 / 4 < f3["bwd_flops"] < (16.0 * 320 + 17.25 * 400) * 2**20
+
+
+def test_graft_entry_build_checks_the_header_version():
+  """__graft_entry__.build() compares the library's ABI version with the header's (a hard-coded number went stale
+  when the ABI moved to v4); its source must not pin a literal."""
+  with open(os.path.join(ROOT, "__graft_entry__.py")) as f:
+    text = f.read()
+  assert "QHBM_ABI_VERSION" in text and not re.search(r"qhbm_abi_version\(\) == \d", text)
+  declared = int(re.search(r"#define QHBM_ABI_VERSION (\d+)", _header_text()).group(1))
+  assert ctypes.CDLL(E.LIB_PATH).qhbm_abi_version() == declared
