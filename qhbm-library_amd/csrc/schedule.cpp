@@ -1180,8 +1180,8 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
     if (left == 0 && planned.size() > greedy_passes + (plan->relabel ? 4 : 1)) planned.clear();
   }
   size_t planned_i = 0;
-  if (adjoint) {  // developer knob: QHBM_ADJ_SETS=hex,hex,... forces the local sets of the first adjoint passes
-    if (const char* env = std::getenv("QHBM_ADJ_SETS")) {
+  {  // developer knobs: QHBM_ADJ_SETS / QHBM_FWD_SETS=hex,hex,... force the local sets of the first passes
+    if (const char* env = std::getenv(adjoint ? "QHBM_ADJ_SETS" : "QHBM_FWD_SETS")) {
       planned.clear();
       for (const char* q = env; *q;) {
         char* end = nullptr;
