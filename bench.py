@@ -119,8 +119,6 @@ def cpu_baseline(n, gates, n_params, op, params, bits, upstream_value, mode):
   reported baseline, never the product.  Returns the record plus the oracle's values [K, 1] and
   [P] VJP of those K states, which `parity_check` compares with what the engine produced."""
   from oracle import qhbm_cpu as C
-  if not os.path.exists(C.LIB_PATH):
-    return None, None, None
   cores = min(C.max_threads(), os.cpu_count() or 1)
   states = bits.shape[0]
   up = np.full((states, 1), upstream_value, np.float32)
@@ -138,12 +136,16 @@ def cpu_baseline(n, gates, n_params, op, params, bits, upstream_value, mode):
   }, vals, grad
 
 
-def parity_check(eng, E, mode, op, bits_k, params, timed_vals_k, oracle_vals, oracle_grad):
+def parity_check(eng, E, mode, op, bits_k, params, timed_vals_k, timed_grad_rows_k, rows_scale, oracle_vals, oracle_grad):
   """The timed workload against the oracle (reference pattern: simulate, compare, assert --
-  tests/inference/qnn_test.py:183-264 of the reference).  Values: rows of the LAST TIMED step.
-  Gradient: the engine's VJP of exactly these K states (a second call outside the timed region, same
-  kernels and plans) with upstream 1/K on both sides -- the timed upstream 1/states_total rescaled,
-  the VJP is linear in it -- so that the tolerance 1e-4 * max(1, |grad|_inf) bites."""
+  tests/inference/qnn_test.py:183-264 of the reference).
+  Values: rows of the LAST TIMED step.
+  Gradient: the per-state gradient rows of the LAST TIMED step's adjoint sweep (qhbm_state_gradients, read after the
+  timed region; row u = upstream_u * d<O>_u / d params), its first K rows summed and rescaled from the timed upstream
+  1/states_total to the oracle's 1/K (`rows_scale`; the VJP is linear in the upstream), so that the tolerance
+  1e-4 * max(1, |grad|_inf) bites -- the timed sweep itself is what is checked.  Parameter-shift steps keep no rows:
+  there the engine's VJP of exactly these K states (a second call outside the timed region, same kernels and plans)
+  is compared instead, and `grad_from` says so."""
   k = bits_k.shape[0]
   sum_abs = float(sum(abs(c) for c, _, _ in op))
   tol_v = 5e-5 * sum_abs
@@ -152,18 +154,23 @@ def parity_check(eng, E, mode, op, bits_k, params, timed_vals_k, oracle_vals, or
          "values_from": "rows of the last timed step vs oracle/qhbm_cpu.c on the same bitstrings and parameters"}
   ok = err_v <= tol_v
   if oracle_grad is not None:
-    up = torch.full((k, 1), 1.0 / k, device="cuda")
-    method = E.GRAD_PARAMETER_SHIFT if mode == "shift" else E.GRAD_ADJOINT
-    _, g = eng.expectation_vjp(torch.from_numpy(bits_k).cuda(), params, up, method=method)
-    g = g.double().cpu().numpy()
-    torch.cuda.synchronize()
+    if timed_grad_rows_k is not None:
+      g = timed_grad_rows_k.astype(np.float64).sum(0) * rows_scale
+      grad_from = ("rows of the last timed step (qhbm_state_gradients of the timed adjoint sweep, first K rows summed, "
+                   "rescaled from upstream 1/states_total to 1/K) vs the oracle's adjoint VJP with upstream 1/K")
+    else:
+      up = torch.full((k, 1), 1.0 / k, device="cuda")
+      method = E.GRAD_PARAMETER_SHIFT if mode == "shift" else E.GRAD_ADJOINT
+      _, g = eng.expectation_vjp(torch.from_numpy(bits_k).cuda(), params, up, method=method)
+      g = g.double().cpu().numpy()
+      torch.cuda.synchronize()
+      grad_from = ("engine VJP of these K states (call outside the timed region, upstream 1/K: this mode keeps no "
+                   "per-state rows) vs the oracle's adjoint VJP with the same upstream")
     want = oracle_grad.astype(np.float64)
     gnorm = float(np.abs(want).max())
     tol_g = 1e-4 * max(1.0, gnorm)
     err_g = float(np.abs(g - want).max())
-    out.update({"max_err_grad": err_g, "tol_grad": tol_g, "grad_inf_norm": gnorm,
-                "grad_from": "engine VJP of these K states (call outside the timed region, upstream 1/K) vs the "
-                             "oracle's adjoint VJP with the same upstream"})
+    out.update({"max_err_grad": err_g, "tol_grad": tol_g, "grad_inf_norm": gnorm, "grad_from": grad_from})
     ok = ok and err_g <= tol_g
   out["ok"] = bool(ok)
   return out
@@ -240,8 +247,10 @@ def main():
                        "(bit-identical for any N; AnalyticQuantumInference(ordered_reduction=True))")
   ap.add_argument("--cpu-sample-states", type=int, default=64)
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--verify", action="store_true",
-                  help="rank 0 re-evaluates the whole batch alone and compares with the sharded result")
+  ap.add_argument("--verify", dest="verify", action="store_true", default=None,
+                  help="rank 0 re-evaluates the whole batch alone (outside the timed region) and compares with the "
+                       "sharded result; default: on for --gpus N > 1, off for N = 1")
+  ap.add_argument("--no-verify", dest="verify", action="store_false")
   args = ap.parse_args()
 
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -344,6 +353,13 @@ def main():
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
   kt = eng.kernel_time_ms(reset=True)
+  if args.verify is None:
+    args.verify = world > 1
+  # per-state gradient rows of the LAST TIMED step, read before anything else runs on the engine (parity_check)
+  timed_grad_rows = None
+  if rank == 0 and args.mode == "vqt" and not args.no_cpu_baseline and spg > 0:
+    k_rows = max(1, min(args.cpu_sample_states, spg, os.cpu_count() or 1))
+    timed_grad_rows = eng.state_gradients(spg)[:k_rows].float().cpu().numpy()
 
   # which physical device each rank ran on (PCI bus id), as the ranks themselves report it
   prop = torch.cuda.get_device_properties(local_rank)
@@ -439,6 +455,12 @@ def main():
             "backend_world_size": dist.get_world_size() if world > 1 else 1,
             "devices": sorted(set(device_ids)),
             "reduction": (args.reduction if args.mode == "vqt" else "allreduce") if world > 1 else None,
+            # bytes one step's exchange moves per rank (N > 1): the all-gather of the values [U, 1] plus either the
+            # all-reduce of the [P] gradient or, with --reduction ordered, the all-gather of the per-state rows [U, P]
+            "exchange_bytes": None if world == 1 else int(
+                4 * total_states * 1 + (0 if args.mode == "forward" else
+                                        4 * (total_states * n_params if (args.reduction == "ordered" and args.mode == "vqt")
+                                             else n_params))),
             "forward_passes": fwd_passes, "adjoint_passes": bwd_passes,
             "bench_py_sha16": bench_sha, "engine_options": args.engine_option,
         },
@@ -497,24 +519,35 @@ def main():
       line["verify"] = {"max_err_values": err_v, "max_err_grad": err_g,
                         "ok": bool(err_v < 1e-4 * len(op) and err_g < 1e-4)}
     if not args.no_cpu_baseline:
-      try:
-        from oracle import qhbm_cpu as C  # pylint: disable=import-outside-toplevel
-        k = max(1, min(args.cpu_sample_states, spg, C.max_threads(), os.cpu_count() or 1))
-        if world > 1:   # the CPU baseline is an N = 1 figure; N > 1 runs keep the parity check on a few states
-          k = min(k, 8)
-        bits_k = all_bits[lo:lo + k]
-        # upstream 1/K: see parity_check; the rate does not depend on the weight
-        oracle_params = params_np
-        if os.environ.get("QHBM_BENCH_CORRUPT_PARITY") == "1":   # test hook: the check must be able to fail
-          oracle_params = params_np + np.float32(0.05)
-        rec, o_vals, o_grad = cpu_baseline(n, gates, n_params, op, oracle_params, bits_k, 1.0 / k, args.mode)
-        line["cpu_baseline"] = rec if world == 1 else None
-        if rec is not None:
+      # The oracle must be there when the check is asked for: a missing checker is an error of its own, never a
+      # silently absent parity_check.
+      from oracle import qhbm_cpu as C  # pylint: disable=import-outside-toplevel
+      if not os.path.exists(C.LIB_PATH):
+        line["cpu_baseline"] = {"error": f"{C.LIB_PATH} is not built (run __graft_entry__.build())"}
+        line["parity_check"] = {"ok": False, "error": "the oracle library is missing: the timed workload was NOT checked"}
+        parity_failed = True
+      else:
+        try:
+          k = max(1, min(args.cpu_sample_states, spg, C.max_threads(), os.cpu_count() or 1))
+          if world > 1:   # the CPU baseline is an N = 1 figure; N > 1 runs keep the parity check on a few states
+            k = min(k, 8)
+          bits_k = all_bits[lo:lo + k]
+          # upstream 1/K: see parity_check; the rate does not depend on the weight
+          oracle_params = params_np
+          if os.environ.get("QHBM_BENCH_CORRUPT_PARITY") == "1":   # test hook: the check must be able to fail
+            oracle_params = params_np + np.float32(0.05)
+          rec, o_vals, o_grad = cpu_baseline(n, gates, n_params, op, oracle_params, bits_k, 1.0 / k, args.mode)
+          line["cpu_baseline"] = rec if world == 1 else None
           timed_rows = vals[:k].float().cpu().numpy()   # global rows lo..lo+k are rank 0's own block
-          line["parity_check"] = parity_check(eng, E, args.mode, op, bits_k, params, timed_rows, o_vals, o_grad)
+          grad_rows = timed_grad_rows[:k] if timed_grad_rows is not None and timed_grad_rows.shape[0] >= k else None
+          line["parity_check"] = parity_check(eng, E, args.mode, op, bits_k, params, timed_rows, grad_rows,
+                                              float(total_states) / float(k), o_vals, o_grad)
           parity_failed = not line["parity_check"]["ok"]
-      except Exception as exc:  # pylint: disable=broad-except
-        line["cpu_baseline"] = {"error": str(exc)}
+        except Exception as exc:  # pylint: disable=broad-except
+          # a check that was requested and could not run is a FAILED check (exit code 3), with the reason on the line
+          line.setdefault("cpu_baseline", {"error": str(exc)})
+          line["parity_check"] = {"ok": False, "error": f"{type(exc).__name__}: {exc}"}
+          parity_failed = True
     print(json.dumps(line), flush=True)
     if parity_failed:
       print("bench.py: parity_check FAILED: the timed workload disagrees with the oracle: "

@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqhbm_cpu.so")
+# (QHBM_ORACLE_LIB: a test hook -- tests/test_bench_gpu.py hides the library to see bench.py fail loudly)
+LIB_PATH = os.environ.get("QHBM_ORACLE_LIB") or os.path.join(_HERE, "libqhbm_cpu.so")
 
 
 class _Gate(ctypes.Structure):

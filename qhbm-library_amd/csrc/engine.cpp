@@ -49,6 +49,8 @@ struct DevBuf {
   }
 };
 
+template <typename T> void swap_buf(DevBuf<T>& a, DevBuf<T>& b) { std::swap(a.p, b.p); std::swap(a.n, b.n); }
+
 struct DevicePlan {
   Plan plan;
   std::vector<PassArgs> args;
@@ -56,6 +58,13 @@ struct DevicePlan {
   DevBuf<CoefJob> jobs;
   DevBuf<float> coef;
   bool uploaded = false;
+  void swap(DevicePlan& o) {
+    std::swap(plan, o.plan);
+    std::swap(args, o.args);
+    swap_buf(prog, o.prog); swap_buf(tables, o.tables); swap_buf(rec_offsets, o.rec_offsets);
+    swap_buf(jobs, o.jobs); swap_buf(coef, o.coef);
+    std::swap(uploaded, o.uploaded);
+  }
 };
 
 struct TimedEvent {
@@ -84,7 +93,7 @@ struct qhbm_engine {
   int opt_wide_last = -1;      // forward: the last gate pass may take a tile one or two bits wider (-1: unless tile_qubits is set)
   int opt_fwd_pair = 1;        // dense lean forward passes run on pairs of states, tiles in registers (pass_fwd2_kernel)
   int opt_adj_relabel = 1;     // adjoint plans move finished index bits out of the 128-byte lines (schedule.h Pass)
-  int opt_obs_xcd_states = 1;  // lambda = O psi: one state per XCD at a time (kernels.hip apply_observable_kernel)
+  int opt_obs_xcd_states = -1; // lambda = O psi: one state per XCD at a time (1), every XCD an eighth of each state (0); -1: by state size
   int opt_adj_exchange = 1;  // lean adjoint passes: register-resident tile pair + one LDS exchange buffer
   int retained_U = 0;  // final states of the last qhbm_expectation_retain still sit in psi
   int state_grad_U = 0;  // rows of state_grad the last adjoint VJP filled (qhbm_state_gradients)
@@ -93,10 +102,23 @@ struct qhbm_engine {
   size_t resolved_budget = 0; // the default budget of THIS engine once a device query has succeeded
   // plans
   bool plans_valid = false;
+  bool adj_valid = false;  // the backward plan matches the gradient mask (qhbm_set_gradient_mask invalidates only this)
+  // Backward plans (and their device copies) of the gradient masks this model has been used with: two inference paths
+  // that alternate on one engine -- the same total circuit once with the data half frozen, once fully trainable --
+  // swap plans instead of re-running the plan search and re-uploading on every step.  Keyed by the
+  // frozen-parameter vector; cleared whenever the circuit, the observables or a planning option changes.
+  std::vector<std::pair<std::vector<char>, std::unique_ptr<DevicePlan>>> adj_cache;
   bool model_uploaded = false;  // everything upload_model copies to the device is current
   DevicePlan fwd, adj;
   DevBuf<DevTerm> terms, global_terms;  // global_terms: measured on the final state in HBM (too wide for a tile)
   DevBuf<ObsGroup> obs_groups;
+  DevBuf<ObsBTerm> obs_bterms;    // the same terms sorted and cut for the block-grouped kernels (observable.hip)
+  DevBuf<ObsBGroup> obs_bgroups;
+  uint32_t n_obs_bgroups = 0;
+  int opt_obs_kernel = -1;      // lambda = O psi / values: 0 = one gather per mask (apply_observable_kernel), 1 = partner blocks through
+                                // LDS (observable_blocks_kernel), -1 = the block kernel whenever the state has a block (>= 13 qubits)
+  int opt_multi_values = -1;    // several observables: values from the block kernel after lean passes (-1: when some term flips >= 2
+                                // qubits or needs a measurement-only pass, at most kMultiValueOps observables)
   DevBuf<float> value_part;  // value mode: one partial of <psi|O|psi> per workgroup of apply_observable_kernel
   uint32_t n_obs_groups = 0;
   DevBuf<float2> psi, lam;
@@ -146,7 +168,7 @@ size_t own_bytes(const qhbm_engine* h) {
          buf_bytes(h->value_part) + buf_bytes(h->upstream_tmp) + buf_bytes(h->vals_tmp) + buf_bytes(h->prog_acc) +
          buf_bytes(h->shift_vals) + buf_bytes(h->shift_weight) + buf_bytes(h->shift_gates) + buf_bytes(h->shift_param) +
          buf_bytes(h->slot_factor) + buf_bytes(h->phase_cs) + buf_bytes(h->shift_phases) + buf_bytes(h->terms) +
-         buf_bytes(h->global_terms) + buf_bytes(h->obs_groups) + buf_bytes(h->op_scale) + buf_bytes(h->op_inv_scale) +
+         buf_bytes(h->global_terms) + buf_bytes(h->obs_groups) + buf_bytes(h->obs_bterms) + buf_bytes(h->obs_bgroups) + buf_bytes(h->op_scale) + buf_bytes(h->op_inv_scale) +
          buf_bytes(h->param_slot_begin) + buf_bytes(h->param_slots) + plan_bytes(h->fwd) + plan_bytes(h->adj);
 }
 
@@ -280,14 +302,18 @@ double adjoint_plan_seconds(const Plan& plan, const Model& m) {
 }
 
 int build_plans(qhbm_engine* h) {
-  if (h->plans_valid) return 0;
+  if (h->plans_valid && h->adj_valid) return 0;
   h->retained_U = 0;
   if (!h->have_circuit) return fail(h, "qhbm_set_circuit has not been called");
   if (h->model.n_ops > kMaxOps) return fail(h, "too many observables (max 1024)");
   std::string err;
-  if (!build_plan(h->model, h->opt_tile, h->opt_round, false, &h->fwd.plan, &err, h->opt_full_fwd, h->opt_meas_tile,
-                  h->opt_cph_wave_bits != 0, false, h->opt_wide_last))
-    return fail(h, "forward plan: " + err);
+  if (!h->plans_valid) {  // (a change of the gradient mask alone keeps the forward plan: it does not depend on it)
+    h->adj_cache.clear();
+    if (!build_plan(h->model, h->opt_tile, h->opt_round, false, &h->fwd.plan, &err, h->opt_full_fwd, h->opt_meas_tile,
+                    h->opt_cph_wave_bits != 0, false, h->opt_wide_last))
+      return fail(h, "forward plan: " + err);
+    h->fwd.uploaded = false;
+  }
   // The backward plan.  Its pass kernel runs at the same fp32 rate whatever the plan (adjoint_plan_seconds), so the
   // plan with the least modelled time -- arithmetic, or tile traffic where a pass has little to compute -- is kept:
   //  * the scheduler's search ranks pass orders by a proxy (gates x live share); the best few complete orders and
@@ -346,11 +372,12 @@ int build_plans(qhbm_engine* h) {
     if (plan_adjoint(13, &wide, &wide_seconds, &err2) && wide.K == 13 && wide_seconds < 0.98 * adj_seconds)
       h->adj.plan = std::move(wide);
   }
-  h->fwd.uploaded = h->adj.uploaded = false;
+  h->adj.uploaded = false;
   h->model_uploaded = false;
   h->shift_ready = false;
-  h->coef_batch_programs = 0;
+  if (!h->plans_valid) h->coef_batch_programs = 0;
   h->plans_valid = true;
+  h->adj_valid = true;
   return 0;
 }
 
@@ -410,6 +437,28 @@ int upload_model(qhbm_engine* h) {
     HIPCHK(h->terms.upload(t));
     HIPCHK(h->obs_groups.upload(groups));
     h->n_obs_groups = uint32_t(groups.size());
+    {  // block-grouped order (kernels.h ObsBTerm): by partner block x >> 13, then by mask, then by observable
+      std::vector<DevTerm> bt = t;
+      std::stable_sort(bt.begin(), bt.end(), [](const DevTerm& a, const DevTerm& b) {
+        const uint32_t ao = a.x >> kObsBlockBits, bo = b.x >> kObsBlockBits;
+        if (ao != bo) return ao < bo;
+        if (a.x != b.x) return a.x < b.x;
+        return a.op < b.op;
+      });
+      std::vector<ObsBTerm> terms2;
+      std::vector<ObsBGroup> groups2;
+      for (size_t k = 0; k < bt.size(); ++k) {
+        const uint32_t xo = bt[k].x >> kObsBlockBits;
+        if (k == 0 || xo != (bt[k - 1].x >> kObsBlockBits)) groups2.push_back(ObsBGroup{xo, uint32_t(k), uint32_t(k), 0u});
+        groups2.back().end = uint32_t(k + 1);
+        const bool new_mask = k == groups2.back().begin || bt[k].x != bt[k - 1].x;
+        terms2.push_back(ObsBTerm{bt[k].coeff, bt[k].z, bt[k].x & ((1u << kObsBlockBits) - 1u),
+                                  (bt[k].op & 1023u) | ((bt[k].ny & 3u) << 10) | (new_mask ? kObsNewMask : 0u)});
+      }
+      HIPCHK(h->obs_bterms.upload(terms2));
+      HIPCHK(h->obs_bgroups.upload(groups2));
+      h->n_obs_bgroups = uint32_t(groups2.size());
+    }
     HIPCHK(h->op_scale.upload(h->h_op_scale));
     HIPCHK(h->op_inv_scale.upload(h->h_op_inv_scale));
   }
@@ -490,21 +539,44 @@ hipEvent_t* timer_begin(qhbm_engine* h, int kind, hipStream_t s) {
 void timer_end(hipEvent_t* e, hipStream_t s) { if (e) (void)hipEventRecord(*e, s); }
 
 // Forward passes for one chunk.
-// One observable: lambda = O psi gives <psi|O|psi> for free (apply_observable_kernel<A, true>), so the
-// paths that compute lambda anyway (value + VJP, and the retained forward of an autograd caller) skip
+// One observable: lambda = O psi gives <psi|O|psi> for free (apply_observable_kernel<A, true> / OBS_LAMBDA_VALUE), so
+// the paths that compute lambda anyway (value + VJP, and the retained forward of an autograd caller) skip
 // every measurement of the forward sweep.
 bool value_mode(const qhbm_engine* h) { return h->opt_values_from_obs != 0 && h->model.n_ops == 1; }
 
-// Forward-only calls: whether <psi|O|psi> comes from the lambda = O psi kernel (storing nothing) after lean passes.
+// lambda = O psi and the values through partner blocks staged in LDS (observable.hip) instead of one gather per mask
+bool block_kernel(const qhbm_engine* h) { return h->opt_obs_kernel != 0 && h->fwd.plan.n_eff >= kObsBlockBits; }
+
+// Some term flips two or more qubits, or some group needs a measurement-only pass: measuring in the tiles costs more
+// than one sweep of the observable kernel over the final state.
+bool wide_observables(const qhbm_engine* h) {
+  bool wide = false;
+  for (const Pass& p : h->fwd.plan.passes) wide |= p.is_measure_only;
+  for (const auto& t : h->model.terms) wide |= __builtin_popcountll(t.x) >= 2;
+  return wide;
+}
+
+// Several observables (qnn.expectation(states, [op...]), /root/reference/tests/inference/qnn_test.py:187-190): the
+// forward sweep runs its lean, paired, measurement-free passes and ONE launch of the block kernel returns every
+// <psi|O_t|psi>; a VJP call adds the launch that forms lambda = sum_t upstream_t O_t psi.  Sums of diagonal and
+// single-flip terms (TFIM, the Z-string shards of a modular Hamiltonian) keep measuring in the tiles -- the
+// Walsh-Hadamard measurement takes hundreds of shards for the price of a few.
+constexpr int kMultiValueOps = 64;
+bool multi_value_mode(const qhbm_engine* h) {
+  if (h->opt_values_from_obs == 0 || h->opt_multi_values == 0 || h->model.n_ops < 2 || !block_kernel(h)) return false;
+  if (h->model.n_ops > int(kObsMaxValueOps)) return false;
+  if (h->opt_multi_values > 0) return true;
+  return h->model.n_ops <= kMultiValueOps && h->fwd.plan.passes.size() > 1 && wide_observables(h);
+}
+
+// Forward-only calls: whether the values come from the observable kernel (storing nothing) after lean passes.
 bool forward_values_from_observable(const qhbm_engine* h) {
+  if (multi_value_mode(h)) return true;
   if (!value_mode(h) || h->opt_fwd_values_obs == 0) return false;
   if (h->opt_fwd_values_obs > 0) return true;
   // measured (scripts/fwd_values_ab.sh): XXZ at 20 qubits - 17 %, 512 random Pauli strings at 24 qubits - 12 %;
   // sums of single-flip and diagonal terms (TFIM) are measured in the tiles at no traffic: + 2 % at 28 and at 16 qubits
-  bool wide = false;
-  for (const Pass& p : h->fwd.plan.passes) wide |= p.is_measure_only;
-  for (const auto& t : h->model.terms) wide |= __builtin_popcountll(t.x) >= 2;
-  return wide && h->fwd.plan.passes.size() > 1;
+  return wide_observables(h) && h->fwd.plan.passes.size() > 1;
 }
 
 // `skip_measure`: the caller takes the values from lambda = O psi (value_mode): measurement groups
@@ -579,6 +651,7 @@ int ensure_state_buffers(qhbm_engine* h, uint32_t cs, bool with_lam) {
 
 int run_observable_chunk(qhbm_engine* h, uint32_t s0, uint32_t c, const float* d_upstream, bool value_mode,
                          hipStream_t stream, bool store_lambda = true);
+int run_values_chunk(qhbm_engine* h, uint32_t row0, uint32_t c, hipStream_t stream);
 
 int forward(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, float* d_out,
             int shift_gate, double shift, hipStream_t stream) {
@@ -598,22 +671,50 @@ int forward(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, 
     const uint32_t c = std::min<uint32_t>(cs, uint32_t(U) - s0);
     if (int rc = run_forward_chunk(h, d_bits, s0, c, from_obs, stream, from_obs)) return rc;
     if (from_obs)
-      if (int rc = run_observable_chunk(h, s0, c, nullptr, true, stream, false)) return rc;
+      if (int rc = run_values_chunk(h, s0, c, stream)) return rc;
   }
   return values_end(h, U, d_out, stream);
 }
 
-// lambda = O psi and the backward passes for one chunk whose final states sit in psi.
+bool observable_xcd_states(const qhbm_engine* h) {
+  if (h->opt_obs_xcd_states >= 0) return h->opt_obs_xcd_states != 0;
+  return true;
+}
+
 // lambda = O psi for the chunk in the workspace.  value_mode (a single observable): unweighted, and
 // <psi|O|psi> goes to the fixed-point value accumulators -- the forward sweep measured nothing.
 int run_observable_chunk(qhbm_engine* h, uint32_t s0, uint32_t c, const float* d_upstream, bool value_mode,
                          hipStream_t stream, bool store_lambda) {
-  if (value_mode) HIPCHK(h->value_part.reserve(observable_value_parts(uint32_t(h->fwd.plan.n_eff), c)));
+  const uint32_t n_eff = uint32_t(h->fwd.plan.n_eff);
+  if (value_mode)
+    HIPCHK(h->value_part.reserve(block_kernel(h) ? observable_blocks_value_parts(n_eff, c, 1u) : observable_value_parts(n_eff, c)));
   hipEvent_t* ev = timer_begin(h, 2, stream);
-  HIPCHK(launch_apply_observable(h->psi.p, store_lambda ? h->lam.p : nullptr, uint32_t(h->fwd.plan.n_eff), c, h->terms.p,
-                                 uint32_t(h->model.terms.size()), h->obs_groups.p, h->n_obs_groups, d_upstream,
-                                 uint32_t(h->model.n_ops), s0, h->op_scale.p, value_mode ? h->vals64.p : nullptr,
-                                 h->value_part.p, h->opt_obs_xcd_states != 0, stream));
+  if (block_kernel(h)) {
+    const int mode = !value_mode ? OBS_LAMBDA : (store_lambda ? OBS_LAMBDA_VALUE : OBS_VALUES);
+    HIPCHK(launch_observable_blocks(mode, h->psi.p, store_lambda ? h->lam.p : nullptr, n_eff, c, h->obs_bterms.p,
+                                    h->obs_bgroups.p, h->n_obs_bgroups, d_upstream, uint32_t(h->model.n_ops), s0,
+                                    h->op_scale.p, value_mode ? h->vals64.p : nullptr, h->value_part.p,
+                                    observable_xcd_states(h), stream));
+  } else {
+    HIPCHK(launch_apply_observable(h->psi.p, store_lambda ? h->lam.p : nullptr, n_eff, c, h->terms.p,
+                                   uint32_t(h->model.terms.size()), h->obs_groups.p, h->n_obs_groups, d_upstream,
+                                   uint32_t(h->model.n_ops), s0, h->op_scale.p, value_mode ? h->vals64.p : nullptr,
+                                   h->value_part.p, observable_xcd_states(h), stream));
+  }
+  timer_end(ev, stream);
+  return 0;
+}
+
+// <psi|O_t|psi> of every observable for `c` final states in psi (rows row0 .. row0 + c of the fixed-point accumulators),
+// nothing stored: one observable through either kernel, several through the block kernel (multi_value_mode).
+int run_values_chunk(qhbm_engine* h, uint32_t row0, uint32_t c, hipStream_t stream) {
+  if (h->model.n_ops == 1) return run_observable_chunk(h, row0, c, nullptr, true, stream, false);
+  const uint32_t n_eff = uint32_t(h->fwd.plan.n_eff);
+  HIPCHK(h->value_part.reserve(observable_blocks_value_parts(n_eff, c, uint32_t(h->model.n_ops))));
+  hipEvent_t* ev = timer_begin(h, 2, stream);
+  HIPCHK(launch_observable_blocks(OBS_VALUES_MULTI, h->psi.p, nullptr, n_eff, c, h->obs_bterms.p, h->obs_bgroups.p,
+                                  h->n_obs_bgroups, nullptr, uint32_t(h->model.n_ops), row0, h->op_scale.p, h->vals64.p,
+                                  h->value_part.p, observable_xcd_states(h), stream));
   timer_end(ev, stream);
   return 0;
 }
@@ -666,10 +767,12 @@ int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_pa
   HIPCHK(hipMemsetAsync(h->state_grad.p, 0, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), stream));
   const uint32_t cs = adjoint_chunk_states(h, U);
   if (int rc = ensure_state_buffers(h, cs, true)) return rc;
-  const bool vm = value_mode(h);
+  const bool vm = value_mode(h), mv = multi_value_mode(h);
   for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += cs) {
     const uint32_t c = std::min<uint32_t>(cs, uint32_t(U) - s0);
-    if (int rc = run_forward_chunk(h, d_bits, s0, c, true, stream, vm)) return rc;
+    if (int rc = run_forward_chunk(h, d_bits, s0, c, true, stream, vm || mv)) return rc;
+    if (mv)  // several observables: their values from one launch over the final states, lambda (weighted) from the next
+      if (int rc = run_values_chunk(h, s0, c, stream)) return rc;
     if (int rc = run_observable_chunk(h, s0, c, d_upstream, vm, stream)) return rc;
     if (int rc = run_adjoint_chunk(h, d_bits, s0, c, stream)) return rc;
   }
@@ -758,10 +861,25 @@ int qhbm_set_gradient_mask(qhbm_engine* h, const uint8_t* needs_grad, int n_para
     if (!any) frozen.clear();
   }
   if (frozen != h->model.param_frozen) {
+    // the backward plan and the shift tables depend on the mask; the forward plan does not
+    if (h->plans_valid && h->adj_valid) {  // keep the plan of the mask that is leaving (at most four)
+      if (h->adj_cache.size() >= 4) h->adj_cache.erase(h->adj_cache.begin());
+      h->adj_cache.emplace_back(h->model.param_frozen, std::unique_ptr<DevicePlan>(new DevicePlan()));
+      h->adj_cache.back().second->swap(h->adj);
+    }
     h->model.param_frozen = std::move(frozen);
-    h->plans_valid = false;  // the backward plan and the shift tables depend on it
+    h->adj_valid = false;
+    for (size_t i = 0; i < h->adj_cache.size(); ++i)
+      if (h->plans_valid && h->adj_cache[i].first == h->model.param_frozen) {  // seen before: swap it back in
+        h->adj.swap(*h->adj_cache[i].second);
+        h->adj_cache.erase(h->adj_cache.begin() + long(i));
+        h->adj_valid = true;
+        h->model_uploaded = false;  // (the parameter -> slot tables follow the plan: a few KiB, no planning)
+        break;
+      }
     h->shift_ready = false;
     h->retained_U = 0;
+    h->state_grad_U = 0;
   }
   return 0;
 }
@@ -826,6 +944,8 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "adjoint_plan_search") { h->opt_adj_plan_search = int(value); h->plans_valid = false; }
   else if (k == "wide_last_pass") { h->opt_wide_last = int(value); h->plans_valid = false; }
   else if (k == "observable_xcd_states") h->opt_obs_xcd_states = int(value);
+  else if (k == "observable_kernel") h->opt_obs_kernel = int(value);
+  else if (k == "multi_observable_values") h->opt_multi_values = int(value);
   else if (k == "measure_tile_qubits") { h->opt_meas_tile = int(value); h->plans_valid = false; }
   else if (k == "values_from_observable") h->opt_values_from_obs = int(value);
   else if (k == "cph_wave_bits") { h->opt_cph_wave_bits = int(value); h->plans_valid = false; }
@@ -886,10 +1006,12 @@ int qhbm_expectation_retain(qhbm_engine* h, const int8_t* d_bits, int U, const f
   HIPCHK(launch_combine_diag(d.coef.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), 1u, 0u, s));
   if (int rc = values_begin(h, U, s)) return rc;
   if (int rc = ensure_state_buffers(h, uint32_t(U), true)) return rc;  // psi AND lambda, so psi is not moved later
-  const bool vm = value_mode(h);
-  if (int rc = run_forward_chunk(h, d_bits, 0, uint32_t(U), true, s, vm)) return rc;
+  const bool vm = value_mode(h), mv = multi_value_mode(h);
+  if (int rc = run_forward_chunk(h, d_bits, 0, uint32_t(U), true, s, vm || mv)) return rc;
   if (vm) {
     if (int rc = run_observable_chunk(h, 0, uint32_t(U), nullptr, true, s)) return rc;
+  } else if (mv) {
+    if (int rc = run_values_chunk(h, 0, uint32_t(U), s)) return rc;
   }
   if (int rc = values_end(h, U, d_out, s)) return rc;
   h->retained_U = U;
@@ -926,7 +1048,7 @@ int qhbm_expectation_vjp_retained(qhbm_engine* h, const int8_t* d_bits, int U, c
 int qhbm_state_gradients(qhbm_engine* h, int U, float* d_rows, void* stream) {
   if (!h || !d_rows) return 1;
   if (int rc = need_device(h)) return rc;
-  if (U <= 0 || U != h->state_grad_U || !h->plans_valid)
+  if (U <= 0 || U != h->state_grad_U || !h->plans_valid || !h->adj_valid)
     return fail(h, "qhbm_state_gradients: the last call was not an adjoint VJP on this many states");
   HIPCHK(launch_scatter_jac(h->state_grad.p, uint32_t(U), uint32_t(h->adj.plan.slot_gate.size()),
                             h->param_slot_begin.p, h->param_slots.p, h->slot_factor.p, d_rows, 1u, 0u,
@@ -994,6 +1116,10 @@ int qhbm_sample(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_para
   if (int rc = need_device(h)) return rc;
   if (U < 0 || n_shots < 0) return fail(h, "negative batch size or shot count");
   if (shift_gate >= int(h->model.gates.size())) return fail(h, "shift_gate out of range");
+  if (shift_gate < 0) shift_gate = -1;  // any negative value = the unshifted circuit (never the sentinel of a lowered fixed op)
+  else if (shift != 0.0 && h->model.gates[size_t(shift_gate)].param_idx < 0)
+    return fail(h, "shift_gate addresses a gate with a constant exponent: only parametrised gates have shifted programs "
+                   "(tfq ParameterShift.get_gradient_circuits shifts symbols), and a lowered constant gate cannot be shifted");
   if (int rc = upload_model(h)) return rc;
   if (U == 0 || n_shots == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1026,6 +1152,9 @@ int qhbm_sample_counts(qhbm_engine* h, const int8_t* d_bits, int U, const float*
   if (h->model.n > 24) return fail(h, "qhbm_sample_counts keeps 2^n counters per (program, state): n_qubits <= 24; use qhbm_sample");
   for (int q = 0; q < n_programs; ++q)
     if (shift_gates[q] >= int(h->model.gates.size())) return fail(h, "shift_gates entry out of range");
+  for (int q = 0; q < n_programs; ++q)
+    if (shift_gates[q] >= 0 && shifts[q] != 0.f && h->model.gates[size_t(shift_gates[q])].param_idx < 0)
+      return fail(h, "shift_gates entry addresses a gate with a constant exponent: only parametrised gates have shifted programs");
   if (int rc = upload_model(h)) return rc;
   if (U == 0 || n_programs == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1035,6 +1164,7 @@ int qhbm_sample_counts(qhbm_engine* h, const int8_t* d_bits, int U, const float*
   h->shift_ready = false;  // the shift tables below replace those of the parameter-shift VJP
   {
     std::vector<int> sg(shift_gates, shift_gates + n_programs);
+    for (int& g : sg) g = std::max(g, -1);  // any negative value = the unshifted circuit
     std::vector<float> sv(shifts, shifts + n_programs);
     HIPCHK(hipStreamSynchronize(s));  // synchronous copies into buffers an earlier call on this stream may still read
     HIPCHK(h->shift_gates.upload(sg));
@@ -1168,6 +1298,10 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const floa
   h->state_grad_U = 0;
   bool measure_only_after = !d.plan.global_terms.empty();
   for (const Pass& p : d.plan.passes) measure_only_after |= p.is_measure_only;
+  // The values of a shifted program come the way a forward-only call takes them: where that is the observable kernel
+  // (wide terms: lean passes, then one sweep over the final states, the lower block of every pair only), the
+  // shifted programs do the same -- config 4's 480 masks cost 51 measurement passes per program otherwise.
+  const bool from_obs = forward_values_from_observable(h);
   for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += Uc) {
     const uint32_t c = std::min<uint32_t>(Uc, uint32_t(U) - s0);
     for (uint32_t q0 = 0; q0 < n_prog; q0 += Pc) {
@@ -1178,10 +1312,12 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const floa
       HIPCHK(hipMemsetAsync(h->vals64.p, 0, size_t(nq) * c * size_t(h->model.n_ops) * sizeof(unsigned long long), s));
       for (size_t i = 0; i < d.plan.passes.size(); ++i) {
         const Pass& p = d.plan.passes[i];
+        if (from_obs && p.is_measure_only) continue;
         PassArgs a = d.args[i];
         a.flags = p.flags & (PASS_INIT_BASIS | PASS_GENERAL | PASS_NO_ZERO_FILL);
         if (h->opt_force_general) a.flags |= PASS_GENERAL;
-        if (!p.is_measure_only && (!p.completes_circuit || measure_only_after)) a.flags |= PASS_STORE;
+        if (from_obs) a.flags |= PASS_SKIP_MEASURE;
+        if (!p.is_measure_only && (!p.completes_circuit || measure_only_after || from_obs)) a.flags |= PASS_STORE;
         a.prog_states = c;
         a.coef_stride = stride;
         hipEvent_t* ev = timer_begin(h, 0, s);
@@ -1189,10 +1325,13 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const floa
                                h->coef_batch.p, h->op_scale.p, h->vals64.p, s0, s));
         timer_end(ev, s);
       }
-      if (!d.plan.global_terms.empty())
+      if (from_obs) {
+        if (int rc = run_values_chunk(h, 0u, nq * c, s)) return rc;
+      } else if (!d.plan.global_terms.empty()) {
         HIPCHK(launch_measure_global(h->psi.p, uint32_t(d.plan.n_eff), nq * c, h->global_terms.p,
                                      uint32_t(d.plan.global_terms.size()), h->op_scale.p, h->vals64.p,
                                      uint32_t(h->model.n_ops), 0u, s));
+      }
       HIPCHK(launch_values_from_fixed(h->vals64.p, h->op_inv_scale.p, h->vals_batch.p,
                                       nq * c * uint32_t(h->model.n_ops), uint32_t(h->model.n_ops), s));
       HIPCHK(launch_shift_program_accumulate(h->vals_batch.p, d_upstream, nq, c, uint32_t(h->model.n_ops), s0,
@@ -1342,7 +1481,7 @@ extern "C" int qhbm_flop_model(qhbm_engine* h, int U, int with_vjp, double* fwd_
   if (int rc = build_plans(h)) return rc;
   const double amps = double(size_t(1) << h->fwd.plan.n_eff) * double(U);
   double f = 0.0, o = 0.0, b = 0.0;
-  const bool from_obs = with_vjp ? value_mode(h) : forward_values_from_observable(h);  // no measurement in the sweep
+  const bool from_obs = with_vjp ? (value_mode(h) || multi_value_mode(h)) : forward_values_from_observable(h);  // no measurement in the sweep
   {
     std::vector<PassArgs> args;
     std::vector<uint32_t> prog, tables;
@@ -1399,7 +1538,7 @@ int qhbm_traffic_model(qhbm_engine* h, int U, int with_vjp, double* fwd_bytes, d
   double f = 0.0, o = 0.0, b = 0.0;
   bool measure_only_after = !h->fwd.plan.global_terms.empty();
   for (const Pass& p : h->fwd.plan.passes) measure_only_after |= p.is_measure_only;
-  const bool from_obs = with_vjp ? value_mode(h) : forward_values_from_observable(h);  // no measurement in the sweep
+  const bool from_obs = with_vjp ? (value_mode(h) || multi_value_mode(h)) : forward_values_from_observable(h);  // no measurement in the sweep
   {
     std::vector<PassArgs> fargs;
     std::vector<uint32_t> fprog, ftables;
@@ -1415,6 +1554,7 @@ int qhbm_traffic_model(qhbm_engine* h, int U, int with_vjp, double* fwd_bytes, d
   if (!with_vjp && from_obs) o = tile_all;  // psi read (gathered through L2), nothing written
   if (with_vjp) {
     o = 2.0 * tile_all;  // psi read (gathered through L2), lambda written
+    if (multi_value_mode(h)) o += tile_all;  // ... and the launch that returns the values of several observables
     std::vector<PassArgs> args;
     std::vector<uint32_t> prog, tables;
     fill_args(h->adj.plan, h->model, &args, &prog, &tables);

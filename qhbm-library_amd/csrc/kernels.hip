@@ -22,6 +22,7 @@
 #include <utility>
 
 #include "../../include/qhbm_engine.h"
+#include "device_common.h"
 #include "kernels.h"
 #include "program.h"
 
@@ -31,31 +32,6 @@ namespace {
 
 
 __device__ __forceinline__ uint32_t swz(uint32_t l) { return l ^ ((l >> 5) & 31u); }
-
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// Sum over the 64 lanes of a wave (the result is wave-uniform).  Rows of 16 lanes are
-// reduced with DPP (no LDS traffic, no waitcnt); the four row sums are combined
-// through readlane.
-template <int CTRL>
-__device__ __forceinline__ float dpp_step(float v) {
-  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
-  return v + __int_as_float(t);
-}
-__device__ __forceinline__ float wave_sum(float v) {
-  v = dpp_step<0xB1>(v);   // quad_perm:[1,0,3,2]
-  v = dpp_step<0x4E>(v);   // quad_perm:[2,3,0,1]
-  v = dpp_step<0x141>(v);  // row_half_mirror
-  v = dpp_step<0x140>(v);  // row_mirror  -> every lane holds its 16-lane row sum
-  const int iv = __float_as_int(v);
-  return __int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16)) +
-         __int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48));
-}
-
-// Fixed-point image of a partial expectation value (two's complement in an unsigned word).
-__device__ __forceinline__ unsigned long long to_fixed(float v, float scale) {
-  return static_cast<unsigned long long>(__float2ll_rn(v * scale));
-}
 
 // Waves per SIMD the register allocator must leave room for: as many workgroups per CU
 // as the LDS footprint admits (160 KiB per CU), capped at 4 waves per SIMD.
@@ -102,7 +78,6 @@ template <int RB> constexpr int ins0(int p) { return ((p >> RB) << (RB + 1)) | (
 // low/high result, neg_lo/neg_hi flip a sign, so a complex multiply-add is one
 // v_pk_mul + one v_pk_fma and nothing is ever re-packed.  cs = (c, s) is a
 // wave-uniform SGPR pair, or a VGPR pair for thread-predicated phases.
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Y**t on a pair: (a0, a1) <- (c a0 - s a1, s a0 + c a1).  Rotated products go to temporaries
 // first, then each amplitude is updated in place -- four packed ops per pair, no register copy.
@@ -1963,7 +1938,7 @@ __global__ void prep_coefs_kernel(const CoefJob* __restrict__ jobs, int n_jobs,
   const CoefJob jb = jobs[j];
   double t = double(jb.offset);
   if (jb.param_idx >= 0) t += double(jb.scalar) * double(params[jb.param_idx]);
-  if (jb.gate == shift_gate) t += shift;
+  if (shift_gate >= 0 && jb.gate == shift_gate) t += shift;  // (negative = unshifted, whatever the value: fixed ops carry gate -2)
   float* o = coef + jb.out_off;
   if (jb.mop == MOP_PHASE) {  // diagonal term exp(i*pi*mult*t) on its index set
     double sn, cs;

@@ -1,0 +1,387 @@
+// observable.hip -- lambda = O psi and <psi|O|psi> for Pauli sums with MANY X-masks (gfx950).
+//
+// The reference hands every PauliSum to tfq.layers.Expectation (/root/reference/qhbmlib/inference/qnn.py:120-139);
+// the adjoint backward starts from lambda = sum_k upstream[s, op_k] c_k P_k psi, and with the state in HBM anyway
+// the same sweep yields the values <psi|O_t|psi>.
+//
+//   (P psi)[j] = i^ny (-1)^{popc((j ^ x) & z)} psi[j ^ x]
+//
+// apply_observable_kernel (kernels.hip) gathers psi[j ^ x] from L2 once per distinct mask x and block of 2048
+// amplitudes: fine for a chain Hamiltonian (20 masks), 453 gathers per block for BASELINE config 4 (512 random
+// strings on 24 qubits, 480 masks) -- 61 GB through L2 per 128-MiB state.  Here a workgroup owns a BLOCK of 2^13
+// amplitudes, a mask is split x = x_out | x_in (bits outside / inside the block), terms arrive sorted by x_out and
+// cut into GROUPS of equal x_out: the partner block b ^ x_out of a group is fetched ONCE (coalesced 16-byte loads,
+// staged through registers one group ahead) into a 64-KiB LDS buffer, and every mask of the group reads it from
+// there at l ^ x_in with ds_read_b128 (256 B/clk/CU against the 64 B/clk/CU a CU gets from L2).  Config 4: 173
+// block fetches instead of 453 gathers.
+//
+// Layout.  512 threads; thread t owns 8 ADJACENT PAIRS of the block, pair index t + 512 p (p = 0..7), i.e. local
+// amplitude l = 2 t + 1024 p + h: slot bits {0, 10, 11, 12}, thread bits 1..9.  The partner of an adjacent pair is an
+// adjacent pair, so every LDS read is one 16-byte word, conflict-free (an XOR on the lane bits permutes the 16-byte
+// chunks of a lane group).  x_in's slot part selects WHICH row (p ^ xp) and which half (h ^ x_0) a slot pairs
+// with: rows through an 8-way scalar switch over ds_read offsets, halves at compile time.
+// Sign of a term at own index j: (-1)^{popc(j & z) + ny}; the block part is scalar, the thread part one popcount
+// per term and thread, and the slot part -- parity(a & zs) for slot a, zs = the four slot bits of z -- is COMPILE
+// TIME: the accumulation of a term is one of 64 straight-line variants (zs x odd x imaginary), 16 packed FMAs
+// whose +-w / re<->im choices are op_sel modifiers on a (w, -w) register pair.  No per-amplitude sign arithmetic.
+//
+// Values.  <psi|P|psi> is real and the (j, j ^ x) and (j ^ x, j) contributions are complex conjugates, so the
+// value-only modes run a group with x_out != 0 on the lower block of each pair only, weight 2 (half the fetches).
+// One partial per (state, block, op) leaves in value_part; value_parts_blocks_kernel adds a state's partials in
+// block order in fp64 into the fixed-point accumulators (bit-reproducible, no float atomics).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <utility>
+
+#include "device_common.h"
+#include "kernels.h"
+
+namespace qhbm {
+
+namespace {
+
+constexpr uint32_t kOT = 512;                                // threads per workgroup
+constexpr uint32_t kOP = 8;                                  // adjacent pairs per thread
+constexpr uint32_t kOBlock = 1u << kObsBlockBits;            // amplitudes per block
+constexpr uint32_t kOWaves = kOT / 64;
+static_assert(kOT * kOP * 2 == kOBlock, "512 threads x 8 pairs = one block");
+
+// 16-byte words as a NATIVE vector type: copies of HIP's v4f struct become memcpy calls between address spaces,
+// which keep the register arrays below in scratch memory
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+
+// ---- one term on eight slots: a jump into a table of 64 straight-line variants ---------------------
+// (scripts/gen_observable_asm.py writes observable_variants.inc and documents the layout.)  A C++ switch over the
+// variants makes the structuriser copy the whole accumulator file into temporaries around every case -- 32 moves
+// for 16 FMAs, and the register file overflows; inside one asm statement the accumulators are updated in place.
+// w = (w, -w): op_sel on source 0 picks the sign per result half, op_sel on source 1 swaps re / im for an
+// imaginary weight.  `off` = 68 * variant + 12 (wave-uniform).  vcc carries the jump target.
+#include "observable_variants.inc"
+__device__ __forceinline__ void obs_fma8(v2f& a0, v2f& a1, v2f& a2, v2f& a3, v2f& a4, v2f& a5, v2f& a6, v2f& a7, v2f v0,
+                                         v2f v1, v2f v2, v2f v3, v2f v4, v2f v5, v2f v6, v2f v7, v2f w, uint32_t off) {
+  asm(OBS_ASM_FMA8
+      : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6), [a7] "+v"(a7)
+      : [w] "v"(w), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [v4] "v"(v4), [v5] "v"(v5), [v6] "v"(v6),
+        [v7] "v"(v7), [off] "s"(off)
+      : "vcc", "scc");
+}
+// value modes: s_{i & 3} += (+-)(own_i . v_i) (imaginary weight: own.y v.x - own.x v.y); the two halves of every s
+// are added, and the sum weighted, after the term
+__device__ __forceinline__ void obs_dot8(v2f& s0, v2f& s1, v2f& s2, v2f& s3, v2f o0, v2f o1, v2f o2, v2f o3, v2f o4, v2f o5,
+                                         v2f o6, v2f o7, v2f v0, v2f v1, v2f v2, v2f v3, v2f v4, v2f v5, v2f v6, v2f v7,
+                                         uint32_t off) {
+  asm(OBS_ASM_DOT8
+      : [s0] "+v"(s0), [s1] "+v"(s1), [s2] "+v"(s2), [s3] "+v"(s3)
+      : [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2), [o3] "v"(o3), [o4] "v"(o4), [o5] "v"(o5), [o6] "v"(o6), [o7] "v"(o7),
+        [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [v4] "v"(v4), [v5] "v"(v5), [v6] "v"(v6), [v7] "v"(v7),
+        [off] "s"(off)
+      : "vcc", "scc");
+}
+
+__device__ __forceinline__ v2f lo_half(const v4f& r) { return v2f{r.x, r.y}; }
+__device__ __forceinline__ v2f hi_half(const v4f& r) { return v2f{r.z, r.w}; }
+
+// One term on the thread's 16 slots (slot a = 2 p + h: row p, half h).  a[]: lambda accumulators (ACC) or the thread's
+// own amplitudes (value modes); r[p]: the partner pair of row p as read from LDS.  off0 / off1: table offsets of the
+// variant for slots 0..7 / 8..15 (they differ in the base sign when the Z mask holds the highest slot bit).
+template <bool ACC>
+__device__ __forceinline__ void obs_term(v2f (&a)[16], const v4f (&r)[8], v2f w, v2f (&s)[4], uint32_t off0, uint32_t off1) {
+  if constexpr (ACC) {
+    obs_fma8(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], lo_half(r[0]), hi_half(r[0]), lo_half(r[1]), hi_half(r[1]),
+             lo_half(r[2]), hi_half(r[2]), lo_half(r[3]), hi_half(r[3]), w, off0);
+    obs_fma8(a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], lo_half(r[4]), hi_half(r[4]), lo_half(r[5]),
+             hi_half(r[5]), lo_half(r[6]), hi_half(r[6]), lo_half(r[7]), hi_half(r[7]), w, off1);
+  } else {
+    obs_dot8(s[0], s[1], s[2], s[3], a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], lo_half(r[0]), hi_half(r[0]),
+             lo_half(r[1]), hi_half(r[1]), lo_half(r[2]), hi_half(r[2]), lo_half(r[3]), hi_half(r[3]), off0);
+    obs_dot8(s[0], s[1], s[2], s[3], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], lo_half(r[4]), hi_half(r[4]),
+             lo_half(r[5]), hi_half(r[5]), lo_half(r[6]), hi_half(r[6]), lo_half(r[7]), hi_half(r[7]), off1);
+  }
+}
+
+// the eight partner rows of a mask whose row part is XP: row p pairs with row p ^ XP (compile-time ds_read offsets)
+template <int XP, int... P>
+__device__ __forceinline__ void obs_rows_(v4f (&r)[8], const v4f* src, std::integer_sequence<int, P...>) {
+  ((r[P] = src[512 * (P ^ XP)]), ...);
+}
+template <int XP>
+__device__ __forceinline__ void obs_rows(v4f (&r)[8], const v4f* src) {
+  obs_rows_<XP>(r, src, std::make_integer_sequence<int, 8>{});
+}
+
+// (register arrays are only ever indexed by compile-time constants: integer_sequence folds, never loops)
+// One block (64 KiB) into the thread's prefetch registers: row P at `blk` + 8192 P + 16 tid, as BUFFER loads -- the
+// block is the buffer (a wave-uniform descriptor in four SGPRs), the row a scalar offset, and the eight loads share
+// ONE 32-bit offset register; flat global loads need eight 64-bit address pairs, which the register file of
+// accumulators + partner rows + prefetch rows has no room for (18 spilled registers).
+typedef int v4i __attribute__((ext_vector_type(4)));
+template <int... P>
+__device__ __forceinline__ void obs_fetch_(v4f (&pf)[8], __amdgpu_buffer_rsrc_t rs, uint32_t tid16, std::integer_sequence<int, P...>) {
+  ((pf[P] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, int(tid16), 8192 * P, 0))), ...);
+}
+__device__ __forceinline__ void obs_fetch(v4f (&pf)[8], const float2* __restrict__ blk, uint32_t tid16) {
+  // 0x00020000: the raw-buffer word 3 of gfx90a / gfx942 / gfx950 (32-bit data format, no swizzle)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(blk), 0, 8 << kObsBlockBits, 0x00020000);
+  obs_fetch_(pf, rs, tid16, std::make_integer_sequence<int, 8>{});
+}
+template <int... P>
+__device__ __forceinline__ void obs_stage_(v4f* dst, const v4f (&pf)[8], std::integer_sequence<int, P...>) {
+  ((dst[512 * P] = pf[P]), ...);
+}
+__device__ __forceinline__ void obs_stage(v4f* dst, const v4f (&pf)[8]) {
+  obs_stage_(dst, pf, std::make_integer_sequence<int, 8>{});
+}
+template <int... P>
+__device__ __forceinline__ void obs_own_(v2f (&a)[16], const v4f* __restrict__ src, std::integer_sequence<int, P...>) {
+  (([&] { const v4f o = src[512 * P]; a[2 * P] = v2f{o.x, o.y}; a[2 * P + 1] = v2f{o.z, o.w}; }()), ...);
+}
+template <int... P>
+__device__ __forceinline__ void obs_store_(v4f* __restrict__ dst, const v2f (&a)[16], std::integer_sequence<int, P...>) {
+  ((dst[512 * P] = v4f{a[2 * P].x, a[2 * P].y, a[2 * P + 1].x, a[2 * P + 1].y}), ...);
+}
+template <int... P>
+__device__ __forceinline__ float obs_energy_(const v4f* __restrict__ src, const v2f (&a)[16], std::integer_sequence<int, P...>) {
+  float e = 0.f;
+  (([&] {
+     const v4f o = src[512 * P];
+     e += (o.x * a[2 * P].x + o.y * a[2 * P].y) + (o.z * a[2 * P + 1].x + o.w * a[2 * P + 1].y);
+   }()), ...);
+  return e;
+}
+template <int... I>
+__device__ __forceinline__ void obs_zero_(v2f (&a)[16], std::integer_sequence<int, I...>) { ((a[I] = v2f{0.f, 0.f}), ...); }
+
+#define OBS_CASE8(F, B) F(B) F(B + 1) F(B + 2) F(B + 3) F(B + 4) F(B + 5) F(B + 6) F(B + 7)
+
+// first group at or after g that this block runs: value modes skip a pair's upper block
+template <bool HALVE>
+__device__ __forceinline__ uint32_t obs_next_group(const ObsBGroup* __restrict__ groups, uint32_t n_groups, uint32_t g, uint32_t bx) {
+  if constexpr (HALVE) {
+    while (g < n_groups) {
+      const uint32_t xo = groups[g].xout;
+      if (xo == 0u || (bx ^ xo) > bx) break;
+      ++g;
+    }
+  }
+  return g;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, 4) void observable_blocks_kernel(
+    const float2* __restrict__ psi, float2* __restrict__ lam, uint32_t n, const ObsBTerm* __restrict__ terms,
+    const ObsBGroup* __restrict__ groups, uint32_t n_groups, const float* __restrict__ upstream, uint32_t n_ops,
+    uint32_t state0, float* __restrict__ value_part, uint32_t nb /* blocks per state */, uint32_t n_states,
+    uint32_t xcd_states) {
+  constexpr bool ACC = MODE == OBS_LAMBDA || MODE == OBS_LAMBDA_VALUE;
+  constexpr bool HALVE = !ACC;
+  constexpr bool MULTI = MODE == OBS_VALUES_MULTI;
+  extern __shared__ v4f lds4[];  // [4096] the partner block of the current group; then the value cells
+  float* cells = reinterpret_cast<float*>(lds4 + kOBlock / 2);
+  // Workgroup -> (state, block).  Workgroups are dealt round-robin to the 8 XCDs (linear id mod 8), each with its own L2:
+  //   xcd_states: XCD k works on state 8 g + k, its blocks in index order;
+  //   otherwise XCD k takes the k-th contiguous eighth of every state (a 128-MiB state then sits in the Infinity
+  //   Cache once and serves all eight L2s).  Either way the workgroups an XCD runs at one time are neighbours in the
+  //   index, walk the groups in the same order, and fetch partner blocks from the same few MiB.
+  uint32_t s_local, bx;
+  {
+    const uint32_t wg = blockIdx.x, per_group = 8u * nb, group = wg / per_group, r = wg - group * per_group;
+    if (xcd_states && (group + 1u) * 8u <= n_states) {
+      s_local = group * 8u + (r & 7u);
+      bx = r >> 3;
+    } else {
+      const uint32_t q = r / nb, b = r - q * nb;
+      s_local = group * 8u + q;
+      bx = (nb & 7u) ? b : (b & 7u) * (nb >> 3) + (b >> 3);
+    }
+  }
+  const uint32_t tid = threadIdx.x;
+  const float2* ps = psi + (size_t(s_local) << n);
+  const v4f* own4 = reinterpret_cast<const v4f*>(ps + (size_t(bx) << kObsBlockBits)) + tid;
+  const float* up = MODE == OBS_LAMBDA ? upstream + size_t(state0 + s_local) * n_ops : nullptr;
+
+  v2f a[16];
+  if constexpr (ACC) obs_zero_(a, std::make_integer_sequence<int, 16>{});
+  else obs_own_(a, own4, std::make_integer_sequence<int, 8>{});
+  if constexpr (MULTI) {
+    for (uint32_t i = tid; i < kOWaves * n_ops; i += kOT) cells[i] = 0.f;
+    __syncthreads();
+  }
+  v4f r[8], pf[8];
+  obs_rows<0>(r, lds4 + tid);  // (defined values before the first mask; never used)
+  v2f d2 = v2f{0.f, 0.f};  // value modes: sum_k W_k (own . partner), both halves
+  uint32_t cur_op = 0;
+
+  uint32_t g = obs_next_group<HALVE>(groups, n_groups, 0u, bx);
+  // (past the last group the prefetch re-reads the block's own amplitudes: no branch around the register file)
+  obs_fetch(pf, ps + (size_t(bx ^ (g < n_groups ? groups[g].xout : 0u)) << kObsBlockBits), tid << 4);
+  while (g < n_groups) {
+    const uint32_t g_xout = groups[g].xout, g_begin = groups[g].begin, g_end = groups[g].end;
+    __syncthreads();  // every wave has finished reading the previous group's block
+    obs_stage(lds4 + tid, pf);
+    __syncthreads();
+    const uint32_t gn = obs_next_group<HALVE>(groups, n_groups, g + 1u, bx);
+    // the next group's partner block: in flight while this group is consumed
+    obs_fetch(pf, ps + (size_t(bx ^ (gn < n_groups ? groups[gn].xout : 0u)) << kObsBlockBits), tid << 4);
+    const float pair_weight = (HALVE && g_xout != 0u) ? 2.f : 1.f;
+    for (uint32_t k = g_begin; k < g_end; ++k) {
+      const ObsBTerm t = terms[k];
+      const uint32_t meta = t.meta;
+      if (meta & kObsNewMask) {
+        const v4f* src = lds4 + (tid ^ ((t.xin >> 1) & 511u));
+        switch ((t.xin >> 10) & 7u) {
+#define OBS_ROWS(V) case V: obs_rows<V>(r, src); break;
+          OBS_CASE8(OBS_ROWS, 0)
+#undef OBS_ROWS
+        }
+      }
+      const uint32_t ny = (meta >> 10) & 3u, op = meta & 1023u;
+      float wv = t.coeff * pair_weight;
+      if constexpr (MODE == OBS_LAMBDA) wv *= up[op];
+      // sign at the thread's own index: block part, ny (and i^2 = -1 for ny >= 2), thread part; the slot part is in the variant
+      const uint32_t sg = (uint32_t(__popc(bx & (t.z >> kObsBlockBits))) + ny + (ny >> 1) +
+                           uint32_t(__popc(tid & (t.z >> 1) & 511u))) & 1u;
+      const float wp = __uint_as_float(__float_as_uint(wv) ^ (sg << 31));
+      const v2f w = v2f{wp, -wp};
+      v2f s[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+      if constexpr (!ACC) {
+        if constexpr (MULTI) {
+          if (op != cur_op) {  // (wave-uniform) the partial of the previous observable goes to this wave's cell
+            const float e = wave_sum(d2.x + d2.y);
+            if ((tid & 63u) == 0u) cells[(tid >> 6) * n_ops + cur_op] += e;
+            d2 = v2f{0.f, 0.f};
+            cur_op = op;
+          }
+        }
+      }
+      // variant: the Z bits of the three low slot bits, odd x, imaginary weight; the highest slot bit's Z bit is the
+      // base sign of slots 8..15
+      const uint32_t zs = (t.z & 1u) | (((t.z >> 10) & 7u) << 1);
+      const uint32_t off0 = ((zs & 7u) | ((t.xin & 1u) << 4) | ((ny & 1u) << 5)) * uint32_t(OBS_CHUNK_BYTES) + uint32_t(OBS_PREAMBLE_BYTES);
+      const uint32_t off1 = off0 + (zs & 8u) * uint32_t(OBS_CHUNK_BYTES);
+      obs_term<ACC>(a, r, w, s, off0, off1);
+      if constexpr (!ACC) {
+        const v2f ss = (s[0] + s[1]) + (s[2] + s[3]);
+        d2 += wp * ss;
+      }
+    }
+    g = gn;
+  }
+
+  if constexpr (ACC) {
+    if (lam) {
+      obs_store_(reinterpret_cast<v4f*>(lam + (size_t(s_local) << n) + (size_t(bx) << kObsBlockBits)) + tid, a,
+                 std::make_integer_sequence<int, 8>{});
+    }
+  }
+  if constexpr (MODE == OBS_LAMBDA) return;
+  if constexpr (MULTI) {
+    {
+      const float e = wave_sum(d2.x + d2.y);
+      if ((tid & 63u) == 0u) cells[(tid >> 6) * n_ops + cur_op] += e;
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < n_ops; t += kOT) {
+      float e = 0.f;
+#pragma unroll
+      for (uint32_t w8 = 0; w8 < kOWaves; ++w8) e += cells[w8 * n_ops + t];  // wave order: bit-reproducible
+      value_part[(size_t(s_local) * nb + bx) * n_ops + t] = e;
+    }
+  } else {
+    float e;
+    if constexpr (MODE == OBS_LAMBDA_VALUE) {  // <psi|O|psi> = sum_j Re(conj(psi_j) lambda_j)
+      e = obs_energy_(own4, a, std::make_integer_sequence<int, 8>{});
+    } else {
+      e = d2.x + d2.y;
+    }
+    e = wave_sum(e);
+    __syncthreads();  // the partner buffer is free now
+    if ((tid & 63u) == 0u) cells[tid >> 6] = e;
+    __syncthreads();
+    if (tid == 0u) {
+      float tot = 0.f;
+#pragma unroll
+      for (uint32_t w8 = 0; w8 < kOWaves; ++w8) tot += cells[w8];
+      value_part[size_t(s_local) * nb + bx] = tot;  // logical block: the sum order does not depend on the XCD map
+    }
+  }
+}
+
+// <psi|O_t|psi> of state s = sum of its blocks' partials, in block order (bit-reproducible), into the
+// fixed-point value accumulator of (s, t).
+__global__ __launch_bounds__(256) void value_parts_blocks_kernel(const float* __restrict__ value_part, uint32_t n_blocks,
+                                                                 uint32_t n_ops, const float* __restrict__ op_scale,
+                                                                 unsigned long long* __restrict__ out64, uint32_t state0) {
+  __shared__ double part[256];
+  const uint32_t s = blockIdx.x, t = blockIdx.y;
+  double acc = 0.0;
+  for (uint32_t b = threadIdx.x; b < n_blocks; b += 256u) acc += double(value_part[(size_t(s) * n_blocks + b) * n_ops + t]);
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (int(threadIdx.x) < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out64[size_t(state0 + s) * n_ops + t] += to_fixed(float(part[0]), op_scale[t]);
+}
+
+constexpr int kMaxDev = 64;
+template <typename Kernel>
+hipError_t obs_opt_in(Kernel kernel, bool (&done)[kMaxDev], size_t lds) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= kMaxDev) return hipErrorInvalidDevice;
+  if (done[dev]) return hipSuccess;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+  if (e == hipSuccess) done[dev] = true;
+  return e;
+}
+
+}  // namespace
+
+size_t observable_blocks_value_parts(uint32_t n, uint32_t n_states, uint32_t n_ops) {
+  return size_t(n_states) * (size_t(1) << (n - kObsBlockBits)) * std::max<uint32_t>(n_ops, 1u);
+}
+
+hipError_t launch_observable_blocks(int mode, const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
+                                    const ObsBTerm* terms, const ObsBGroup* groups, uint32_t n_groups,
+                                    const float* upstream, uint32_t n_ops, uint32_t state0, const float* op_scale,
+                                    unsigned long long* out64, float* value_part, bool xcd_states, hipStream_t stream) {
+  if (n < uint32_t(kObsBlockBits) || n_states == 0) return n_states ? hipErrorInvalidValue : hipSuccess;
+  if (mode == OBS_VALUES_MULTI && n_ops > kObsMaxValueOps) return hipErrorInvalidValue;
+  const uint32_t nb = 1u << (n - kObsBlockBits);
+  const uint32_t xs = xcd_states && nb >= 64u ? 1u : 0u;  // (a state must at least fill an XCD's workgroup slots)
+  // the largest cell area any mode uses, so that every instantiation is opted in once for the same size
+  const size_t lds = size_t(kOBlock) * 8u + size_t(kOWaves) * kObsMaxValueOps * sizeof(float);
+  static bool done[4][kMaxDev];
+  hipError_t e = hipSuccess;
+#define QHBM_OBSB(M_)                                                                                                   \
+  {                                                                                                                    \
+    e = obs_opt_in(observable_blocks_kernel<M_>, done[M_], lds);                                                        \
+    if (e != hipSuccess) return e;                                                                                     \
+    const size_t use = size_t(kOBlock) * 8u + (M_ == OBS_VALUES_MULTI ? size_t(kOWaves) * n_ops * sizeof(float) : 64u); \
+    hipLaunchKernelGGL((observable_blocks_kernel<M_>), dim3(nb * n_states), dim3(kOT), use, stream, psi, lam, n, terms, \
+                       groups, n_groups, upstream, n_ops, state0, value_part, nb, n_states, xs);                       \
+  }
+  switch (mode) {
+    case OBS_LAMBDA: QHBM_OBSB(OBS_LAMBDA) break;
+    case OBS_LAMBDA_VALUE: QHBM_OBSB(OBS_LAMBDA_VALUE) break;
+    case OBS_VALUES: QHBM_OBSB(OBS_VALUES) break;
+    case OBS_VALUES_MULTI: QHBM_OBSB(OBS_VALUES_MULTI) break;
+    default: return hipErrorInvalidValue;
+  }
+#undef QHBM_OBSB
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (mode != OBS_LAMBDA) {
+    const uint32_t T = mode == OBS_VALUES_MULTI ? n_ops : 1u;
+    hipLaunchKernelGGL(value_parts_blocks_kernel, dim3(n_states, T), dim3(256), 0, stream, value_part, nb, T, op_scale,
+                       out64, state0);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+}  // namespace qhbm

@@ -21,6 +21,19 @@ class QHBM(torch.nn.Module):
     self._q_inference = input_qnn
     self._modular_hamiltonian = hamiltonian.Hamiltonian(self.e_inference.energy,
                                                         self.q_inference.circuit)
+    self._seeds_agreed_for = None
+
+  def agree_seeds(self):
+    """When the quantum inference shards its expectation over a process group, every rank's EBM sampler must draw
+    the same samples (one sample set, dedup, then the hot path: ebm.py:271-280 of the reference): the sampler takes
+    rank 0's seed, ONCE per group.  COLLECTIVE over that group -- and only ever called from inside calls that are
+    collective already (`expectation`, `circuits`, `vqt`, `qmhl`), never at construction time.  A no-op without a
+    process group, so ranks that run independent models keep independent seeds."""
+    group = getattr(self.q_inference, "_group", lambda: None)()
+    if group is None or self._seeds_agreed_for is group:
+      return
+    self.e_inference.agree_seed(group)
+    self._seeds_agreed_for = group
 
   @property
   def e_inference(self):
@@ -41,6 +54,7 @@ class QHBM(torch.nn.Module):
   def circuits(self, num_samples: int):
     """Unique sampled eigenstates and their counts (qhbm.py:97-122).  States are
     returned as (bitstrings, circuit) -- see QuantumCircuit.forward."""
+    self.agree_seeds()
     samples = self.e_inference.sample(num_samples)
     bitstrings, _, counts = utils.unique_bitstrings_with_counts(samples)
     states = self.q_inference.circuit(bitstrings)
@@ -48,5 +62,6 @@ class QHBM(torch.nn.Module):
 
   def expectation(self, observables):
     """Sample-averaged expectation values, shape [n_ops] (qhbm.py:124-147)."""
+    self.agree_seeds()
     return self.e_inference.expectation(
         functools.partial(self.q_inference.expectation, observables=observables))

@@ -138,9 +138,10 @@ class QuantumInference(torch.nn.Module, abc.ABC):
     else:
       total_circuit = self.circuit
     circuits = ResolvedCircuits(*total_circuit(unique_states))
-    tiled_values = total_circuit.symbol_values.unsqueeze(0).expand(circuits.num_circuits, -1)
+    values, flags = total_circuit.symbol_values_and_flags()   # (one pass through the value layers)
+    tiled_values = values.unsqueeze(0).expand(circuits.num_circuits, -1)
     if tiled_values.requires_grad:  # which symbols a backward pass will want (e.g. not a fixed data circuit's)
-      circuits.gradient_mask = total_circuit.symbol_requires_grad()
+      circuits.gradient_mask = flags
     unique_expectations = self._expectation(circuits, total_circuit.symbol_names, tiled_values, observables)
     return utils.expand_unique_results(unique_expectations, idx)
 
@@ -237,7 +238,9 @@ class AnalyticQuantumInference(QuantumInference):
       return None
     if not (dist.is_available() and dist.is_initialized()):
       raise _engine.EngineError("process_group given but torch.distributed is not initialised")
-    return dist.group.WORLD if g is True else g
+    g = dist.group.WORLD if g is True else g
+    # a group of ONE rank is no group: no gathers of per-state rows, no consistency exchange (VERDICT r3 #6b)
+    return g if dist.get_world_size(g) > 1 else None
 
   def _engine_for(self, n_qubits, flat_gates, n_symbols, op_masks):
     key = (n_qubits, tuple(flat_gates), n_symbols, tuple(tuple(m) for m in op_masks))
@@ -336,6 +339,18 @@ class SampledQuantumInference(QuantumInference):
   `MAX_COUNT_QUBITS` qubits, from materialised shots (`qhbm_sample`, one program per call) above."""
 
   MAX_COUNT_QUBITS = 16   # 2^n counters per (program, state)
+  # The counts of one engine call are [programs, states, 2^n] int32 and their frequencies the same again in float32:
+  # a backward pass asks for 2 G programs at once, which at 16 qubits, ~100 gates and ~100 states would be tens of
+  # GB.  The programs therefore go in slices of at most this many bytes, each reduced to its [Q, U, T] estimates
+  # before the next is drawn; a single program above the budget falls back to materialised shots.
+  COUNT_BYTES_BUDGET = 1 << 30
+
+  def _count_slice(self, n_programs, n_states, n_qubits):
+    """Programs per `qhbm_sample_counts` call (0: not even one fits -- use shots)."""
+    per_program = max(1, n_states) * (1 << n_qubits) * 8
+    if n_qubits > self.MAX_COUNT_QUBITS or per_program > self.COUNT_BYTES_BUDGET:
+      return 0
+    return max(1, min(n_programs, self.COUNT_BYTES_BUDGET // per_program))
 
   def __init__(self, input_circuit: circuit.QuantumCircuit, expectation_samples: int,
                name: Union[None, str] = None, device: Union[None, int] = None,
@@ -406,10 +421,13 @@ class SampledQuantumInference(QuantumInference):
     def estimator(shift_gates=(-1,), shifts=(0.0,)):
       shift_gates, shifts = list(shift_gates), list(shifts)
       out = torch.ones((len(shift_gates), bits.shape[0], len(strings)), dtype=torch.float32, device=values.device)
+      step = self._count_slice(len(shift_gates), bits.shape[0], n) if use_counts else 0
       for eng, members, masks, signs in plans:
-        if signs is not None:
-          freq = self._counts(eng, bits, values, shift_gates, shifts)               # [Q, U, 2^n]
-          out[:, :, members] = torch.matmul(freq, signs.to(freq.device)).to(out.device)
+        if signs is not None and step:
+          for lo in range(0, len(shift_gates), step):                               # bounded slices of programs
+            freq = self._counts(eng, bits, values, shift_gates[lo:lo + step], shifts[lo:lo + step])   # [q, U, 2^n]
+            out[lo:lo + step, :, members] = torch.matmul(freq, signs.to(freq.device)).to(out.device)
+            del freq
         else:                                                                       # wide registers: shots, one program at a time
           for q, (g, sh) in enumerate(zip(shift_gates, shifts)):
             shots = eng.sample(bits, values, self._expectation_samples, self._next_seed(), g, sh)
@@ -446,11 +464,17 @@ class SampledQuantumInference(QuantumInference):
       def mean_energy(shift_gates, shifts):
         """[Q, U, 1] shot average of energy(x) under each of the Q shifted programs."""
         n_prog, n_states = len(shift_gates), bits.shape[0]
-        if n <= self.MAX_COUNT_QUBITS:
-          freq = self._counts(eng, bits, values, shift_gates, shifts).reshape(n_prog * n_states, 1 << n)
-          nz = torch.nonzero(freq)                                      # the outcomes that occurred
-          keys = (nz[:, 0] << n) | nz[:, 1]
-          return weighted_energy(keys, freq[nz[:, 0], nz[:, 1]], n_prog * n_states).reshape(n_prog, n_states, 1)
+        step = self._count_slice(n_prog, n_states, n)
+        if step:
+          parts = []
+          for lo in range(0, n_prog, step):                               # bounded slices of programs
+            q = min(step, n_prog - lo)
+            freq = self._counts(eng, bits, values, shift_gates[lo:lo + q], shifts[lo:lo + q]).reshape(q * n_states, 1 << n)
+            nz = torch.nonzero(freq)                                      # the outcomes that occurred
+            keys = (nz[:, 0] << n) | nz[:, 1]
+            parts.append(weighted_energy(keys, freq[nz[:, 0], nz[:, 1]], q * n_states).reshape(q, n_states, 1))
+            del freq
+          return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
         outs = []
         for g, sh in zip(shift_gates, shifts):
           samples = eng.sample(bits, values, self._expectation_samples, self._next_seed(), g, sh)

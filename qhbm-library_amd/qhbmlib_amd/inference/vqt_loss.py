@@ -16,6 +16,7 @@ def vqt(input_qhbm: "qhbm.QHBM", target_hamiltonian, beta):
     energies = input_qhbm.e_inference.energy(bitstrings).detach()
     return beta_h_expectations - energies.to(h_expectations.device)
 
+  input_qhbm.agree_seeds()   # (a no-op unless the quantum inference is sharded over a process group)
   average_expectation = input_qhbm.e_inference.expectation(f_vqt)
   current_partition = input_qhbm.e_inference.log_partition().detach()
   return average_expectation - current_partition.to(average_expectation.device)

@@ -65,29 +65,29 @@ class QuantumCircuit(torch.nn.Module):
   def trainable_variables(self):
     return [p for p in self._params if p.requires_grad]
 
-  @property
-  def symbol_values(self):
-    """1-D tensor, `symbol_values[i]` is the value of `symbol_names[i]` (circuit.py:93-107)."""
-    intermediate = []
+  def symbol_values_and_flags(self):
+    """(`symbol_values`, one bool per symbol: does that value depend on a tensor that requires grad?) from ONE pass
+    through the value layers (the engine does no gradient work for symbols nobody differentiates --
+    `qhbm_set_gradient_mask` --, e.g. the circuit of a fixed data QHBM)."""
+    intermediate, flags = [], []
     for inputs, layers in zip(self.value_layers_inputs, self.value_layers):
       x = inputs
       for layer in layers:
         x = layer(x)
       intermediate.append(x.reshape(-1))
+      flags += [bool(x.requires_grad)] * int(x.numel())
     if not intermediate:
-      return torch.zeros((0,), dtype=torch.float32)
-    return torch.cat(intermediate, 0)
+      return torch.zeros((0,), dtype=torch.float32), []
+    return torch.cat(intermediate, 0), flags
+
+  @property
+  def symbol_values(self):
+    """1-D tensor, `symbol_values[i]` is the value of `symbol_names[i]` (circuit.py:93-107)."""
+    return self.symbol_values_and_flags()[0]
 
   def symbol_requires_grad(self):
-    """One bool per symbol: does `symbol_values[i]` depend on a tensor that requires grad?  (The engine does no
-    gradient work for the others -- `qhbm_set_gradient_mask` -- e.g. for the circuit of a fixed data QHBM.)"""
-    flags = []
-    for inputs, layers in zip(self.value_layers_inputs, self.value_layers):
-      x = inputs
-      for layer in layers:
-        x = layer(x)
-      flags += [bool(x.requires_grad)] * int(x.numel())
-    return flags
+    """One bool per symbol: does `symbol_values[i]` depend on a tensor that requires grad?"""
+    return self.symbol_values_and_flags()[1]
 
   @property
   def pqc(self):

@@ -70,23 +70,40 @@ def default_group_size() -> int:
   return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-def agreed_seed(seed: int, group=None) -> int:
+def _collective_device(group, device=None) -> torch.device:
+  """Where a small tensor must live for a collective on `group`: the host for gloo, an explicit GPU for nccl
+  (= RCCL) -- `device` if given, else the current one (never an implicit cuda:0 before torch.cuda.set_device)."""
+  if _via_host(group):
+    return torch.device("cpu")
+  if device is not None and torch.device(device).type == "cuda":
+    return torch.device(device)
+  return torch.device("cuda", torch.cuda.current_device())
+
+
+def agreed_seed(seed: int, group=None, device=None) -> int:
   """Rank 0's `seed` on every rank of `group` (the default group when None; the identity without
-  torch.distributed).  The sharded expectation deals ONE set of unique bitstrings out over the
-  ranks (reference: one sample set, dedup, then the hot path -- qhbmlib/inference/ebm.py:271-280),
-  so every rank's sampler must draw the same samples: samplers created with `initial_seed=None`
-  route their fresh seed through here."""
+  torch.distributed).  COLLECTIVE: every rank of the group must call it.  The sharded expectation deals ONE set of
+  unique bitstrings out over the ranks (reference: one sample set, dedup, then the hot path --
+  qhbmlib/inference/ebm.py:271-280), so every rank's sampler must draw the same samples.  Nothing calls this at
+  construction time (round 3 did: a hidden collective per `initial_seed=None` object, deadlocking ranks that build
+  different objects): `QHBM.agree_seeds()` runs it once, lazily, inside the first sharded call -- which is
+  collective anyway -- and `agree_seeds(...)` below is the explicit form."""
   if default_group_size() == 1:
     return int(seed)
-  box = torch.tensor([int(seed)], dtype=torch.int64)
-  if not _via_host(group):
-    box = box.cuda()
+  box = torch.tensor([int(seed)], dtype=torch.int64, device=_collective_device(group, device))
   dist.broadcast(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
   return int(box.item())
 
 
+def agree_seeds(*samplers, group=None) -> None:
+  """Gives every sampler (objects with `agree_seed(group)`: the EnergyInference classes) rank 0's seed.
+  COLLECTIVE over `group`; call it with the same samplers in the same order on every rank."""
+  for s in samplers:
+    s.agree_seed(group)
+
+
 def fingerprint(*arrays) -> int:
-  """63-bit content hash (blake2b) of the given tensors / arrays: shapes, dtypes and bytes."""
+  """63-bit content hash (blake2b) of the given tensors / arrays: shapes, dtypes and bytes (host side)."""
   h = hashlib.blake2b(digest_size=8)
   for a in arrays:
     a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
@@ -96,26 +113,62 @@ def fingerprint(*arrays) -> int:
   return int.from_bytes(h.digest(), "little") & (2**63 - 1)
 
 
+_GOLDEN = -7046029254386353131  # 0x9E3779B97F4A7C15 as int64
+
+
+def device_fingerprint(*tensors) -> torch.Tensor:
+  """int64 [1] content hash computed WHERE THE TENSORS LIVE (no copy of the data to the host, no sync): every
+  tensor's elements, widened to int64 bit patterns, times position-dependent odd multipliers, summed mod 2^64, mixed
+  with the shapes.  Not cryptographic -- it only has to tell apart ranks that sampled different bitstrings or hold
+  different parameters."""
+  dev = next((t.device for t in tensors if torch.is_tensor(t)), torch.device("cpu"))
+  acc = torch.zeros((), dtype=torch.int64, device=dev)
+  salt = 1
+  for t in tensors:
+    t = torch.as_tensor(t, device=dev).detach().contiguous()
+    if t.dtype in (torch.float32,):
+      bits = t.view(torch.int32).to(torch.int64)
+    elif t.dtype in (torch.float64,):
+      bits = t.view(torch.int64)
+    else:
+      bits = t.to(torch.int64)
+    flat = bits.reshape(-1)
+    idx = torch.arange(flat.numel(), dtype=torch.int64, device=dev)
+    mult = (idx * _GOLDEN + (2 * salt + 1)) | 1            # int64 arithmetic wraps: that is the modulus
+    acc = acc * 31 + ((flat + 1) * mult).sum() + sum((d + 7) * (k + 3) for k, d in enumerate(t.shape)) * salt
+    salt += 1
+  return (acc & (2**63 - 1)).reshape(1)
+
+
 def assert_same_on_all_ranks(what: str, *arrays, group=None) -> None:
-  """Raises ShardMismatchError (on EVERY rank) unless all ranks of the group hold the same
-  `arrays`.  One all-gather of 8 bytes per rank.  Without this check ranks that sampled different
-  bitstrings -- differently seeded samplers -- or hold different parameters would partition different
-  unique sets and all-gather rows that do not belong together, silently."""
+  """Raises ShardMismatchError (on EVERY rank) unless all ranks of the group hold the same `arrays` (same shapes,
+  same content).  The hash is computed on the device (`device_fingerprint`: the [U, n] bitstrings and the [P] values
+  are never copied to the host); what crosses is ONE all-gather of 16 bytes per rank (hash, row count) and one
+  16 x world byte read-back.  It runs BEFORE the sharded call on purpose: ranks that sampled different numbers of
+  unique bitstrings would otherwise enter all-gathers with different block sizes.  Without this check ranks that
+  sampled different bitstrings -- differently seeded samplers -- or hold different parameters would partition
+  different unique sets and all-gather rows that do not belong together, silently."""
   world = dist.get_world_size(group)
   if world == 1:
     return
-  mine = torch.tensor([fingerprint(*arrays)], dtype=torch.int64)
-  if not _via_host(group):
-    mine = mine.cuda()
+  first = next((a for a in arrays if torch.is_tensor(a)), None)
+  dev = _collective_device(group, first.device if first is not None else None)
+  tensors = [torch.as_tensor(a) for a in arrays]
+  on_device = [t.to(dev) if t.device != dev and not t.is_cuda else t for t in tensors]
+  tag = device_fingerprint(*on_device)
+  rows = int(tensors[0].shape[0]) if tensors and tensors[0].dim() else 0
+  mine = torch.cat([tag.to(dev), torch.tensor([rows], dtype=torch.int64, device=dev)])
   every = [torch.empty_like(mine) for _ in range(world)]
   dist.all_gather(every, mine, group=group)
-  prints = [int(t.item()) for t in every]
+  prints = torch.stack(every).cpu().tolist()
   if any(p != prints[0] for p in prints):
     raise ShardMismatchError(
-        f"sharded expectation: {what} differ between the ranks of the process group (fingerprints "
-        f"{[hex(p) for p in prints]}).  Every rank must pass the same bitstrings and hold the same parameters: "
-        "give the EBM samplers one seed (initial_seed=None is agreed over the default group automatically; an "
-        "explicit initial_seed must be the same on all ranks) and initialise the model identically.")
+        f"sharded expectation: {what} differ between the ranks of the process group ((fingerprint, rows) per rank: "
+        f"{[(hex(p[0]), p[1]) for p in prints]}).  Every rank must pass the same bitstrings and hold the same "
+        "parameters: give the EBM samplers one seed -- an explicit initial_seed must be the same on all ranks; "
+        "samplers built with initial_seed=None are agreed by QHBM.agree_seeds() (run lazily by vqt / qmhl / "
+        "QHBM.expectation when the quantum inference is sharded) or explicitly by parallel.agree_seeds(...) -- and "
+        "initialise the model identically.")
 
 
 class ShardedExpectation:

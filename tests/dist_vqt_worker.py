@@ -2,7 +2,8 @@
 training steps the way the reference's loop does (sample -> dedup -> hot path, ebm.py:271-280):
 `inference.vqt(qhbm, [H], beta)` + `backward()` with `AnalyticEnergyInference(initial_seed=None)` and
 `AnalyticQuantumInference(process_group=True)`.  Each rank seeds torch's global generator DIFFERENTLY
-(100 + rank): only the seed agreement of `parallel.agreed_seed` makes the ranks draw one sample set.
+(100 + rank): only the seed agreement (`QHBM.agree_seeds`, run lazily by `vqt`; called explicitly here so
+that the agreed seed can be recorded before the first step) makes the ranks draw one sample set.
 QHBM_TEST_DESYNC=1 gives the samplers explicit, different seeds instead: the run must then fail with
 ShardMismatchError on every rank.  One GPU on the test box: every rank uses cuda:0, collectives over gloo."""
 import os
@@ -46,6 +47,8 @@ def main():
   xxz = ir.PauliSum()
   for a, b in zip(qubits, qubits[1:]):
     xxz += ir.PX(a) * ir.PX(b) + ir.PY(a) * ir.PY(b) + 0.5 * ir.PZ(a) * ir.PZ(b)
+  seed_before = e_inf.seed     # local draw from this rank's global generator (100 + rank): differs between ranks
+  qhbm.agree_seeds()
   first_seed = e_inf.seed
   record = {}
   try:
@@ -62,7 +65,7 @@ def main():
     dist.destroy_process_group()
     sys.exit(7)
   if rank == 0:
-    np.savez(out_path, world=world, first_seed=first_seed, **record)
+    np.savez(out_path, world=world, first_seed=first_seed, seed_before=seed_before, **record)
   dist.barrier()
   dist.destroy_process_group()
 

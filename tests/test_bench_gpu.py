@@ -45,6 +45,18 @@ def test_bench_single_process_line():
   pc = line["parity_check"]
   assert pc["ok"] and pc["states"] == 2 and pc["max_err_values"] <= pc["tol_values"]
   assert pc["max_err_grad"] <= pc["tol_grad"]
+  # the gradient that is checked is the TIMED one: rows of the last timed adjoint sweep, not a second call
+  assert pc["grad_from"].startswith("rows of the last timed step")
+  assert line["config"]["exchange_bytes"] is None
+
+
+def test_bench_parameter_shift_mode_says_where_its_checked_gradient_comes_from():
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--qubits", "12", "--layers", "1",
+                        "--states-total", "4", "--steps", "1", "--warmup", "0", "--hamiltonian", "tfim", "--mode", "shift",
+                        "--cpu-sample-states", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+  assert out.returncode == 0, out.stderr[-2000:]
+  pc = _line(out.stdout)["parity_check"]
+  assert pc["ok"] and pc["grad_from"].startswith("engine VJP of these K states")
 
 
 def test_bench_config3_timed_batch_against_the_oracle():
@@ -61,6 +73,7 @@ def test_bench_config3_timed_batch_against_the_oracle():
   assert pc["ok"] and pc["states"] == 8, pc
   assert pc["max_err_values"] <= pc["tol_values"] == pytest.approx(5e-5 * 47.5)
   assert pc["max_err_grad"] <= pc["tol_grad"] and pc["grad_inf_norm"] > 1e-2
+  assert pc["grad_from"].startswith("rows of the last timed step")
 
 
 def test_bench_exits_non_zero_when_the_oracle_disagrees():
@@ -69,7 +82,22 @@ def test_bench_exits_non_zero_when_the_oracle_disagrees():
   out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--cpu-sample-states", "2"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
   assert out.returncode != 0 and "parity_check FAILED" in out.stderr
-  assert not _line(out.stdout)["parity_check"]["ok"]
+  pc = _line(out.stdout)["parity_check"]
+  assert not pc["ok"]
+  # BOTH legs see the corruption: the timed values and the rows of the timed gradient
+  assert pc["max_err_values"] > pc["tol_values"] and pc["max_err_grad"] > pc["tol_grad"]
+  assert pc["grad_from"].startswith("rows of the last timed step")
+
+
+def test_bench_fails_when_the_requested_check_cannot_run(tmp_path):
+  """A parity check that was asked for and could not run (here: the oracle library is hidden) is a failed run with
+  the reason on the line -- never a line that merely lacks `parity_check`."""
+  env = dict(os.environ, QHBM_ORACLE_LIB=str(tmp_path / "missing.so"))
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--cpu-sample-states", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+  assert out.returncode != 0
+  line = _line(out.stdout)
+  assert line["parity_check"]["ok"] is False and "error" in line["parity_check"]
 
 
 @pytest.mark.parametrize("reduction", ["allreduce", "ordered"])
@@ -91,6 +119,9 @@ def test_bench_two_ranks_as_the_driver_launches_it(reduction):
   assert line["config"]["reduction"] == reduction and len(line["config"]["devices"]) >= 1
   assert line["verify"]["ok"], line["verify"]
   assert line["parity_check"]["ok"], line["parity_check"]
+  # bytes of the step's exchange: values [32] + the [P] gradient, or + the rows [32, P]
+  n_params = 2 * (3 * 12 - 1)
+  assert line["config"]["exchange_bytes"] == 4 * 32 + 4 * (32 * n_params if reduction == "ordered" else n_params)
 
 
 def test_bench_gpus_flag_starts_its_own_ranks_and_shards_a_fixed_total():

@@ -271,6 +271,87 @@ def test_gate_conventions():
   np.testing.assert_allclose(O.gate_matrix(O.GATE_XPOW, 0.0), np.eye(2))
 
 
+def test_every_gate_kind_against_the_documented_matrix():
+  """All twelve kinds (and the rx / ry / rz forms) against cirq's documented closed-form matrices, written out
+  entry by entry in tests/gate_docs.py -- not only unitarity (VERDICT r3 'finish the oracle pin')."""
+  from tests import gate_docs as D
+  for t in (0.37, -1.3, 1.0, 0.5):
+    for kind in range(12):
+      np.testing.assert_allclose(O.gate_matrix(kind, t), D.documented_matrix(kind, t), atol=1e-12, err_msg=f"kind {kind}")
+  theta = 0.9
+  for axis, kind in (("x", O.GATE_XPOW), ("y", O.GATE_YPOW), ("z", O.GATE_ZPOW)):
+    np.testing.assert_allclose(O.gate_matrix(kind, theta / math.pi, -0.5), D.documented_rotation(axis, theta), atol=1e-12)
+  # involutions at t = 1 (with cirq's phase: none for these kinds) and the sign convention of the controlled phase
+  np.testing.assert_allclose(O.gate_matrix(O.GATE_HPOW, 1.0), O._H, atol=1e-12)
+  np.testing.assert_allclose(O.gate_matrix(O.GATE_CNOTPOW, 1.0), [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], atol=1e-12)
+  np.testing.assert_allclose(O.gate_matrix(O.GATE_SWAPPOW, 1.0), [[1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], atol=1e-12)
+  np.testing.assert_allclose(O.gate_matrix(O.GATE_ISWAPPOW, 1.0), [[1, 0, 0, 0], [0, 0, 1j, 0], [0, 1j, 0, 0], [0, 0, 0, 1]], atol=1e-12)
+
+
+def _kat_gate(kind, q0, q1, t):
+  return (kind, q0, q1, -1, 0.0, t)
+
+
+def test_z_and_cz_powers_hand_derived_values_both_oracles():
+  """Config 3's Z**t / CZ**t conventions made observable (no reference-held number covers them):
+    H Z**t on |0>:            (|0> + e^{i pi t}|1>) / sqrt 2      =>  <X> = cos pi t, <Y> = sin pi t, <Z> = 0
+    (H x H) CZ**t on |00>:    (|00> + |01> + |10> + e^{i pi t}|11>) / 2
+                              =>  <X0 X1> = <X0> = <X1> = (1 + cos pi t) / 2,  <X0 Z1> = (1 - cos pi t) / 2,
+                                  <Y0 Z1> = -sin(pi t) / 2 ... (sign: see below), <Z0 Z1> = 0
+  derived by hand from the amplitudes; run through the numpy oracle and the C restatement."""
+  from oracle import qhbm_cpu as C
+  import os
+  for t in (0.3, -0.85, 1.7):
+    gates = [_kat_gate(O.GATE_HPOW, 0, -1, 1.0), _kat_gate(O.GATE_ZPOW, 0, -1, t)]
+    ops = [[(1.0, 1, 0)], [(1.0, 1, 1)], [(1.0, 0, 1)]]   # X, Y, Z on qubit 0
+    want = np.array([[math.cos(math.pi * t), math.sin(math.pi * t), 0.0]])
+    bits = np.zeros((1, 1), np.int8)
+    np.testing.assert_allclose(O.expectation(1, gates, [], bits, ops), want, atol=1e-12)
+    if os.path.exists(C.LIB_PATH):
+      np.testing.assert_allclose(C.expectation(1, gates, np.zeros(0, np.float32), bits, ops), want, atol=2e-6)
+    gates = [_kat_gate(O.GATE_HPOW, 0, -1, 1.0), _kat_gate(O.GATE_HPOW, 1, -1, 1.0), _kat_gate(O.GATE_CZPOW, 0, 1, t)]
+    cp, sp = math.cos(math.pi * t), math.sin(math.pi * t)
+    # Y0 Z1: <psi|Y (x) Z|psi> with Y = [[0,-i],[i,0]]: pairs (|0b>, |1b>) with sign (-1)^b:
+    #   b = 0: conj(a00)(-i)a10 + conj(a10)(i)a00 = 0 (both real, equal);  b = 1: -[conj(a01)(-i)a11 + conj(a11)(i)a01]
+    #   = -(1/4)[-i e^{i pi t} + i e^{-i pi t}] = -(1/4)(2 sin pi t) = -sin(pi t) / 2
+    ops = [[(1.0, 3, 0)], [(1.0, 1, 0)], [(1.0, 2, 0)], [(1.0, 1, 2)], [(1.0, 1, 3)], [(1.0, 0, 3)]]
+    #       X0 X1          X0             X1             X0 Z1          Y0 Z1          Z0 Z1
+    want = np.array([[(1 + cp) / 2, (1 + cp) / 2, (1 + cp) / 2, (1 - cp) / 2, -sp / 2, 0.0]])
+    bits = np.zeros((1, 2), np.int8)
+    np.testing.assert_allclose(O.expectation(2, gates, [], bits, ops), want, atol=1e-12)
+    if os.path.exists(C.LIB_PATH):
+      np.testing.assert_allclose(C.expectation(2, gates, np.zeros(0, np.float32), bits, ops), want, atol=2e-6)
+
+
+def test_every_gate_kind_probe_values_from_documented_matrices_both_oracles():
+  """X**p-prepared product states through each gate kind: expectation values computed from the documented matrices
+  alone (tests/gate_docs.py::probe_values) against both oracles."""
+  from oracle import qhbm_cpu as C
+  from tests import gate_docs as D
+  import os
+  rng = np.random.default_rng(12)
+  for kind in range(1, 12):
+    nq = O.gate_num_qubits(kind)
+    for _ in range(3):
+      t = float(rng.uniform(-1.5, 1.5))
+      probes = [float(rng.uniform(0.1, 0.9)) for _ in range(nq)]
+      bits = rng.integers(0, 2, size=(1, nq)).astype(np.int8)
+      gates = [_kat_gate(O.GATE_XPOW, q, -1, probes[q]) for q in range(nq)]
+      gates.append(_kat_gate(kind, 0, 1 if nq == 2 else -1, t))
+      strings = ["X", "Y", "Z"] if nq == 1 else ["XI", "IY", "ZZ", "XY", "YZ", "ZX", "YY"]
+      code = {"I": (0, 0), "X": (1, 0), "Y": (1, 1), "Z": (0, 1)}
+      ops = []
+      for st in strings:
+        x = sum(code[ch][0] << q for q, ch in enumerate(st))
+        z = sum(code[ch][1] << q for q, ch in enumerate(st))
+        ops.append([(1.0, x, z)])
+      want = D.probe_values(kind, t, bits[0], probes, strings)[None, :]
+      np.testing.assert_allclose(O.expectation(nq, gates, [], bits, ops), want, atol=1e-12, err_msg=f"kind {kind}")
+      if os.path.exists(C.LIB_PATH):
+        np.testing.assert_allclose(C.expectation(nq, gates, np.zeros(0, np.float32), bits, ops), want, atol=3e-6,
+                                   err_msg=f"kind {kind} (C)")
+
+
 def test_jacobian_matches_shift_rule_and_finite_differences():
   n = 3
   rng = np.random.default_rng(3)

@@ -150,3 +150,33 @@ def test_sample_counts_of_shifted_programs_match_the_born_rule(n, tile, shots):
   assert int(eng.sample_counts(bits, params, 0, shift_gates=[-1], shifts=[0.0]).sum()) == 0
   with pytest.raises(E.EngineError, match="out of range"):
     eng.sample_counts(bits, params, 4, shift_gates=[len(gates)], shifts=[0.5])
+
+
+def test_negative_shift_gates_mean_unshifted_and_constant_gates_cannot_be_shifted():
+  """any shift_gate < 0 is the unshifted circuit -- also -2, the scheduler's internal tag of the fixed ops a
+  gate is lowered to (a Y power = S . X**t . S^dagger: its two S phases must never be shifted) -- and a gate with a
+  constant exponent has no shifted program (its lowering would apply the shift to the wrong ops): rejected."""
+  n = 3
+  gates = [(O.GATE_HPOW, 0, -1, -1, 0.0, 1.0),        # constant H: lowered to three fixed ops
+           (O.GATE_YPOW, 1, -1, 0, 1.0, 0.0),         # Y**t: S X**t S^dagger
+           (O.GATE_CNOTPOW, 0, 2, -1, 0.0, 1.0)]
+  eng = E.Engine(0)
+  eng.set_circuit(n, gates, 1)
+  bits = np.zeros((1, n), np.int8)
+  params = np.array([0.3], np.float32)
+  base = eng.sample(bits, params, 4096, seed=5)
+  for g in (-1, -2, -7):
+    assert torch.equal(eng.sample(bits, params, 4096, seed=5, shift_gate=g, shift=0.5), base)
+  c0 = eng.sample_counts(bits, params, 4096, seed=9, shift_gates=[-1, -2], shifts=[0.0, 0.5])
+  np.testing.assert_array_equal(c0[0].cpu().numpy(), eng.sample_counts(bits, params, 4096, seed=9)[0].cpu().numpy())
+  # same distribution for the "-2" program (its own random stream: compare frequencies, not shots)
+  f = c0.float().cpu().numpy() / 4096
+  assert np.abs(f[0] - f[1]).max() < 0.05
+  with pytest.raises(E.EngineError, match="constant exponent"):
+    eng.sample(bits, params, 16, seed=1, shift_gate=0, shift=0.5)
+  with pytest.raises(E.EngineError, match="constant exponent"):
+    eng.sample_counts(bits, params, 16, seed=1, shift_gates=[1, 2], shifts=[0.5, -0.5])
+  # the parametrised gate shifts as before
+  shifted = eng.sample_counts(bits, params, 1 << 14, seed=2, shift_gates=[1], shifts=[0.5])[0, 0].float().cpu().numpy() / (1 << 14)
+  want = np.abs(O.simulate(n, gates[:1] + [(O.GATE_YPOW, 1, -1, -1, 0.0, 0.8)] + gates[2:], np.zeros(0), bits[0]).reshape(-1)) ** 2
+  assert np.abs(shifted - want).max() < 0.03
