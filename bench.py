@@ -113,7 +113,7 @@ def distinct_bitstrings(n, count, seed):
   return bits
 
 
-def cpu_baseline(n, gates, n_params, op, params, bits, upstream_value, mode):
+def cpu_baseline(n, gates, n_params, ops, params, bits, upstream, mode):
   """The oracle's C restatement (oracle/qhbm_cpu.c) timed on this host's cores on a bounded sample
   of the TIMED batch itself (its first K bitstrings, same parameters, same upstream weight) -- a
   reported baseline, never the product.  Returns the record plus the oracle's values [K, 1] and
@@ -121,22 +121,23 @@ def cpu_baseline(n, gates, n_params, op, params, bits, upstream_value, mode):
   from oracle import qhbm_cpu as C
   cores = min(C.max_threads(), os.cpu_count() or 1)
   states = bits.shape[0]
-  up = np.full((states, 1), upstream_value, np.float32)
+  up = np.ascontiguousarray(upstream, np.float32)
   t0 = time.perf_counter()
   if mode == "forward":
-    vals, grad = C.expectation(n, gates, params, bits, [op], n_threads=cores), None
+    vals, grad = C.expectation(n, gates, params, bits, ops, n_threads=cores), None
   else:
-    vals, grad = C.expectation_vjp(n, gates, params, bits, [op], up, n_threads=cores)
+    vals, grad = C.expectation_vjp(n, gates, params, bits, ops, up, n_threads=cores)
   dt = time.perf_counter() - t0
   return {
-      "value": states * len(op) / dt, "unit": "evals/s", "cores": int(min(cores, states)),
+      "value": states * sum(len(op) for op in ops) / dt, "unit": "evals/s", "cores": int(min(cores, states)),
       "kind": "port",
       "sample": f"the first {states} states of the timed batch ({mode} step, same parameters), one state "
                 f"per thread, {dt:.2f} s wall",
   }, vals, grad
 
 
-def parity_check(eng, E, mode, op, bits_k, params, timed_vals_k, timed_grad_rows_k, rows_scale, oracle_vals, oracle_grad):
+def parity_check(eng, E, mode, ops, bits_k, params, timed_vals_k, timed_grad_rows_k, rows_scale, upstream_k, oracle_vals,
+                 oracle_grad):
   """The timed workload against the oracle (reference pattern: simulate, compare, assert --
   tests/inference/qnn_test.py:183-264 of the reference).
   Values: rows of the LAST TIMED step.
@@ -147,7 +148,7 @@ def parity_check(eng, E, mode, op, bits_k, params, timed_vals_k, timed_grad_rows
   there the engine's VJP of exactly these K states (a second call outside the timed region, same kernels and plans)
   is compared instead, and `grad_from` says so."""
   k = bits_k.shape[0]
-  sum_abs = float(sum(abs(c) for c, _, _ in op))
+  sum_abs = float(max(sum(abs(c) for c, _, _ in op) for op in ops))   # (per observable: the largest bound)
   tol_v = 5e-5 * sum_abs
   err_v = float(np.abs(timed_vals_k - oracle_vals).max())
   out = {"states": k, "max_err_values": err_v, "tol_values": tol_v,
@@ -159,7 +160,7 @@ def parity_check(eng, E, mode, op, bits_k, params, timed_vals_k, timed_grad_rows
       grad_from = ("rows of the last timed step (qhbm_state_gradients of the timed adjoint sweep, first K rows summed, "
                    "rescaled from upstream 1/states_total to 1/K) vs the oracle's adjoint VJP with upstream 1/K")
     else:
-      up = torch.full((k, 1), 1.0 / k, device="cuda")
+      up = torch.from_numpy(np.ascontiguousarray(upstream_k, np.float32)).cuda()
       method = E.GRAD_PARAMETER_SHIFT if mode == "shift" else E.GRAD_ADJOINT
       _, g = eng.expectation_vjp(torch.from_numpy(bits_k).cuda(), params, up, method=method)
       g = g.double().cpu().numpy()
@@ -235,8 +236,15 @@ def main():
                   help="states of one step over ALL ranks (strong scaling; BASELINE config 3: 4096)")
   ap.add_argument("--states-per-gpu", type=int, default=0,
                   help="fixed states per rank instead (weak scaling)")
-  ap.add_argument("--hamiltonian", choices=["xxz", "tfim", "random512"], default="xxz")
-  ap.add_argument("--mode", choices=["vqt", "forward", "shift"], default="vqt")
+  ap.add_argument("--hamiltonian", choices=["xxz", "xxz3", "tfim", "random512"], default="xxz",
+                  help="xxz3: the XXZ chain as THREE observables (its XX, YY and ZZ sums) in one call -- several operators "
+                       "per call is the reference's normal usage (tests/inference/qnn_test.py:187-190)")
+  ap.add_argument("--mode", choices=["vqt", "forward", "shift", "qmhl"], default="vqt",
+                  help="vqt: values + adjoint VJP of one Hamiltonian; forward: values only; shift: values + "
+                       "parameter-shift VJP; qmhl: the engine work of a QMHL step (qmhl_loss.py:33-34) -- the circuit "
+                       "U_data then U_model^dagger, the KOBE-2 Z-string shards of the model's modular Hamiltonian as "
+                       "observables, the adjoint VJP of sum_k theta_k <Z_k> with respect to the MODEL's parameters only "
+                       "(the data circuit is frozen: qhbm_set_gradient_mask)")
   ap.add_argument("--tile-qubits", type=int, default=0)
   ap.add_argument("--adjoint-tile-qubits", type=int, default=0)
   ap.add_argument("--engine-option", action="append", default=[], metavar="NAME=VALUE",
@@ -294,14 +302,39 @@ def main():
   blocks = parallel.partition(total_states, world)
   lo, hi = blocks[rank]
   spg = hi - lo
-  gates, n_params = hea_gates(n, layers)
-  op = {"xxz": xxz_op, "tfim": tfim_op, "random512": lambda m: random_pauli_op(m, 512, 24)}[args.hamiltonian](n)
   rng = np.random.default_rng(1234)
+  grad_mask = None
+  if args.mode == "qmhl":
+    # qmhl(data, qhbm) = <K_model>_data + log Z (qmhl_loss.py:33-34); data.expectation(K_model) runs the total circuit
+    # bit-inject . U_data(phi_d) . U_model(phi_m)^dagger and measures the Z-string shards of the model's energy
+    # (qnn.py:120-139, energy.py:200-209: all 1- and 2-subsets in itertools.combinations order), combined by theta.
+    import itertools  # pylint: disable=import-outside-toplevel
+    g_data, p_data = hea_gates(n, layers, "d")
+    g_model, p_model = hea_gates(n, layers, "m")
+    # inverse circuit = reversed gate list, scalar and offset negated, same variables (circuit.py:164-176)
+    inverse = [(k, q0, q1, p_data + pi, -sc, -off) for (k, q0, q1, pi, sc, off) in reversed(g_model)]
+    gates, n_params = g_data + inverse, p_data + p_model
+    ops = [[(1.0, 0, sum(1 << q for q in subset))] for order in (1, 2) for subset in itertools.combinations(range(n), order)]
+    thetas = rng.uniform(-1, 1, len(ops)).astype(np.float32)
+    grad_mask = np.arange(n_params) >= p_data
+    ham_name, args.hamiltonian = f"KOBE-2 shards ({len(ops)} Z strings)", "kobe2_shards"
+  else:
+    gates, n_params = hea_gates(n, layers)
+    if args.hamiltonian == "xxz3":
+      whole = xxz_op(n)
+      ops = [whole[0::3], whole[1::3], whole[2::3]]          # the XX, the YY and the ZZ terms
+    else:
+      ops = [{"xxz": xxz_op, "tfim": tfim_op, "random512": lambda m: random_pauli_op(m, 512, 24)}[args.hamiltonian](n)]
+    thetas = np.ones(len(ops), np.float32)
+    ham_name = {"xxz": "XXZ(delta=0.5) open chain", "tfim": "TFIM ring", "xxz3": "XXZ chain as 3 observables (XX, YY, ZZ sums)",
+                "random512": "random 512-term Pauli sum"}[args.hamiltonian]
+  n_ops = len(ops)
   params_np = rng.uniform(-1, 1, n_params).astype(np.float32)
   all_bits = distinct_bitstrings(n, total_states, 4321)
   bits = torch.from_numpy(all_bits[lo:hi]).cuda()
   params = torch.from_numpy(params_np).cuda()
-  upstream = torch.full((spg, 1), 1.0 / total_states, device="cuda")
+  # upstream[u, k] = theta_k / states: the weight of <O_k>_u in the loss (one Hamiltonian: 1 / states)
+  upstream = (torch.from_numpy(thetas).cuda() / float(total_states)).repeat(spg, 1).contiguous()
 
   eng = E.Engine(local_rank)
   if args.tile_qubits:
@@ -312,7 +345,9 @@ def main():
     key, _, val = item.partition("=")
     eng.set_option(key, int(val))
   eng.set_circuit(n, gates, n_params)
-  eng.set_observables([op])
+  eng.set_observables(ops)
+  if grad_mask is not None:
+    eng.set_gradient_mask(grad_mask)
   eng.set_option("profile_events", 1)
   fwd_passes, bwd_passes = eng.num_passes()
 
@@ -320,11 +355,13 @@ def main():
     if args.mode == "forward":
       vals = eng.expectation(bits, params)
       grad = None
+    elif args.mode == "qmhl":
+      vals, grad = eng.expectation_vjp(bits, params, upstream)
     else:
       vals, grad = eng.expectation_vjp(bits, params, upstream,
                                        method=E.GRAD_PARAMETER_SHIFT if args.mode == "shift" else E.GRAD_ADJOINT)
     if world > 1:
-      if grad is not None and args.reduction == "ordered" and args.mode == "vqt":
+      if grad is not None and args.reduction == "ordered" and args.mode in ("vqt", "qmhl"):
         rows = eng.state_gradients(spg) if spg else grad.new_zeros((0, grad.numel()))
         rows = parallel.all_gather_rows(rows, blocks)
         grad = rows.to(torch.float64).sum(0).to(torch.float32)
@@ -357,7 +394,7 @@ def main():
     args.verify = world > 1
   # per-state gradient rows of the LAST TIMED step, read before anything else runs on the engine (parity_check)
   timed_grad_rows = None
-  if rank == 0 and args.mode == "vqt" and not args.no_cpu_baseline and spg > 0:
+  if rank == 0 and args.mode in ("vqt", "qmhl") and not args.no_cpu_baseline and spg > 0:
     k_rows = max(1, min(args.cpu_sample_states, spg, os.cpu_count() or 1))
     timed_grad_rows = eng.state_gradients(spg)[:k_rows].float().cpu().numpy()
 
@@ -371,7 +408,7 @@ def main():
 
   parity_failed = False
   if rank == 0:
-    n_terms = len(op)
+    n_terms = sum(len(op) for op in ops)
     evals_per_step = total_states * n_terms
     ms_per_step = dt / args.steps * 1e3
     # ---- roofline of the dominant kernel -------------------------------------------------------
@@ -385,9 +422,10 @@ def main():
     shift_factor = (1 + 2 * n_params) if args.mode == "shift" else 1
     fwd_unfused = spg * (16.0 * n_gate + 8.0 * n_terms + 8.0) * amp * shift_factor
     bwd_unfused = spg * 48.0 * n_gate * amp
-    tm = eng.traffic_model(spg, with_vjp=args.mode == "vqt")
-    fm = eng.flop_model(spg, with_vjp=args.mode == "vqt")
-    use_bwd = args.mode == "vqt" and kt["bwd_ms"] >= kt["fwd_ms"]
+    adjoint_mode = args.mode in ("vqt", "qmhl")
+    tm = eng.traffic_model(spg, with_vjp=adjoint_mode)
+    fm = eng.flop_model(spg, with_vjp=adjoint_mode)
+    use_bwd = adjoint_mode and kt["bwd_ms"] >= kt["fwd_ms"]
     if use_bwd:
       launches, ms, unfused, name, model, flops = (kt["bwd_launches"], kt["bwd_ms"], bwd_unfused, "pass_adj_kernel",
                                                    tm["bwd_bytes"], fm["bwd_flops"])
@@ -424,13 +462,25 @@ def main():
       valu = dict(vj[family(vj)], source=f"stored profile profiles/valu.json (git {vj.get('git_head', '?')})")
     with open(os.path.abspath(__file__), "rb") as f:
       bench_sha = hashlib.sha256(f.read()).hexdigest()[:16]
-    ham_name = {"xxz": "XXZ(delta=0.5) open chain", "tfim": "TFIM ring",
-                "random512": "random 512-term Pauli sum"}[args.hamiltonian]
     mode_name = {"vqt": "VQT step = values + adjoint VJP", "forward": "forward values only",
-                 "shift": "values + parameter-shift VJP"}[args.mode]
+                 "shift": "values + parameter-shift VJP",
+                 "qmhl": "QMHL step = shard values of U_data U_model^dagger + adjoint VJP w.r.t. the model's parameters"}[args.mode]
     is_c3 = (n, layers, args.hamiltonian, args.mode) == (20, 16, "xxz", "vqt")
-    label = ("BASELINE configs[2] (20-qubit XXZ, depth 16, 4096-sample VQT step)" if is_c3 and total_states == 4096
-             else "BASELINE configs[2] circuit at a different batch" if is_c3 else "custom workload")
+    shape = (n, layers, args.hamiltonian)
+    if is_c3:
+      label = ("BASELINE configs[2] (20-qubit XXZ, depth 16, 4096-sample VQT step)" if total_states == 4096
+               else "BASELINE configs[2] circuit at a different batch")
+    elif shape == (12, 8, "tfim"):
+      label = "BASELINE configs[1] (12-qubit TFIM, depth-8 HEA" + (", 1024 samples)" if total_states == 1024 else ") at another batch")
+    elif shape == (24, 16, "random512"):
+      label = ("BASELINE configs[3]'s shape (24-qubit random 512-term Pauli sum; depth 16 assumed, SURVEY 8d) with "
+               + ("parameter-shift gradients" if args.mode == "shift" else "adjoint gradients"))
+    elif shape == (28, 32, "tfim"):
+      label = "BASELINE configs[4]'s shape (28-qubit TFIM, depth 32)"
+    elif args.mode == "qmhl" and (n, layers) == (20, 16):
+      label = "QMHL step at BASELINE configs[2]'s size (20 qubits, depth 16, KOBE-2 model)"
+    else:
+      label = "custom workload"
     line = {
         "metric": "circuit-expectation evals/sec (samples×Pauli terms) at n qubits; VQT step time",
         "value": evals_per_step / (dt / args.steps),
@@ -448,23 +498,24 @@ def main():
             "workload": (f"{label}: {n}-qubit {ham_name}, HEA depth {layers} ({n_params} params), "
                          f"{total_states} states in total = {spg} on rank 0 of {world}, {mode_name}"),
             "n_qubits": n, "layers": layers, "states_total": total_states, "states_per_gpu": spg,
-            "pauli_terms": n_terms, "hamiltonian": args.hamiltonian,
+            "pauli_terms": n_terms, "observables": n_ops, "hamiltonian": args.hamiltonian,
             "mode": args.mode, "parallelism": f"batch-sharded x{world}",
             # what the collective backend itself reports: a SCALE record shows that RCCL saw N ranks
             "backend": dist.get_backend() if world > 1 else None,
             "backend_world_size": dist.get_world_size() if world > 1 else 1,
             "devices": sorted(set(device_ids)),
-            "reduction": (args.reduction if args.mode == "vqt" else "allreduce") if world > 1 else None,
+            "reduction": (args.reduction if args.mode in ("vqt", "qmhl") else "allreduce") if world > 1 else None,
             # bytes one step's exchange moves per rank (N > 1): the all-gather of the values [U, 1] plus either the
             # all-reduce of the [P] gradient or, with --reduction ordered, the all-gather of the per-state rows [U, P]
             "exchange_bytes": None if world == 1 else int(
-                4 * total_states * 1 + (0 if args.mode == "forward" else
-                                        4 * (total_states * n_params if (args.reduction == "ordered" and args.mode == "vqt")
-                                             else n_params))),
+                4 * total_states * n_ops + (0 if args.mode == "forward" else
+                                            4 * (total_states * n_params
+                                                 if (args.reduction == "ordered" and args.mode in ("vqt", "qmhl")) else n_params))),
             "forward_passes": fwd_passes, "adjoint_passes": bwd_passes,
             "bench_py_sha16": bench_sha, "engine_options": args.engine_option,
         },
         "vqt_step_ms": ms_per_step if args.mode == "vqt" else None,
+        "qmhl_step_ms": ms_per_step if args.mode == "qmhl" else None,
         "kernel_ms_per_step": {"forward": kt["fwd_ms"] / args.steps, "adjoint": kt["bwd_ms"] / args.steps,
                                "apply_observable": kt["obs_ms"] / args.steps},
         "roofline": {
@@ -507,7 +558,7 @@ def main():
     if args.verify:
       # the sharded step against one process evaluating every state (same engine, same inputs)
       full_bits = torch.from_numpy(all_bits).cuda()
-      full_up = torch.full((total_states, 1), 1.0 / total_states, device="cuda")
+      full_up = (torch.from_numpy(thetas).cuda() / float(total_states)).repeat(total_states, 1).contiguous()
       if args.mode == "forward":
         ref_vals, ref_grad = eng.expectation(full_bits, params), None
       else:
@@ -517,7 +568,7 @@ def main():
       err_v = float((vals - ref_vals).abs().max())
       err_g = float((grad - ref_grad).abs().max()) if ref_grad is not None else 0.0
       line["verify"] = {"max_err_values": err_v, "max_err_grad": err_g,
-                        "ok": bool(err_v < 1e-4 * len(op) and err_g < 1e-4)}
+                        "ok": bool(err_v < 1e-4 * max(len(op) for op in ops) and err_g < 1e-4)}
     if not args.no_cpu_baseline:
       # The oracle must be there when the check is asked for: a missing checker is an error of its own, never a
       # silently absent parity_check.
@@ -536,12 +587,15 @@ def main():
           oracle_params = params_np
           if os.environ.get("QHBM_BENCH_CORRUPT_PARITY") == "1":   # test hook: the check must be able to fail
             oracle_params = params_np + np.float32(0.05)
-          rec, o_vals, o_grad = cpu_baseline(n, gates, n_params, op, oracle_params, bits_k, 1.0 / k, args.mode)
+          up_k = np.tile(thetas[None, :] / float(k), (k, 1))
+          rec, o_vals, o_grad = cpu_baseline(n, gates, n_params, ops, oracle_params, bits_k, up_k, args.mode)
+          if o_grad is not None and grad_mask is not None:
+            o_grad = np.where(grad_mask, o_grad, 0.0)   # the engine returns 0 for the frozen (data) parameters
           line["cpu_baseline"] = rec if world == 1 else None
           timed_rows = vals[:k].float().cpu().numpy()   # global rows lo..lo+k are rank 0's own block
           grad_rows = timed_grad_rows[:k] if timed_grad_rows is not None and timed_grad_rows.shape[0] >= k else None
-          line["parity_check"] = parity_check(eng, E, args.mode, op, bits_k, params, timed_rows, grad_rows,
-                                              float(total_states) / float(k), o_vals, o_grad)
+          line["parity_check"] = parity_check(eng, E, args.mode, ops, bits_k, params, timed_rows, grad_rows,
+                                              float(total_states) / float(k), up_k, o_vals, o_grad)
           parity_failed = not line["parity_check"]["ok"]
         except Exception as exc:  # pylint: disable=broad-except
           # a check that was requested and could not run is a FAILED check (exit code 3), with the reason on the line

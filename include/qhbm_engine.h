@@ -152,7 +152,13 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
  * pass stores its tiles), "forward_pairs" (1 = dense lean forward passes run on pairs of states with the
  * tiles in registers), "wide_last_pass" (-1 = the last forward gate pass may take a tile one or two bits
  * wider when that saves a pass, unless tile_qubits is set; 0 = never; 1 = always), "observable_xcd_states"
- * (1 = lambda = O psi works on one state per XCD at a time).
+ * (lambda = O psi: 1 = one state per XCD at a time, 0 = every XCD an eighth of each state, -1 = by state size: states of
+ * 64 MiB and more are shared), "observable_kernel" (lambda = O psi and <psi|O|psi>: 0 = one L2 gather per X-mask and
+ * block of 2^11 amplitudes, 1 = partner blocks of 2^13 amplitudes staged in LDS once per group of masks that share them
+ * (states of >= 13 qubits), -1 = whichever a fitted cost model prefers: the block kernel for operators with many masks),
+ * "multi_observable_values" (several observables: -1 = their values come from ONE launch of the block kernel over the
+ * final states, after lean measurement-free passes, when some term flips two or more qubits and there are at most 64
+ * observables; 0 = always measured in the passes; 1 = always from the kernel, up to 256 observables).
  */
 int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value);
 

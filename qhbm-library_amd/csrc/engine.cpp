@@ -117,6 +117,7 @@ struct qhbm_engine {
   uint32_t n_obs_bgroups = 0;
   int opt_obs_kernel = -1;      // lambda = O psi / values: 0 = one gather per mask (apply_observable_kernel), 1 = partner blocks through
                                 // LDS (observable_blocks_kernel), -1 = the block kernel whenever the state has a block (>= 13 qubits)
+  mutable int block_choice = -1;  // cached verdict of block_kernel() (-1: not computed for the installed model / options)
   int opt_multi_values = -1;    // several observables: values from the block kernel after lean passes (-1: when some term flips >= 2
                                 // qubits or needs a measurement-only pass, at most kMultiValueOps observables)
   DevBuf<float> value_part;  // value mode: one partial of <psi|O|psi> per workgroup of apply_observable_kernel
@@ -398,6 +399,26 @@ int upload_plan(qhbm_engine* h, DevicePlan* d) {
   return 0;
 }
 
+// One term of the block-grouped kernels (kernels.h ObsBTerm): slot bits of the block layout are index bits 0, 10, 11, 12.
+ObsBTerm obs_block_term(const DevTerm& d, bool new_mask) {
+  const uint32_t xin = d.x & ((1u << kObsBlockBits) - 1u);
+  const uint32_t zs = (d.z & 1u) | (((d.z >> 10) & 7u) << 1);
+  // variant (scripts/gen_observable_asm.py): Z bits of the three low slot bits | base sign << 3 | odd x << 4 | imaginary << 5
+  const uint32_t variant = (zs & 7u) | ((xin & 1u) << 4) | ((d.ny & 1u) << 5);
+  const uint32_t chunk = kObsChunkBytes, preamble = kObsPreambleBytes;
+  ObsBTerm t;
+  t.coeff = d.coeff;
+  t.zt = (d.z >> 1) & 511u;
+  t.zb = d.z >> kObsBlockBits;
+  t.xrow = (((xin >> 1) & 511u) << 4) | (((xin >> 10) & 7u) << 13);
+  t.off0 = variant * chunk + preamble;
+  t.off1 = (variant | (zs & 8u)) * chunk + preamble;
+  // sign at the own index: (-1)^ny from the x & z overlap, and i^2 = -1 once ny >= 2
+  t.meta = (d.op & 1023u) | (new_mask ? kObsNewMask : 0u) | (((d.ny + (d.ny >> 1)) & 1u) ? kObsSignBit : 0u);
+  t.pad = 0u;
+  return t;
+}
+
 // Copies plans, observable tables and the parameter -> slot map to the device ONCE per model: a
 // compute call on an unchanged model issues no host copy and no synchronisation (it can be captured
 // into a hipGraph by the caller).
@@ -447,14 +468,45 @@ int upload_model(qhbm_engine* h) {
       });
       std::vector<ObsBTerm> terms2;
       std::vector<ObsBGroup> groups2;
-      for (size_t k = 0; k < bt.size(); ++k) {
+      for (size_t k = 0; k < bt.size();) {
         const uint32_t xo = bt[k].x >> kObsBlockBits;
-        if (k == 0 || xo != (bt[k - 1].x >> kObsBlockBits)) groups2.push_back(ObsBGroup{xo, uint32_t(k), uint32_t(k), 0u});
-        groups2.back().end = uint32_t(k + 1);
-        const bool new_mask = k == groups2.back().begin || bt[k].x != bt[k - 1].x;
-        terms2.push_back(ObsBTerm{bt[k].coeff, bt[k].z, bt[k].x & ((1u << kObsBlockBits) - 1u),
-                                  (bt[k].op & 1023u) | ((bt[k].ny & 3u) << 10) | (new_mask ? kObsNewMask : 0u)});
+        size_t e = k;
+        while (e < bt.size() && (bt[e].x >> kObsBlockBits) == xo) ++e;
+        // the masks of the group [k, e) and their term ranges
+        std::vector<std::pair<size_t, size_t>> masks;
+        for (size_t i = k; i < e;) {
+          size_t j = i;
+          while (j < e && bt[j].x == bt[i].x) ++j;
+          masks.emplace_back(i, j);
+          i = j;
+        }
+        // dealt to the two half-workgroups by term count, largest first (the halves run in step: a group costs what
+        // its larger half costs)
+        std::vector<size_t> order(masks.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+          return masks[a].second - masks[a].first > masks[b].second - masks[b].first;
+        });
+        std::vector<size_t> half[2];
+        size_t load[2] = {0, 0};
+        for (size_t m : order) {
+          const int hsel = load[1] < load[0] ? 1 : 0;
+          half[hsel].push_back(m);
+          load[hsel] += masks[m].second - masks[m].first;
+        }
+        ObsBGroup g{xo, uint32_t(terms2.size()), 0u, 0u};
+        for (int hsel = 0; hsel < 2; ++hsel) {
+          std::sort(half[hsel].begin(), half[hsel].end());  // (mask order = x order: neighbouring masks, neighbouring rows)
+          for (size_t m : half[hsel])
+            for (size_t i = masks[m].first; i < masks[m].second; ++i)
+              terms2.push_back(obs_block_term(bt[i], i == masks[m].first));
+          if (hsel == 0) g.mid = uint32_t(terms2.size());
+        }
+        g.end = uint32_t(terms2.size());
+        groups2.push_back(g);
+        k = e;
       }
+      terms2.push_back(ObsBTerm{0.f, 0u, 0u, 0u, 0u, 0u, 0u, 0u});  // (the kernel reads one record ahead)
       HIPCHK(h->obs_bterms.upload(terms2));
       HIPCHK(h->obs_bgroups.upload(groups2));
       h->n_obs_bgroups = uint32_t(groups2.size());
@@ -545,7 +597,32 @@ void timer_end(hipEvent_t* e, hipStream_t s) { if (e) (void)hipEventRecord(*e, s
 bool value_mode(const qhbm_engine* h) { return h->opt_values_from_obs != 0 && h->model.n_ops == 1; }
 
 // lambda = O psi and the values through partner blocks staged in LDS (observable.hip) instead of one gather per mask
-bool block_kernel(const qhbm_engine* h) { return h->opt_obs_kernel != 0 && h->fwd.plan.n_eff >= kObsBlockBits; }
+// (apply_observable_kernel).  The gather kernel pays per mask that leaves its block of 2^11 amplitudes (one L2 gather
+// of the state each), the block kernel per GROUP of masks with the same partner block of 2^13 (one staged fetch of the
+// state each) plus a little per term: picoseconds per amplitude fitted on config 3 (XXZ, 20 qubits: 9 masks leave,
+// 8 groups; 5.8 against 7.5) and config 4 (512 random strings, 24 qubits: 453 leave, 173 groups; 177 against 100):
+//   gather  2.3 + 0.385 x (masks leaving its block)        block  0.9 + 0.43 x groups + 0.045 x terms
+bool block_kernel(const qhbm_engine* h) {
+  if (h->fwd.plan.n_eff < kObsBlockBits || h->opt_obs_kernel == 0) return false;
+  if (h->opt_obs_kernel > 0) return true;
+  if (h->block_choice >= 0) return h->block_choice != 0;
+  std::vector<uint32_t> xs;
+  for (const PauliTerm& t : h->model.terms) xs.push_back(t.x);
+  std::sort(xs.begin(), xs.end());
+  xs.erase(std::unique(xs.begin(), xs.end()), xs.end());
+  const uint32_t gather_block = 256u * obs_amps_per_thread(uint32_t(h->fwd.plan.n_eff));
+  double leaving = 0.0;
+  std::vector<uint32_t> outs;
+  for (uint32_t x : xs) {
+    leaving += x >= gather_block ? 1.0 : 0.0;
+    outs.push_back(x >> kObsBlockBits);
+  }
+  std::sort(outs.begin(), outs.end());
+  const double groups = double(std::unique(outs.begin(), outs.end()) - outs.begin());
+  const double gather = 2.3 + 0.385 * leaving, block = 0.9 + 0.43 * groups + 0.045 * double(h->model.terms.size());
+  h->block_choice = block < gather ? 1 : 0;
+  return h->block_choice != 0;
+}
 
 // Some term flips two or more qubits, or some group needs a measurement-only pass: measuring in the tiles costs more
 // than one sweep of the observable kernel over the final state.
@@ -563,7 +640,10 @@ bool wide_observables(const qhbm_engine* h) {
 // Walsh-Hadamard measurement takes hundreds of shards for the price of a few.
 constexpr int kMultiValueOps = 64;
 bool multi_value_mode(const qhbm_engine* h) {
-  if (h->opt_values_from_obs == 0 || h->opt_multi_values == 0 || h->model.n_ops < 2 || !block_kernel(h)) return false;
+  // (the values of several observables always come from the block kernel -- the gather kernel has no such mode --,
+  // whichever of the two forms lambda)
+  if (h->opt_values_from_obs == 0 || h->opt_multi_values == 0 || h->model.n_ops < 2) return false;
+  if (h->fwd.plan.n_eff < kObsBlockBits || h->opt_obs_kernel == 0) return false;
   if (h->model.n_ops > int(kObsMaxValueOps)) return false;
   if (h->opt_multi_values > 0) return true;
   return h->model.n_ops <= kMultiValueOps && h->fwd.plan.passes.size() > 1 && wide_observables(h);
@@ -676,9 +756,13 @@ int forward(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, 
   return values_end(h, U, d_out, stream);
 }
 
+// One state per XCD at a time (1) or every XCD an eighth of each state (0)?  Measured on the block kernel, config 4
+// (24 qubits): 61.1 against 53.6 ms per 32 states -- a 128-MiB state that all eight XCDs read sits in the Infinity
+// Cache once; the gather kernel at config 3 (20 qubits): one state per XCD wins (3.7 against 5.1 fabric reads of the
+// state).  By size: states of 64 MiB and more are shared by the XCDs.
 bool observable_xcd_states(const qhbm_engine* h) {
   if (h->opt_obs_xcd_states >= 0) return h->opt_obs_xcd_states != 0;
-  return true;
+  return h->fwd.plan.n_eff < 23;
 }
 
 // lambda = O psi for the chunk in the workspace.  value_mode (a single observable): unweighted, and
@@ -846,6 +930,7 @@ int qhbm_set_circuit(qhbm_engine* h, int n_qubits, int n_gates, const qhbm_gate*
   h->model = std::move(m);
   h->have_circuit = true;
   h->plans_valid = false;
+  h->block_choice = -1;
   return 0;
 }
 
@@ -923,6 +1008,7 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
   h->model.n_ops = n_ops;
   h->model.terms = std::move(terms);
   h->plans_valid = false;
+  h->block_choice = -1;
   h->terms.release();
   return 0;
 }
@@ -930,7 +1016,7 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
 int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   if (!h || !name) return 1;
   const std::string k(name);
-  if (k == "tile_qubits") { h->opt_tile = int(value); h->plans_valid = false; }
+  if (k == "tile_qubits") { h->opt_tile = int(value); h->plans_valid = false; h->block_choice = -1; }
   else if (k == "round_qubits") { h->opt_round = int(value); h->plans_valid = false; }
   else if (k == "force_general_kernels") h->opt_force_general = int(value);
   else if (k == "full_diag_threshold") { h->opt_full_fwd = int(value); h->plans_valid = false; }
@@ -944,7 +1030,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "adjoint_plan_search") { h->opt_adj_plan_search = int(value); h->plans_valid = false; }
   else if (k == "wide_last_pass") { h->opt_wide_last = int(value); h->plans_valid = false; }
   else if (k == "observable_xcd_states") h->opt_obs_xcd_states = int(value);
-  else if (k == "observable_kernel") h->opt_obs_kernel = int(value);
+  else if (k == "observable_kernel") { h->opt_obs_kernel = int(value); h->block_choice = -1; }
   else if (k == "multi_observable_values") h->opt_multi_values = int(value);
   else if (k == "measure_tile_qubits") { h->opt_meas_tile = int(value); h->plans_valid = false; }
   else if (k == "values_from_observable") h->opt_values_from_obs = int(value);

@@ -40,17 +40,23 @@ constexpr uint32_t kObsTermChunk = 512;  // 2 x the terms staged in LDS at a tim
 // l ^ x_in (config 4: 173 fetches per block instead of 453 gathers).
 constexpr int kObsBlockBits = 13;
 constexpr uint32_t kObsNewMask = 1u << 12;   // ObsBTerm::meta: the term's x differs from the previous term's
-constexpr uint32_t kObsMaxValueOps = 256;    // per-op value cells of a workgroup (one row per wave) must fit LDS
-struct ObsBTerm {
+constexpr uint32_t kObsMaxValueOps = 256;    // per-op value cells of a workgroup (one row per wave: 16 KiB) must fit LDS
+struct ObsBTerm {  // 32 bytes, one s_load_dwordx8: everything the kernel would otherwise derive per term with scalar ALU work
   float coeff;
-  uint32_t z;     // full Z mask (index-bit space)
-  uint32_t xin;   // x & (2^kObsBlockBits - 1)
-  uint32_t meta;  // op (bits 0..9) | (ny & 3) << 10 | kObsNewMask
+  uint32_t zt;     // Z mask on the thread bits: (z >> 1) & 511
+  uint32_t zb;     // Z mask on the block bits: z >> kObsBlockBits
+  uint32_t xrow;   // byte-address XOR of the partner rows in the LDS buffer: ((x >> 1) & 511) << 4 | ((x >> 10) & 7) << 13
+  uint32_t off0;   // jump-table offset of the variant for slots 0..7 (observable_variants.inc) ...
+  uint32_t off1;   // ... and for slots 8..15 (base sign flipped when z holds the highest slot bit)
+  uint32_t meta;   // op (bits 0..9) | kObsNewMask | kObsSignBit when i^ny (-1)^ny contributes a minus sign
+  uint32_t pad;
 };
+constexpr uint32_t kObsSignBit = 1u << 13;
+constexpr uint32_t kObsChunkBytes = 68, kObsPreambleBytes = 12;  // layout of the variant tables (scripts/gen_observable_asm.py)
 struct ObsBGroup {
   uint32_t xout;  // x >> kObsBlockBits: partner block = block ^ xout
-  uint32_t begin, end;  // terms [begin, end)
-  uint32_t pad;
+  uint32_t begin, end;  // terms [begin, end) ...
+  uint32_t mid;         // ... of which [begin, mid) are the first half-workgroup's masks, [mid, end) the second's
 };
 enum ObsBlocksMode : int {
   OBS_LAMBDA = 0,        // lambda = sum_k upstream[s, op_k] c_k P_k psi

@@ -10,16 +10,30 @@
 // amplitudes: fine for a chain Hamiltonian (20 masks), 453 gathers per block for BASELINE config 4 (512 random
 // strings on 24 qubits, 480 masks) -- 61 GB through L2 per 128-MiB state.  Here a workgroup owns a BLOCK of 2^13
 // amplitudes, a mask is split x = x_out | x_in (bits outside / inside the block), terms arrive sorted by x_out and
-// cut into GROUPS of equal x_out: the partner block b ^ x_out of a group is fetched ONCE (coalesced 16-byte loads,
-// staged through registers one group ahead) into a 64-KiB LDS buffer, and every mask of the group reads it from
-// there at l ^ x_in with ds_read_b128 (256 B/clk/CU against the 64 B/clk/CU a CU gets from L2).  Config 4: 173
-// block fetches instead of 453 gathers.
+// cut into GROUPS of equal x_out: the partner block b ^ x_out of a group is fetched ONCE (coalesced 16-byte buffer
+// loads, staged through registers) into LDS, and every mask of the group reads it from there at l ^ x_in with
+// ds_read_b128 (256 B/clk/CU against the 64 B/clk/CU a CU gets from L2).  Config 4: 173 block fetches instead of 453
+// gathers.
 //
-// Layout.  512 threads; thread t owns 8 ADJACENT PAIRS of the block, pair index t + 512 p (p = 0..7), i.e. local
-// amplitude l = 2 t + 1024 p + h: slot bits {0, 10, 11, 12}, thread bits 1..9.  The partner of an adjacent pair is an
-// adjacent pair, so every LDS read is one 16-byte word, conflict-free (an XOR on the lane bits permutes the 16-byte
-// chunks of a lane group).  x_in's slot part selects WHICH row (p ^ xp) and which half (h ^ x_0) a slot pairs
-// with: rows through an 8-way scalar switch over ds_read offsets, halves at compile time.
+// One workgroup of 1024 threads per CU, as two HALVES of 512.  Thread t of either half owns the same 8 ADJACENT PAIRS
+// of the block, pair index t + 512 p (p = 0..7), i.e. local amplitude l = 2 t + 1024 p + h: slot bits {0, 10, 11,
+// 12}, thread bits 1..9 -- and the two halves share every fetched block but split its MASKS (the scheduler deals a
+// group's masks to the halves by term count), each into its own accumulators, merged through LDS at the end.
+// Why one fat workgroup instead of two of 512 threads per CU (the first version): the blocks an XCD has in flight --
+// one per workgroup -- read, group by group, the same "window" of partner blocks (b ^ x_out for neighbouring b), and
+// that window must survive in the 4-MiB L2 from one group to the next while the workgroups drift apart.  64 blocks of
+// 64 KiB in flight per XCD make a 4-MiB window: measured hit rate 0.61 (0.18 with eight XCDs on one state), fabric
+// reads 9.4 GB per 128-MiB state, the kernel bound by them.  32 blocks in flight: 0.76, 5.5 GB -- what the count of
+// distinct windows predicts.  (Two workgroups SHARING a block and taking alternate groups drift apart by whole windows
+// -- 0.13; a resident grid walking the blocks with a stride loses the compact sliding window -- both measured, both
+// dropped.)  The halves of one workgroup are kept in step by its barrier.
+// Pipeline per group: the block of group s + 1 goes from registers to the OTHER of two 64-KiB LDS buffers while the
+// masks of group s are applied from the first; the blocks of groups s + 2 and s + 3 are in flight in the two
+// four-row prefetch sets of every thread (128 KiB per CU); ONE barrier per group.
+// The partner of an adjacent pair is an adjacent pair, so every LDS read is one 16-byte word, conflict-free (an XOR
+// on the lane bits permutes the 16-byte chunks of a lane group).  x_in's slot part selects WHICH row (p ^ xp) and
+// which half (h ^ x_0) a slot pairs with: rows through an 8-way scalar switch over ds_read offsets, halves at
+// compile time.
 // Sign of a term at own index j: (-1)^{popc(j & z) + ny}; the block part is scalar, the thread part one popcount
 // per term and thread, and the slot part -- parity(a & zs) for slot a, zs = the four slot bits of z -- is COMPILE
 // TIME: the accumulation of a term is one of 64 straight-line variants (zs x odd x imaginary), 16 packed FMAs
@@ -41,11 +55,13 @@ namespace qhbm {
 
 namespace {
 
-constexpr uint32_t kOT = 512;                                // threads per workgroup
+constexpr uint32_t kOH = 512;                                // threads of one half: one per eight adjacent pairs
+constexpr uint32_t kOT = 2 * kOH;                            // threads per workgroup
 constexpr uint32_t kOP = 8;                                  // adjacent pairs per thread
 constexpr uint32_t kOBlock = 1u << kObsBlockBits;            // amplitudes per block
 constexpr uint32_t kOWaves = kOT / 64;
-static_assert(kOT * kOP * 2 == kOBlock, "512 threads x 8 pairs = one block");
+constexpr uint32_t kOBuf = kOBlock / 2;                      // 16-byte words of one LDS block buffer
+static_assert(kOH * kOP * 2 == kOBlock, "512 threads x 8 pairs = one block");
 
 // 16-byte words as a NATIVE vector type: copies of HIP's v4f struct become memcpy calls between address spaces,
 // which keep the register arrays below in scratch memory
@@ -59,6 +75,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // w = (w, -w): op_sel on source 0 picks the sign per result half, op_sel on source 1 swaps re / im for an
 // imaginary weight.  `off` = 68 * variant + 12 (wave-uniform).  vcc carries the jump target.
 #include "observable_variants.inc"
+static_assert(OBS_CHUNK_BYTES == kObsChunkBytes && OBS_PREAMBLE_BYTES == kObsPreambleBytes, "engine.cpp builds the jump offsets");
 __device__ __forceinline__ void obs_fma8(v2f& a0, v2f& a1, v2f& a2, v2f& a3, v2f& a4, v2f& a5, v2f& a6, v2f& a7, v2f v0,
                                          v2f v1, v2f v2, v2f v3, v2f v4, v2f v5, v2f v6, v2f v7, v2f w, uint32_t off) {
   asm(OBS_ASM_FMA8
@@ -101,37 +118,65 @@ __device__ __forceinline__ void obs_term(v2f (&a)[16], const v4f (&r)[8], v2f w,
   }
 }
 
-// the eight partner rows of a mask whose row part is XP: row p pairs with row p ^ XP (compile-time ds_read offsets)
-template <int XP, int... P>
-__device__ __forceinline__ void obs_rows_(v4f (&r)[8], const v4f* src, std::integer_sequence<int, P...>) {
-  ((r[P] = src[512 * (P ^ XP)]), ...);
+// The eight partner rows of a mask: row p pairs with row p ^ xp and thread t with t ^ xt, i.e. the LDS byte address of
+// slot row p is (t << 4 | p << 13 | buffer) ^ xrow with xrow = xt << 4 | xp << 13 from the term record: one XOR per row
+// (an 8-way switch over compile-time ds_read offsets costs three taken scalar branches per mask).
+template <int... P>
+__device__ __forceinline__ void obs_rows_(v4f (&r)[8], const char* lds, uint32_t base, std::integer_sequence<int, P...>) {
+  ((r[P] = *reinterpret_cast<const v4f*>(lds + (base ^ uint32_t(P << 13)))), ...);
 }
-template <int XP>
-__device__ __forceinline__ void obs_rows(v4f (&r)[8], const v4f* src) {
-  obs_rows_<XP>(r, src, std::make_integer_sequence<int, 8>{});
+__device__ __forceinline__ void obs_rows(v4f (&r)[8], const char* lds, uint32_t base) {
+  obs_rows_(r, lds, base, std::make_integer_sequence<int, 8>{});
 }
-
 // (register arrays are only ever indexed by compile-time constants: integer_sequence folds, never loops)
 // One block (64 KiB) into the thread's prefetch registers: row P at `blk` + 8192 P + 16 tid, as BUFFER loads -- the
 // block is the buffer (a wave-uniform descriptor in four SGPRs), the row a scalar offset, and the eight loads share
 // ONE 32-bit offset register; flat global loads need eight 64-bit address pairs, which the register file of
 // accumulators + partner rows + prefetch rows has no room for (18 spilled registers).
 typedef int v4i __attribute__((ext_vector_type(4)));
-template <int... P>
-__device__ __forceinline__ void obs_fetch_(v4f (&pf)[8], __amdgpu_buffer_rsrc_t rs, uint32_t tid16, std::integer_sequence<int, P...>) {
-  ((pf[P] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, int(tid16), 8192 * P, 0))), ...);
-}
-__device__ __forceinline__ void obs_fetch(v4f (&pf)[8], const float2* __restrict__ blk, uint32_t tid16) {
+// A thread fetches and stages FOUR of its pair column's eight rows: rows 4 hh .. 4 hh + 3 for half hh (wave-uniform).
+// The loads are volatile asm with MANUAL s_waitcnt: two prefetch sets are in flight across the loop's back edge, and
+// the compiler's own wait insertion, exact inside straight-line code, gives up at the loop header -- it waited for
+// vmcnt(0), i.e. for the set issued one step ago as well, which halves the prefetch distance (measured).  The
+// compiler does not know these registers are pending: nothing may touch a set between obs_fetch and obs_wait_older
+// (the sets are written and read by unconditional straight-line code only -- no phi, hence no copy).
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void obs_fetch(v4f (&pf)[4], const float2* __restrict__ blk, uint32_t t16, uint32_t row0) {
   // 0x00020000: the raw-buffer word 3 of gfx90a / gfx942 / gfx950 (32-bit data format, no swizzle)
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(blk), 0, 8 << kObsBlockBits, 0x00020000);
-  obs_fetch_(pf, rs, tid16, std::make_integer_sequence<int, 8>{});
+  // (descriptor words: base[31:0] | base[47:32], stride 0 | bytes of the block | word 3)
+  const uint64_t addr = reinterpret_cast<uint64_t>(blk);
+  const v4i rsi = v4i{int(uint32_t(addr)), int(uint32_t(addr >> 32) & 0xffffu), 8 << kObsBlockBits, 0x00020000};
+  const uint32_t o0 = 8192u * row0, o1 = o0 + 8192u, o2 = o0 + 16384u, o3 = o0 + 24576u;
+  asm volatile("buffer_load_dwordx4 %0, %4, %5, %6 offen\n\t"
+               "buffer_load_dwordx4 %1, %4, %5, %7 offen\n\t"
+               "buffer_load_dwordx4 %2, %4, %5, %8 offen\n\t"
+               "buffer_load_dwordx4 %3, %4, %5, %9 offen"
+               : "=&v"(pf[0]), "=&v"(pf[1]), "=&v"(pf[2]), "=&v"(pf[3])
+               : "v"(t16), "s"(rsi), "s"(o0), "s"(o1), "s"(o2), "s"(o3)
+               : "memory");
+}
+// every obs_fetch but the `newer` most recent ones has landed (4 loads each)
+template <int NEWER>
+__device__ __forceinline__ void obs_wait_older() {
+  static_assert(NEWER == 0 || NEWER == 1, "two sets");
+  if constexpr (NEWER == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+template <int... J>
+__device__ __forceinline__ void obs_stage_(v4f* dst, const v4f (&pf)[4], std::integer_sequence<int, J...>) {
+  ((dst[512 * J] = pf[J]), ...);
+}
+__device__ __forceinline__ void obs_stage(v4f* dst, const v4f (&pf)[4]) {   // dst = buffer + t + 512 row0
+  obs_stage_(dst, pf, std::make_integer_sequence<int, 4>{});
+}
+// the second half hands its accumulators to the first through an LDS buffer
+template <int... P>
+__device__ __forceinline__ void obs_acc_out_(v4f* dst, const v2f (&a)[16], std::integer_sequence<int, P...>) {
+  ((dst[512 * P] = v4f{a[2 * P].x, a[2 * P].y, a[2 * P + 1].x, a[2 * P + 1].y}), ...);
 }
 template <int... P>
-__device__ __forceinline__ void obs_stage_(v4f* dst, const v4f (&pf)[8], std::integer_sequence<int, P...>) {
-  ((dst[512 * P] = pf[P]), ...);
-}
-__device__ __forceinline__ void obs_stage(v4f* dst, const v4f (&pf)[8]) {
-  obs_stage_(dst, pf, std::make_integer_sequence<int, 8>{});
+__device__ __forceinline__ void obs_acc_in_(v2f (&a)[16], const v4f* src, std::integer_sequence<int, P...>) {
+  (([&] { const v4f o = src[512 * P]; a[2 * P] += v2f{o.x, o.y}; a[2 * P + 1] += v2f{o.z, o.w}; }()), ...);
 }
 template <int... P>
 __device__ __forceinline__ void obs_own_(v2f (&a)[16], const v4f* __restrict__ src, std::integer_sequence<int, P...>) {
@@ -139,7 +184,8 @@ __device__ __forceinline__ void obs_own_(v2f (&a)[16], const v4f* __restrict__ s
 }
 template <int... P>
 __device__ __forceinline__ void obs_store_(v4f* __restrict__ dst, const v2f (&a)[16], std::integer_sequence<int, P...>) {
-  ((dst[512 * P] = v4f{a[2 * P].x, a[2 * P].y, a[2 * P + 1].x, a[2 * P + 1].y}), ...);
+  // (non-temporal: lambda is read next by another kernel -- it must not displace the partner blocks in L2)
+  ((__builtin_nontemporal_store(v4f{a[2 * P].x, a[2 * P].y, a[2 * P + 1].x, a[2 * P + 1].y}, dst + 512 * P)), ...);
 }
 template <int... P>
 __device__ __forceinline__ float obs_energy_(const v4f* __restrict__ src, const v2f (&a)[16], std::integer_sequence<int, P...>) {
@@ -152,8 +198,6 @@ __device__ __forceinline__ float obs_energy_(const v4f* __restrict__ src, const 
 }
 template <int... I>
 __device__ __forceinline__ void obs_zero_(v2f (&a)[16], std::integer_sequence<int, I...>) { ((a[I] = v2f{0.f, 0.f}), ...); }
-
-#define OBS_CASE8(F, B) F(B) F(B + 1) F(B + 2) F(B + 3) F(B + 4) F(B + 5) F(B + 6) F(B + 7)
 
 // first group at or after g that this block runs: value modes skip a pair's upper block
 template <bool HALVE>
@@ -169,7 +213,60 @@ __device__ __forceinline__ uint32_t obs_next_group(const ObsBGroup* __restrict__
 }
 
 template <int MODE>
-__global__ __launch_bounds__(512, 4) void observable_blocks_kernel(
+struct ObsCtx {
+  const ObsBTerm* terms;
+  const float* up;
+  const char* lds;   // the workgroup's LDS (byte address 0 of the dynamic array)
+  float* cells;
+  uint32_t n_ops, bx, t, tid;
+};
+
+// One term on the thread's 16 slots, from its 32-byte record.
+template <int MODE>
+__device__ __forceinline__ void obs_one_term(const ObsCtx<MODE>& c, const ObsBTerm t, uint32_t cur_bytes, float pair_weight,
+                                             v2f (&a)[16], v4f (&r)[8], v2f& d2, uint32_t& cur_op, v2f (&dq)[4]) {
+  constexpr bool ACC = MODE == OBS_LAMBDA || MODE == OBS_LAMBDA_VALUE;
+  constexpr bool MULTI = MODE == OBS_VALUES_MULTI;
+  if (t.meta & kObsNewMask) obs_rows(r, c.lds, ((c.t << 4) | cur_bytes) ^ t.xrow);
+  const uint32_t op = t.meta & 1023u;
+  float wv = t.coeff * pair_weight;
+  if constexpr (MODE == OBS_LAMBDA) wv *= c.up[op];
+  // sign at the thread's own index: block part and the (-1)^ny i^2 constant (scalar), thread part (one popcount); the
+  // slot part is in the variant
+  const uint32_t sg = uint32_t(__popc(c.bx & t.zb)) + ((t.meta >> 13) & 1u) + uint32_t(__popc(c.t & t.zt));
+  const float wp = __uint_as_float(__float_as_uint(wv) ^ (sg << 31));
+  const v2f w = v2f{wp, -wp};
+  v2f s[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+  obs_term<ACC>(a, r, w, s, t.off0, t.off1);
+  if constexpr (!ACC) {
+    const v2f inc = wp * ((s[0] + s[1]) + (s[2] + s[3]));
+    if constexpr (MULTI) {
+      // The first four observables keep a register accumulator each (four wave-uniform triangles: terms of
+      // neighbouring masks alternate between observables -- XX, YY, XX, ... -- and a wave reduction per change costs
+      // more than the term); the others share d2, reduced into this wave's LDS cell whenever the observable changes.
+      if (op == 0u) dq[0] += inc;
+      if (op == 1u) dq[1] += inc;
+      if (op == 2u) dq[2] += inc;
+      if (op == 3u) dq[3] += inc;
+      if (op >= 4u) {
+        if (op != cur_op) {
+          if (cur_op != ~0u) {
+            const float e = wave_sum(d2.x + d2.y);
+            if ((c.tid & 63u) == 0u) c.cells[(c.tid >> 6) * c.n_ops + cur_op] += e;
+          }
+          d2 = v2f{0.f, 0.f};
+          cur_op = op;
+        }
+        d2 += inc;
+      }
+    } else {
+      d2 += inc;
+    }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
     const float2* __restrict__ psi, float2* __restrict__ lam, uint32_t n, const ObsBTerm* __restrict__ terms,
     const ObsBGroup* __restrict__ groups, uint32_t n_groups, const float* __restrict__ upstream, uint32_t n_ops,
     uint32_t state0, float* __restrict__ value_part, uint32_t nb /* blocks per state */, uint32_t n_states,
@@ -177,13 +274,13 @@ __global__ __launch_bounds__(512, 4) void observable_blocks_kernel(
   constexpr bool ACC = MODE == OBS_LAMBDA || MODE == OBS_LAMBDA_VALUE;
   constexpr bool HALVE = !ACC;
   constexpr bool MULTI = MODE == OBS_VALUES_MULTI;
-  extern __shared__ v4f lds4[];  // [4096] the partner block of the current group; then the value cells
-  float* cells = reinterpret_cast<float*>(lds4 + kOBlock / 2);
+  extern __shared__ v4f lds4[];  // two block buffers of 4096 16-byte words; then the value cells
+  float* cells = reinterpret_cast<float*>(lds4 + 2 * kOBuf);
   // Workgroup -> (state, block).  Workgroups are dealt round-robin to the 8 XCDs (linear id mod 8), each with its own L2:
   //   xcd_states: XCD k works on state 8 g + k, its blocks in index order;
-  //   otherwise XCD k takes the k-th contiguous eighth of every state (a 128-MiB state then sits in the Infinity
-  //   Cache once and serves all eight L2s).  Either way the workgroups an XCD runs at one time are neighbours in the
-  //   index, walk the groups in the same order, and fetch partner blocks from the same few MiB.
+  //   otherwise XCD k takes the k-th contiguous eighth of every state.
+  // Either way the workgroups an XCD runs at one time are neighbours in the index, walk the groups in the same
+  // order, and fetch partner blocks from the same 2 MiB.
   uint32_t s_local, bx;
   {
     const uint32_t wg = blockIdx.x, per_group = 8u * nb, group = wg / per_group, r = wg - group * per_group;
@@ -196,107 +293,132 @@ __global__ __launch_bounds__(512, 4) void observable_blocks_kernel(
       bx = (nb & 7u) ? b : (b & 7u) * (nb >> 3) + (b >> 3);
     }
   }
-  const uint32_t tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x, t = tid & (kOH - 1u), hh = uni(tid >> 9);
   const float2* ps = psi + (size_t(s_local) << n);
-  const v4f* own4 = reinterpret_cast<const v4f*>(ps + (size_t(bx) << kObsBlockBits)) + tid;
-  const float* up = MODE == OBS_LAMBDA ? upstream + size_t(state0 + s_local) * n_ops : nullptr;
+  const v4f* own4 = reinterpret_cast<const v4f*>(ps + (size_t(bx) << kObsBlockBits)) + t;
+  ObsCtx<MODE> c;
+  c.terms = terms; c.lds = reinterpret_cast<const char*>(lds4); c.cells = cells; c.n_ops = n_ops; c.bx = bx; c.t = t; c.tid = tid;
+  c.up = MODE == OBS_LAMBDA ? upstream + size_t(state0 + s_local) * n_ops : nullptr;
 
   v2f a[16];
   if constexpr (ACC) obs_zero_(a, std::make_integer_sequence<int, 16>{});
   else obs_own_(a, own4, std::make_integer_sequence<int, 8>{});
   if constexpr (MULTI) {
     for (uint32_t i = tid; i < kOWaves * n_ops; i += kOT) cells[i] = 0.f;
-    __syncthreads();
   }
-  v4f r[8], pf[8];
-  obs_rows<0>(r, lds4 + tid);  // (defined values before the first mask; never used)
+  v4f r[8], pfa[4], pfb[4];
+  obs_rows(r, c.lds, t << 4);  // (defined values before the first mask; never used)
   v2f d2 = v2f{0.f, 0.f};  // value modes: sum_k W_k (own . partner), both halves
-  uint32_t cur_op = 0;
+  uint32_t cur_op = ~0u;  // (several observables: the one d2 is collecting, none yet)
+  v2f dq[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+  const uint32_t t16 = t << 4, row0 = 4u * hh;
+  // the block a group pairs this one with (past the last group: the block itself -- no branch around the registers)
+  auto partner = [&](uint32_t g) { return ps + (size_t(bx ^ (g < n_groups ? groups[g].xout : 0u)) << kObsBlockBits); };
 
-  uint32_t g = obs_next_group<HALVE>(groups, n_groups, 0u, bx);
-  // (past the last group the prefetch re-reads the block's own amplitudes: no branch around the register file)
-  obs_fetch(pf, ps + (size_t(bx ^ (g < n_groups ? groups[g].xout : 0u)) << kObsBlockBits), tid << 4);
-  while (g < n_groups) {
-    const uint32_t g_xout = groups[g].xout, g_begin = groups[g].begin, g_end = groups[g].end;
-    __syncthreads();  // every wave has finished reading the previous group's block
-    obs_stage(lds4 + tid, pf);
-    __syncthreads();
-    const uint32_t gn = obs_next_group<HALVE>(groups, n_groups, g + 1u, bx);
-    // the next group's partner block: in flight while this group is consumed
-    obs_fetch(pf, ps + (size_t(bx ^ (gn < n_groups ? groups[gn].xout : 0u)) << kObsBlockBits), tid << 4);
-    const float pair_weight = (HALVE && g_xout != 0u) ? 2.f : 1.f;
-    for (uint32_t k = g_begin; k < g_end; ++k) {
-      const ObsBTerm t = terms[k];
-      const uint32_t meta = t.meta;
-      if (meta & kObsNewMask) {
-        const v4f* src = lds4 + (tid ^ ((t.xin >> 1) & 511u));
-        switch ((t.xin >> 10) & 7u) {
-#define OBS_ROWS(V) case V: obs_rows<V>(r, src); break;
-          OBS_CASE8(OBS_ROWS, 0)
-#undef OBS_ROWS
-        }
-      }
-      const uint32_t ny = (meta >> 10) & 3u, op = meta & 1023u;
-      float wv = t.coeff * pair_weight;
-      if constexpr (MODE == OBS_LAMBDA) wv *= up[op];
-      // sign at the thread's own index: block part, ny (and i^2 = -1 for ny >= 2), thread part; the slot part is in the variant
-      const uint32_t sg = (uint32_t(__popc(bx & (t.z >> kObsBlockBits))) + ny + (ny >> 1) +
-                           uint32_t(__popc(tid & (t.z >> 1) & 511u))) & 1u;
-      const float wp = __uint_as_float(__float_as_uint(wv) ^ (sg << 31));
-      const v2f w = v2f{wp, -wp};
-      v2f s[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
-      if constexpr (!ACC) {
-        if constexpr (MULTI) {
-          if (op != cur_op) {  // (wave-uniform) the partial of the previous observable goes to this wave's cell
-            const float e = wave_sum(d2.x + d2.y);
-            if ((tid & 63u) == 0u) cells[(tid >> 6) * n_ops + cur_op] += e;
-            d2 = v2f{0.f, 0.f};
-            cur_op = op;
-          }
-        }
-      }
-      // variant: the Z bits of the three low slot bits, odd x, imaginary weight; the highest slot bit's Z bit is the
-      // base sign of slots 8..15
-      const uint32_t zs = (t.z & 1u) | (((t.z >> 10) & 7u) << 1);
-      const uint32_t off0 = ((zs & 7u) | ((t.xin & 1u) << 4) | ((ny & 1u) << 5)) * uint32_t(OBS_CHUNK_BYTES) + uint32_t(OBS_PREAMBLE_BYTES);
-      const uint32_t off1 = off0 + (zs & 8u) * uint32_t(OBS_CHUNK_BYTES);
-      obs_term<ACC>(a, r, w, s, off0, off1);
-      if constexpr (!ACC) {
-        const v2f ss = (s[0] + s[1]) + (s[2] + s[3]);
-        d2 += wp * ss;
+  // groups of the next four steps
+  uint32_t g0 = obs_next_group<HALVE>(groups, n_groups, 0u, bx);
+  uint32_t g1 = obs_next_group<HALVE>(groups, n_groups, g0 + 1u, bx);
+  uint32_t g2 = obs_next_group<HALVE>(groups, n_groups, g1 + 1u, bx);
+  // (plain vector loads before this point -- the block's own amplitudes in the value modes -- must have landed before
+  // the manual counting starts)
+  obs_wait_older<0>();
+  obs_fetch(pfa, partner(g0), t16, row0);
+  obs_fetch(pfb, partner(g1), t16, row0);
+  obs_wait_older<1>();
+  obs_stage(lds4 + t + 512u * row0, pfa);
+  obs_fetch(pfa, partner(g2), t16, row0);
+  __syncthreads();
+  // Two steps per iteration (the prefetch sets alternate; a run-time choice between them would make the compiler copy
+  // them).  Step: the block of g1 moves from its set to the buffer nobody reads in this step, the set is refilled
+  // with the block of g3, the masks of g0 (this half's share) are applied from the other buffer; one barrier.
+  auto terms_of = [&](const ObsBGroup gr, uint32_t cur_bytes) {
+    const float pair_weight = (!ACC && gr.xout != 0u) ? 2.f : 1.f;
+    uint32_t k = hh ? gr.mid : gr.begin;
+    const uint32_t k1 = hh ? gr.end : gr.mid;  // this half's masks
+    // two records in flight: the scalar load of the next one runs behind the arithmetic of the current one (the
+    // array is padded by one record)
+    if (k < k1) {
+      ObsBTerm ta = terms[k];
+      for (;;) {
+        const ObsBTerm tb = terms[k + 1u];
+        obs_one_term<MODE>(c, ta, cur_bytes, pair_weight, a, r, d2, cur_op, dq);
+        if (++k >= k1) break;
+        ta = terms[k + 1u];
+        obs_one_term<MODE>(c, tb, cur_bytes, pair_weight, a, r, d2, cur_op, dq);
+        if (++k >= k1) break;
       }
     }
-    g = gn;
+  };
+  while (g0 < n_groups) {
+    {  // even step: masks of g0 from buffer 0; g1's block pfb -> buffer 1; pfb <- g3's block
+      const ObsBGroup gr = groups[g0];
+      const uint32_t g3 = obs_next_group<HALVE>(groups, n_groups, g2 + 1u, bx);
+      obs_wait_older<1>();
+      obs_stage(lds4 + kOBuf + t + 512u * row0, pfb);
+      obs_fetch(pfb, partner(g3), t16, row0);
+      terms_of(gr, 0u);
+      __syncthreads();
+      g0 = g1; g1 = g2; g2 = g3;
+    }
+    if (g0 >= n_groups) break;
+    {  // odd step: masks of g0 from buffer 1; g1's block pfa -> buffer 0; pfa <- g3's block
+      const ObsBGroup gr = groups[g0];
+      const uint32_t g3 = obs_next_group<HALVE>(groups, n_groups, g2 + 1u, bx);
+      obs_wait_older<1>();
+      obs_stage(lds4 + t + 512u * row0, pfa);
+      obs_fetch(pfa, partner(g3), t16, row0);
+      terms_of(gr, 8u * kOBlock);
+      __syncthreads();
+      g0 = g1; g1 = g2; g2 = g3;
+    }
   }
+  obs_wait_older<0>();  // (the last refills re-read the block itself: nothing is pending past this point)
 
+  v4f* const buf0 = lds4;
   if constexpr (ACC) {
-    if (lam) {
-      obs_store_(reinterpret_cast<v4f*>(lam + (size_t(s_local) << n) + (size_t(bx) << kObsBlockBits)) + tid, a,
-                 std::make_integer_sequence<int, 8>{});
+    // the second half's accumulators join the first half's through an LDS buffer (every wave is past its last read)
+    if (hh) obs_acc_out_(buf0 + t, a, std::make_integer_sequence<int, 8>{});
+    __syncthreads();
+    if (!hh) {
+      obs_acc_in_(a, buf0 + t, std::make_integer_sequence<int, 8>{});
+      if (lam)
+        obs_store_(reinterpret_cast<v4f*>(lam + (size_t(s_local) << n) + (size_t(bx) << kObsBlockBits)) + t, a,
+                   std::make_integer_sequence<int, 8>{});
     }
   }
   if constexpr (MODE == OBS_LAMBDA) return;
   if constexpr (MULTI) {
-    {
+    if (cur_op != ~0u) {
       const float e = wave_sum(d2.x + d2.y);
       if ((tid & 63u) == 0u) cells[(tid >> 6) * n_ops + cur_op] += e;
     }
+    {  // the register accumulators of observables 0..3 (cells nobody else of this wave touches any more)
+      const float e0 = wave_sum(dq[0].x + dq[0].y), e1 = wave_sum(dq[1].x + dq[1].y);
+      const float e2 = wave_sum(dq[2].x + dq[2].y), e3 = wave_sum(dq[3].x + dq[3].y);
+      if ((tid & 63u) == 0u) {
+        float* row = cells + (tid >> 6) * n_ops;
+        row[0] += e0;
+        if (n_ops > 1u) row[1] += e1;
+        if (n_ops > 2u) row[2] += e2;
+        if (n_ops > 3u) row[3] += e3;
+      }
+    }
     __syncthreads();
-    for (uint32_t t = tid; t < n_ops; t += kOT) {
+    for (uint32_t q = tid; q < n_ops; q += kOT) {
       float e = 0.f;
 #pragma unroll
-      for (uint32_t w8 = 0; w8 < kOWaves; ++w8) e += cells[w8 * n_ops + t];  // wave order: bit-reproducible
-      value_part[(size_t(s_local) * nb + bx) * n_ops + t] = e;
+      for (uint32_t w8 = 0; w8 < kOWaves; ++w8) e += cells[w8 * n_ops + q];  // wave order: bit-reproducible
+      value_part[(size_t(s_local) * nb + bx) * n_ops + q] = e;
     }
   } else {
     float e;
-    if constexpr (MODE == OBS_LAMBDA_VALUE) {  // <psi|O|psi> = sum_j Re(conj(psi_j) lambda_j)
-      e = obs_energy_(own4, a, std::make_integer_sequence<int, 8>{});
+    if constexpr (MODE == OBS_LAMBDA_VALUE) {  // <psi|O|psi> = sum_j Re(conj(psi_j) lambda_j): the first half holds lambda
+      e = hh ? 0.f : obs_energy_(own4, a, std::make_integer_sequence<int, 8>{});
     } else {
       e = d2.x + d2.y;
     }
     e = wave_sum(e);
-    __syncthreads();  // the partner buffer is free now
+    __syncthreads();  // the buffers are free now
     if ((tid & 63u) == 0u) cells[tid >> 6] = e;
     __syncthreads();
     if (tid == 0u) {
@@ -354,14 +476,14 @@ hipError_t launch_observable_blocks(int mode, const float2* psi, float2* lam, ui
   const uint32_t nb = 1u << (n - kObsBlockBits);
   const uint32_t xs = xcd_states && nb >= 64u ? 1u : 0u;  // (a state must at least fill an XCD's workgroup slots)
   // the largest cell area any mode uses, so that every instantiation is opted in once for the same size
-  const size_t lds = size_t(kOBlock) * 8u + size_t(kOWaves) * kObsMaxValueOps * sizeof(float);
+  const size_t lds = 2u * size_t(kOBlock) * 8u + size_t(kOWaves) * kObsMaxValueOps * sizeof(float);
   static bool done[4][kMaxDev];
   hipError_t e = hipSuccess;
 #define QHBM_OBSB(M_)                                                                                                   \
   {                                                                                                                    \
     e = obs_opt_in(observable_blocks_kernel<M_>, done[M_], lds);                                                        \
     if (e != hipSuccess) return e;                                                                                     \
-    const size_t use = size_t(kOBlock) * 8u + (M_ == OBS_VALUES_MULTI ? size_t(kOWaves) * n_ops * sizeof(float) : 64u); \
+    const size_t use = 2u * size_t(kOBlock) * 8u + (M_ == OBS_VALUES_MULTI ? size_t(kOWaves) * n_ops * sizeof(float) : 64u); \
     hipLaunchKernelGGL((observable_blocks_kernel<M_>), dim3(nb * n_states), dim3(kOT), use, stream, psi, lam, n, terms, \
                        groups, n_groups, upstream, n_ops, state0, value_part, nb, n_states, xs);                       \
   }

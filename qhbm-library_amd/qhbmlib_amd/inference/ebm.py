@@ -59,9 +59,16 @@ class EnergyInferenceBase(torch.nn.Module, abc.ABC):
       self._seed = int(initial_seed)
 
   def agree_seed(self, group=None):
-    """COLLECTIVE over `group`: this sampler takes rank 0's current seed (parallel.agreed_seed), on the device of
-    the energy's variables when the group's backend moves device memory."""
-    self._seed = parallel.agreed_seed(self._seed, group, device=_device_of(self._energy))
+    """COLLECTIVE over `group` (every rank takes part in the broadcast): a sampler built with `initial_seed=None`
+    takes rank 0's current seed (parallel.agreed_seed), on the device of the energy's variables when the group's
+    backend moves device memory.  An EXPLICIT seed is the caller's: it is kept, and ranks whose explicit seeds
+    differ fail loudly in the consistency check of the sharded call instead of being re-seeded silently.
+    Returns True when the seed was replaced."""
+    agreed = parallel.agreed_seed(self._seed, group, device=_device_of(self._energy))
+    if not self._update_seed or agreed == self._seed:
+      return False
+    self._seed = agreed
+    return True
 
   @property
   def variables_updated(self):
@@ -390,11 +397,13 @@ class GibbsWithGradientsInference(EnergyInference):
 
   def agree_seed(self, group=None):
     """... and the chain restarts from the agreed seed (its generator and initial state were drawn from the old one)."""
-    super().agree_seed(group)
+    if not super().agree_seed(group):
+      return False
     self._chain_generator.manual_seed(self._seed % (2**63))
     self._chain_state = torch.bernoulli(torch.full((self.energy.num_bits,), 0.5),
                                         generator=self._chain_generator).to(torch.int8)
     self._first_inference = True   # burn in again
+    return True
 
   def _ready_inference(self):
     state = self._chain_state

@@ -39,6 +39,8 @@ def _via_host(group) -> bool:
 
 def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
   """In-place sum of `t` over the group."""
+  if dist.get_world_size(group) == 1:
+    return t
   if t.is_cuda and _via_host(group):
     c = t.cpu()
     dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
@@ -52,6 +54,8 @@ def all_gather_rows(local: torch.Tensor, blocks: List[Tuple[int, int]], group=No
   """Concatenates the ranks' row blocks (`blocks[r]` = rank r's [lo, hi)) into the full tensor,
   identical on every rank.  Blocks are padded to the widest one so a single all-gather serves."""
   world = dist.get_world_size(group)
+  if world == 1:   # a group of one rank exchanges nothing (the ordered fp64 row sum that follows stays: it is what makes
+    return local   # one rank and N ranks bit-identical)
   rank = dist.get_rank(group)
   lo, hi = blocks[rank]
   width = max(h - l for l, h in blocks)

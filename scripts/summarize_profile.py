@@ -21,7 +21,7 @@ publish = "--publish" in sys.argv
 SRC = os.path.join(ROOT, "gpurun_out", f"profile_{tag}")
 DST = os.path.join(ROOT, "profiles")
 CLOCK_GHZ, SIMDS = 2.4, 1024
-ISSUE_CYCLES_PER_VALU = 4.5  # measured on this chip (scripts/micro/valu_rate.hip): v_fma 4.0, v_pk_* 4.6-4.8
+ISSUE_CYCLES_PER_VALU = 4.5  # measured on this chip (scripts/experiments/micro/valu_rate.hip): v_fma 4.0, v_pk_* 4.6-4.8
 
 
 def short(name):
@@ -47,7 +47,7 @@ for i in range(1, 9):
   if not os.path.exists(path):
     continue
   d = pd.read_csv(path)
-  d = d[d.Kernel_Name.str.contains("pass_|apply_obs|reduce_")].copy()
+  d = d[d.Kernel_Name.str.contains("pass_|apply_obs|observable_blocks|reduce_")].copy()
   d["Name"] = d.Kernel_Name.map(short)
   g = d.groupby(["Name", "Counter_Name"]).agg(calls=("Dispatch_Id", "nunique"), total=("Counter_Value", "sum"))
   for (name, ctr), r in g.iterrows():

@@ -128,7 +128,7 @@ def test_adjoint_pass_order_is_searched_for_early_finished_bits():
 def test_adjoint_plan_is_chosen_by_the_time_model():
   """The backward plan is the one with the least modelled time (per pass: arithmetic of the flop model at the rate
   the kernel sustains, or tile traffic) among the scheduler's best pass orders and the greedy one, with tiles of
-  2^12 and -- `adjoint_tile_qubits` = 0 -- of 2^13 amplitudes (scripts/adj_tile_ab.sh, adj_search_ab.sh): config 3
+  2^12 and -- `adjoint_tile_qubits` = 0 -- of 2^13 amplitudes (scripts/experiments/adj_tile_ab.sh, adj_search_ab.sh): config 3
   keeps the scheduler's first choice on 2^12, deep TFIM circuits (nothing finishes early) take other orders and
   / or the larger tile.  Explicit options are obeyed."""
   def tile_bits(eng):

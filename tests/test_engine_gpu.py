@@ -794,7 +794,7 @@ def test_forward_only_values_from_the_observable_kernel(n, tile):
   """A forward-only call with one observable on a multi-pass plan takes <psi|O|psi> from the lambda = O psi
   kernel (nothing stored) when some term flips two or more qubits (`forward_values_from_observable`: auto),
   and keeps measuring in the tiles for single-flip + diagonal sums (TFIM) and on single-pass plans.  Both
-  routes against the oracle and against each other, chunked too; several observables always measure."""
+  routes against the oracle and against each other, chunked too; several observables: see the end."""
   rng = np.random.default_rng(70 + n)
   gates, names = O.hea_gates(n, 3, "fo")
   params = rng.uniform(-1, 1, len(names))
@@ -820,9 +820,14 @@ def test_forward_only_values_from_the_observable_kernel(n, tile):
   if single.num_passes()[0] == 1:                      # one tile: the state never reaches HBM
     single.expectation(_random_bits(rng, 3, min(n, 12)), rng.uniform(-1, 1, len(O.hea_gates(min(n, 12), 2, "fo")[1])))
     assert single.kernel_time_ms()["obs_launches"] == 0
+  # several observables: measured in the passes below 13 qubits and whenever `multi_observable_values` is off; from
+  # ONE launch of the block kernel (csrc/observable.hip) otherwise -- some term flips two qubits
   both = _engine(n, gates, len(names), [xxz, tfim], tile_qubits=tile, forward_values_from_observable=1, profile_events=1)
   check_values(both, n, gates, params, bits, [xxz, tfim])
-  assert both.kernel_time_ms()["obs_launches"] == 0
+  assert both.kernel_time_ms()["obs_launches"] == (1 if n >= 13 else 0)
+  measured = _engine(n, gates, len(names), [xxz, tfim], tile_qubits=tile, multi_observable_values=0, profile_events=1)
+  check_values(measured, n, gates, params, bits, [xxz, tfim])
+  assert measured.kernel_time_ms()["obs_launches"] == 0
 
 
 # ---- round-3 layouts: relabeling adjoint plans, compact grids, paired forward passes ---------------

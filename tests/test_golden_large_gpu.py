@@ -65,6 +65,43 @@ def test_c3_values_and_vjp_against_oracle(c3, opts):
     assert opts.get("chunk_states", 0) and opts["chunk_states"] < len(bits)
 
 
+@pytest.mark.parametrize("opts", [{}, {"multi_observable_values": 0}, {"observable_kernel": 0}],
+                         ids=["values-from-the-block-kernel", "measured-in-the-passes", "gather-kernel"])
+def test_c3_three_observables_values_and_vjp_against_oracle(c3, opts):
+  """Config 3's circuit with the XXZ chain as THREE observables (XX, YY, ZZ sums) -- several operators per call, the
+  reference's normal usage (tests/inference/qnn_test.py:187-190,266-369): lean forward passes + one launch for the
+  three values, one for lambda = sum_t upstream_t O_t psi.  Against the committed fixture (the three values add up to
+  the fixture's XXZ value; with equal upstream weights the VJP is the fixture's) and, per observable with unequal
+  weights, against the C oracle run live on the host."""
+  from oracle import qhbm_cpu as C
+  n, gates, ops = int(c3["n"]), G.gates_of(c3["gates"]), G.ops_of(c3["ops"])
+  whole = ops[0]
+  ops3 = [whole[0::3], whole[1::3], whole[2::3]]
+  assert all(x != 0 and z == 0 for _, x, z in ops3[0]) and all(x == z != 0 for _, x, z in ops3[1]) and all(x == 0 for _, x, z in ops3[2])
+  eng = _engine(n, gates, len(c3["params"]), ops3, **opts)
+  bits, params = c3["bits"], c3["params"]
+  norm = sum(abs(c) for c, _, _ in whole)
+  vals = eng.expectation(bits, params).cpu().numpy()
+  assert vals.shape == (len(bits), 3)
+  assert np.abs(vals.sum(1) - c3["values"]).max() <= 5e-5 * norm
+  w = np.array([[0.7], [-0.4], [0.25], [1.1]], np.float32)
+  vals2, grad = eng.expectation_vjp(bits, params, np.repeat(w, 3, axis=1))
+  want = (w * c3["grads"]).sum(0)
+  tol = 1e-4 * max(1.0, np.abs(want).max())
+  assert np.abs(vals2.cpu().numpy() - vals).max() <= 2e-5 * norm
+  assert np.abs(grad.cpu().numpy() - want).max() <= tol, np.abs(grad.cpu().numpy() - want).max()
+  # unequal weights per observable: the live C oracle
+  up3 = np.array([[0.7, -0.2, 0.4], [-0.4, 0.9, 0.1], [0.25, 0.3, -0.8], [1.1, -0.6, 0.5]], np.float32)
+  o_vals, o_grad = C.expectation_vjp(n, gates, params, bits, ops3, up3)
+  vals3, grad3 = eng.expectation_vjp(bits, params, up3)
+  assert np.abs(vals3.cpu().numpy() - o_vals).max() <= 5e-5 * max(sum(abs(c) for c, _, _ in op) for op in ops3)
+  assert np.abs(grad3.cpu().numpy() - o_grad).max() <= 1e-4 * max(1.0, np.abs(o_grad).max())
+  eng.expectation(bits, params, retain=True)
+  if eng.retained is not None:
+    grad_r = eng.expectation_vjp_retained(bits, params, up3)
+    assert np.abs(grad_r.cpu().numpy() - o_grad).max() <= 1e-4 * max(1.0, np.abs(o_grad).max())
+
+
 def test_c3_per_state_jacobian_and_shift_rule_against_oracle(c3):
   n, gates, ops = int(c3["n"]), G.gates_of(c3["gates"]), G.ops_of(c3["ops"])
   eng = _engine(n, gates, len(c3["params"]), ops)

@@ -133,7 +133,8 @@ def test_many_masks_at_19_qubits_values_lambda_and_both_xcd_maps(xcd):
   _check(eng, n, gates, params, bits, ops, up)
 
 
-def test_three_observables_xxz_split_at_16_qubits_match_the_single_sum():
+@pytest.mark.parametrize("kernel", [-1, 1])
+def test_three_observables_xxz_split_at_16_qubits_match_the_single_sum(kernel):
   """XXZ split into its XX, YY and ZZ sums (the reference's normal usage: several operators per call,
   tests/inference/qnn_test.py:187-190): the three values add up to the one-observable value, gradients agree."""
   n = 16
@@ -148,7 +149,7 @@ def test_three_observables_xxz_split_at_16_qubits_match_the_single_sum():
     zz.append((0.5, 0, m))
   bits = rng.integers(0, 2, size=(6, n)).astype(np.int8)
   up3 = rng.normal(size=(6, 3))
-  eng3 = _engine(n, gates, len(names), [xx, yy, zz])
+  eng3 = _engine(n, gates, len(names), [xx, yy, zz], observable_kernel=kernel)   # (-1: values by the block kernel, lambda by the gather kernel)
   assert eng3.num_passes()[0] > 1
   v3, _ = _check(eng3, n, gates, params, bits, [xx, yy, zz], up3)
   eng1 = _engine(n, gates, len(names), [xx + yy + zz])

@@ -1,5 +1,5 @@
 """Developer scripts that must not rot: the ablation builder's text anchors into kernels.hip
-(scripts/ablate/build.py builds the variants DESIGN.md's ablation tables quote)."""
+(scripts/experiments/ablate/build.py builds the variants HISTORY.md's ablation tables quote)."""
 import importlib.util
 import os
 
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_every_ablation_variant_still_applies_to_the_kernel_source():
-  spec = importlib.util.spec_from_file_location("ablate_build", os.path.join(ROOT, "scripts", "ablate", "build.py"))
+  spec = importlib.util.spec_from_file_location("ablate_build", os.path.join(ROOT, "scripts", "experiments", "ablate", "build.py"))
   mod = importlib.util.module_from_spec(spec)
   spec.loader.exec_module(mod)
   assert len(mod.VARIANTS) >= 25
