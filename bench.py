@@ -425,13 +425,16 @@ def main():
     adjoint_mode = args.mode in ("vqt", "qmhl")
     tm = eng.traffic_model(spg, with_vjp=adjoint_mode)
     fm = eng.flop_model(spg, with_vjp=adjoint_mode)
-    use_bwd = adjoint_mode and kt["bwd_ms"] >= kt["fwd_ms"]
-    if use_bwd:
-      launches, ms, unfused, name, model, flops = (kt["bwd_launches"], kt["bwd_ms"], bwd_unfused, "pass_adj_kernel",
-                                                   tm["bwd_bytes"], fm["bwd_flops"])
-    else:
-      launches, ms, unfused, name, model, flops = (kt["fwd_launches"], kt["fwd_ms"], fwd_unfused, "pass_fwd_kernel",
-                                                   tm["fwd_bytes"] * shift_factor, fm["fwd_flops"] * shift_factor)
+    # the dominant kernel family of the step: forward passes, adjoint passes, or the observable kernel (lambda = O psi /
+    # values: config 4's 480 X-masks make it the largest)
+    families = {
+        "pass_fwd_kernel": (kt["fwd_launches"], kt["fwd_ms"], fwd_unfused, tm["fwd_bytes"] * shift_factor, fm["fwd_flops"] * shift_factor),
+        "pass_adj_kernel": (kt["bwd_launches"], kt["bwd_ms"], bwd_unfused, tm["bwd_bytes"], fm["bwd_flops"]),
+        "apply_observable_kernel": (kt["obs_launches"], kt["obs_ms"], spg * 8.0 * n_terms * amp * shift_factor,
+                                    tm["obs_bytes"] * shift_factor, fm["obs_flops"] * shift_factor),
+    }
+    name = max(families, key=lambda k: families[k][1])
+    launches, ms, unfused, model, flops = families[name]
     per_step_launches = max(1, launches // max(1, args.steps))
     avg_ms = ms / max(1, launches)
     bytes_per_launch = model / per_step_launches

@@ -25,7 +25,7 @@ ISSUE_CYCLES_PER_VALU = 4.5  # measured on this chip (scripts/experiments/micro/
 
 
 def short(name):
-  return name.split("(")[0].replace("void ", "").replace("qhbm::", "").replace("(anonymous namespace)::", "")
+  return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("qhbm::", "")
 
 
 st = pd.read_csv(os.path.join(SRC, "stats", "bench_kernel_stats.csv"))
