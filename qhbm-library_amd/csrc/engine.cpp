@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <iterator>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -468,43 +470,92 @@ int upload_model(qhbm_engine* h) {
       });
       std::vector<ObsBTerm> terms2;
       std::vector<ObsBGroup> groups2;
+      // A UNIT = the masks one step of the kernel applies from one fetched partner block.  A step costs the larger of
+      // its block fetch (~2000 cycles: the fabric, then L2) and its masks (~950 cycles per term and half-workgroup),
+      // and the memory pipeline can run only three blocks ahead: after a group with many masks (x_out = 0: 65 of config
+      // 4's 480) it idles.  Inside a window of partner blocks (x_out >> 5: what the L2 holds at a time -- the order
+      // inside it is free) heavy and light units therefore ALTERNATE (config 4: 53.6 -> 52.8 ms).  Cutting a heavy
+      // group into several units that fetch the block again was measured and lost -- a fetch costs more than the
+      // bubble it removes (units of at most 16 / 8 / 4 / 2 terms: 54.7 / 57.1 / 62.6 / 75.4 ms); QHBM_OBS_UNIT_TERMS
+      // keeps the knob.
+      static const size_t cap = std::getenv("QHBM_OBS_UNIT_TERMS") ? size_t(std::max(1, std::atoi(std::getenv("QHBM_OBS_UNIT_TERMS")))) : ~size_t(0) / 2;
+      static const bool interleave = !std::getenv("QHBM_OBS_NO_INTERLEAVE");
+      struct Unit { uint32_t xo; std::vector<std::pair<size_t, size_t>> masks; size_t terms = 0; };
+      std::vector<Unit> units;
       for (size_t k = 0; k < bt.size();) {
         const uint32_t xo = bt[k].x >> kObsBlockBits;
         size_t e = k;
         while (e < bt.size() && (bt[e].x >> kObsBlockBits) == xo) ++e;
-        // the masks of the group [k, e) and their term ranges
-        std::vector<std::pair<size_t, size_t>> masks;
+        std::vector<std::pair<size_t, size_t>> masks;  // the masks of the group [k, e) and their term ranges
         for (size_t i = k; i < e;) {
           size_t j = i;
           while (j < e && bt[j].x == bt[i].x) ++j;
           masks.emplace_back(i, j);
           i = j;
         }
-        // dealt to the two half-workgroups by term count, largest first (the halves run in step: a group costs what
-        // its larger half costs)
-        std::vector<size_t> order(masks.size());
+        std::stable_sort(masks.begin(), masks.end(), [](const std::pair<size_t, size_t>& a, const std::pair<size_t, size_t>& b) {
+          return a.second - a.first > b.second - b.first;
+        });
+        const size_t first_unit = units.size();
+        for (const auto& m : masks) {  // first fit, largest first
+          const size_t len = m.second - m.first;
+          size_t u = first_unit;
+          while (u < units.size() && units[u].terms + len > cap && units[u].terms > 0) ++u;
+          if (u == units.size()) { units.emplace_back(); units.back().xo = xo; }
+          units[u].masks.push_back(m);
+          units[u].terms += len;
+        }
+        k = e;
+      }
+      if (interleave) {  // inside every window: the heaviest unit while the running load is behind the average, else the lightest
+        std::vector<Unit> ordered;
+        for (size_t a = 0; a < units.size();) {
+          size_t b = a;
+          while (b < units.size() && (units[b].xo >> 5) == (units[a].xo >> 5)) ++b;
+          std::vector<Unit> win(std::make_move_iterator(units.begin() + long(a)), std::make_move_iterator(units.begin() + long(b)));
+          std::stable_sort(win.begin(), win.end(), [](const Unit& x, const Unit& y) { return x.terms > y.terms; });
+          double total = 0.0;
+          for (const Unit& u : win) total += double(u.terms);
+          const double avg = total / double(win.size());
+          size_t lo = 0, hi = win.size();
+          double done = 0.0;
+          for (size_t step = 0; lo < hi; ++step) {
+            const bool heavy = done <= avg * double(step);
+            Unit& pick = heavy ? win[lo] : win[hi - 1];
+            done += double(pick.terms);
+            ordered.push_back(std::move(pick));
+            if (heavy) ++lo; else --hi;
+          }
+          a = b;
+        }
+        units.swap(ordered);
+      }
+      for (const Unit& u : units) {
+        // the unit's masks dealt to the two half-workgroups by term count, largest first (the halves run in step: a unit
+        // costs what its larger half costs)
+        std::vector<size_t> order(u.masks.size());
         for (size_t i = 0; i < order.size(); ++i) order[i] = i;
         std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
-          return masks[a].second - masks[a].first > masks[b].second - masks[b].first;
+          return u.masks[a].second - u.masks[a].first > u.masks[b].second - u.masks[b].first;
         });
         std::vector<size_t> half[2];
         size_t load[2] = {0, 0};
         for (size_t m : order) {
           const int hsel = load[1] < load[0] ? 1 : 0;
           half[hsel].push_back(m);
-          load[hsel] += masks[m].second - masks[m].first;
+          load[hsel] += u.masks[m].second - u.masks[m].first;
         }
-        ObsBGroup g{xo, uint32_t(terms2.size()), 0u, 0u};
+        ObsBGroup g{u.xo, uint32_t(terms2.size()), 0u, 0u};
         for (int hsel = 0; hsel < 2; ++hsel) {
-          std::sort(half[hsel].begin(), half[hsel].end());  // (mask order = x order: neighbouring masks, neighbouring rows)
+          // (mask order = x order: neighbouring masks, neighbouring rows)
+          std::sort(half[hsel].begin(), half[hsel].end(), [&](size_t a, size_t b) { return u.masks[a].first < u.masks[b].first; });
           for (size_t m : half[hsel])
-            for (size_t i = masks[m].first; i < masks[m].second; ++i)
-              terms2.push_back(obs_block_term(bt[i], i == masks[m].first));
+            for (size_t i = u.masks[m].first; i < u.masks[m].second; ++i)
+              terms2.push_back(obs_block_term(bt[i], i == u.masks[m].first));
           if (hsel == 0) g.mid = uint32_t(terms2.size());
         }
         g.end = uint32_t(terms2.size());
         groups2.push_back(g);
-        k = e;
       }
       terms2.push_back(ObsBTerm{0.f, 0u, 0u, 0u, 0u, 0u, 0u, 0u});  // (the kernel reads one record ahead)
       HIPCHK(h->obs_bterms.upload(terms2));
