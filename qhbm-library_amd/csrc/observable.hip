@@ -152,15 +152,17 @@ __device__ __forceinline__ void obs_fetch(v4f (&pf)[4], const float2* __restrict
                "buffer_load_dwordx4 %2, %4, %5, %8 offen\n\t"
                "buffer_load_dwordx4 %3, %4, %5, %9 offen"
                : "=&v"(pf[0]), "=&v"(pf[1]), "=&v"(pf[2]), "=&v"(pf[3])
-               : "v"(t16), "s"(rsi), "s"(o0), "s"(o1), "s"(o2), "s"(o3)
-               : "memory");
+               : "v"(t16), "s"(rsi), "s"(o0), "s"(o1), "s"(o2), "s"(o3));
 }
-// every obs_fetch but the `newer` most recent ones has landed (4 loads each)
+// Every obs_fetch but the `NEWER` most recent ones has landed (4 loads each).  The set that is about to be staged goes
+// THROUGH the statement ("+v"): its consumers depend on the wait by data flow.  (No "memory" clobber on these asm
+// statements: an asm that may write memory makes the compiler load the term records -- read-only kernel arguments --
+// through the vector path instead of the scalar one.)
 template <int NEWER>
-__device__ __forceinline__ void obs_wait_older() {
+__device__ __forceinline__ void obs_wait_older(v4f (&pf)[4]) {
   static_assert(NEWER == 0 || NEWER == 1, "two sets");
-  if constexpr (NEWER == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (NEWER == 1) asm volatile("s_waitcnt vmcnt(4)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]));
+  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]));
 }
 template <int... J>
 __device__ __forceinline__ void obs_stage_(v4f* dst, const v4f (&pf)[4], std::integer_sequence<int, J...>) {
@@ -321,10 +323,10 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
   uint32_t g2 = obs_next_group<HALVE>(groups, n_groups, g1 + 1u, bx);
   // (plain vector loads before this point -- the block's own amplitudes in the value modes -- must have landed before
   // the manual counting starts)
-  obs_wait_older<0>();
+  asm volatile("s_waitcnt vmcnt(0)");
   obs_fetch(pfa, partner(g0), t16, row0);
   obs_fetch(pfb, partner(g1), t16, row0);
-  obs_wait_older<1>();
+  obs_wait_older<1>(pfa);
   obs_stage(lds4 + t + 512u * row0, pfa);
   obs_fetch(pfa, partner(g2), t16, row0);
   __syncthreads();
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
     {  // even step: masks of g0 from buffer 0; g1's block pfb -> buffer 1; pfb <- g3's block
       const ObsBGroup gr = groups[g0];
       const uint32_t g3 = obs_next_group<HALVE>(groups, n_groups, g2 + 1u, bx);
-      obs_wait_older<1>();
+      obs_wait_older<1>(pfb);
       obs_stage(lds4 + kOBuf + t + 512u * row0, pfb);
       obs_fetch(pfb, partner(g3), t16, row0);
       terms_of(gr, 0u);
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
     {  // odd step: masks of g0 from buffer 1; g1's block pfa -> buffer 0; pfa <- g3's block
       const ObsBGroup gr = groups[g0];
       const uint32_t g3 = obs_next_group<HALVE>(groups, n_groups, g2 + 1u, bx);
-      obs_wait_older<1>();
+      obs_wait_older<1>(pfa);
       obs_stage(lds4 + t + 512u * row0, pfa);
       obs_fetch(pfa, partner(g3), t16, row0);
       terms_of(gr, 8u * kOBlock);
@@ -372,7 +374,8 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
       g0 = g1; g1 = g2; g2 = g3;
     }
   }
-  obs_wait_older<0>();  // (the last refills re-read the block itself: nothing is pending past this point)
+  obs_wait_older<0>(pfa);  // (the last refills re-read the block itself: nothing is pending past this point)
+  obs_wait_older<0>(pfb);
 
   v4f* const buf0 = lds4;
   if constexpr (ACC) {
