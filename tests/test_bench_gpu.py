@@ -159,3 +159,34 @@ def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
   assert out.returncode == 0, out.stderr[-3000:]
   line = _line(out.stdout)
   assert line["n_gpus"] == 2 and line["verify"]["ok"], line
+
+
+def test_bench_qmhl_mode_checks_the_masked_gradient_of_the_timed_step():
+  """`--mode qmhl`: U_data then U_model^dagger, the KOBE-2 shards of the model as observables, the adjoint VJP with
+  respect to the model's parameters only (qmhl_loss.py:33-34, qnn.py:120-139).  Values [U, T] and the gradient rows of
+  the timed step against the C oracle; the frozen (data) half of the gradient is exactly zero."""
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "qmhl", "--qubits", "13", "--layers", "2",
+                        "--states-total", "24", "--steps", "1", "--warmup", "1", "--cpu-sample-states", "4"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert out.returncode == 0, out.stderr[-2000:]
+  line = _line(out.stdout)
+  cfg = line["config"]
+  assert cfg["mode"] == "qmhl" and cfg["observables"] == 13 + 13 * 12 // 2 and cfg["hamiltonian"] == "kobe2_shards"
+  assert line["qmhl_step_ms"] == line["ms_per_step"] and line["vqt_step_ms"] is None
+  pc = line["parity_check"]
+  assert pc["ok"] and pc["states"] == 4 and pc["grad_from"].startswith("rows of the last timed step"), pc
+  assert pc["max_err_values"] <= pc["tol_values"] == pytest.approx(5e-5) and pc["grad_inf_norm"] > 1e-3
+
+
+def test_bench_three_observables_in_one_call():
+  """`--hamiltonian xxz3`: the XXZ chain as its XX, YY and ZZ sums (several operators per call, the reference's
+  normal usage, tests/inference/qnn_test.py:187-190): values of the timed step per observable and the VJP against
+  the oracle; the three values come from the observable kernel (one launch), not from measuring passes."""
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--hamiltonian", "xxz3", "--qubits", "14",
+                        "--layers", "3", "--states-total", "16", "--steps", "1", "--warmup", "1", "--cpu-sample-states", "4"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert out.returncode == 0, out.stderr[-2000:]
+  line = _line(out.stdout)
+  assert line["config"]["observables"] == 3 and line["config"]["pauli_terms"] == 3 * 13
+  assert line["parity_check"]["ok"], line["parity_check"]
+  assert line["kernel_ms_per_step"]["apply_observable"] > 0
