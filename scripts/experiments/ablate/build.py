@@ -184,6 +184,20 @@ VARIANTS.update({
 })
 
 
+VARIANTS.update({
+    # the adjoint WITHOUT its HBM traffic (every pass: tiles neither loaded nor stored; constants instead): the compute
+    # and exchange time of a pass alone -- with `no_instances` (the I/O and the exchange alone) it says how much of a pass
+    # is the sum of the two and how much their maximum (round 4: pass 0 of config 3)
+    "adj_no_io": lambda t: once(once(once(t,
+        "  prefetch_tile<K, NT, true>(rp, sp, t, tid);\n  prefetch_tile<K, NT, true>(rl, sl, t, tid);\n  if (a.frozen_old_local) {",
+        "  rp = TileRegs{}; rl = TileRegs{}; rp.p0.x = 1e-3f; rl.p0.y = 1e-3f;\n  if (a.frozen_old_local) {"),
+        "  if (a.flags & PASS_RELABEL) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile_relabeled<K, NT>(xt, sp, a, tables, t.tile_base, in_local, tid);",
+        "  if ((a.flags & PASS_RELABEL) && tid == 100000) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile_relabeled<K, NT>(xt, sp, a, tables, t.tile_base, in_local, tid);"),
+        "  } else if (a.flags & PASS_STORE) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT, true>(xt, sp, t, tid);",
+        "  } else if ((a.flags & PASS_STORE) && tid == 100000) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT, true>(xt, sp, t, tid);"),
+})
+
+
 _OBS_LOOP = "      if (live) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);  // else: the group vanishes on the whole block"
 VARIANTS.update({
     # lambda = O psi (wrong lambda): without the masks that leave the block (no gathers: staging + the masks served
@@ -228,7 +242,8 @@ def main(which):
     try:
       subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-c", path, "-o", obj], cwd=CSRC)
       subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", obj,
-                             os.path.join(CSRC, "engine.o"), os.path.join(CSRC, "schedule.o"), "-o",
+                             os.path.join(CSRC, "engine.o"), os.path.join(CSRC, "schedule.o"),
+                             os.path.join(CSRC, "observable.o"), "-o",
                              os.path.join(OUT, f"lib_{name}.so")], cwd=CSRC)
       print("built", name, flush=True)
     except subprocess.CalledProcessError as exc:

@@ -110,6 +110,51 @@ def test_c3_per_state_jacobian_and_shift_rule_against_oracle(c3):
   assert np.abs(jac - c3["grads"]).max() <= 1e-4 * max(1.0, np.abs(c3["grads"]).max())
 
 
+def test_c3_full_batch_of_4096_states_oracle_rows_and_position_independence(c3):
+  """BASELINE config 3 AT ITS FULL SIZE (4096 states in one resident chunk: 64 GiB of psi and lambda): the
+  fixture's four bitstrings sit at the head, in the middle and at the tail of the batch among 4084 random ones.
+  Their values and per-state gradient rows must equal the oracle's wherever they sit, bit-identically between
+  the three positions (a state's result does not depend on its neighbours, its XCD or its place in the chunk);
+  the [P] gradient of the call is the upstream-weighted sum of the rows; a 5-state call returns the same bits."""
+  n, gates, ops = int(c3["n"]), G.gates_of(c3["gates"]), G.ops_of(c3["ops"])
+  norm = sum(abs(c) for c, _, _ in ops[0])
+  eng = _engine(n, gates, len(c3["params"]), ops)
+  free, _ = torch.cuda.mem_get_info(0)
+  if free < 80 * 2**30:
+    pytest.skip("needs 64 GiB of workspace for the resident 4096-state chunk")
+  U = 4096
+  rng = np.random.default_rng(2024)
+  bits = rng.integers(0, 2, size=(U, n)).astype(np.int8)
+  places = [0, 2046, U - 4]
+  for p0 in places:
+    bits[p0:p0 + 4] = c3["bits"]
+  up = rng.uniform(0.5, 1.5, size=(U, 1)).astype(np.float32) / U
+  vals, grad = eng.expectation_vjp(bits, c3["params"], up)
+  rows = eng.state_gradients(U)
+  vals, grad, rows = vals.cpu().numpy()[:, 0], grad.cpu().numpy(), rows.cpu().numpy().astype(np.float64)
+  tol_g = 1e-4 * max(1.0, np.abs(c3["grads"]).max())
+  for p0 in places:
+    assert np.abs(vals[p0:p0 + 4] - c3["values"]).max() <= 5e-5 * norm
+    got = rows[p0:p0 + 4] / up[p0:p0 + 4].astype(np.float64)
+    assert np.abs(got - c3["grads"]).max() <= tol_g, (p0, np.abs(got - c3["grads"]).max())
+    assert np.array_equal(vals[p0:p0 + 4], vals[0:4])
+  # rows carry the upstream weight: compare the un-weighted rows bit for bit through a call with equal weights
+  flat = np.full((U, 1), 1.0 / U, np.float32)
+  vals_f, grad_f = eng.expectation_vjp(bits, c3["params"], flat)
+  rows_f = eng.state_gradients(U).cpu().numpy()
+  for p0 in places[1:]:
+    assert np.array_equal(rows_f[p0:p0 + 4], rows_f[0:4])
+  assert np.array_equal(vals_f.cpu().numpy()[:, 0], vals)
+  assert np.abs(rows_f.astype(np.float64).sum(0) - grad_f.cpu().numpy()).max() <= 1e-5 * max(1.0, np.abs(grad_f.cpu().numpy()).max())
+  assert np.abs(rows.sum(0) - grad).max() <= 1e-5 * max(1.0, np.abs(grad).max())
+  # the same five states alone
+  few = np.concatenate([bits[0:4], bits[1000:1001]])
+  v5, _ = eng.expectation_vjp(few, c3["params"], np.full((5, 1), 1.0 / U, np.float32))
+  r5 = eng.state_gradients(5).cpu().numpy()
+  assert np.array_equal(v5.cpu().numpy()[:, 0], np.concatenate([vals[0:4], vals[1000:1001]]))
+  assert np.array_equal(r5, np.concatenate([rows_f[0:4], rows_f[1000:1001]]))
+
+
 def test_c3_kobe2_shards_through_the_modular_hamiltonian_circuit(c3):
   """bit . U(phi) . V(phi_h)^dagger (1888 gates) measured in the 210 Z-string shards of a KOBE-2
   energy (qnn.py:120-127): all of them come out of one measurement pass."""
