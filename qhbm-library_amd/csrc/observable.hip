@@ -203,11 +203,17 @@ __device__ __forceinline__ void obs_zero_(v2f (&a)[16], std::integer_sequence<in
 
 // first group at or after g that this block runs: value modes skip a pair's upper block
 template <bool HALVE>
-__device__ __forceinline__ uint32_t obs_next_group(const ObsBGroup* __restrict__ groups, uint32_t n_groups, uint32_t g, uint32_t bx) {
+__device__ __forceinline__ uint32_t obs_next_group(const ObsBGroup* __restrict__ groups, uint32_t n_groups, uint32_t g, uint32_t bx,
+                                                   uint32_t pivot_mask) {
+  // Value modes: <psi|P|psi> is real, so of the two blocks a mask pairs only ONE applies it (weight 2) -- the one with
+  // the group's PIVOT bit clear.  The pivot is the highest bit of x_out inside `pivot_mask`, else its highest bit:
+  // when every XCD owns an eighth of each state (the top three block bits), a pivot among those bits would leave the
+  // first XCD all the work of that group and the last one none (config 4: 148 against 32 groups per block, the
+  // kernel as slow as without halving); below them the halves alternate inside every XCD's range.
   if constexpr (HALVE) {
     while (g < n_groups) {
-      const uint32_t xo = groups[g].xout;
-      if (xo == 0u || (bx ^ xo) > bx) break;
+      const uint32_t xo = groups[g].xout, m = xo & pivot_mask;
+      if (xo == 0u || !((bx >> (31 - __builtin_clz(m ? m : xo))) & 1u)) break;
       ++g;
     }
   }
@@ -283,13 +289,14 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
   //   otherwise XCD k takes the k-th contiguous eighth of every state.
   // Either way the workgroups an XCD runs at one time are neighbours in the index, walk the groups in the same
   // order, and fetch partner blocks from the same 2 MiB.
-  uint32_t s_local, bx;
+  uint32_t s_local, bx, pivot_mask = ~0u;
   {
     const uint32_t wg = blockIdx.x, per_group = 8u * nb, group = wg / per_group, r = wg - group * per_group;
     if (xcd_states && (group + 1u) * 8u <= n_states) {
       s_local = group * 8u + (r & 7u);
       bx = r >> 3;
     } else {
+      if (!(nb & 7u) && nb > 8u) pivot_mask = (nb >> 3) - 1u;  // (obs_next_group: not the bits that select the XCD)
       const uint32_t q = r / nb, b = r - q * nb;
       s_local = group * 8u + q;
       bx = (nb & 7u) ? b : (b & 7u) * (nb >> 3) + (b >> 3);
@@ -318,9 +325,9 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
   auto partner = [&](uint32_t g) { return ps + (size_t(bx ^ (g < n_groups ? groups[g].xout : 0u)) << kObsBlockBits); };
 
   // groups of the next four steps
-  uint32_t g0 = obs_next_group<HALVE>(groups, n_groups, 0u, bx);
-  uint32_t g1 = obs_next_group<HALVE>(groups, n_groups, g0 + 1u, bx);
-  uint32_t g2 = obs_next_group<HALVE>(groups, n_groups, g1 + 1u, bx);
+  uint32_t g0 = obs_next_group<HALVE>(groups, n_groups, 0u, bx, pivot_mask);
+  uint32_t g1 = obs_next_group<HALVE>(groups, n_groups, g0 + 1u, bx, pivot_mask);
+  uint32_t g2 = obs_next_group<HALVE>(groups, n_groups, g1 + 1u, bx, pivot_mask);
   // (plain vector loads before this point -- the block's own amplitudes in the value modes -- must have landed before
   // the manual counting starts)
   asm volatile("s_waitcnt vmcnt(0)");
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
   while (g0 < n_groups) {
     {  // even step: masks of g0 from buffer 0; g1's block pfb -> buffer 1; pfb <- g3's block
       const ObsBGroup gr = groups[g0];
-      const uint32_t g3 = obs_next_group<HALVE>(groups, n_groups, g2 + 1u, bx);
+      const uint32_t g3 = obs_next_group<HALVE>(groups, n_groups, g2 + 1u, bx, pivot_mask);
       obs_wait_older<1>(pfb);
       obs_stage(lds4 + kOBuf + t + 512u * row0, pfb);
       obs_fetch(pfb, partner(g3), t16, row0);
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
     if (g0 >= n_groups) break;
     {  // odd step: masks of g0 from buffer 1; g1's block pfa -> buffer 0; pfa <- g3's block
       const ObsBGroup gr = groups[g0];
-      const uint32_t g3 = obs_next_group<HALVE>(groups, n_groups, g2 + 1u, bx);
+      const uint32_t g3 = obs_next_group<HALVE>(groups, n_groups, g2 + 1u, bx, pivot_mask);
       obs_wait_older<1>(pfa);
       obs_stage(lds4 + t + 512u * row0, pfa);
       obs_fetch(pfa, partner(g3), t16, row0);
