@@ -118,6 +118,9 @@ __device__ __forceinline__ void obs_term(v2f (&a)[16], const v4f (&r)[8], v2f w,
   }
 }
 
+#ifndef QHBM_OBS_LOAD_MOD
+#define QHBM_OBS_LOAD_MOD ""  // cache-policy bits of the partner-block loads (A/B builds: " nt", " sc1", ...)
+#endif
 // The eight partner rows of a mask: row p pairs with row p ^ xp and thread t with t ^ xt, i.e. the LDS byte address of
 // slot row p is (t << 4 | p << 13 | buffer) ^ xrow with xrow = xt << 4 | xp << 13 from the term record: one XOR per row
 // (an 8-way switch over compile-time ds_read offsets costs three taken scalar branches per mask).
@@ -147,10 +150,10 @@ __device__ __forceinline__ void obs_fetch(v4f (&pf)[4], const float2* __restrict
   const uint64_t addr = reinterpret_cast<uint64_t>(blk);
   const v4i rsi = v4i{int(uint32_t(addr)), int(uint32_t(addr >> 32) & 0xffffu), 8 << kObsBlockBits, 0x00020000};
   const uint32_t o0 = 8192u * row0, o1 = o0 + 8192u, o2 = o0 + 16384u, o3 = o0 + 24576u;
-  asm volatile("buffer_load_dwordx4 %0, %4, %5, %6 offen\n\t"
-               "buffer_load_dwordx4 %1, %4, %5, %7 offen\n\t"
-               "buffer_load_dwordx4 %2, %4, %5, %8 offen\n\t"
-               "buffer_load_dwordx4 %3, %4, %5, %9 offen"
+  asm volatile("buffer_load_dwordx4 %0, %4, %5, %6 offen" QHBM_OBS_LOAD_MOD "\n\t"
+               "buffer_load_dwordx4 %1, %4, %5, %7 offen" QHBM_OBS_LOAD_MOD "\n\t"
+               "buffer_load_dwordx4 %2, %4, %5, %8 offen" QHBM_OBS_LOAD_MOD "\n\t"
+               "buffer_load_dwordx4 %3, %4, %5, %9 offen" QHBM_OBS_LOAD_MOD
                : "=&v"(pf[0]), "=&v"(pf[1]), "=&v"(pf[2]), "=&v"(pf[3])
                : "v"(t16), "s"(rsi), "s"(o0), "s"(o1), "s"(o2), "s"(o3));
 }
