@@ -118,12 +118,22 @@ __device__ __forceinline__ void obs_term(v2f (&a)[16], const v4f (&r)[8], v2f w,
   }
 }
 
+#ifdef QHBM_OBS_TIMING  // diagnostic build: cycles of one workgroup's waves per phase, printed (never shipped)
+#define OBS_T(slot) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); tacc[slot] += now_ - tlast; tlast = now_; }
+#else
+#define OBS_T(slot)
+#endif
+#ifndef QHBM_OBS_SKEW
+#define QHBM_OBS_SKEW 1
+#endif
 #ifndef QHBM_OBS_LOAD_MOD
 #define QHBM_OBS_LOAD_MOD ""  // cache-policy bits of the partner-block loads (A/B builds: " nt", " sc1", ...)
 #endif
 // The eight partner rows of a mask: row p pairs with row p ^ xp and thread t with t ^ xt, i.e. the LDS byte address of
-// slot row p is (t << 4 | p << 13 | buffer) ^ xrow with xrow = xt << 4 | xp << 13 from the term record: one XOR per row
-// (an 8-way switch over compile-time ds_read offsets costs three taken scalar branches per mask).
+// slot row p is (t << 4 | p << 13 | buffer) ^ xrow with xrow = xt << 4 | xp << 13 from the term record: one XOR per row.
+// (Measured and dropped: the rows as immediate ds_read offsets behind an 8-way jump table like the term variants --
+// 15 vector instructions fewer per term, the LDS wait inside the asm statement -- 51.4 -> 52.5 ms on config 4: the mask
+// phase is bound by the LDS reads themselves, 8 KiB per wave and term, not by VALU issue.)
 template <int... P>
 __device__ __forceinline__ void obs_rows_(v4f (&r)[8], const char* lds, uint32_t base, std::integer_sequence<int, P...>) {
   ((r[P] = *reinterpret_cast<const v4f*>(lds + (base ^ uint32_t(P << 13)))), ...);
@@ -361,29 +371,64 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
       }
     }
   };
+  // The halves take their two jobs of a step in OPPOSITE order: half 0 moves its rows of the next block into LDS and
+  // then applies its masks, half 1 applies its masks first.  All sixteen waves storing at once is a burst the LDS
+  // takes 830 cycles for (ds_write_b128: 79 B/clk) with the vector units idle; this way each half's stores run under
+  // the other half's arithmetic.  (-DQHBM_OBS_SKEW=0: both halves store first, for A/B measurements.)
+  const bool skew = QHBM_OBS_SKEW && hh;
+#ifdef QHBM_OBS_TIMING
+  uint64_t tacc[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
+  auto refill_a = [&](uint32_t g3) {
+    OBS_T(4)
+    obs_wait_older<1>(pfa);
+    OBS_T(0)
+    obs_stage(lds4 + t + 512u * row0, pfa);
+    obs_fetch(pfa, partner(g3), t16, row0);
+    OBS_T(1)
+  };
+  auto refill_b = [&](uint32_t g3) {
+    OBS_T(4)
+    obs_wait_older<1>(pfb);
+    OBS_T(0)
+    obs_stage(lds4 + kOBuf + t + 512u * row0, pfb);
+    obs_fetch(pfb, partner(g3), t16, row0);
+    OBS_T(1)
+  };
   while (g0 < n_groups) {
     {  // even step: masks of g0 from buffer 0; g1's block pfb -> buffer 1; pfb <- g3's block
       const ObsBGroup gr = groups[g0];
       const uint32_t g3 = obs_next_group<HALVE>(groups, n_groups, g2 + 1u, bx, pivot_mask);
-      obs_wait_older<1>(pfb);
-      obs_stage(lds4 + kOBuf + t + 512u * row0, pfb);
-      obs_fetch(pfb, partner(g3), t16, row0);
+      if (!skew) refill_b(g3);
+      OBS_T(4)
       terms_of(gr, 0u);
+      OBS_T(2)
+      if (skew) refill_b(g3);
+      OBS_T(4)
       __syncthreads();
+      OBS_T(3)
       g0 = g1; g1 = g2; g2 = g3;
     }
     if (g0 >= n_groups) break;
     {  // odd step: masks of g0 from buffer 1; g1's block pfa -> buffer 0; pfa <- g3's block
       const ObsBGroup gr = groups[g0];
       const uint32_t g3 = obs_next_group<HALVE>(groups, n_groups, g2 + 1u, bx, pivot_mask);
-      obs_wait_older<1>(pfa);
-      obs_stage(lds4 + t + 512u * row0, pfa);
-      obs_fetch(pfa, partner(g3), t16, row0);
+      if (!skew) refill_a(g3);
+      OBS_T(4)
       terms_of(gr, 8u * kOBlock);
+      OBS_T(2)
+      if (skew) refill_a(g3);
+      OBS_T(4)
       __syncthreads();
+      OBS_T(3)
       g0 = g1; g1 = g2; g2 = g3;
     }
   }
+#ifdef QHBM_OBS_TIMING
+  if ((blockIdx.x == 5000u || blockIdx.x == 20001u) && (tid & 63u) == 0u)
+    printf("obs timing wg %u wave %2u: groups %u  wait %llu  stage+fetch %llu  terms %llu  barrier %llu  other %llu (x10 ns)\n", blockIdx.x, tid >> 6,
+           n_groups, (unsigned long long)tacc[0], (unsigned long long)tacc[1], (unsigned long long)tacc[2], (unsigned long long)tacc[3], (unsigned long long)tacc[4]);
+#endif
   obs_wait_older<0>(pfa);  // (the last refills re-read the block itself: nothing is pending past this point)
   obs_wait_older<0>(pfb);
 
