@@ -470,14 +470,16 @@ int upload_model(qhbm_engine* h) {
       });
       std::vector<ObsBTerm> terms2;
       std::vector<ObsBGroup> groups2;
-      // A UNIT = the masks one step of the kernel applies from one fetched partner block.  A step costs the larger of
-      // its block fetch (~2000 cycles: the fabric, then L2) and its masks (~950 cycles per term and half-workgroup),
-      // and the memory pipeline can run only three blocks ahead: after a group with many masks (x_out = 0: 65 of config
-      // 4's 480) it idles.  Inside a window of partner blocks (x_out >> 5: what the L2 holds at a time -- the order
-      // inside it is free) heavy and light units therefore ALTERNATE (config 4: 53.6 -> 52.8 ms).  Cutting a heavy
-      // group into several units that fetch the block again was measured and lost -- a fetch costs more than the
-      // bubble it removes (units of at most 16 / 8 / 4 / 2 terms: 54.7 / 57.1 / 62.6 / 75.4 ms); QHBM_OBS_UNIT_TERMS
-      // keeps the knob.
+      // A UNIT = the masks one step of the kernel applies from one fetched partner block.  The phase-timing build of
+      // the kernel (-DQHBM_OBS_TIMING, profiles/r04_c4_observable_experiments.txt) shows a step of ~2750 cycles as
+      // 15 - 25 % the 64-KiB store burst into LDS, 33 - 43 % the masks (~790 cycles per term and wave: 8 KiB of LDS reads
+      // each), 18 - 32 % barrier skew, and NO time waiting for the prefetched blocks -- but the pipeline runs only three
+      // blocks ahead, and after a group with many masks (x_out = 0: 65 of config 4's 480) it would.  Inside a window of
+      // partner blocks (x_out >> 5: what the L2 holds at a time -- the order inside it is free) heavy and light units
+      // therefore ALTERNATE (config 4: 53.6 -> 52.8 ms).  Cutting a heavy group into several units that fetch the block
+      // again was measured and lost (units of at most 16 / 8 / 4 / 2 terms: 54.7 / 57.1 / 62.6 / 75.4 ms);
+      // QHBM_OBS_UNIT_TERMS keeps the knob.  Dealing a group's odd term to BOTH halves by slot rows was measured too
+      // (55.5 against 51.4 ms: scripts/experiments/patches/obs_row_split_terms.patch).
       static const size_t cap = std::getenv("QHBM_OBS_UNIT_TERMS") ? size_t(std::max(1, std::atoi(std::getenv("QHBM_OBS_UNIT_TERMS")))) : ~size_t(0) / 2;
       static const bool interleave = !std::getenv("QHBM_OBS_NO_INTERLEAVE");
       struct Unit { uint32_t xo; std::vector<std::pair<size_t, size_t>> masks; size_t terms = 0; };

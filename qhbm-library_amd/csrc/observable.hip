@@ -29,7 +29,8 @@
 // dropped.)  The halves of one workgroup are kept in step by its barrier.
 // Pipeline per group: the block of group s + 1 goes from registers to the OTHER of two 64-KiB LDS buffers while the
 // masks of group s are applied from the first; the blocks of groups s + 2 and s + 3 are in flight in the two
-// four-row prefetch sets of every thread (128 KiB per CU); ONE barrier per group.
+// four-row prefetch sets of every thread (128 KiB per CU); ONE barrier per group.  The two halves do the store burst
+// and their masks in opposite order, so that each half's 32 KiB of ds_write_b128 run under the other half's masks.
 // The partner of an adjacent pair is an adjacent pair, so every LDS read is one 16-byte word, conflict-free (an XOR
 // on the lane bits permutes the 16-byte chunks of a lane group).  x_in's slot part selects WHICH row (p ^ xp) and
 // which half (h ^ x_0) a slot pairs with: rows through an 8-way scalar switch over ds_read offsets, halves at
@@ -40,7 +41,8 @@
 // whose +-w / re<->im choices are op_sel modifiers on a (w, -w) register pair.  No per-amplitude sign arithmetic.
 //
 // Values.  <psi|P|psi> is real and the (j, j ^ x) and (j ^ x, j) contributions are complex conjugates, so the
-// value-only modes run a group with x_out != 0 on the lower block of each pair only, weight 2 (half the fetches).
+// value-only modes run a group with x_out != 0 on ONE block of each pair only, weight 2 (half the fetches): the block
+// whose pivot bit of x_out is clear, the pivot taken below the bits that select the XCD (obs_next_group).
 // One partial per (state, block, op) leaves in value_part; value_parts_blocks_kernel adds a state's partials in
 // block order in fp64 into the fixed-point accumulators (bit-reproducible, no float atomics).
 #include <hip/hip_runtime.h>
