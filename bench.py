@@ -27,6 +27,7 @@ import argparse
 import hashlib
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -435,6 +436,11 @@ def main():
     }
     name = max(families, key=lambda k: families[k][1])
     launches, ms, unfused, model, flops = families[name]
+    kernel_label = name
+    if name == "apply_observable_kernel":  # which of the two observable kernels ran (qhbm_describe_schedule's last line)
+      m = re.search(r"observable kernel: lambda = (\w+) values = ([\w ]+)", eng.describe_schedule())
+      if m:
+        kernel_label = m.group(1) if adjoint_mode else m.group(2).strip()
     per_step_launches = max(1, launches // max(1, args.steps))
     avg_ms = ms / max(1, launches)
     bytes_per_launch = model / per_step_launches
@@ -524,7 +530,7 @@ def main():
         "roofline": {
             # the bound is whichever ceiling the dominant kernel sits closer to; achieved / peak / unit /
             # frac are those of that ceiling, and both are spelled out in "hbm" and "compute"
-            "bound": "fp32_valu" if compute_bound else "hbm", "kernel": name,
+            "bound": "fp32_valu" if compute_bound else "hbm", "kernel": kernel_label,
             "achieved": achieved_tfs if compute_bound else achieved,
             "peak": FP32_PEAK_TFLOPS if compute_bound else HBM_PEAK_GBPS,
             "unit": "TFLOP/s" if compute_bound else "GB/s",

@@ -1517,7 +1517,14 @@ int qhbm_num_passes(qhbm_engine* h, int* forward_passes, int* backward_passes) {
 int qhbm_describe_schedule(qhbm_engine* h, char* buf, size_t buf_len) {
   if (!h || !buf || !buf_len) return 1;
   if (int rc = build_plans(h)) return rc;
-  const std::string s = describe_plan(h->fwd.plan) + describe_plan(h->adj.plan);
+  std::string s = describe_plan(h->fwd.plan) + describe_plan(h->adj.plan);
+  if (!h->model.terms.empty()) {  // which kernel forms lambda = O psi / the values (bench.py names it in `roofline.kernel`)
+    s += std::string("observable kernel: lambda = ") + (block_kernel(h) ? "observable_blocks_kernel" : "apply_observable_kernel");
+    s += std::string(" values = ") + (multi_value_mode(h) || (value_mode(h) && block_kernel(h)) ? "observable_blocks_kernel"
+                                      : value_mode(h)                                            ? "apply_observable_kernel"
+                                                                                                  : "measured in the passes");
+    s += "\n";
+  }
   std::snprintf(buf, buf_len, "%s", s.c_str());
   return 0;
 }

@@ -207,3 +207,15 @@ def test_graft_entry_build_checks_the_header_version():
   assert "QHBM_ABI_VERSION" in text and not re.search(r"qhbm_abi_version\(\) == \d", text)
   declared = int(re.search(r"#define QHBM_ABI_VERSION (\d+)", _header_text()).group(1))
   assert ctypes.CDLL(E.LIB_PATH).qhbm_abi_version() == declared
+
+
+def test_schedule_names_the_observable_kernel_of_the_operator():
+  """`qhbm_describe_schedule` ends with the kernel that forms lambda = O psi and the values for the installed operator
+  (bench.py quotes it as `roofline.kernel`): the gather kernel for a chain Hamiltonian, the block-grouped kernel for
+  hundreds of X-masks (engine.cpp block_kernel), the passes themselves for sums of single flips and diagonal terms."""
+  last = lambda eng: eng.describe_schedule().splitlines()[-1]
+  assert last(_planner(20, 16, O.xxz_chain_op(20))) == "observable kernel: lambda = apply_observable_kernel values = apply_observable_kernel"
+  many = _planner(16, 2, O.random_pauli_op(16, 300, 7, p_identity=0.75))
+  assert last(many) == "observable kernel: lambda = observable_blocks_kernel values = observable_blocks_kernel"
+  small = _planner(6, 2, O.tfim_ring_op(6))
+  assert last(small).startswith("observable kernel: lambda = apply_observable_kernel")
