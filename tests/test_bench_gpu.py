@@ -190,3 +190,18 @@ def test_bench_three_observables_in_one_call():
   assert line["config"]["observables"] == 3 and line["config"]["pauli_terms"] == 3 * 13
   assert line["parity_check"]["ok"], line["parity_check"]
   assert line["kernel_ms_per_step"]["apply_observable"] > 0
+
+
+def test_bench_names_the_block_kernel_when_the_pauli_sum_has_hundreds_of_masks():
+  """Config 4's operator (512 random strings) on 16 qubits: lambda = O psi is the largest kernel of the step and
+  `roofline.kernel` names the kernel that ran -- the block-grouped one (engine.cpp block_kernel), not the family label."""
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--qubits", "16", "--layers", "2", "--hamiltonian", "random512",
+                        "--states-total", "8", "--steps", "1", "--warmup", "1", "--cpu-sample-states", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+  assert out.returncode == 0, out.stderr[-2000:]
+  line = _line(out.stdout)
+  assert line["parity_check"]["ok"], line["parity_check"]
+  assert line["config"]["pauli_terms"] == 512
+  k = line["kernel_ms_per_step"]
+  if k["apply_observable"] > max(k["forward"], k["adjoint"]):
+    assert line["roofline"]["kernel"] == "observable_blocks_kernel", line["roofline"]
