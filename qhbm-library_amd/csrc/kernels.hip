@@ -526,6 +526,9 @@ __device__ __forceinline__ v2f rec_cs(const uint32_t (&rv)[NV]) {
 // sweeps VALU-issue bound this beats the v_readlane decode by 2 % (it did not in round 1, when the
 // kernels still waited on memory); the coalesced vector fetch stays for the per-lane slot vector.
 // -DQHBM_SCALAR_RECORDS=0 restores the v_readlane decode for A/B measurements.
+#ifndef QHBM_OBS_NT_STORE
+#define QHBM_OBS_NT_STORE 1
+#endif
 #ifndef QHBM_SCALAR_RECORDS
 #define QHBM_SCALAR_RECORDS 1
 #endif
@@ -1814,8 +1817,17 @@ __global__ __launch_bounds__(256, 5) void apply_observable_kernel(
   if (lam) {  // (null: a forward-only call that wants <psi|O|psi> alone)
     float2* ls = lam + (size_t(s_local) << n) + jb;
 #pragma unroll
-    for (int p = 0; p < P; ++p)
-      *reinterpret_cast<float4*>(&ls[tb + 512u * p]) = make_float4(acc[2 * p].x, acc[2 * p].y, acc[2 * p + 1].x, acc[2 * p + 1].y);
+    for (int p = 0; p < P; ++p) {
+      // streamed past the L2 (QHBM_OBS_NT_STORE): lambda is not read again in this launch, and every line it would
+      // occupy there is a line of psi that another workgroup is about to gather
+      typedef float v4f_nt __attribute__((ext_vector_type(4)));
+      const v4f_nt v = {acc[2 * p].x, acc[2 * p].y, acc[2 * p + 1].x, acc[2 * p + 1].y};
+#if QHBM_OBS_NT_STORE
+      __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(&ls[tb + 512u * p]));
+#else
+      *reinterpret_cast<v4f_nt*>(&ls[tb + 512u * p]) = v;
+#endif
+    }
   }
   if constexpr (VALUE) {
     float e = 0.f;
