@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r04_tcc
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-C4="--qubits 24 --layers 16 --states-total 32 --hamiltonian random512 --steps 1 --warmup 1 --no-cpu-baseline"
+C4="${BENCH_ARGS:---qubits 24 --layers 16 --states-total 32 --hamiltonian random512} --steps 1 --warmup 1 --no-cpu-baseline"
 i=0
 while IFS= read -r line; do
   [ -z "$line" ] && continue
