@@ -12,3 +12,31 @@ def test_every_ablation_variant_still_applies_to_the_kernel_source():
   spec.loader.exec_module(mod)
   assert len(mod.VARIANTS) >= 25
   assert mod.check_variants() == {}
+
+
+def test_the_block_observable_kernels_compile_without_register_spills():
+  """csrc/observable.hip keeps two prefetch sets per thread as PENDING loads the compiler does not know about (volatile
+  asm, manual s_waitcnt): a spilled register next to them would be stored before its data has landed.  Every mode of
+  the kernel must fit its 128 registers (four waves per SIMD at 1024 threads) with no spill and no scratch -- an
+  experiment that pushed the several-observables mode to 12 spills failed parity on the GPU (HISTORY.md round 4)."""
+  import re
+  import shutil
+  import subprocess
+  import pytest
+  hipcc = "/opt/rocm/bin/hipcc"
+  if not shutil.which(hipcc):
+    pytest.skip("no hipcc")
+  csrc = os.path.join(ROOT, "qhbm-library_amd", "csrc")
+  out = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-disable-promote-alloca-to-vector=1",
+                        "-mllvm", "-amdgpu-sched-strategy=max-ilp", "--cuda-device-only", "-c", "observable.hip", "-o", os.devnull,
+                        "-Rpass-analysis=kernel-resource-usage"], cwd=csrc, capture_output=True, text=True, timeout=600).stderr
+  blocks = re.split(r"remark: Function Name: ", out)[1:]
+  seen = 0
+  for b in blocks:
+    if "observable_blocks_kernel" not in b.split()[0]:
+      continue
+    seen += 1
+    field = lambda name: int(re.search(name + r"[^:]*: (\d+)", b).group(1))
+    assert field("VGPRs Spill") == 0 and field("SGPRs Spill") == 0 and field("ScratchSize") == 0, b[:400]
+    assert field("VGPRs") <= 128 and field("Occupancy") >= 4, b[:400]
+  assert seen == 4
