@@ -437,7 +437,8 @@ def main():
     name = max(families, key=lambda k: families[k][1])
     launches, ms, unfused, model, flops = families[name]
     kernel_label = name
-    if name == "apply_observable_kernel":  # which of the two observable kernels ran (qhbm_describe_schedule's last line)
+    observable_family = name == "apply_observable_kernel"
+    if observable_family:  # which of the two observable kernels ran (qhbm_describe_schedule's last line)
       m = re.search(r"observable kernel: lambda = (\w+) values = ([\w ]+)", eng.describe_schedule())
       if m:
         kernel_label = m.group(1) if adjoint_mode else m.group(2).strip()
@@ -551,17 +552,26 @@ def main():
             "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_ms": avg_ms, "launches_per_step": per_step_launches,
             "bytes_per_launch": bytes_per_launch,
-            "bytes_definition": "every tile the launch touches read once + written once (qhbm_traffic_model); "
-                                "achieved = bytes_per_launch / avg_launch_ms (HIP events on the launch stream)",
+            "bytes_definition": (
+                "the final states read once (+ lambda written once in a VJP call): the least this kernel could move "
+                "(qhbm_traffic_model); what it does move through L2 and the fabric is in the committed counter profiles"
+                if observable_family else
+                "every tile the launch touches read once + written once (qhbm_traffic_model); "
+                "achieved = bytes_per_launch / avg_launch_ms (HIP events on the launch stream)"),
             "unfused_bytes_per_launch": unfused / per_step_launches,
             "fusion_factor": unfused / model if model > 0 else None,
-            "gates_per_launch": n_gate / per_step_launches,
+            "gates_per_launch": None if observable_family else n_gate / per_step_launches,
             "valu": valu,
-            "note": ("the pass kernels are bound by fp32 VALU issue (valu.valu_active_frac), not by HBM: "
-                     "hbm.frac is the HBM rate of a launch that applies gates_per_launch gates per tile round "
-                     "trip, and it FALLS when the scheduler fuses more gates into a launch while the step "
-                     "gets faster; compute.frac is the share of the fp32 peak the gate arithmetic reaches "
-                     "(DESIGN.md section 5)"),
+            "note": (("the observable kernel is the largest launch of this step: compute.frac counts one complex "
+                      "multiply-add per Pauli term and amplitude against the fp32 peak; the block-grouped kernel is bound "
+                      "by its LDS pipeline (store burst of the partner block, the masks' reads, barrier skew: DESIGN.md "
+                      "section 5.2), the gather kernel by the fabric reads of its partner runs -- neither by HBM nor by VALU issue")
+                     if observable_family else
+                     ("the pass kernels are bound by fp32 VALU issue (valu.valu_active_frac), not by HBM: "
+                      "hbm.frac is the HBM rate of a launch that applies gates_per_launch gates per tile round "
+                      "trip, and it FALLS when the scheduler fuses more gates into a launch while the step "
+                      "gets faster; compute.frac is the share of the fp32 peak the gate arithmetic reaches "
+                      "(DESIGN.md section 5)")),
         },
     }
     if args.verify:
