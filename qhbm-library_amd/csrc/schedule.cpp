@@ -827,10 +827,12 @@ bool build_plan(const Model& m, int tile_bits, int round_bits, bool adjoint, Pla
   const int k_cap = adjoint ? kMaxTileBits - 1 : kMaxTileBits;
   int K;
   if (tile_bits == 0) {
-    // Tiles of 2^12 amplitudes (four 256-thread workgroups per CU) measured best for both sweeps up
-    // to 24 qubits (config 3 forward: 29.3 vs 31.1 ms per 512 states with 2^13); at 28 qubits the
-    // forward's five extra passes cost more than they save (config 5: 707 vs 687 ms per 16 states).
-    K = n_eff <= k_cap ? n_eff : (adjoint || n_eff <= 24 ? 12 : 13);
+    // Tiles of 2^12 amplitudes (four 256-thread workgroups per CU) are best for the adjoint sweep (the
+    // engine tries 2^13 against the model, engine.cpp) and for the forward sweep up to 21 qubits; from 22
+    // on the forward's extra passes cost more than the smaller tiles save.  XXZ chain, depth 16, forward ms
+    // with 2^12 / 2^13 (round 4): 20 qubits 97.2 / 123.4 per 4096 states, 21: 109.4 / 108.9 per 2048,
+    // 22: 7.1 / 6.7 per 64, 23: 16.0 / 15.7, 24 (config 4's lean passes): 2793 / 2639 per 4546 programs.
+    K = n_eff <= k_cap ? n_eff : (adjoint || n_eff <= 21 ? 12 : 13);
   } else {
     if (tile_bits < kMinTileBits || tile_bits > k_cap) {
       *err = "tile_qubits out of range";
