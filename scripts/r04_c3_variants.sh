@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 4, VERDICT #5: config 3's step under engine-option variants -- time (un-profiled run) and SQ_INSTS_VALU per
-# launch of the pass kernels (one rocprofv3 --pmc pass each).  One variant per stdin line ("name opt=val ...").
+# launch of the pass kernels (one rocprofv3 --pmc pass each).  One variant per stdin line ("name opt=val ..."):
+#   gpurun -- "bash scripts/r04_c3_variants.sh < scripts/r04_c3_variants.txt"
 set -u
 ulimit -c 0
 R=${GRAFT_REPO_ROOT:-$(pwd)}
