@@ -1,7 +1,7 @@
 """Randomised parity stress of the block-grouped Pauli-sum kernels against the numpy oracle (developer tool; GPU):
 qubit counts 13..18, 1..4 observables, sparse and dense strings, 1..11 states (whole groups of eight AND leftovers:
 both XCD maps and both pivot rules of the value modes), values / VJP / retained backward.
-    python scripts/experiments/stress_observable_blocks.py [seeds]"""
+    python scripts/experiments/stress_observable_blocks.py [seeds [first seed]]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "qhbm-library_amd"))
@@ -10,7 +10,8 @@ from oracle import qhbm_oracle as O
 from tests.test_observable_blocks_gpu import _engine, _random_ops, _check
 
 bad, t0 = 0, time.time()
-for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+for seed in range(first, first + (int(sys.argv[1]) if len(sys.argv) > 1 else 40)):
   rng = np.random.default_rng(7000 + seed)
   n = 13 + seed % 6
   n_ops = 1 + seed % 4

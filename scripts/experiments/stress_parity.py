@@ -5,7 +5,8 @@ from oracle import qhbm_oracle as O
 from qhbmlib_amd import _engine as E
 from tests.test_engine_gpu import random_circuit, _engine, check_values, check_jacobian
 bad=0
-for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):
+first=int(sys.argv[2]) if len(sys.argv) > 2 else 0
+for seed in range(first, first+(int(sys.argv[1]) if len(sys.argv) > 1 else 24)):
   rng=np.random.default_rng(1000+seed)
   n=13+seed%2
   if seed%3==0:
