@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define QHBM_ABI_VERSION 4
+#define QHBM_ABI_VERSION 5
 
 /* Gate kinds: the one-parameter "power gate" families of cirq 0.14.1 that
  * tensorflow-quantum 0.6.1 serialises.  A gate is
@@ -299,6 +299,31 @@ int qhbm_traffic_model(qhbm_engine* h, int U, int with_vjp, double* fwd_bytes,
  * peak (157.3 TFLOP/s). */
 int qhbm_flop_model(qhbm_engine* h, int U, int with_vjp, double* fwd_flops,
                     double* obs_flops, double* bwd_flops);
+
+/* Executed micro-ops of every pass of the forward (adjoint == 0) or backward schedule, in
+ * WAVE-EXECUTIONS per state (a micro-op a wave of 64 threads runs once counts 1; tiles and waves the
+ * kernels skip excluded): out[pass * QHBM_CENSUS_COLUMNS + column], at most max_passes rows;
+ * *n_passes = passes of the schedule.  scripts/instruction_mix.py weighs the per-micro-op
+ * instruction counts of the compiled pass kernels with it (the dynamic instruction mix). */
+enum {
+  QHBM_CENSUS_TILES = 0,         /* workgroups per state */
+  QHBM_CENSUS_ROUNDS,            /* register rounds (one LDS exchange each but the first) */
+  QHBM_CENSUS_ROUNDS_BARRIER,    /* ... whose exchange needs the barriers */
+  QHBM_CENSUS_ROUNDS_NO_BARRIER,
+  QHBM_CENSUS_INSTANCES,         /* instance records decoded */
+  QHBM_CENSUS_X,                 /* X**t (adjoint: with a gradient slot) */
+  QHBM_CENSUS_X_NO_SLOT,         /* adjoint: X**t of a frozen parameter (no inner product) */
+  QHBM_CENSUS_FULL,              /* 15-entry diagonal table */
+  QHBM_CENSUS_PH1,
+  QHBM_CENSUS_PH2,
+  QHBM_CENSUS_CPH_TILE_ON,       /* boundary phase, predicate = tile bit, on */
+  QHBM_CENSUS_CPH_WAVE_ON,       /* predicate = thread bit that is uniform over the wave, on */
+  QHBM_CENSUS_CPH_LANE,          /* predicate varies inside the wave */
+  QHBM_CENSUS_CPH_OFF,           /* predicate evaluated, off in the whole wave */
+  QHBM_CENSUS_REDUCE8,           /* adjoint: eight-wide wave reductions of gradient partials */
+  QHBM_CENSUS_COLUMNS
+};
+int qhbm_op_census(qhbm_engine* h, int adjoint, int max_passes, double* out, int* n_passes);
 
 #ifdef __cplusplus
 }

@@ -1619,6 +1619,86 @@ double pass_flops_per_amplitude(const Plan& plan, const Pass& p) {
   return total;
 }
 
+// Executed micro-ops of one pass, in WAVE-EXECUTIONS per state (a micro-op a wave runs once counts 1): the weights
+// of a dynamic instruction mix (scripts/instruction_mix.py multiplies them with the per-micro-op instruction counts of
+// the compiled kernel).  Columns: qhbm_engine.h QHBM_CENSUS_*.
+void pass_census(const Plan& plan, const Pass& p, double tiles_per_state, double* out) {
+  const RecordLayout L(plan.R, plan.adjoint);
+  const bool adj = plan.adjoint;
+  const double waves = double(size_t(1) << (plan.K - plan.R)) / 64.0 * tiles_per_state;
+  out[QHBM_CENSUS_TILES] += tiles_per_state;
+  size_t round_i = 0;
+  for (size_t pc = 0; pc < p.prog.size();) {
+    const uint32_t w0 = p.prog[pc], opc = w0 & 0xffu;
+    if (opc == OP_END) break;
+    if (opc != OP_ROUND) {
+      if (opc == OP_GATE2) pc += kGate2Words;
+      else if (opc == OP_MEASURE_WHT) pc += size_t(kWhtHeaderWords) + size_t(w0 >> 8) * kMeasTermWords;
+      else {
+        const uint32_t n_groups = w0 >> 8;
+        ++pc;
+        for (uint32_t g = 0; g < n_groups; ++g) pc += 2 + size_t(p.prog[pc + 1]) * kMeasTermWords;
+      }
+      continue;
+    }
+    const uint32_t n_inst = (w0 & ~kRoundNoBarrier) >> 8, first = p.prog[pc + 2], dead = p.prog[pc + 4];
+    const uint32_t wmask = round_i < p.round_wavemasks.size() ? p.round_wavemasks[round_i] : 0u;
+    const double alive = (adj ? 1.0 / double(1u << __builtin_popcount(dead)) : 1.0) * waves;
+    out[QHBM_CENSUS_ROUNDS] += waves;
+    out[(w0 & kRoundNoBarrier) ? QHBM_CENSUS_ROUNDS_NO_BARRIER : QHBM_CENSUS_ROUNDS_BARRIER] += waves;
+    for (uint32_t i = 0; i < n_inst; ++i) {
+      const uint32_t* rec = &plan.coef_init[first + size_t(i) * size_t(L.words())];
+      const uint32_t h0 = rec[0], h1 = rec[1];
+      const bool full = (h1 & kFullDiagFlag) != 0;
+      out[QHBM_CENSUS_INSTANCES] += alive;
+      for (int j = 0; j < 4; ++j) {
+        if (!(h0 >> j & 1u)) continue;
+        const bool slot = !adj || rec[L.slot_x(j)] != 0xffffffffu;
+        out[slot ? QHBM_CENSUS_X : QHBM_CENSUS_X_NO_SLOT] += alive;
+      }
+      if (full) out[QHBM_CENSUS_FULL] += alive;
+      out[QHBM_CENSUS_PH1] += alive * __builtin_popcount((h0 >> 8) & 0xfu);
+      out[QHBM_CENSUS_PH2] += alive * __builtin_popcount((h0 >> 16) & 0x3fu);
+      for (int k = 0; k < 8; ++k) {
+        if (!(h1 >> k & 1u)) continue;
+        const uint32_t pred = rec[L.pred(k)];
+        if ((pred >> 8) != 0) { out[QHBM_CENSUS_CPH_TILE_ON] += 0.5 * alive; out[QHBM_CENSUS_CPH_OFF] += 0.5 * alive; }
+        else if (wmask >> (pred & 0xffu) & 1u) { out[QHBM_CENSUS_CPH_WAVE_ON] += 0.5 * alive; out[QHBM_CENSUS_CPH_OFF] += 0.5 * alive; }
+        else out[QHBM_CENSUS_CPH_LANE] += alive;
+      }
+      if (adj) {  // eight-wide reductions (instance_adj): CPH group; PH2 group (per-term or FULL with pair terms); X + PH1 group
+        if (h1 & 0xffu) out[QHBM_CENSUS_REDUCE8] += alive;
+        if (full && ((h0 >> 24) & 0x3fu)) out[QHBM_CENSUS_REDUCE8] += alive;
+        if ((h0 >> 16) & 0x3fu) out[QHBM_CENSUS_REDUCE8] += alive;
+        if ((h0 & 0xf0fu) || (full && ((h0 >> 4) & 0xfu))) out[QHBM_CENSUS_REDUCE8] += alive;
+      }
+    }
+    ++round_i;
+    pc += kRoundWords;
+  }
+}
+
+}  // namespace
+
+extern "C" int qhbm_op_census(qhbm_engine* h, int adjoint, int max_passes, double* out, int* n_passes) {
+  if (!h || !out || !n_passes) return 1;
+  if (int rc = build_plans(h)) return rc;
+  const DevicePlan& d = adjoint ? h->adj : h->fwd;
+  std::vector<PassArgs> args;
+  std::vector<uint32_t> prog, tables;
+  fill_args(d.plan, h->model, &args, &prog, &tables);
+  *n_passes = int(args.size());
+  for (int i = 0; i < max_passes * QHBM_CENSUS_COLUMNS; ++i) out[i] = 0.0;
+  for (size_t i = 0; i < args.size() && int(i) < max_passes; ++i) {
+    const Pass& p = d.plan.passes[i];
+    // the first forward pass computes on ONE tile per state; later passes on the tiles they launch
+    const double tiles = (!adjoint && (p.flags & PASS_INIT_BASIS)) ? 1.0 : double(size_t(1) << args[i].n_free);
+    pass_census(d.plan, p, tiles, out + i * QHBM_CENSUS_COLUMNS);
+  }
+  return 0;
+}
+
+namespace {
 }  // namespace
 
 extern "C" int qhbm_flop_model(qhbm_engine* h, int U, int with_vjp, double* fwd_flops, double* obs_flops,

@@ -196,6 +196,29 @@ __device__ __forceinline__ void phase_v8(v2f& a0, v2f& a1, v2f& a2, v2f& a3, v2f
 #undef QHBM_PH_MUL
 #undef QHBM_PH_FMA
 }
+// ... with a wave-uniform coefficient (SGPR pair): the boundary phases run it under the predicate's EXEC mask
+// instead of selecting a per-lane coefficient (two v_mov + two v_cndmask per micro-op, VCC ones in the forward
+// kernels: 23 cycles each on gfx950, scripts/experiments/micro/valu_cycles.hip).
+__device__ __forceinline__ void phase_s8(v2f& a0, v2f& a1, v2f& a2, v2f& a3, v2f& a4, v2f& a5, v2f& a6, v2f& a7, v2f cs) {
+  v2f t0, t1, t2, t3, t4, t5, t6, t7;
+#define QHBM_PH_MUL(K_) "v_pk_mul_f32 %[t" #K_ "], %[a" #K_ "], %[cs] op_sel_hi:[1,0]\n\t"
+#define QHBM_PH_FMA(K_) "v_pk_fma_f32 %[a" #K_ "], %[a" #K_ "], %[cs], %[t" #K_ "] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+  asm(QHBM_PH_MUL(0) QHBM_PH_MUL(1) QHBM_PH_MUL(2) QHBM_PH_MUL(3) QHBM_PH_MUL(4) QHBM_PH_MUL(5) QHBM_PH_MUL(6) QHBM_PH_MUL(7)
+      QHBM_PH_FMA(0) QHBM_PH_FMA(1) QHBM_PH_FMA(2) QHBM_PH_FMA(3) QHBM_PH_FMA(4) QHBM_PH_FMA(5) QHBM_PH_FMA(6) "v_pk_fma_f32 %[a7], %[a7], %[cs], %[t7] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+      : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6),
+        [a7] "+v"(a7), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5),
+        [t6] "=&v"(t6), [t7] "=&v"(t7)
+      : [cs] "s"(cs));
+#undef QHBM_PH_MUL
+#undef QHBM_PH_FMA
+}
+template <int R, int RB>
+__device__ __forceinline__ void apply_ph1_s8(v2f (&a)[1 << R], v2f cs) {
+  static_assert(R == 4, "eight amplitudes with register bit RB set");
+  constexpr int B = 1 << RB;
+  phase_s8(a[ins0<RB>(0) | B], a[ins0<RB>(1) | B], a[ins0<RB>(2) | B], a[ins0<RB>(3) | B], a[ins0<RB>(4) | B],
+           a[ins0<RB>(5) | B], a[ins0<RB>(6) | B], a[ins0<RB>(7) | B], cs);
+}
 template <int R, int RB>
 __device__ __forceinline__ void apply_ph1_v_(v2f (&a)[1 << R], v2f cs, std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>) {
   constexpr int B = 1 << RB;
@@ -654,35 +677,38 @@ __device__ __forceinline__ void full_partials(const v2f (&p)[16], const v2f (&l)
 }
 
 // Controlled phase: register bit J AND (a thread bit | a tile bit).  One code path for both
-// predicate kinds (a two-way branch would make the structuriser copy the register file): the
+// predicate kinds: `tlx` = the thread's local index | the tile id << K (program.h CPHPRED), so a predicate is one
+// bit of one word (a select between the two sources compiled to a VCC v_cndmask_b32: 23 cycles per wave on gfx950
+// against 2.2 for a plain 32-bit VALU op -- scripts/experiments/micro/valu_cycles.hip); the
 // phase degenerates to 1 where the predicate is false.  The scheduler maps the predicate bits of a
 // round to WAVE bits where it can, so most predicates are uniform over a wave and half the waves
 // skip the micro-op altogether.
 template <int R, int J>
-__device__ __forceinline__ void cph_fwd(v2f (&a)[1 << R], v2f cs, uint32_t pred, uint32_t tl,
-                                        uint32_t tile_base) {
-  const bool on = (((pred >> 8) ? tile_base : tl) >> (pred & 0xffu)) & 1u;
+__device__ __forceinline__ void cph_fwd(v2f (&a)[1 << R], v2f cs, uint32_t pred, uint32_t tlx) {
+  const bool on = (tlx >> (pred & 0x1fu)) & 1u;
   if (__builtin_amdgcn_ballot_w64(on) == 0) return;  // off in the whole wave (tile bit, or a wave bit: schedule.cpp emit_round)
-  apply_ph1_v<R, J>(a, v2f{on ? cs.x : 1.f, on ? cs.y : 0.f});
+  if (on) apply_ph1_s8<R, J>(a, cs);
 }
 
 template <int R, int J>
 __device__ __forceinline__ float cph_adj(v2f (&p)[1 << R], v2f (&l)[1 << R], v2f cs, uint32_t pred,
-                                         uint32_t tl, uint32_t tile_base) {
-  const bool on = (((pred >> 8) ? tile_base : tl) >> (pred & 0xffu)) & 1u;
+                                         uint32_t tlx) {
+  const bool on = (tlx >> (pred & 0x1fu)) & 1u;
   if (__builtin_amdgcn_ballot_w64(on) == 0) return 0.f;  // off in the whole wave: nothing to do
-  const float g = on ? sum_w1<R, J>(p, l) : 0.f;
-  const v2f c2 = v2f{on ? cs.x : 1.f, on ? -cs.y : 0.f};
-  apply_ph1_v<R, J>(p, c2);
-  apply_ph1_v<R, J>(l, c2);
+  float g = 0.f;
+  if (on) {
+    g = sum_w1<R, J>(p, l);
+    const v2f c2 = conj_cs(cs);
+    apply_ph1_s8<R, J>(p, c2);
+    apply_ph1_s8<R, J>(l, c2);
+  }
   return g;
 }
 
 // One forward instance on the register file.
 template <int R, int NV, bool GEN>
 __device__ __forceinline__ void instance_fwd(const uint32_t (&rv)[NV], const uint32_t* __restrict__ recs,
-                                             uint32_t rec_off, int lane, v2f (&a)[1 << R], uint32_t tl,
-                                             uint32_t tile_base) {
+                                             uint32_t rec_off, int lane, v2f (&a)[1 << R], uint32_t tlx) {
   constexpr RecordLayout L(R, false);
   const RecBase rb{recs + rec_off};
   const uint32_t h0 = rec_word<0>(rv, rb), h1 = rec_word<1>(rv, rb);
@@ -711,27 +737,26 @@ __device__ __forceinline__ void instance_fwd(const uint32_t (&rv)[NV], const uin
   if (h1 & 0xffu) {
     QHBM_FOR_RB(R,
       if ((h1 >> (2 * J)) & 1u)
-        cph_fwd<R, J>(a, rec_cs<L.cph(2 * J)>(rv, rb), rec_word<L.pred(2 * J)>(rv, rb), tl, tile_base);
+        cph_fwd<R, J>(a, rec_cs<L.cph(2 * J)>(rv, rb), rec_word<L.pred(2 * J)>(rv, rb), tlx);
       if ((h1 >> (2 * J + 1)) & 1u)
-        cph_fwd<R, J>(a, rec_cs<L.cph(2 * J + 1)>(rv, rb), rec_word<L.pred(2 * J + 1)>(rv, rb), tl, tile_base);)
+        cph_fwd<R, J>(a, rec_cs<L.cph(2 * J + 1)>(rv, rb), rec_word<L.pred(2 * J + 1)>(rv, rb), tlx);)
   }
 }
 
 // The same instance on TWO register files (pass_fwd2_kernel: the same tile of two states): every micro-op's
 // scalar predicate, record fields and branch are paid once for both.  Lean programs only.
 template <int R, int J>
-__device__ __forceinline__ void cph_fwd2(v2f (&a)[1 << R], v2f (&b)[1 << R], v2f cs, uint32_t pred, uint32_t tl,
-                                         uint32_t tile_base) {
-  const bool on = (((pred >> 8) ? tile_base : tl) >> (pred & 0xffu)) & 1u;
+__device__ __forceinline__ void cph_fwd2(v2f (&a)[1 << R], v2f (&b)[1 << R], v2f cs, uint32_t pred, uint32_t tlx) {
+  const bool on = (tlx >> (pred & 0x1fu)) & 1u;
   if (__builtin_amdgcn_ballot_w64(on) == 0) return;
-  const v2f c2 = v2f{on ? cs.x : 1.f, on ? cs.y : 0.f};
-  apply_ph1_v<R, J>(a, c2);
-  apply_ph1_v<R, J>(b, c2);
+  if (on) {
+    apply_ph1_s8<R, J>(a, cs);
+    apply_ph1_s8<R, J>(b, cs);
+  }
 }
 template <int R, int NV>
 __device__ __forceinline__ void instance_fwd_pair(const uint32_t (&rv)[NV], const uint32_t* __restrict__ recs,
-                                                  uint32_t rec_off, v2f (&a)[1 << R], v2f (&b)[1 << R], uint32_t tl,
-                                                  uint32_t tile_base) {
+                                                  uint32_t rec_off, v2f (&a)[1 << R], v2f (&b)[1 << R], uint32_t tlx) {
   constexpr RecordLayout L(R, false);
   const RecBase rb{recs + rec_off};
   const uint32_t h0 = rec_word<0>(rv, rb), h1 = rec_word<1>(rv, rb);
@@ -749,9 +774,9 @@ __device__ __forceinline__ void instance_fwd_pair(const uint32_t (&rv)[NV], cons
   if (h1 & 0xffu) {
     QHBM_FOR_RB(R,
       if ((h1 >> (2 * J)) & 1u)
-        cph_fwd2<R, J>(a, b, rec_cs<L.cph(2 * J)>(rv, rb), rec_word<L.pred(2 * J)>(rv, rb), tl, tile_base);
+        cph_fwd2<R, J>(a, b, rec_cs<L.cph(2 * J)>(rv, rb), rec_word<L.pred(2 * J)>(rv, rb), tlx);
       if ((h1 >> (2 * J + 1)) & 1u)
-        cph_fwd2<R, J>(a, b, rec_cs<L.cph(2 * J + 1)>(rv, rb), rec_word<L.pred(2 * J + 1)>(rv, rb), tl, tile_base);)
+        cph_fwd2<R, J>(a, b, rec_cs<L.cph(2 * J + 1)>(rv, rb), rec_word<L.pred(2 * J + 1)>(rv, rb), tlx);)
   }
 }
 
@@ -902,6 +927,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
   if ((a.flags & PASS_INIT_BASIS) | a.zero_mask | a.frozen_old_local) idx = uni(basis_index(bits + size_t(bits_row) * n_user, n_user));
   const uint32_t tile_id = launched_tile(a, blockIdx.x, idx);
   const TileCtx t = make_tile_ctx(a, tables, tile_id);
+  const uint32_t tile_hi = tile_id << K;  // tile-bit predicates of boundary phases (cph_*): bit K + i = tile-id bit i
   float2* st = psi + (size_t(s_local) << a.n);
 
   if (a.flags & PASS_INIT_BASIS) {
@@ -963,7 +989,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
       round_load<R>(tile, T, DB, amp);
       for (uint32_t i = 0; i < n_inst; ++i) {
         rec_load<NV>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
-        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);
+        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL | tile_hi);
         rec_off += L.words();
 #pragma unroll
         for (int v = 0; v < NV; ++v) cur[v] = nxt[v];
@@ -1089,6 +1115,7 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_ker
   const uint32_t pair = blockIdx.x >> a.n_nonlocal;
   const uint32_t s_a = 2u * pair, s_b = min(2u * pair + 1u, n_states - 1u);  // (an odd batch: the last state twice)
   const TileCtx t = make_tile_ctx(a, tables, tile_id);
+  const uint32_t tile_hi = tile_id << K;  // tile-bit predicates of boundary phases (cph_*): bit K + i = tile-id bit i
   float2* st_a = psi + (size_t(s_a) << a.n);
   float2* st_b = psi + (size_t(s_b) << a.n);
   TileRegs ra, rb;
@@ -1128,7 +1155,7 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_ker
     const uint32_t n_inst = (w0 & ~kRoundNoBarrier) >> 8;
     for (uint32_t inst = 0; inst < n_inst; ++inst) {
       rec_load<1>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
-      instance_fwd_pair<R, 1>(cur, recs, rec_off, p, q, TL, t.tile_base);
+      instance_fwd_pair<R, 1>(cur, recs, rec_off, p, q, TL | tile_hi);
       rec_off += L.words();
       cur[0] = nxt[0];
     }
@@ -1185,8 +1212,8 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_ker
 template <int R, int NW, bool GEN>
 __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uint32_t (&sv)[1],
                                              const uint32_t* __restrict__ recs, uint32_t rec_off, int lane,
-                                             uint32_t wave, v2f (&p)[1 << R], v2f (&l)[1 << R], uint32_t TL,
-                                             uint32_t tile_base, float* cells) {
+                                             uint32_t wave, v2f (&p)[1 << R], v2f (&l)[1 << R], uint32_t TLX,
+                                             float* cells) {
   constexpr RecordLayout L(R, true);
   constexpr int NB = 1;
   constexpr int S0 = L.slot0();
@@ -1197,10 +1224,9 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
     float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     QHBM_FOR_RB(R,
       if ((h1 >> (2 * J)) & 1u)
-        g[2 * J] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J)>(cur, rb), rec_word<L.pred(2 * J)>(cur, rb), TL, tile_base);
+        g[2 * J] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J)>(cur, rb), rec_word<L.pred(2 * J)>(cur, rb), TLX);
       if ((h1 >> (2 * J + 1)) & 1u)
-        g[2 * J + 1] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J + 1)>(cur, rb), rec_word<L.pred(2 * J + 1)>(cur, rb), TL,
-                                    tile_base);)
+        g[2 * J + 1] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J + 1)>(cur, rb), rec_word<L.pred(2 * J + 1)>(cur, rb), TLX);)
     add_slots8<2, NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
   }
   float g1[4] = {0.f, 0.f, 0.f, 0.f};  // PH1 partials: reduced together with the X partials (slot group 0)
@@ -1345,6 +1371,7 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   // tail of the sweep: the tiles on which psi is identically zero are not launched (launched_tile)
   const uint32_t tile_id = launched_tile(a, blockIdx.x, idx);
   const TileCtx t = make_tile_ctx(a, tables, tile_id);
+  const uint32_t tile_hi = tile_id << K;  // tile-bit predicates of boundary phases (cph_*): bit K + i = tile-id bit i
   float* grow = tile_grad + size_t(blockIdx.x) * a.n_slots;
   const uint32_t* prog = prog_base + a.prog_off;
   uint32_t w0 = uni(prog[0]);
@@ -1397,7 +1424,7 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
       for (uint32_t inst = 0; inst < n_inst; ++inst) {
         rec_load<1>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
         rec_load<1>(recs, rec_off + L.words() + L.slot0(), lane, svn);
-        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);
+        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL | tile_hi, cells);
         rec_off += L.words();
         cur[0] = nxt[0];
         sv[0] = svn[0];
@@ -1477,6 +1504,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
   // never relabel: logical = physical index bits)
   const uint32_t tile_id = launched_tile(a, blockIdx.x, uni(basis_index(bits + size_t(state0 + s_local) * n_user, n_user)));
   const TileCtx t = make_tile_ctx(a, tables, tile_id);
+  const uint32_t tile_hi = tile_id << K;  // tile-bit predicates of boundary phases (cph_*): bit K + i = tile-id bit i
   float* grow = tile_grad + size_t(blockIdx.x) * a.n_slots;
   float2* sp = psi + (size_t(s_local) << a.n);
   float2* sl = lam + (size_t(s_local) << a.n);
@@ -1516,7 +1544,7 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
       for (uint32_t inst = 0; inst < n_inst; ++inst) {
         rec_load<1>(recs, rec_off + L.words(), lane, nxt);  // prefetch (the buffer is padded)
         rec_load<1>(recs, rec_off + L.words() + L.slot0(), lane, svn);
-        instance_adj<R, NW, GEN>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);
+        instance_adj<R, NW, GEN>(cur, sv, recs, rec_off, lane, wave, p, l, TL | tile_hi, cells);
         rec_off += L.words();
         cur[0] = nxt[0];
         sv[0] = svn[0];

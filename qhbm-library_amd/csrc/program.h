@@ -101,7 +101,9 @@ constexpr int pair_index(int lo, int hi) { return hi * (hi - 1) / 2 + lo; }  // 
 //           [1] cph_mask | y_mask<<16 | dense_mask<<24 | FULL<<31
 //           X[4]{c,s}  CPH[8]{c,s}  CPHPRED[8]  then EITHER  PH1[4]{c,s} PH2[6]{c,s} Y[4]{c,s}
 //                                               OR (FULL)  FULL[15]{c,s}
-//           CPHPRED = pos | kind<<8; kind 0 = local thread bit, kind 1 = tile (non-local) index bit
+//           CPHPRED = pos | kind<<8: bit `pos` of the index word TL[tid] | tile_id << K -- kind 0 = a local thread
+//           bit (pos < K), kind 1 = a tile (non-local) index bit (pos = K + its rank among the non-local bits); the
+//           kernels read `pos` only, `kind` serves the host's accounting
 //           FULL[m-1] = product of the instance's PH1/PH2 phases whose bits are all set in the
 //           register value m: the whole diagonal on the register bits is then ONE complex
 //           multiply per amplitude.  A FULL instance keeps its term masks in fph1/fph2 and has

@@ -607,7 +607,12 @@ class Builder {
         int j2 = -1;
         if (popc(in_reg) == 2) { pl.kind = 4; j2 = rank_of(in_reg & (in_reg - 1)); }
         else if (other_local) { pl.kind = 5; pl.pred = uint32_t(__builtin_ctz(other_local)); }
-        else if (other_nonlocal) { pl.kind = 5; pl.pred = uint32_t(p->phys_of[size_t(__builtin_ctz(other_nonlocal))]) | (1u << 8); }
+        else if (other_nonlocal) {  // a tile bit: bit K + i of the kernels' index word = bit i of the tile id (kernels.hip cph_*)
+          const int b = __builtin_ctz(other_nonlocal);
+          const size_t i = size_t(std::find(p->nonlocal_pos.begin(), p->nonlocal_pos.end(), b) - p->nonlocal_pos.begin());
+          pl.kind = 5;
+          pl.pred = uint32_t(K_ + int(i)) | (1u << 8);
+        }
         else pl.kind = 3;
         const uint32_t touch = (1u << j) | (j2 >= 0 ? (1u << j2) : 0u);
         auto fits = [&](const Instance& in) {

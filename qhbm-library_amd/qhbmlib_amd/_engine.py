@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "qhbm_expectation_retain", "qhbm_expectation_vjp_retained", "qhbm_retained_states", "qhbm_state_gradients",
     "qhbm_expectation_jacobian", "qhbm_statevector", "qhbm_sample", "qhbm_sample_counts", "qhbm_parity_energy", "qhbm_parity_energy_vjp",
     "qhbm_num_passes", "qhbm_describe_schedule",
-    "qhbm_kernel_time_ms", "qhbm_traffic_model", "qhbm_flop_model",
+    "qhbm_kernel_time_ms", "qhbm_traffic_model", "qhbm_flop_model", "qhbm_op_census",
 )
 
 
@@ -100,6 +100,7 @@ def load_library():
       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
   lib.qhbm_traffic_model.argtypes = [vp, i32, i32] + [ctypes.POINTER(ctypes.c_double)] * 3
   lib.qhbm_flop_model.argtypes = [vp, i32, i32] + [ctypes.POINTER(ctypes.c_double)] * 3
+  lib.qhbm_op_census.argtypes = [vp, i32, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i32)]
   _lib = lib
   return lib
 
@@ -292,6 +293,20 @@ class Engine:
     self._check(self._lib.qhbm_flop_model(self._h, int(num_states), int(with_vjp), ctypes.byref(f),
                                           ctypes.byref(o), ctypes.byref(b)))
     return {"fwd_flops": f.value, "obs_flops": o.value, "bwd_flops": b.value}
+
+  CENSUS_COLUMNS = ("tiles", "rounds", "rounds_barrier", "rounds_no_barrier", "instances", "x", "x_no_slot", "full",
+                    "ph1", "ph2", "cph_tile_on", "cph_wave_on", "cph_lane", "cph_off", "reduce8")
+
+  def op_census(self, adjoint=True, max_passes=64):
+    """Executed micro-ops per pass in wave-executions per state (include/qhbm_engine.h qhbm_op_census):
+    a list of dicts, one per pass of the forward or backward schedule."""
+    import numpy as np  # pylint: disable=import-outside-toplevel
+    ncol = len(self.CENSUS_COLUMNS)
+    out = np.zeros((max_passes, ncol), np.float64)
+    n = ctypes.c_int()
+    self._check(self._lib.qhbm_op_census(self._h, int(bool(adjoint)), max_passes,
+                                         out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.byref(n)))
+    return [dict(zip(self.CENSUS_COLUMNS, out[i])) for i in range(min(n.value, max_passes))]
 
   # ---- hot path --------------------------------------------------------------
   def _prep(self, bits, params):

@@ -45,14 +45,14 @@ VARIANTS = {
     # scalar-load latency of the record fields costs
     "const_coefs": lambda t: once(t, "  if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];", "  if constexpr (W >= 2) return 0x3f19999au; else if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];"),
     # wave priority: instances at high priority, exchanges / tile I/O at low
-    "setprio": lambda t: once(once(t, "        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n        rec_off += L.words();\n        cur[0] = nxt[0];",
-                                      "        __builtin_amdgcn_s_setprio(3);\n        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n        __builtin_amdgcn_s_setprio(0);\n        rec_off += L.words();\n        cur[0] = nxt[0];"),
-                              "        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);",
-                              "        __builtin_amdgcn_s_setprio(3);\n        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);\n        __builtin_amdgcn_s_setprio(0);"),
-    "setprio_inv": lambda t: once(once(t, "        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n        rec_off += L.words();\n        cur[0] = nxt[0];",
-                                      "        __builtin_amdgcn_s_setprio(0);\n        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n        __builtin_amdgcn_s_setprio(3);\n        rec_off += L.words();\n        cur[0] = nxt[0];"),
-                              "        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);",
-                              "        __builtin_amdgcn_s_setprio(0);\n        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);\n        __builtin_amdgcn_s_setprio(3);"),
+    "setprio": lambda t: once(once(t, "        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL | tile_hi, cells);\n        rec_off += L.words();\n        cur[0] = nxt[0];",
+                                      "        __builtin_amdgcn_s_setprio(3);\n        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL | tile_hi, cells);\n        __builtin_amdgcn_s_setprio(0);\n        rec_off += L.words();\n        cur[0] = nxt[0];"),
+                              "        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL | tile_hi);",
+                              "        __builtin_amdgcn_s_setprio(3);\n        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL | tile_hi);\n        __builtin_amdgcn_s_setprio(0);"),
+    "setprio_inv": lambda t: once(once(t, "        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL | tile_hi, cells);\n        rec_off += L.words();\n        cur[0] = nxt[0];",
+                                      "        __builtin_amdgcn_s_setprio(0);\n        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL | tile_hi, cells);\n        __builtin_amdgcn_s_setprio(3);\n        rec_off += L.words();\n        cur[0] = nxt[0];"),
+                              "        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL | tile_hi);",
+                              "        __builtin_amdgcn_s_setprio(0);\n        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL | tile_hi);\n        __builtin_amdgcn_s_setprio(3);"),
     # adjoint without the LDS staging of the tile pair at the start and the end of a pass (registers filled
     # from / stored to HBM in the prefetch layout -- wrong amplitudes, same traffic): the upper bound of
     # loading and storing in the first / last round's geometry directly
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
     round_store<R>(xt, T, DB, l);
     round_load<R>(xt, Tn, DBn, l);
 """),
-    "no_instances": lambda t: once(t, "        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n        rec_off += L.words();\n        cur[0] = nxt[0];",
-                                   "        if (lane == 77) instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL, t.tile_base, cells);\n        rec_off += L.words();\n        cur[0] = nxt[0];"),
+    "no_instances": lambda t: once(t, "        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL | tile_hi, cells);\n        rec_off += L.words();\n        cur[0] = nxt[0];",
+                                   "        if (lane == 77) instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL | tile_hi, cells);\n        rec_off += L.words();\n        cur[0] = nxt[0];"),
 }
 
 def in_fwd_instance(text, old, new, count=-1):
@@ -118,8 +118,8 @@ def in_fwd_instance(text, old, new, count=-1):
 
 
 VARIANTS.update({
-    "fwd_no_instances": lambda t: once(t, "        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);",
-                                       "        if (lane == 77) instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL, t.tile_base);"),
+    "fwd_no_instances": lambda t: once(t, "        instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL | tile_hi);",
+                                       "        if (lane == 77) instance_fwd<R, NV, GEN>(cur, recs, rec_off, lane, amp, TL | tile_hi);"),
     "fwd_no_x": lambda t: in_fwd_instance(t, "if ((h0 >> J) & 1u) apply_x<R, J>(a, rec_cs<L.x(J)>(rv, rb));", "if (((h0 >> J) & 1u) && lane == 77) apply_x<R, J>(a, rec_cs<L.x(J)>(rv, rb));"),
     "fwd_no_full": lambda t: in_fwd_instance(t, "if (h1 & kFullDiagFlag) apply_full<NV>(a, rv, rb, false);", "if ((h1 & kFullDiagFlag) && lane == 77) apply_full<NV>(a, rv, rb, false);"),
     "fwd_no_cph": lambda t: in_fwd_instance(t, "  if (h1 & 0xffu) {", "  if ((h1 & 0xffu) && lane == 77) {"),

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported():
   lib = ctypes.CDLL(E.LIB_PATH)
   for sym in declared:
     assert hasattr(lib, sym), sym
-  assert lib.qhbm_abi_version() == 4
+  assert lib.qhbm_abi_version() == 5
 
 
 def test_gate_kind_enum_matches_host_and_oracle():

@@ -85,8 +85,8 @@ def test_c2_full_size_against_c_oracle_sample_and_properties():
   # duplicates and row order (qnn_test.py:437-442)
   dup = np.concatenate([bits[:8], bits[:8][::-1]])
   got = eng.expectation(dup, params).cpu().numpy()
-  # equal up to the order of the fp32 atomic partial sums (tile/wave reductions are unordered)
-  np.testing.assert_allclose(got[:8], got[8:][::-1], atol=2e-6 * 24)
+  # bit-identical: values accumulate as 64-bit fixed point, no floating-point atomics
+  np.testing.assert_array_equal(got[:8], got[8:][::-1])
 
 
 # ---- BASELINE config 3 shape at full qubit count: 20 qubits, depth 16, XXZ ----------------------
