@@ -391,6 +391,14 @@ def main():
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
   kt = eng.kernel_time_ms(reset=True)
+  # the chip's sustained packed-fp32 rate and clock, probed straight after the timed region (as warm as the timed
+  # kernels left it): the ATTAINABLE compute ceiling of this run, next to the nominal 157.3 TFLOP/s
+  probe = None
+  if rank == 0:
+    try:
+      probe = eng.clock_probe()
+    except Exception as exc:  # pylint: disable=broad-except
+      probe = {"error": f"{type(exc).__name__}: {exc}"}
   if args.verify is None:
     args.verify = world > 1
   # per-state gradient rows of the LAST TIMED step, read before anything else runs on the engine (parity_check)
@@ -539,6 +547,11 @@ def main():
             "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_frac},
             "compute": {"flops_per_launch": flops_per_launch, "achieved_TFs": achieved_tfs, "peak": FP32_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": compute_frac,
+                        # measured in THIS run (qhbm_clock_probe): every SIMD issuing v_pk_fma_f32 from four waves --
+                        # what the chip sustains under packed fp32 at the clock it holds right after the timed region
+                        "attainable_peak": (probe or {}).get("tflops"),
+                        "attainable_frac": (achieved_tfs / probe["tflops"]) if probe and probe.get("tflops") else None,
+                        "probe": probe,
                         "flops_definition": "fp32 operations of the gate arithmetic (FMA = 2) from the plan's instance "
                                             "records (qhbm_flop_model), skipped tiles and dead waves excluded; peak = "
                                             "fp32 vector rate = dense f32 MFMA rate on gfx950",

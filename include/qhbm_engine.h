@@ -325,6 +325,13 @@ enum {
 };
 int qhbm_op_census(qhbm_engine* h, int adjoint, int max_passes, double* out, int* n_passes);
 
+/* Sustained packed-fp32 rate and shader clock of the device RIGHT NOW: one probe launch (every SIMD issues
+ * v_pk_fma_f32 from four waves, the pass kernels' occupancy) timed with HIP events, s_memtime / s_memrealtime read
+ * inside the waves.  ghz: shader clock during the probe; cycles_per_pk_fma: issue cost per wave instruction and SIMD;
+ * tflops: the packed-fp32 rate that follows (4 flop x 64 lanes per instruction) -- the ATTAINABLE ceiling bench.py
+ * prints beside the nominal 157.3 TFLOP/s.  Synchronises `stream`.  Any out pointer may be NULL. */
+int qhbm_clock_probe(qhbm_engine* h, double* ghz, double* cycles_per_pk_fma, double* tflops, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1680,6 +1680,47 @@ void pass_census(const Plan& plan, const Pass& p, double tiles_per_state, double
 
 }  // namespace
 
+// The chip's sustained packed-fp32 rate and shader clock right now (bench.py calls it straight after its timed region,
+// with the chip as warm as the timed kernels left it): one probe launch (kernels.hip clock_probe_kernel) timed with HIP
+// events.  ghz = shader cycles per real time inside the waves; cycles_per_pk_fma = kernel time x ghz / instructions of a
+// SIMD; tflops = 4 flop x 64 lanes x SIMDs / cycles_per_pk_fma x ghz.  Synchronises the stream.
+extern "C" int qhbm_clock_probe(qhbm_engine* h, double* ghz, double* cycles_per_pk_fma, double* tflops, void* stream_v) {
+  if (!h) return 1;
+  if (int rc = need_device(h)) return rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, h->device));
+  const uint32_t n_cus = uint32_t(prop.multiProcessorCount);
+  const uint32_t n_waves = clock_probe_waves(n_cus);
+  DevBuf<uint64_t> out;
+  DevBuf<float> sink;
+  HIPCHK(out.reserve(size_t(2) * n_waves));
+  HIPCHK(sink.reserve(1));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  HIPCHK(launch_clock_probe(out.p, sink.p, n_cus, stream));  // warm-up: code object load, clocks
+  HIPCHK(hipEventRecord(e0, stream));
+  HIPCHK(launch_clock_probe(out.p, sink.p, n_cus, stream));
+  HIPCHK(hipEventRecord(e1, stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  std::vector<uint64_t> host(size_t(2) * n_waves);
+  HIPCHK(hipMemcpy(host.data(), out.p, host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  double cyc = 0.0, ticks = 0.0;
+  for (uint32_t w = 0; w < n_waves; ++w) { cyc += double(host[2 * w]); ticks += double(host[2 * w + 1]); }
+  if (ticks <= 0.0 || ms <= 0.f) return fail(h, "clock probe: no time elapsed");
+  const double g = cyc / ticks * 0.1;  // s_memrealtime ticks at 100 MHz
+  const double per = double(ms) * 1e6 * g / clock_probe_instructions_per_simd();
+  if (ghz) *ghz = g;
+  if (cycles_per_pk_fma) *cycles_per_pk_fma = per;
+  if (tflops) *tflops = 256.0 / per * g * 1e9 * double(n_cus) * 4.0 / 1e12;
+  return 0;
+}
+
 extern "C" int qhbm_op_census(qhbm_engine* h, int adjoint, int max_passes, double* out, int* n_passes) {
   if (!h || !out || !n_passes) return 1;
   if (int rc = build_plans(h)) return rc;

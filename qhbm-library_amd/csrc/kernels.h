@@ -148,6 +148,10 @@ hipError_t launch_reduce_grad(const float* state_grad, uint32_t U, uint32_t n_sl
                               const float* slot_factor, float* grad, int n_params, int accumulate,
                               hipStream_t stream);
 hipError_t launch_scale_rows(float* rows, uint32_t U, uint32_t width, const float* w, hipStream_t stream);
+// sustained packed-fp32 issue rate and shader clock (engine.cpp qhbm_clock_probe)
+hipError_t launch_clock_probe(uint64_t* out, float* sink, uint32_t n_cus, hipStream_t stream);
+uint32_t clock_probe_waves(uint32_t n_cus);
+double clock_probe_instructions_per_simd();
 hipError_t launch_scatter_jac(const float* state_grad, uint32_t U, uint32_t n_slots,
                               const int* param_slot_begin, const int* param_slots,
                               const float* slot_factor, float* jac, uint32_t n_ops, uint32_t op,

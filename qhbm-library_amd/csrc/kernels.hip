@@ -252,6 +252,20 @@ __device__ __forceinline__ void acc_re(v2f& acc, v2f l, v2f p) {
 
 // sum over selected registers of Im(conj(lam) psi); two packed accumulators break the chain
 // Eight accumulations into two partial sums in one asm statement (see x_pair4).
+// The same with the two partial sums STARTED here (products 0 and 1 are multiplies): no zeroed accumulators
+// (two v_mov_b64 per sum: 4.1 cycles each on gfx950, scripts/experiments/micro/valu_cycles.hip).
+__device__ __forceinline__ void acc_im8_first(v2f& a0, v2f& a1, v2f l0, v2f p0, v2f l1, v2f p1, v2f l2, v2f p2, v2f l3, v2f p3,
+                                              v2f l4, v2f p4, v2f l5, v2f p5, v2f l6, v2f p6, v2f l7, v2f p7) {
+#define QHBM_ACC(A_, K_) "v_pk_fma_f32 %[" #A_ "], %[l" #K_ "], %[p" #K_ "], %[" #A_ "] op_sel:[0,1,0] op_sel_hi:[1,0,1]\n\t"
+  asm("v_pk_mul_f32 %[a0], %[l0], %[p0] op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[a1], %[l1], %[p1] op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      QHBM_ACC(a0, 2) QHBM_ACC(a1, 3) QHBM_ACC(a0, 4) QHBM_ACC(a1, 5) QHBM_ACC(a0, 6)
+      "v_pk_fma_f32 %[a1], %[l7], %[p7], %[a1] op_sel:[0,1,0] op_sel_hi:[1,0,1]"
+      : [a0] "=&v"(a0), [a1] "=&v"(a1)
+      : [l0] "v"(l0), [p0] "v"(p0), [l1] "v"(l1), [p1] "v"(p1), [l2] "v"(l2), [p2] "v"(p2), [l3] "v"(l3), [p3] "v"(p3),
+        [l4] "v"(l4), [p4] "v"(p4), [l5] "v"(l5), [p5] "v"(p5), [l6] "v"(l6), [p6] "v"(p6), [l7] "v"(l7), [p7] "v"(p7));
+#undef QHBM_ACC
+}
 __device__ __forceinline__ void acc_im8(v2f& a0, v2f& a1, v2f l0, v2f p0, v2f l1, v2f p1, v2f l2, v2f p2, v2f l3, v2f p3,
                                         v2f l4, v2f p4, v2f l5, v2f p5, v2f l6, v2f p6, v2f l7, v2f p7) {
 #define QHBM_ACC(A_, K_) "v_pk_fma_f32 %[" #A_ "], %[l" #K_ "], %[p" #K_ "], %[" #A_ "] op_sel:[0,1,0] op_sel_hi:[1,0,1]\n\t"
@@ -265,8 +279,8 @@ __device__ __forceinline__ void acc_im8(v2f& a0, v2f& a1, v2f l0, v2f p0, v2f l1
 template <int R, int RB>
 __device__ __forceinline__ float sum_w1_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>) {
   constexpr int B = 1 << RB;
-  v2f a0 = v2f{0.f, 0.f}, a1 = v2f{0.f, 0.f};
-  acc_im8(a0, a1, l[ins0<RB>(0) | B], p[ins0<RB>(0) | B], l[ins0<RB>(1) | B], p[ins0<RB>(1) | B], l[ins0<RB>(2) | B],
+  v2f a0, a1;
+  acc_im8_first(a0, a1, l[ins0<RB>(0) | B], p[ins0<RB>(0) | B], l[ins0<RB>(1) | B], p[ins0<RB>(1) | B], l[ins0<RB>(2) | B],
           p[ins0<RB>(2) | B], l[ins0<RB>(3) | B], p[ins0<RB>(3) | B], l[ins0<RB>(4) | B], p[ins0<RB>(4) | B],
           l[ins0<RB>(5) | B], p[ins0<RB>(5) | B], l[ins0<RB>(6) | B], p[ins0<RB>(6) | B], l[ins0<RB>(7) | B],
           p[ins0<RB>(7) | B]);
@@ -278,8 +292,15 @@ __device__ __forceinline__ float sum_w1(const v2f (&p)[1 << R], const v2f (&l)[1
 }
 template <int R, int RA, int RB, int... P>
 __device__ __forceinline__ float sum_w2_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], std::integer_sequence<int, P...>) {
-  v2f a0 = v2f{0.f, 0.f}, a1 = v2f{0.f, 0.f};
-  (acc_im((P & 1) ? a1 : a0, l[ins11<RA, RB>(P)], p[ins11<RA, RB>(P)]), ...);
+  static_assert(sizeof...(P) == 4, "four amplitudes with both register bits set");
+  v2f a0, a1;
+  asm("v_pk_mul_f32 %[a0], %[l0], %[p0] op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[a1], %[l1], %[p1] op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %[a0], %[l2], %[p2], %[a0] op_sel:[0,1,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[a1], %[l3], %[p3], %[a1] op_sel:[0,1,0] op_sel_hi:[1,0,1]"
+      : [a0] "=&v"(a0), [a1] "=&v"(a1)
+      : [l0] "v"(l[ins11<RA, RB>(0)]), [p0] "v"(p[ins11<RA, RB>(0)]), [l1] "v"(l[ins11<RA, RB>(1)]), [p1] "v"(p[ins11<RA, RB>(1)]),
+        [l2] "v"(l[ins11<RA, RB>(2)]), [p2] "v"(p[ins11<RA, RB>(2)]), [l3] "v"(l[ins11<RA, RB>(3)]), [p3] "v"(p[ins11<RA, RB>(3)]));
   return (a0.x + a1.x) - (a0.y + a1.y);
 }
 template <int R, int RA, int RB>
@@ -293,9 +314,9 @@ template <int R, int RB, int... M>
 __device__ __forceinline__ float im_lam_x_psi_(const v2f (&p)[1 << R], const v2f (&l)[1 << R], std::integer_sequence<int, M...>) {
   static_assert(sizeof...(M) == 16, "two statements of eight");
   constexpr int B = 1 << RB;
-  v2f a0 = v2f{0.f, 0.f}, a1 = v2f{0.f, 0.f};  // Im(conj(lam_m) * psi_{m ^ bit}) over all m
-  acc_im8(a0, a1, l[0], p[0 ^ B], l[1], p[1 ^ B], l[2], p[2 ^ B], l[3], p[3 ^ B], l[4], p[4 ^ B], l[5], p[5 ^ B], l[6],
-          p[6 ^ B], l[7], p[7 ^ B]);
+  v2f a0, a1;  // Im(conj(lam_m) * psi_{m ^ bit}) over all m
+  acc_im8_first(a0, a1, l[0], p[0 ^ B], l[1], p[1 ^ B], l[2], p[2 ^ B], l[3], p[3 ^ B], l[4], p[4 ^ B], l[5], p[5 ^ B], l[6],
+                p[6 ^ B], l[7], p[7 ^ B]);
   acc_im8(a0, a1, l[8], p[8 ^ B], l[9], p[9 ^ B], l[10], p[10 ^ B], l[11], p[11 ^ B], l[12], p[12 ^ B], l[13], p[13 ^ B],
           l[14], p[14 ^ B], l[15], p[15 ^ B]);
   return (a0.x + a1.x) - (a0.y + a1.y);
@@ -582,38 +603,79 @@ __device__ __forceinline__ void add_slot(float* cells, int tid, uint32_t slot, f
   if ((tid & 63) == 0) cells[slot * NW + (uint32_t(tid) >> 6)] = v;
 }
 
-// Gradient partials of the EIGHT slots of record slot group G8 (program.h slot_lane8), reduced over
-// the wave together: two select+quad_perm butterflies leave lane l with the quad sums of values
-// (l & 3) and (l & 3) + 4; v_permlane16_swap (gfx950) adds the rows of a row pair and keeps value
-// (l & 3) in even rows, (l & 3) + 4 in odd rows; row_ror 4 / 8 sum the four quads of a row and
-// v_permlane32_swap the two row pairs.  The lanes whose slot-vector word `sv` IS the slot of the
-// value they hold then store into their wave's cells (see add_slot): 24 instructions + the store
-// for eight slots.  (Four slots at a time cost 23; with 2 of 4 filled on average the reductions
-// were 15 % of the adjoint's instructions.  `sv` holds slots LOCAL to the pass and the chain-rule
-// scale of the slot class is folded into the plan's slot_factor.)
+// Gradient partials of the EIGHT slots of record slot group G8 (program.h slot_lane8), reduced over the wave together
+// WITHOUT selects, and only as far as the values that exist (`present`, a wave-uniform bit per value: the instance's own
+// micro-op masks).  Value v = (v0, v1, v2) ends up in the lanes whose bits (2, 3, 4) spell v:
+//   level 1  lane bit 2 (adjacent banks of four lanes): value 2k adds its partner bank's share under bank_mask 0x5
+//            (row_shl:4), value 2k + 1 under 0xa (row_shr:4) into the SAME register -- one DPP add per PRESENT value;
+//   level 2  lane bit 3: pair (2k, 2k + 1) with pair (2k + 2, 2k + 3) under bank masks 0x3 / 0xc (row_shl:8 / row_shr:8)
+//            -- one DPP add per present pair;
+//   level 3  v_permlane16_swap + add: values 0..3 stay in even rows, 4..7 in odd rows (summed over the row pair);
+//   then the sums nobody selects on: two quad butterflies (lane bits 0, 1) and v_permlane32_swap + add (lane bit 5).
+// Round 4's butterfly paid two v_cndmask_b32 (4.2 cycles each on gfx950, as much as a packed FMA:
+// scripts/experiments/micro/valu_cycles.hip) per DPP add and all eight inputs whether they existed or not: 12 selects +
+// 8 DPP + 2 swaps = 105 cycles per call at an average of 2.7 present values; here (values + pairs) DPP adds + a 31-cycle
+// tail = ~51.  An input that does not exist is never read.  One asm statement: the DPP hazards (a VGPR written by the
+// previous VALU instruction needs two wait states before a DPP read) are spelled out, and the branches are scalar.
+// The lanes whose slot-vector word `sv` IS the slot of the value they hold then store into their wave's cells (see
+// add_slot).  (`sv` holds slots LOCAL to the pass; the chain-rule scale of the slot class is folded into slot_factor.)
 template <int CTRL>
 __device__ __forceinline__ float dpp_get(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 template <int G8, int NW>
-__device__ __forceinline__ void add_slots8(float* cells, int lane, uint32_t wave, uint32_t sv, float g0, float g1,
-                                           float g2, float g3, float g4, float g5, float g6, float g7) {
-  const bool b0 = lane & 1, b1 = lane & 2;
-  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2 = b0 ? g5 : g4, t3 = b0 ? g7 : g6;
-  t0 += dpp_get<0xB1>(b0 ? g0 : g1);  // quad_perm:[1,0,3,2]
-  t1 += dpp_get<0xB1>(b0 ? g2 : g3);
-  t2 += dpp_get<0xB1>(b0 ? g4 : g5);
-  t3 += dpp_get<0xB1>(b0 ? g6 : g7);
-  float u0 = b1 ? t1 : t0, u1 = b1 ? t3 : t2;
-  u0 += dpp_get<0x4E>(b1 ? t0 : t1);  // quad_perm:[2,3,0,1]
-  u1 += dpp_get<0x4E>(b1 ? t2 : t3);
-  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u0), __float_as_uint(u1), false, false);
-  float v = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // even rows: values 0..3, odd rows: 4..7
-  v += dpp_get<0x124>(v);                                   // row_ror:4
-  v += dpp_get<0x128>(v);                                   // row_ror:8
-  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  if (((lane >> 2) & 3) == (G8 & 3) && (lane >> 5) == (G8 >> 2) && sv != 0xffffffffu) cells[sv * NW + wave] = v;
+__device__ __forceinline__ void add_slots8(float* cells, int lane, uint32_t wave, uint32_t sv, uint32_t present, float g0,
+                                           float g1, float g2, float g3, float g4, float g5, float g6, float g7) {
+  float t0, t1, t2, t3, u0, u1, w, x;
+#define QHBM_L1(BIT_, T_, G_, DIR_, BANKS_)                                                        \
+  "s_bitcmp1_b32 %[m], " #BIT_ "\n\t"                                                              \
+  "s_cbranch_scc0 .Lred%=_a" #BIT_ "\n\t"                                                          \
+  "v_add_f32_dpp %[" #T_ "], %[" #G_ "], %[" #G_ "] " DIR_ ":4 row_mask:0xf bank_mask:" BANKS_ "\n" \
+  ".Lred%=_a" #BIT_ ":\n\t"
+#define QHBM_L2(MASK_, TAG_, U_, T_, DIR_, BANKS_)                                                 \
+  "s_and_b32 %[sc], %[m], " MASK_ "\n\t"                                                          \
+  "s_cbranch_scc0 .Lred%=_b" #TAG_ "\n\t"                                                         \
+  "v_add_f32_dpp %[" #U_ "], %[" #T_ "], %[" #T_ "] " DIR_ ":8 row_mask:0xf bank_mask:" BANKS_ "\n" \
+  ".Lred%=_b" #TAG_ ":\n\t"
+  uint32_t sc;
+  asm volatile(
+      "s_nop 1\n\t"
+      QHBM_L1(0, t0, g0, "row_shl", "0x5") QHBM_L1(2, t1, g2, "row_shl", "0x5") QHBM_L1(4, t2, g4, "row_shl", "0x5")
+      QHBM_L1(6, t3, g6, "row_shl", "0x5") QHBM_L1(1, t0, g1, "row_shr", "0xa") QHBM_L1(3, t1, g3, "row_shr", "0xa")
+      QHBM_L1(5, t2, g5, "row_shr", "0xa") QHBM_L1(7, t3, g7, "row_shr", "0xa")
+      "s_nop 1\n\t"
+      QHBM_L2("0x03", 0, u0, t0, "row_shl", "0x3") QHBM_L2("0x30", 2, u1, t2, "row_shl", "0x3")
+      QHBM_L2("0x0c", 1, u0, t1, "row_shr", "0xc") QHBM_L2("0xc0", 3, u1, t3, "row_shr", "0xc")
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %[u0], %[u1]\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32 %[w], %[u0], %[u1]\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %[w], %[w], %[w] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %[w], %[w], %[w] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32 %[x], %[w]\n\t"
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %[w], %[x]\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32 %[w], %[w], %[x]"
+      : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [u0] "=&v"(u0), [u1] "=&v"(u1), [w] "=&v"(w),
+        [x] "=&v"(x), [sc] "=&s"(sc)
+      : [m] "s"(present), [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [g3] "v"(g3), [g4] "v"(g4), [g5] "v"(g5), [g6] "v"(g6),
+        [g7] "v"(g7)
+      : "scc");
+#undef QHBM_L1
+#undef QHBM_L2
+  if ((lane & 3) == (G8 & 3) && (lane >> 5) == (G8 >> 2) && sv != 0xffffffffu) cells[sv * NW + wave] = w;
+}
+
+// A float nobody has written: an input of the eight-wide reduction whose slot does not exist.  The butterfly never adds
+// DIFFERENT values (each level selects, then adds the same value of the partner lane), so what an unused input holds
+// reaches no stored sum -- and a zero would cost a v_mov_b32 per input and instance (4 % of the adjoint's instructions).
+__device__ __forceinline__ float any_float() {
+  float v;
+  asm volatile("" : "=v"(v));  // (volatile: one register per use -- a shared one would be copied into every input)
+  return v;
 }
 
 // FULL diagonal table: amplitude with register value m (1..15) times FULL[m-1].
@@ -1221,27 +1283,27 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
   const uint32_t h0 = rec_word<0>(cur, rb), h1 = rec_word<1>(cur, rb);
   // ---- CPH (slot group 2) ----
   if (h1 & 0xffu) {
-    float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float g[8] = {any_float(), any_float(), any_float(), any_float(), any_float(), any_float(), any_float(), any_float()};
     QHBM_FOR_RB(R,
       if ((h1 >> (2 * J)) & 1u)
         g[2 * J] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J)>(cur, rb), rec_word<L.pred(2 * J)>(cur, rb), TLX);
       if ((h1 >> (2 * J + 1)) & 1u)
         g[2 * J + 1] = cph_adj<R, J>(p, l, rec_cs<L.cph(2 * J + 1)>(cur, rb), rec_word<L.pred(2 * J + 1)>(cur, rb), TLX);)
-    add_slots8<2, NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
+    add_slots8<2, NW>(cells, lane, wave, sv[0], h1 & 0xffu, g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
   }
-  float g1[4] = {0.f, 0.f, 0.f, 0.f};  // PH1 partials: reduced together with the X partials (slot group 0)
+  float g1[4] = {any_float(), any_float(), any_float(), any_float()};  // PH1 partials: reduced together with the X partials (slot group 0)
   if (h1 & kFullDiagFlag) {
     // ---- all PH1/PH2 terms at once: the per-term gradients are sums of Im(conj(lam) psi) over
     // the term's index set (full_partials), then ONE conj-table multiply ----
     float g[6];
     full_partials(p, l, g1, g);
-    if ((h0 >> 24) & 0x3fu) add_slots8<1, NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3], g[4], g[5], 0.f, 0.f);
+    if ((h0 >> 24) & 0x3fu) add_slots8<1, NW>(cells, lane, wave, sv[0], (h0 >> 24) & 0x3fu, g[0], g[1], g[2], g[3], g[4], g[5], any_float(), any_float());
     apply_full<NB>(p, cur, rb, true);
     apply_full<NB>(l, cur, rb, true);
   }
   // ---- PH2 (slot group 1) ----
   if ((h0 >> 16) & 0x3fu) {
-    float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float g[6] = {any_float(), any_float(), any_float(), any_float(), any_float(), any_float()};
     QHBM_FOR_PAIR(R,
       if ((h0 >> (16 + pair_index(JA, JB))) & 1u) {
         const v2f cs = conj_cs(rec_cs<L.ph2(pair_index(JA, JB))>(cur, rb));
@@ -1249,7 +1311,7 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
         apply_ph2<R, JA, JB>(p, cs);
         apply_ph2<R, JA, JB>(l, cs);
       })
-    add_slots8<1, NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3], g[4], g[5], 0.f, 0.f);
+    add_slots8<1, NW>(cells, lane, wave, sv[0], (h0 >> 16) & 0x3fu, g[0], g[1], g[2], g[3], g[4], g[5], any_float(), any_float());
   }
   // ---- PH1 ----
   if ((h0 >> 8) & 0xfu) {
@@ -1263,19 +1325,20 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
   }
   // ---- one-qubit gates: X (slot group 0, with the PH1 partials), Y and dense (slot group 3) ----
   {
-    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    float g[4] = {any_float(), any_float(), any_float(), any_float()};
     if (h0 & 0xfu) {
       QHBM_FOR_RB(R,
         if ((h0 >> J) & 1u) {
           const v2f xs = rec_cs<L.x(J)>(cur, rb);
           const v2f cs = v2f{-xs.x, -xs.y};  // U^dagger = c*I + i*s*X: both shear coefficients negated
-          if (rec_word<L.slot_x(J) - S0>(sv) != 0xffffffffu) g[J] = im_lam_x_psi<R, J>(p, l);
+          if ((h0 >> (12 + J)) & 1u) g[J] = im_lam_x_psi<R, J>(p, l);  // (the X gates that own a gradient slot: a header bit, not a v_readlane of the slot vector)
           apply_x<R, J>(p, cs);
           apply_x<R, J>(l, cs);
         })
     }
-    if ((h0 & 0xf0fu) || ((h1 & kFullDiagFlag) && ((h0 >> 4) & 0xfu)))
-      add_slots8<0, NW>(cells, lane, wave, sv[0], g[0], g[1], g[2], g[3], g1[0], g1[1], g1[2], g1[3]);
+    // the values that exist: X gates that own a slot (word 0 bits 12..15), PH1 terms (per-term: bits 8..11, FULL: 4..7)
+    const uint32_t present = ((h0 >> 12) & 0xfu) | ((((h0 >> 8) | (h0 >> 4)) & 0xfu) << 4);
+    if (present) add_slots8<0, NW>(cells, lane, wave, sv[0], present, g[0], g[1], g[2], g[3], g1[0], g1[1], g1[2], g1[3]);
   }
   if constexpr (GEN) {
   if ((h1 >> 16) & 0xf0fu) {
@@ -1298,7 +1361,7 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
           apply_mat1<R, J>(l, rec_cs<16 * J>(dv), rec_cs<16 * J + 2>(dv), rec_cs<16 * J + 4>(dv), rec_cs<16 * J + 6>(dv));
         })
     }
-    add_slots8<3, NW>(cells, lane, wave, sv[0], gy[0], gy[1], gy[2], gy[3], gd[0], gd[1], gd[2], gd[3]);
+    add_slots8<3, NW>(cells, lane, wave, sv[0], (h1 >> 16) & 0xf0fu ? (((h1 >> 16) & 0xfu) | (((h1 >> 24) & 0xfu) << 4)) : 0u, gy[0], gy[1], gy[2], gy[3], gd[0], gd[1], gd[2], gd[3]);
   }
   }
 }
@@ -2843,6 +2906,36 @@ hipError_t launch_reduce_grad(const float* state_grad, uint32_t U, uint32_t n_sl
                      param_slot_begin, param_slots, slot_factor, grad, accumulate);
   return hipGetLastError();
 }
+
+// ---- sustained packed-fp32 rate and shader clock (qhbm_clock_probe; bench.py roofline.compute.attainable_peak) ----
+// Every wave runs kProbeIters x 16 independent v_pk_fma_f32 with a scalar coefficient operand (the form of the pass
+// kernels) between two s_memtime (shader cycles) / s_memrealtime (100 MHz) reads; one workgroup of 1024 threads per
+// CU: four waves per SIMD.  out[wave] = (cycles, real-time ticks).
+constexpr int kProbeIters = 4096;
+__global__ __launch_bounds__(1024) void clock_probe_kernel(uint64_t* __restrict__ out, float x, float* __restrict__ sink) {
+  v2f a0{x, 1.f}, a1{x, 2.f}, a2{x, 3.f}, a3{x, 4.f}, a4{x, 5.f}, a5{x, 6.f}, a6{x, 7.f}, a7{x, 8.f};
+  const v2f c{1.0001f, 0.0001f};
+  uint64_t t0, t1, r0, r1;
+  asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0), "=s"(t0));
+  for (int i = 0; i < kProbeIters; ++i) {
+#define QHBM_PB(A_) "v_pk_fma_f32 %" #A_ ", %" #A_ ", %8, %" #A_ "\n\t"
+    asm volatile(QHBM_PB(0) QHBM_PB(1) QHBM_PB(2) QHBM_PB(3) QHBM_PB(4) QHBM_PB(5) QHBM_PB(6) QHBM_PB(7)
+                 QHBM_PB(0) QHBM_PB(1) QHBM_PB(2) QHBM_PB(3) QHBM_PB(4) QHBM_PB(5) QHBM_PB(6) "v_pk_fma_f32 %7, %7, %8, %7"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(c));
+#undef QHBM_PB
+  }
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1));
+  const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if ((threadIdx.x & 63u) == 0u) { out[2 * gw] = t1 - t0; out[2 * gw + 1] = r1 - r0; }
+  const v2f sum = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  if (sum.x == 12345.678f) sink[0] = sum.y;  // (keeps the arithmetic alive)
+}
+hipError_t launch_clock_probe(uint64_t* out, float* sink, uint32_t n_cus, hipStream_t stream) {
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(n_cus), dim3(1024), 0, stream, out, 1.0f, sink);
+  return hipGetLastError();
+}
+uint32_t clock_probe_waves(uint32_t n_cus) { return n_cus * 16u; }
+double clock_probe_instructions_per_simd() { return double(kProbeIters) * 16.0 * 4.0; }
 
 hipError_t launch_scale_rows(float* rows, uint32_t U, uint32_t width, const float* w, hipStream_t stream) {
   const size_t total = size_t(U) * width;

@@ -97,7 +97,7 @@ constexpr int pair_index(int lo, int hi) { return hi * (hi - 1) / 2 + lo; }  // 
 // per-entry pointer chasing.  Static words (masks, predicates, gradient slots) are written once
 // at upload; coefficient words are rewritten on every call by prep_coefs_kernel (one (cos, sin)
 // or matrix per gate) and combine_diag_kernel (the FULL table).  Rounds hold R = 4 register bits.
-//   vec 0:  [0] x_mask | fph1<<4 | ph1_mask<<8 | ph2_mask<<16 | fph2<<24
+//   vec 0:  [0] x_mask | fph1<<4 | ph1_mask<<8 | x_slot_mask<<12 (adjoint: X gates that own a gradient slot) | ph2_mask<<16 | fph2<<24
 //           [1] cph_mask | y_mask<<16 | dense_mask<<24 | FULL<<31
 //           X[4]{c,s}  CPH[8]{c,s}  CPHPRED[8]  then EITHER  PH1[4]{c,s} PH2[6]{c,s} Y[4]{c,s}
 //                                               OR (FULL)  FULL[15]{c,s}
@@ -131,11 +131,11 @@ struct RecordLayout {
   constexpr int dense(int j) const { return 128 + dense_words() * j; }
   constexpr int slot0() const { return 192; }
   // Gradient slots of an instance are reduced over the wave EIGHT at a time (kernels.hip add_slots8):
-  // value v of slot group g8 ends up in the lanes with bits (0, 1, 4) = v and bits (2, 3, 5) = g8, and
+  // value v of slot group g8 ends up in the lanes with bits (2, 3, 4) = v and bits (0, 1, 5) = g8, and
   // the slot-vector word of that lane IS the slot.  Groups: 0 = X[4] + PH1[4], 1 = PH2[6],
   // 2 = CPH[8], 3 = Y[4] + DENSE[4].
   constexpr int slot_lane8(int g8, int v) const {
-    return slot0() + ((v & 3) | ((g8 & 3) << 2) | ((v >> 2) << 4) | ((g8 >> 2) << 5));
+    return slot0() + ((g8 & 3) | ((v & 3) << 2) | ((v >> 2) << 4) | ((g8 >> 2) << 5));
   }
   constexpr int slot_x(int j) const { return slot_lane8(0, j); }
   constexpr int slot_ph1(int j) const { return slot_lane8(0, 4 + j); }

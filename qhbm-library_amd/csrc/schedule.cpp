@@ -689,6 +689,7 @@ class Builder {
       const float kPiF = 3.14159265358979323846f;
       const int slot = new_slot(p, op, pl.kind <= 1 ? kPiF : (pl.kind == 2 ? 1.f : -2.f * kPiF));
       if (adjoint_) rec[slot_lane] = uint32_t(slot);
+      if (adjoint_ && pl.kind == 0 && slot >= 0) rec[0] |= 1u << (12 + pl.j);  // X with a gradient slot (program.h word 0)
     }
     p->round_words.push_back(uint32_t(p->prog.size()));
     p->prog.push_back(OP_ROUND | (uint32_t(insts.size()) << 8));

@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "qhbm_expectation_retain", "qhbm_expectation_vjp_retained", "qhbm_retained_states", "qhbm_state_gradients",
     "qhbm_expectation_jacobian", "qhbm_statevector", "qhbm_sample", "qhbm_sample_counts", "qhbm_parity_energy", "qhbm_parity_energy_vjp",
     "qhbm_num_passes", "qhbm_describe_schedule",
-    "qhbm_kernel_time_ms", "qhbm_traffic_model", "qhbm_flop_model", "qhbm_op_census",
+    "qhbm_kernel_time_ms", "qhbm_traffic_model", "qhbm_flop_model", "qhbm_op_census", "qhbm_clock_probe",
 )
 
 
@@ -101,6 +101,10 @@ def load_library():
   lib.qhbm_traffic_model.argtypes = [vp, i32, i32] + [ctypes.POINTER(ctypes.c_double)] * 3
   lib.qhbm_flop_model.argtypes = [vp, i32, i32] + [ctypes.POINTER(ctypes.c_double)] * 3
   lib.qhbm_op_census.argtypes = [vp, i32, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i32)]
+  try:
+    lib.qhbm_clock_probe.argtypes = [vp] + [ctypes.POINTER(ctypes.c_double)] * 3 + [vp]
+  except AttributeError:  # an older library given through QHBM_ENGINE_LIB (A/B runs): the probe is optional there
+    pass
   _lib = lib
   return lib
 
@@ -293,6 +297,13 @@ class Engine:
     self._check(self._lib.qhbm_flop_model(self._h, int(num_states), int(with_vjp), ctypes.byref(f),
                                           ctypes.byref(o), ctypes.byref(b)))
     return {"fwd_flops": f.value, "obs_flops": o.value, "bwd_flops": b.value}
+
+  def clock_probe(self):
+    """The chip's sustained packed-fp32 rate right now: dict of `ghz` (shader clock during the probe),
+    `cycles_per_pk_fma` and `tflops` (include/qhbm_engine.h qhbm_clock_probe).  Synchronises the stream."""
+    g, c, t = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    self._check(self._lib.qhbm_clock_probe(self._h, ctypes.byref(g), ctypes.byref(c), ctypes.byref(t), self._stream()))
+    return {"ghz": g.value, "cycles_per_pk_fma": c.value, "tflops": t.value}
 
   CENSUS_COLUMNS = ("tiles", "rounds", "rounds_barrier", "rounds_no_barrier", "instances", "x", "x_no_slot", "full",
                     "ph1", "ph2", "cph_tile_on", "cph_wave_on", "cph_lane", "cph_off", "reduce8")

@@ -211,9 +211,11 @@ class AnalyticQuantumInference(QuantumInference):
 
   `process_group`: a `torch.distributed` group (or True for the default group) over which the
   unique bitstrings are sharded, one process per GPU; None (default) runs on this process's GPU
-  only.  `ordered_reduction` (default True) gathers per-state gradient rows and adds them in global
-  state order, so losses and gradients are bit-identical for 1, 2, 4 or 8 ranks; False all-reduces
-  the [P] gradient instead (a few hundred floats instead of [U, P], not order-stable).
+  only.  The gradient leaves a sharded call through ONE all-reduce of the [P] vector (default: config 3
+  moves 3.7 KiB per step and rank; the sum order, hence the last bits, depend on the number of ranks);
+  `ordered_reduction=True` gathers the per-state gradient rows [U, P] instead (config 3: 15.5 MB) and adds
+  them in global state order in fp64, so losses and gradients are bit-identical for 1, 2, 4 or 8 ranks --
+  for regression runs that compare rank counts, not for throughput.
   `check_consistency` (default True): before a sharded call the ranks compare a fingerprint of the
   unique bitstrings and the symbol values (8 bytes each) and raise `parallel.ShardMismatchError` if
   they differ -- differently seeded samplers would otherwise shard different sets, silently."""
@@ -222,7 +224,7 @@ class AnalyticQuantumInference(QuantumInference):
 
   def __init__(self, input_circuit: circuit.QuantumCircuit, name: Union[None, str] = None,
                device: Union[None, int] = None, gradient_method: int = _engine.GRAD_ADJOINT,
-               process_group=None, max_cached_engines: int = 4, ordered_reduction: bool = True,
+               process_group=None, max_cached_engines: int = 4, ordered_reduction: bool = False,
                check_consistency: bool = True):
     super().__init__(input_circuit, name)
     self._device = device

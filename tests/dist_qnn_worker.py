@@ -42,7 +42,8 @@ def main():
   states = torch.from_numpy(np.concatenate([uniq, uniq[[3, 3, 7]]]))     # duplicates, as EBM samples have
   weights = torch.from_numpy(rng.normal(size=(states.shape[0], 2)).astype(np.float32))
   T("model built")
-  qnn = inference.AnalyticQuantumInference(circ, process_group=True)
+  qnn = inference.AnalyticQuantumInference(circ, process_group=True,
+                                                   ordered_reduction=os.environ.get("QHBM_TEST_ORDERED", "1") == "1")
   out = qnn.expectation(states, [xxz, zsum])
   T("forward done")
   (out * weights.to(out.device)).sum().backward()

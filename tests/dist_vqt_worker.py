@@ -42,7 +42,8 @@ def main():
     circ.trainable_variables[0].copy_(torch.as_tensor(rng.uniform(-1, 1, len(circ.symbol_names)), dtype=torch.float32))
   desync = os.environ.get("QHBM_TEST_DESYNC") == "1"
   e_inf = inference.AnalyticEnergyInference(ebm, samples, initial_seed=(rank + 1) if desync else None)
-  q_inf = inference.AnalyticQuantumInference(circ, process_group=True)
+  q_inf = inference.AnalyticQuantumInference(circ, process_group=True,
+                                                   ordered_reduction=os.environ.get("QHBM_TEST_ORDERED", "1") == "1")
   qhbm = inference.QHBM(e_inf, q_inf)
   xxz = ir.PauliSum()
   for a, b in zip(qubits, qubits[1:]):

@@ -7,6 +7,7 @@ at these sizes inside the GPU tests, so its outputs are committed as fixtures:
     python tests/golden/make_golden_large.py c5      # ~10 min, one thread, 4.5 GiB
     python tests/golden/make_golden_large.py c4qmhl  # ~10 min, 6 threads
     python tests/golden/make_golden_large.py c5vjp   # ~25 min, 3 threads, 13 GiB
+    python tests/golden/make_golden_large.py c4d16   # ~15 min, one state
 
   c3_n20_l16.npz  BASELINE config 3's circuit: 20 qubits, HEA depth 16 (944 parameters), XXZ
                   chain.  4 states: values and per-state gradient rows by the numpy complex128
@@ -28,6 +29,10 @@ at these sizes inside the GPU tests, so its outputs are committed as fixtures:
   c5_n28_d2_vjp.npz   config 5's width with a BATCH: three 2 GiB states at 28 qubits, HEA depth 2, TFIM
                   ring: the 56 term values of every state and the [P] VJP of the weighted sum
                   (C oracle adjoint) -- what a streamed (chunk_states = 1) engine run is compared with.
+
+  c4_n24_d16_shift.npz  config 4 at its stated depth 16 (1136 parameters), 24 of the 512 terms: term values and
+                  the gradient of their sum (C oracle adjoint) for one state -- the reference for the engine's
+                  parameter-shift gradient at config 4's literal size.
 
 Inputs follow SURVEY.md 8(d): phi ~ U[-1, 1] from a fixed seed, seeded bitstrings.  Gate lists are
 [G, 6] = (kind, q0, q1, param_idx, scalar, offset); ops are [T, 4] = (op, coeff, x_mask, z_mask).
@@ -186,6 +191,29 @@ def make_c5_vjp():
        ops=pack_ops([op]), term_values=term_values, upstream=up, grad=grad.astype(np.float64))
 
 
+def make_c4_d16():
+  """BASELINE config 4 at its STATED depth: 24 qubits, HEA depth 16 (1136 parameters), the first 24 terms of the
+  random 512-term Pauli sum plus their sum: term values and the [P] gradient of the sum for one state, by the C
+  oracle's adjoint -- what the engine's PARAMETER-SHIFT gradient at this size is compared with
+  (tests/test_golden_large_gpu.py::test_c4_depth16_parameter_shift_against_the_c_oracle)."""
+  n, layers, n_terms = 24, 16, 24
+  rng = np.random.default_rng(2416)
+  gates, names = O.hea_gates(n, layers, "b")
+  params = rng.uniform(-1, 1, len(names))
+  bits = rng.integers(0, 2, size=(1, n)).astype(np.int8)
+  op = O.random_pauli_op(n, 512, 24)[:n_terms]
+  t0 = time.time()
+  term_values = C.expectation(n, gates, params, bits, [[t] for t in op])[0].astype(np.float64)
+  print(f"c4d16 C forward: {time.time() - t0:.0f} s; sum {term_values.sum():.6f}", flush=True)
+  t0 = time.time()
+  vals, grad = C.expectation_vjp(n, gates, params, bits, [op], np.ones((1, 1), np.float32))
+  print(f"c4d16 C adjoint: {time.time() - t0:.0f} s; |grad|_inf {np.abs(grad).max():.4f}", flush=True)
+  assert abs(float(vals[0, 0]) - term_values.sum()) < 5e-5 * sum(abs(c) for c, _, _ in op)
+  save("c4_n24_d16_shift.npz", n=n, layers=layers, gates=np.array(gates, dtype=np.float64), params=params, bits=bits,
+       ops=pack_ops([op]), term_values=term_values, grad=grad.astype(np.float64))
+
+
 if __name__ == "__main__":
   for which in sys.argv[1:] or ["c3", "c4", "c5"]:
-    {"c3": make_c3, "c4": make_c4, "c5": make_c5, "c4qmhl": make_c4_qmhl, "c5vjp": make_c5_vjp}[which]()
+    {"c3": make_c3, "c4": make_c4, "c5": make_c5, "c4qmhl": make_c4_qmhl, "c5vjp": make_c5_vjp,
+     "c4d16": make_c4_d16}[which]()

@@ -124,6 +124,32 @@ def test_bench_two_ranks_as_the_driver_launches_it(reduction):
   assert line["config"]["exchange_bytes"] == 4 * 32 + 4 * (32 * n_params if reduction == "ordered" else n_params)
 
 
+def test_bench_eight_ranks_as_the_driver_launches_it():
+  """The 8-rank code path of the round-end scaling run (no 8-GPU node here: eight gloo ranks share the one device, tiny
+  size): 36 states split 5 + 5 + 5 + 5 + 4 + 4 + 4 + 4, --verify against rank 0's own evaluation of the whole batch,
+  the exchange bytes and what the backend reports about its world."""
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  env = dict(os.environ, QHBM_BENCH_SHARE_DEVICE="1", QHBM_BENCH_BACKEND="gloo")
+  args = ["--qubits", "12", "--layers", "2", "--states-total", "36", "--steps", "2", "--warmup", "1",
+          "--hamiltonian", "tfim", "--cpu-sample-states", "2"]
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8"] + args
+  out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+  assert out.returncode == 0, out.stderr[-3000:]
+  line = _line(out.stdout)
+  assert line["n_gpus"] == 8 and line["scaling"] == "strong"
+  assert line["config"]["parallelism"] == "batch-sharded x8"
+  assert line["config"]["backend"] == "gloo" and line["config"]["backend_world_size"] == 8
+  assert line["config"]["states_total"] == 36 and line["config"]["states_per_gpu"] == 5
+  assert line["config"]["reduction"] == "allreduce"           # the default: [P] floats, not the [U, P] rows
+  n_params = 2 * (3 * 12 - 1)
+  assert line["config"]["exchange_bytes"] == 4 * 36 + 4 * n_params
+  assert line["verify"]["ok"], line["verify"]                 # on by default for N > 1
+  assert line["parity_check"]["ok"], line["parity_check"]
+
+
 def test_bench_gpus_flag_starts_its_own_ranks_and_shards_a_fixed_total():
   """`bench.py --gpus 2` outside torchrun launches two ranks itself (strong scaling: 33 states split
   17 + 16); on this one-GPU box that needs the share-device test hook, and WITHOUT it the run must

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(world, out_path, backend="gloo"):
+def _run(world, out_path, backend="gloo", ordered=True):
   with socket.socket() as s:
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -22,7 +22,7 @@ def _run(world, out_path, backend="gloo"):
          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_qnn_worker.py"),
          out_path]
   out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
-                       env=dict(os.environ, QHBM_TEST_BACKEND=backend))
+                       env=dict(os.environ, QHBM_TEST_BACKEND=backend, QHBM_TEST_ORDERED="1" if ordered else "0"))
   assert out.returncode == 0, out.stderr[-3000:]
   return dict(np.load(out_path))
 
@@ -38,6 +38,12 @@ def test_sharded_expectation_is_bit_identical_for_any_number_of_ranks(tmp_path):
   rccl = _run(1, str(tmp_path / "rccl.npz"), backend="nccl")
   np.testing.assert_array_equal(rccl["values"], runs[0]["values"])
   np.testing.assert_array_equal(rccl["grad"], runs[0]["grad"])
+  # the DEFAULT reduction (one all-reduce of the [P] gradient instead of the gathered rows): the same numbers up to
+  # the order of the fp32 sum, values identical (they are gathered either way)
+  for w in (1, 2):
+    ar = _run(w, str(tmp_path / f"allreduce{w}.npz"), ordered=False)
+    np.testing.assert_array_equal(ar["values"], runs[0]["values"])
+    np.testing.assert_allclose(ar["grad"], runs[0]["grad"], rtol=0, atol=2e-6 * max(1.0, np.abs(runs[0]["grad"]).max()))
   # and they are right: the numpy oracle on the same model
   from oracle import qhbm_oracle as O
   n, layers = 14, 2

@@ -269,6 +269,28 @@ def test_c4_depth16_parameter_shift_equals_adjoint_on_every_parameter():
   assert np.abs(g_shift - g_adj).max() <= 1e-4 * max(1.0, np.abs(g_adj).max()), np.abs(g_shift - g_adj).max()
 
 
+def test_c4_depth16_parameter_shift_against_the_c_oracle():
+  """BASELINE config 4 at its STATED combination -- 24 qubits, depth 16, parameter-shift gradients, terms of the random
+  512-term sum -- against the C oracle: the engine's shift VJP (2 x 1136 shifted programs) of the sum
+  of the first 24 terms on ALL 1136 parameters, and the 24 term values, against tests/golden/c4_n24_d16_shift.npz
+  (make_golden_large.py c4d16: oracle/qhbm_cpu.c adjoint, an independent method on an independent code path).
+  Tolerances: values 5e-5 * max(1, |c|); gradient 1e-4 * max(1, |g|_inf)."""
+  g = G.load("c4_n24_d16_shift.npz")
+  n, gates, (op,) = int(g["n"]), G.gates_of(g["gates"]), G.ops_of(g["ops"])
+  assert n == 24 and len(op) == 24 and len(g["params"]) == 1136
+  eng = _engine(n, gates, len(g["params"]), [[t] for t in op])
+  vals = eng.expectation(g["bits"], g["params"]).cpu().numpy()[0]
+  coeff = np.array([abs(c) for c, _, _ in op])
+  assert (np.abs(vals - g["term_values"]) <= 5e-5 * np.maximum(1.0, coeff)).all(), np.abs(vals - g["term_values"]).max()
+  eng = _engine(n, gates, len(g["params"]), [op])
+  total, grad = eng.expectation_vjp(g["bits"], g["params"], np.ones((1, 1), np.float32), method=E.GRAD_PARAMETER_SHIFT)
+  grad = grad.cpu().numpy()
+  assert abs(float(total[0, 0]) - g["term_values"].sum()) <= 5e-5 * coeff.sum()
+  tol = 1e-4 * max(1.0, np.abs(g["grad"]).max())
+  assert np.abs(g["grad"]).max() > 1e-2 and np.count_nonzero(np.abs(g["grad"]) > 1e-3) >= 8
+  assert np.abs(grad - g["grad"]).max() <= tol, (np.abs(grad - g["grad"]).max(), tol)
+
+
 def test_c5_streamed_batch_of_three_28_qubit_states_values_and_vjp_against_oracle():
   """Config 5's point is streaming (2 GiB per state, "256 samples, 32 per GPU streamed"): with
   chunk_states = 1 the three states of the fixture go through the workspace one after the other --

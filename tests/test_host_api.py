@@ -80,6 +80,29 @@ def test_bit_injection_order_quirk():
   assert models.DirectQuantumCircuit(pqc, tfq_compat_bit_order=True).bit_column_to_qubit()[:4] == [0, 1, 10, 11]
 
 
+def test_unchosen_bit_order_is_announced_once_from_eleven_qubits_on():
+  """From 11 qubits on the reference's lexicographic symbol sort permutes the bitstring columns
+  (circuit.py:59-62,131-134): the mirror's default order then differs from the reference on the same inputs, and a
+  circuit built without choosing says so -- once per process; an explicit True / False is silent (VERDICT r4 #6)."""
+  import warnings
+  from qhbmlib_amd.models import circuit as circuit_module
+  pqc12 = ir.Circuit(ir.X(q)**ir.Symbol(f"s{i}") for i, q in enumerate(ir.GridQubit.rect(1, 12)))
+  pqc10 = ir.Circuit(ir.X(q)**ir.Symbol(f"s{i}") for i, q in enumerate(ir.GridQubit.rect(1, 10)))
+  circuit_module._bit_order_warned = False
+  with warnings.catch_warnings(record=True) as seen:
+    warnings.simplefilter("always")
+    models.DirectQuantumCircuit(pqc10)                                # below 11 qubits the orders coincide
+    models.DirectQuantumCircuit(pqc12, tfq_compat_bit_order=False)    # chosen
+    models.DirectQuantumCircuit(pqc12, tfq_compat_bit_order=True)
+    assert not [w for w in seen if issubclass(w.category, circuit_module.BitOrderWarning)]
+    c = models.DirectQuantumCircuit(pqc12)
+    assert c.tfq_compat_bit_order is False
+    _ = c + models.DirectQuantumCircuit(ir.Circuit(ir.Z(q)**ir.Symbol(f"t{i}") for i, q in enumerate(ir.GridQubit.rect(1, 12))))
+    _ = c**-1
+    hits = [w for w in seen if issubclass(w.category, circuit_module.BitOrderWarning)]
+    assert len(hits) == 1 and "tfq_compat_bit_order=True" in str(hits[0].message)
+
+
 def test_qubits_sorted_row_major():
   qs = [ir.GridQubit(1, 0), ir.GridQubit(0, 1), ir.GridQubit(0, 0)]
   c = models.DirectQuantumCircuit(ir.Circuit(ir.X(q)**ir.Symbol(f"s{i}") for i, q in enumerate(qs)))
