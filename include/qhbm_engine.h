@@ -325,6 +325,10 @@ enum {
 };
 int qhbm_op_census(qhbm_engine* h, int adjoint, int max_passes, double* out, int* n_passes);
 
+/* Plan searches this engine has run so far: forward plans (rebuilt when the circuit, the observables or a planning
+ * option changes) and backward plans (also per gradient mask; a mask the engine has seen before is served from its
+ * cache and builds nothing).  Either pointer may be NULL. */
+int qhbm_plan_builds(qhbm_engine* h, int64_t* forward_plans, int64_t* backward_plans);
 /* Sustained packed-fp32 rate and shader clock of the device RIGHT NOW: one probe launch (every SIMD issues
  * v_pk_fma_f32 from four waves, the pass kernels' occupancy) timed with HIP events, s_memtime / s_memrealtime read
  * inside the waves.  ghz: shader clock during the probe; cycles_per_pk_fma: issue cost per wave instruction and SIMD;

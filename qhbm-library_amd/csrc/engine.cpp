@@ -110,6 +110,7 @@ struct qhbm_engine {
   // swap plans instead of re-running the plan search and re-uploading on every step.  Keyed by the
   // frozen-parameter vector; cleared whenever the circuit, the observables or a planning option changes.
   std::vector<std::pair<std::vector<char>, std::unique_ptr<DevicePlan>>> adj_cache;
+  int64_t fwd_plans_built = 0, adj_plans_built = 0;  // plan searches run so far (qhbm_plan_builds: a cache hit builds nothing)
   bool model_uploaded = false;  // everything upload_model copies to the device is current
   DevicePlan fwd, adj;
   DevBuf<DevTerm> terms, global_terms;  // global_terms: measured on the final state in HBM (too wide for a tile)
@@ -118,7 +119,7 @@ struct qhbm_engine {
   DevBuf<ObsBGroup> obs_bgroups;
   uint32_t n_obs_bgroups = 0;
   int opt_obs_kernel = -1;      // lambda = O psi / values: 0 = one gather per mask (apply_observable_kernel), 1 = partner blocks through
-                                // LDS (observable_blocks_kernel), -1 = the block kernel whenever the state has a block (>= 13 qubits)
+                                // LDS (observable_blocks_kernel), -1 = whichever the fitted cost model prices lower (block_kernel())
   mutable int block_choice = -1;  // cached verdict of block_kernel() (-1: not computed for the installed model / options)
   int opt_multi_values = -1;    // several observables: values from the block kernel after lean passes (-1: when some term flips >= 2
                                 // qubits or needs a measurement-only pass, at most kMultiValueOps observables)
@@ -172,7 +173,11 @@ size_t own_bytes(const qhbm_engine* h) {
          buf_bytes(h->shift_vals) + buf_bytes(h->shift_weight) + buf_bytes(h->shift_gates) + buf_bytes(h->shift_param) +
          buf_bytes(h->slot_factor) + buf_bytes(h->phase_cs) + buf_bytes(h->shift_phases) + buf_bytes(h->terms) +
          buf_bytes(h->global_terms) + buf_bytes(h->obs_groups) + buf_bytes(h->obs_bterms) + buf_bytes(h->obs_bgroups) + buf_bytes(h->op_scale) + buf_bytes(h->op_inv_scale) +
-         buf_bytes(h->param_slot_begin) + buf_bytes(h->param_slots) + plan_bytes(h->fwd) + plan_bytes(h->adj);
+         buf_bytes(h->param_slot_begin) + buf_bytes(h->param_slots) + plan_bytes(h->fwd) + plan_bytes(h->adj) + [&] {
+           size_t cached = 0;  // backward plans of other gradient masks, kept with their device copies (adj_cache)
+           for (const auto& kv : h->adj_cache) cached += plan_bytes(*kv.second);
+           return cached;
+         }();
 }
 
 int need_device(qhbm_engine* h) {
@@ -316,6 +321,7 @@ int build_plans(qhbm_engine* h) {
                     h->opt_cph_wave_bits != 0, false, h->opt_wide_last))
       return fail(h, "forward plan: " + err);
     h->fwd.uploaded = false;
+    ++h->fwd_plans_built;
   }
   // The backward plan.  Its pass kernel runs at the same fp32 rate whatever the plan (adjoint_plan_seconds), so the
   // plan with the least modelled time -- arithmetic, or tile traffic where a pass has little to compute -- is kept:
@@ -376,6 +382,7 @@ int build_plans(qhbm_engine* h) {
       h->adj.plan = std::move(wide);
   }
   h->adj.uploaded = false;
+  ++h->adj_plans_built;
   h->model_uploaded = false;
   h->shift_ready = false;
   if (!h->plans_valid) h->coef_batch_programs = 0;
@@ -1718,6 +1725,13 @@ extern "C" int qhbm_clock_probe(qhbm_engine* h, double* ghz, double* cycles_per_
   if (ghz) *ghz = g;
   if (cycles_per_pk_fma) *cycles_per_pk_fma = per;
   if (tflops) *tflops = 256.0 / per * g * 1e9 * double(n_cus) * 4.0 / 1e12;
+  return 0;
+}
+
+extern "C" int qhbm_plan_builds(qhbm_engine* h, int64_t* forward_plans, int64_t* backward_plans) {
+  if (!h) return 1;
+  if (forward_plans) *forward_plans = h->fwd_plans_built;
+  if (backward_plans) *backward_plans = h->adj_plans_built;
   return 0;
 }
 

@@ -704,38 +704,63 @@ __device__ __forceinline__ void q8(v2f& q0, v2f& q1, v2f& q2, v2f& q3, v2f& q4, 
         [l4] "v"(l4), [p4] "v"(p4), [l5] "v"(l5), [p5] "v"(p5), [l6] "v"(l6), [p6] "v"(p6), [l7] "v"(l7), [p7] "v"(p7));
 #undef QHBM_Q
 }
-// Superset sums over three index bits, in place: z[k] <- sum of z[k'] over k' containing k.
-__device__ __forceinline__ void zeta3(v2f& z0, v2f& z1, v2f& z2, v2f& z3, v2f& z4, v2f& z5, v2f& z6, v2f& z7) {
-  z0 += z1; z2 += z3; z4 += z5; z6 += z7;
-  z0 += z2; z1 += z3; z4 += z6; z5 += z7;
-  z0 += z4; z1 += z5; z2 += z6; z3 += z7;
+// d_k = Im(conj(lam_k) psi_k) = lam.re psi.im - lam.im psi.re for four amplitudes, as SCALARS: the sums below need the
+// difference only, and a plain 32-bit VALU op issues in 2.2 cycles against 4.2 for a packed one (valu_cycles.hip) -- the
+// packed form (q = (lam.re psi.im, lam.im psi.re), subtract last) carried both halves through 28 packed adds.
+__device__ __forceinline__ void im4(float& d0, float& d1, float& d2, float& d3, v2f l0, v2f p0, v2f l1, v2f p1, v2f l2, v2f p2,
+                                    v2f l3, v2f p3) {
+  asm("v_mul_f32 %[d0], %[l0x], %[p0y]\n\t"
+      "v_mul_f32 %[d1], %[l1x], %[p1y]\n\t"
+      "v_mul_f32 %[d2], %[l2x], %[p2y]\n\t"
+      "v_mul_f32 %[d3], %[l3x], %[p3y]\n\t"
+      "v_fma_f32 %[d0], -%[l0y], %[p0x], %[d0]\n\t"
+      "v_fma_f32 %[d1], -%[l1y], %[p1x], %[d1]\n\t"
+      "v_fma_f32 %[d2], -%[l2y], %[p2x], %[d2]\n\t"
+      "v_fma_f32 %[d3], -%[l3y], %[p3x], %[d3]"
+      : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3)
+      : [l0x] "v"(l0.x), [l0y] "v"(l0.y), [p0x] "v"(p0.x), [p0y] "v"(p0.y), [l1x] "v"(l1.x), [l1y] "v"(l1.y), [p1x] "v"(p1.x),
+        [p1y] "v"(p1.y), [l2x] "v"(l2.x), [l2y] "v"(l2.y), [p2x] "v"(p2.x), [p2y] "v"(p2.y), [l3x] "v"(l3.x), [l3y] "v"(l3.y),
+        [p3x] "v"(p3.x), [p3y] "v"(p3.y));
 }
-// Gradient partials of ALL one- and two-bit phase terms on the four register bits at once (FULL
-// instances): with A[k] = q[2k] + q[2k+1] and B[k] = q[2k+1] (k = register bits 1..3), the superset
-// sums of B are the terms that contain bit 0 and those of A the ones that do not -- 28 live packed
-// adds for the ten sums.  g1[J] = PH1 on bit J, g2[pair_index(JA, JB)] = PH2 on (JA, JB); sums of
-// terms the instance does not have are computed too and never stored (their slot is 0xffffffff).
+// Gradient partials of ALL one- and two-bit phase terms on the four register bits at once (FULL instances): with
+// d[m] = Im(conj(lam_m) psi_m), A[k] = d[2k] + d[2k+1] and B[k] = d[2k+1] (k = register bits 1..3), the superset sums
+// (z[k] <- sum of z[k'] over k' containing k) of B are the terms that contain bit 0 and those of A the ones that do not:
+// 28 scalar adds for the ten sums, in place, in ONE asm statement (plain C++ here is SLP-packed into v_pk_add_f32 with a
+// v_mov per operand).  g1[J] = PH1 on bit J, g2[pair_index(JA, JB)] = PH2 on (JA, JB); sums of terms the instance does
+// not have are computed too and never stored (their slot is 0xffffffff).
 __device__ __forceinline__ void full_partials(const v2f (&p)[16], const v2f (&l)[16], float (&g1)[4], float (&g2)[6]) {
-  v2f q[16];
-  q8(q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], l[0], p[0], l[1], p[1], l[2], p[2], l[3], p[3], l[4], p[4], l[5],
-     p[5], l[6], p[6], l[7], p[7]);
-  q8(q[8], q[9], q[10], q[11], q[12], q[13], q[14], q[15], l[8], p[8], l[9], p[9], l[10], p[10], l[11], p[11], l[12],
-     p[12], l[13], p[13], l[14], p[14], l[15], p[15]);
-  v2f A0 = q[0] + q[1], A1 = q[2] + q[3], A2 = q[4] + q[5], A3 = q[6] + q[7], A4 = q[8] + q[9], A5 = q[10] + q[11],
-      A6 = q[12] + q[13], A7 = q[14] + q[15];
-  v2f B0 = q[1], B1 = q[3], B2 = q[5], B3 = q[7], B4 = q[9], B5 = q[11], B6 = q[13], B7 = q[15];
-  zeta3(A0, A1, A2, A3, A4, A5, A6, A7);
-  zeta3(B0, B1, B2, B3, B4, B5, B6, B7);
-  g1[0] = B0.x - B0.y;
-  g1[1] = A1.x - A1.y;
-  g1[2] = A2.x - A2.y;
-  g1[3] = A4.x - A4.y;
-  g2[0] = B1.x - B1.y;  // (0, 1)
-  g2[1] = B2.x - B2.y;  // (0, 2)
-  g2[2] = A3.x - A3.y;  // (1, 2)
-  g2[3] = B4.x - B4.y;  // (0, 3)
-  g2[4] = A5.x - A5.y;  // (1, 3)
-  g2[5] = A6.x - A6.y;  // (2, 3)
+  float d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11, d12, d13, d14, d15;
+  im4(d0, d1, d2, d3, l[0], p[0], l[1], p[1], l[2], p[2], l[3], p[3]);
+  im4(d4, d5, d6, d7, l[4], p[4], l[5], p[5], l[6], p[6], l[7], p[7]);
+  im4(d8, d9, d10, d11, l[8], p[8], l[9], p[9], l[10], p[10], l[11], p[11]);
+  im4(d12, d13, d14, d15, l[12], p[12], l[13], p[13], l[14], p[14], l[15], p[15]);
+  // A[k] lives in d[2k], B[k] in d[2k+1].  Not needed and not computed: A[0] (the sum over everything), A[7] / B[3] /
+  // B[5] / B[6] / B[7] as RESULTS (three-bit terms do not exist) -- they still feed the others.
+#define QHBM_ADD(X_, Y_) "v_add_f32 %[d" #X_ "], %[d" #X_ "], %[d" #Y_ "]\n\t"
+  asm(// A[k] = d[2k] + d[2k+1]
+      QHBM_ADD(2, 3) QHBM_ADD(4, 5) QHBM_ADD(6, 7) QHBM_ADD(8, 9) QHBM_ADD(10, 11) QHBM_ADD(12, 13) QHBM_ADD(14, 15)
+      // zeta over A (indices 2k), level k bit 0, 1, 2 -- without the chain into A[0]
+      QHBM_ADD(4, 6) QHBM_ADD(8, 10) QHBM_ADD(12, 14)      // A2 += A3, A4 += A5, A6 += A7
+      QHBM_ADD(2, 6) QHBM_ADD(8, 12) QHBM_ADD(10, 14)      // A1 += A3, A4 += A6, A5 += A7
+      QHBM_ADD(2, 10) QHBM_ADD(4, 12) QHBM_ADD(6, 14)      // A1 += A5, A2 += A6, A3 += A7
+      // zeta over B (indices 2k + 1)
+      QHBM_ADD(1, 3) QHBM_ADD(5, 7) QHBM_ADD(9, 11) QHBM_ADD(13, 15)   // B0 += B1, B2 += B3, B4 += B5, B6 += B7
+      QHBM_ADD(1, 5) QHBM_ADD(3, 7) QHBM_ADD(9, 13) QHBM_ADD(11, 15)   // B0 += B2, B1 += B3, B4 += B6, B5 += B7
+      QHBM_ADD(1, 9) QHBM_ADD(3, 11) "v_add_f32 %[d5], %[d5], %[d13]"  // B0 += B4, B1 += B5, B2 += B6
+      : [d0] "+v"(d0), [d1] "+v"(d1), [d2] "+v"(d2), [d3] "+v"(d3), [d4] "+v"(d4), [d5] "+v"(d5), [d6] "+v"(d6), [d7] "+v"(d7),
+        [d8] "+v"(d8), [d9] "+v"(d9), [d10] "+v"(d10), [d11] "+v"(d11), [d12] "+v"(d12), [d13] "+v"(d13), [d14] "+v"(d14),
+        [d15] "+v"(d15));
+#undef QHBM_ADD
+  g1[0] = d1;   // B0: every amplitude with bit 0
+  g1[1] = d2;   // A1
+  g1[2] = d4;   // A2
+  g1[3] = d8;   // A4
+  g2[0] = d3;   // B1: bits (0, 1)
+  g2[1] = d5;   // B2: (0, 2)
+  g2[2] = d6;   // A3: (1, 2)
+  g2[3] = d9;   // B4: (0, 3)
+  g2[4] = d10;  // A5: (1, 3)
+  g2[5] = d12;  // A6: (2, 3)
 }
 
 // Controlled phase: register bit J AND (a thread bit | a tile bit).  One code path for both
@@ -760,9 +785,8 @@ __device__ __forceinline__ float cph_adj(v2f (&p)[1 << R], v2f (&l)[1 << R], v2f
   float g = 0.f;
   if (on) {
     g = sum_w1<R, J>(p, l);
-    const v2f c2 = conj_cs(cs);
-    apply_ph1_s8<R, J>(p, c2);
-    apply_ph1_s8<R, J>(l, c2);
+    apply_ph1_s8<R, J>(p, cs);  // (cs: the conjugate phase, as the adjoint records hold it)
+    apply_ph1_s8<R, J>(l, cs);
   }
   return g;
 }
@@ -1298,15 +1322,15 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
     float g[6];
     full_partials(p, l, g1, g);
     if ((h0 >> 24) & 0x3fu) add_slots8<1, NW>(cells, lane, wave, sv[0], (h0 >> 24) & 0x3fu, g[0], g[1], g[2], g[3], g[4], g[5], any_float(), any_float());
-    apply_full<NB>(p, cur, rb, true);
-    apply_full<NB>(l, cur, rb, true);
+    apply_full<NB>(p, cur, rb, false);  // (adjoint records hold the CONJUGATE phases: prep_coefs_kernel, CoefJob::dagger)
+    apply_full<NB>(l, cur, rb, false);
   }
   // ---- PH2 (slot group 1) ----
   if ((h0 >> 16) & 0x3fu) {
     float g[6] = {any_float(), any_float(), any_float(), any_float(), any_float(), any_float()};
     QHBM_FOR_PAIR(R,
       if ((h0 >> (16 + pair_index(JA, JB))) & 1u) {
-        const v2f cs = conj_cs(rec_cs<L.ph2(pair_index(JA, JB))>(cur, rb));
+        const v2f cs = rec_cs<L.ph2(pair_index(JA, JB))>(cur, rb);
         g[pair_index(JA, JB)] = sum_w2<R, JA, JB>(p, l);
         apply_ph2<R, JA, JB>(p, cs);
         apply_ph2<R, JA, JB>(l, cs);
@@ -1317,7 +1341,7 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
   if ((h0 >> 8) & 0xfu) {
     QHBM_FOR_RB(R,
       if ((h0 >> (8 + J)) & 1u) {
-        const v2f cs = conj_cs(rec_cs<L.ph1(J)>(cur, rb));
+        const v2f cs = rec_cs<L.ph1(J)>(cur, rb);
         g1[J] = sum_w1<R, J>(p, l);
         apply_ph1<R, J>(p, cs);
         apply_ph1<R, J>(l, cs);
@@ -1329,8 +1353,7 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
     if (h0 & 0xfu) {
       QHBM_FOR_RB(R,
         if ((h0 >> J) & 1u) {
-          const v2f xs = rec_cs<L.x(J)>(cur, rb);
-          const v2f cs = v2f{-xs.x, -xs.y};  // U^dagger = c*I + i*s*X: both shear coefficients negated
+          const v2f cs = rec_cs<L.x(J)>(cur, rb);  // (U^dagger's shear coefficients: negated at preparation)
           if ((h0 >> (12 + J)) & 1u) g[J] = im_lam_x_psi<R, J>(p, l);  // (the X gates that own a gradient slot: a header bit, not a v_readlane of the slot vector)
           apply_x<R, J>(p, cs);
           apply_x<R, J>(l, cs);
@@ -1345,7 +1368,7 @@ __device__ __forceinline__ void instance_adj(const uint32_t (&cur)[1], const uin
     float gy[4] = {0.f, 0.f, 0.f, 0.f}, gd[4] = {0.f, 0.f, 0.f, 0.f};
     QHBM_FOR_RB(R,
       if ((h1 >> (16 + J)) & 1u) {
-        const v2f cs = conj_cs(rec_cs<L.y(J)>(cur, rb));
+        const v2f cs = rec_cs<L.y(J)>(cur, rb);
         if (rec_word<L.slot_y(J) - S0>(sv) != 0xffffffffu) gy[J] = im_lam_y_psi<R, J>(p, l);
         apply_y<R, J>(p, cs);
         apply_y<R, J>(l, cs);
@@ -2047,23 +2070,24 @@ __global__ void prep_coefs_kernel(const CoefJob* __restrict__ jobs, int n_jobs,
     double sn, cs;
     sincospi(double(jb.mult) * t, &sn, &cs);
     o[0] = float(cs);
-    o[1] = float(sn);
-    return;
+    o[1] = float(jb.dagger ? -sn : sn);  // adjoint plans un-apply: the conjugate phase, stored ready to use (a conjugation
+    return;                              // in the kernel is an s_xor per coefficient and instance: 15 for a FULL table)
   }
   if (jb.mop == MOP_X) {  // X**t has period 2 in t: theta = pi t / 2 in [-pi/2, pi/2], |tan(theta/2)| <= 1
     t *= double(jb.mult);  // (1 except for the X**(1/2) of a lowered constant Hadamard)
     const double tr = t - 2.0 * rint(0.5 * t);
     double s2, c2;
     sincospi(0.5 * tr, &s2, &c2);
-    o[0] = float(s2 / (1.0 + c2));  // tan(theta / 2)
-    o[1] = float(s2);               // sin(theta)           (x_pair4's three shears)
+    const double sgn = jb.dagger ? -1.0 : 1.0;  // U^dagger = c*I + i*s*X: both shear coefficients negated
+    o[0] = float(sgn * s2 / (1.0 + c2));  // tan(theta / 2)
+    o[1] = float(sgn * s2);               // sin(theta)           (x_pair4's three shears)
     return;
   }
   double sh, ch;  // sin, cos of pi*t/2
   sincospi(0.5 * t, &sh, &ch);
   if (jb.mop == MOP_Y) {
     o[0] = float(ch);
-    o[1] = float(sh);
+    o[1] = float(jb.dagger ? -sh : sh);
     return;
   }
   // U = sum_k exp(i pi t e_k) P_k;   for an involution G:  U = a*I + b*G,

@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "qhbm_expectation_retain", "qhbm_expectation_vjp_retained", "qhbm_retained_states", "qhbm_state_gradients",
     "qhbm_expectation_jacobian", "qhbm_statevector", "qhbm_sample", "qhbm_sample_counts", "qhbm_parity_energy", "qhbm_parity_energy_vjp",
     "qhbm_num_passes", "qhbm_describe_schedule",
-    "qhbm_kernel_time_ms", "qhbm_traffic_model", "qhbm_flop_model", "qhbm_op_census", "qhbm_clock_probe",
+    "qhbm_kernel_time_ms", "qhbm_traffic_model", "qhbm_flop_model", "qhbm_op_census", "qhbm_clock_probe", "qhbm_plan_builds",
 )
 
 
@@ -102,6 +102,7 @@ def load_library():
   lib.qhbm_flop_model.argtypes = [vp, i32, i32] + [ctypes.POINTER(ctypes.c_double)] * 3
   lib.qhbm_op_census.argtypes = [vp, i32, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i32)]
   try:
+    lib.qhbm_plan_builds.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     lib.qhbm_clock_probe.argtypes = [vp] + [ctypes.POINTER(ctypes.c_double)] * 3 + [vp]
   except AttributeError:  # an older library given through QHBM_ENGINE_LIB (A/B runs): the probe is optional there
     pass
@@ -297,6 +298,12 @@ class Engine:
     self._check(self._lib.qhbm_flop_model(self._h, int(num_states), int(with_vjp), ctypes.byref(f),
                                           ctypes.byref(o), ctypes.byref(b)))
     return {"fwd_flops": f.value, "obs_flops": o.value, "bwd_flops": b.value}
+
+  def plan_builds(self):
+    """(forward, backward) plan searches run so far (include/qhbm_engine.h qhbm_plan_builds)."""
+    f, b = ctypes.c_int64(), ctypes.c_int64()
+    self._check(self._lib.qhbm_plan_builds(self._h, ctypes.byref(f), ctypes.byref(b)))
+    return f.value, b.value
 
   def clock_probe(self):
     """The chip's sustained packed-fp32 rate right now: dict of `ghz` (shader clock during the probe),

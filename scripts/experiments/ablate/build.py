@@ -37,10 +37,11 @@ def in_instance(text, old, new, count=-1):
 
 VARIANTS = {
     "base": lambda t: t,
-    "no_reduce": lambda t: once(t, "  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2",
-                                "  if (sv == 0x12345u) return;\n  if (true) return;\n  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2"),
-    "no_butterfly": lambda t: once(t, "  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2",
-                                   "  if (lane >= 0) { const float vv = ((g0 + g1) + (g2 + g3)) + ((g4 + g5) + (g6 + g7)); if (((lane >> 2) & 3) == (G8 & 3) && (lane >> 5) == (G8 >> 2) && sv != 0xffffffffu) cells[sv * NW + wave] = vv; return; }\n  const bool b0 = lane & 1, b1 = lane & 2;\n  float t0 = b0 ? g1 : g0, t1 = b0 ? g3 : g2, t2"),
+    "no_reduce": lambda t: once(t, "  float t0, t1, t2, t3, u0, u1, w, x;\n#define QHBM_L1(",
+                                "  if (sv == 0x12345u) return;\n  if (true) return;\n  float t0, t1, t2, t3, u0, u1, w, x;\n#define QHBM_L1("),
+    # the reductions' cross-lane part compiled out: the inputs that exist are added per lane and stored
+    "no_butterfly": lambda t: once(t, "  float t0, t1, t2, t3, u0, u1, w, x;\n#define QHBM_L1(",
+                                   "  if (lane >= 0) { float vv = 0.f; if (present & 1u) vv += g0; if (present & 2u) vv += g1; if (present & 4u) vv += g2; if (present & 8u) vv += g3; if (present & 16u) vv += g4; if (present & 32u) vv += g5; if (present & 64u) vv += g6; if (present & 128u) vv += g7; if ((lane & 3) == (G8 & 3) && (lane >> 5) == (G8 >> 2) && sv != 0xffffffffu) cells[sv * NW + wave] = vv; return; }\n  float t0, t1, t2, t3, u0, u1, w, x;\n#define QHBM_L1("),
     # record coefficients as compile-time constants (only the two header words are loaded): what the
     # scalar-load latency of the record fields costs
     "const_coefs": lambda t: once(t, "  if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];", "  if constexpr (W >= 2) return 0x3f19999au; else if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];"),
@@ -195,6 +196,16 @@ VARIANTS.update({
         "  if ((a.flags & PASS_RELABEL) && tid == 100000) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile_relabeled<K, NT>(xt, sp, a, tables, t.tile_base, in_local, tid);"),
         "  } else if (a.flags & PASS_STORE) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT, true>(xt, sp, t, tid);",
         "  } else if ((a.flags & PASS_STORE) && tid == 100000) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT, true>(xt, sp, t, tid);"),
+})
+
+
+VARIANTS.update({
+    # round 5: the paired forward kernel at FIVE waves per SIMD (its LDS -- one 32-KiB exchange tile -- admits five
+    # workgroups per CU; 96 registers instead of 111: the compiler spills 16 in the tile prologue)
+    "fwd2_five_waves": lambda t: once(t,
+        "template <int K>\n__global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_kernel(",
+        "constexpr int fwd2_min_waves(int K) { return clampi(wg_per_cu(8 << K) * (1 << (K - 4)) / 256, 1, 5); }\n"
+        "template <int K>\n__global__ __launch_bounds__(1 << (K - 4), fwd2_min_waves(K)) void pass_fwd2_kernel("),
 })
 
 

@@ -21,7 +21,11 @@ publish = "--publish" in sys.argv
 SRC = os.path.join(ROOT, "gpurun_out", f"profile_{tag}")
 DST = os.path.join(ROOT, "profiles")
 CLOCK_GHZ, SIMDS = 2.4, 1024
-ISSUE_CYCLES_PER_VALU = 4.5  # measured on this chip (scripts/experiments/micro/valu_rate.hip): v_fma 4.0, v_pk_* 4.6-4.8
+# Issue cost per wave instruction and SIMD, in SHADER CYCLES (scripts/experiments/micro/valu_cycles.hip, s_memtime next to
+# s_memrealtime, round 5): v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / DPP / v_cndmask_b32_e64 / v_readlane 4.2, plain
+# 32-bit VOP1 / VOP2 2.2, v_permlane*_swap 8.1.  (Rounds 2-4 converted wall time at a nominal 2.4 GHz and read 4.6-4.8
+# for the packed ops: that was the clock, 2.07 GHz under the adjoint kernel, not the instruction.)
+PACKED_ISSUE_CYCLES = 4.2
 
 
 def short(name):
@@ -71,13 +75,17 @@ for name, c in per.items():
     if c.get("GRBM_GUI_ACTIVE"):
       cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # the counter is summed over the 8 XCDs
       k["effective_clock_GHz_under_profiler"] = cycles / avg_ns[name]
-    k["valu_issue_frac"] = c["SQ_INSTS_VALU"] * ISSUE_CYCLES_PER_VALU / (cycles * SIMDS)
+    k["simd_cycles_per_valu_inst"] = cycles * SIMDS / c["SQ_INSTS_VALU"]
+    k["valu_issue_frac"] = c["SQ_INSTS_VALU"] * PACKED_ISSUE_CYCLES / (cycles * SIMDS)
     if "SQ_ACTIVE_INST_VALU" in c:
       k["valu_active_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * SIMDS)
     valu[key] = {"kernel": name, "valu_insts_per_launch": c["SQ_INSTS_VALU"], "valu_issue_frac": k["valu_issue_frac"],
-                 "valu_active_frac": k.get("valu_active_frac"),
-                 "definition": "valu_issue_frac = SQ_INSTS_VALU x 4.5 issue cycles / (kernel cycles x 1024 SIMDs); "
-                               "valu_active_frac = SQ_ACTIVE_INST_VALU x 4 / (kernel cycles x 1024 SIMDs)"}
+                 "valu_active_frac": k.get("valu_active_frac"), "simd_cycles_per_valu_inst": k["simd_cycles_per_valu_inst"],
+                 "effective_clock_GHz_under_profiler": k.get("effective_clock_GHz_under_profiler"),
+                 "definition": "kernel cycles = GRBM_GUI_ACTIVE / 8 (measured, not a nominal clock); valu_issue_frac = "
+                               "SQ_INSTS_VALU x 4.2 cycles (the issue cost of a packed-fp32 op: an UPPER bound, plain "
+                               "32-bit ops cost 2.2) / (kernel cycles x 1024 SIMDs); valu_active_frac = "
+                               "SQ_ACTIVE_INST_VALU x 4 / (kernel cycles x 1024 SIMDs)"}
   counters["kernels"][name] = k
 with open(os.path.join(DST, f"{tag}_counters.json"), "w") as f:
   json.dump(counters, f, indent=1)
