@@ -158,7 +158,10 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
  * (states of >= 13 qubits), -1 = whichever a fitted cost model prefers: the block kernel for operators with many masks),
  * "multi_observable_values" (several observables: -1 = their values come from ONE launch of the block kernel over the
  * final states, after lean measurement-free passes, when some term flips two or more qubits and there are at most 64
- * observables; 0 = always measured in the passes; 1 = always from the kernel, up to 256 observables).
+ * observables; 0 = always measured in the passes; 1 = always from the kernel, up to 256 observables),
+ * "gather_multi_values" (2..4 observables: 1 = the gather kernel forms lambda AND carries a value accumulator per
+ * observable -- one launch instead of two; 0 (default) = the values from the block kernel's own launch: the one-launch
+ * form measured SLOWER, 103 against 64.7 ms on BASELINE config 3 split into its XX / YY / ZZ sums).
  */
 int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value);
 

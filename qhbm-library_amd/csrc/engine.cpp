@@ -115,12 +115,17 @@ struct qhbm_engine {
   DevicePlan fwd, adj;
   DevBuf<DevTerm> terms, global_terms;  // global_terms: measured on the final state in HBM (too wide for a tile)
   DevBuf<ObsGroup> obs_groups;
+  bool terms_by_op = false;  // the uploaded terms / groups are in the (mask, observable) order of gather_multi_mode
   DevBuf<ObsBTerm> obs_bterms;    // the same terms sorted and cut for the block-grouped kernels (observable.hip)
   DevBuf<ObsBGroup> obs_bgroups;
   uint32_t n_obs_bgroups = 0;
   int opt_obs_kernel = -1;      // lambda = O psi / values: 0 = one gather per mask (apply_observable_kernel), 1 = partner blocks through
                                 // LDS (observable_blocks_kernel), -1 = whichever the fitted cost model prices lower (block_kernel())
   mutable int block_choice = -1;  // cached verdict of block_kernel() (-1: not computed for the installed model / options)
+  int opt_gather_multi = 0;     // 2..4 observables: 1 = the gather kernel forms lambda AND carries a value accumulator per observable
+                                // (one launch).  Measured slower than the block kernel's value launch + the gather launch for lambda
+                                // (config 3 as XX / YY / ZZ sums: 103 against 64.7 ms, profiles/r05_xxz3_gather_multi_ab.txt): off
+                                // by default, kept selectable (tests, A/B runs)
   int opt_multi_values = -1;    // several observables: values from the block kernel after lean passes (-1: when some term flips >= 2
                                 // qubits or needs a measurement-only pass, at most kMultiValueOps observables)
   DevBuf<float> value_part;  // value mode: one partial of <psi|O|psi> per workgroup of apply_observable_kernel
@@ -431,8 +436,14 @@ ObsBTerm obs_block_term(const DevTerm& d, bool new_mask) {
 // Copies plans, observable tables and the parameter -> slot map to the device ONCE per model: a
 // compute call on an unchanged model issues no host copy and no synchronisation (it can be captured
 // into a hipGraph by the caller).
+bool gather_multi_mode(const qhbm_engine* h);  // (below, with the other mode predicates)
+
 int upload_model(qhbm_engine* h) {
   if (int rc = build_plans(h)) return rc;
+  if (h->terms.p && h->terms_by_op != gather_multi_mode(h)) {  // an option changed which order the gather kernel wants
+    h->terms.release();
+    h->model_uploaded = false;
+  }
   if (h->model_uploaded) return 0;
   if (int rc = upload_plan(h, &h->fwd)) return rc;
   if (int rc = upload_plan(h, &h->adj)) return rc;
@@ -441,10 +452,19 @@ int upload_model(qhbm_engine* h) {
     std::vector<DevTerm> t;
     for (const PauliTerm& pt : h->model.terms)
       t.push_back(DevTerm{pt.coeff, pt.x, pt.z, uint32_t(pt.ny), uint32_t(pt.op)});
-    std::stable_sort(t.begin(), t.end(), [](const DevTerm& a, const DevTerm& b) { return a.x < b.x; });
+    // (several observables with a value accumulator each -- gather_multi_mode --: by mask, then by observable; a group is
+    // one observable's share of a mask and re-uses the partners its predecessor gathered when the mask is the same)
+    const bool by_op = gather_multi_mode(h);
+    h->terms_by_op = by_op;
+    std::stable_sort(t.begin(), t.end(), [by_op](const DevTerm& a, const DevTerm& b) {
+      return a.x != b.x ? a.x < b.x : (by_op && a.op < b.op);
+    });
     std::vector<ObsGroup> groups;
     for (size_t k = 0; k < t.size(); ++k) {
-      if (k == 0 || t[k].x != t[k - 1].x || k % (kObsTermChunk / 2) == 0) groups.push_back(ObsGroup{t[k].x, 0, 0, 0, 0});
+      const bool new_mask = k == 0 || t[k].x != t[k - 1].x;
+      if (new_mask || (by_op && t[k].op != t[k - 1].op) || k % (kObsTermChunk / 2) == 0) {
+        groups.push_back(ObsGroup{t[k].x, 0, 0, 0, 0, t[k].op, (new_mask ? 0u : 1u) | (by_op ? 2u : 0u)});
+      }
       groups.back().end = uint32_t(k + 1);
       groups.back().has_imag |= t[k].ny & 1u;
     }
@@ -662,7 +682,14 @@ bool value_mode(const qhbm_engine* h) { return h->opt_values_from_obs != 0 && h-
 // state each) plus a little per term: picoseconds per amplitude fitted on config 3 (XXZ, 20 qubits: 9 masks leave,
 // 8 groups; 5.8 against 7.5) and config 4 (512 random strings, 24 qubits: 453 leave, 173 groups; 177 against 100):
 //   gather  2.3 + 0.385 x (masks leaving its block)        block  0.9 + 0.43 x groups + 0.045 x terms
+// ("gather_multi_values" = 1: 2..4 observables go through the gather kernel's per-observable accumulators whatever the
+// cost model says -- tests and A/B runs)
+bool gather_multi_forced(const qhbm_engine* h) {
+  return h->opt_gather_multi > 0 && h->model.n_ops >= 2 && h->model.n_ops <= int(kObsGatherMultiOps) &&
+         h->opt_values_from_obs != 0 && h->opt_multi_values != 0;
+}
 bool block_kernel(const qhbm_engine* h) {
+  if (gather_multi_forced(h)) return false;
   if (h->fwd.plan.n_eff < kObsBlockBits || h->opt_obs_kernel == 0) return false;
   if (h->opt_obs_kernel > 0) return true;
   if (h->block_choice >= 0) return h->block_choice != 0;
@@ -703,11 +730,18 @@ bool multi_value_mode(const qhbm_engine* h) {
   // (the values of several observables always come from the block kernel -- the gather kernel has no such mode --,
   // whichever of the two forms lambda)
   if (h->opt_values_from_obs == 0 || h->opt_multi_values == 0 || h->model.n_ops < 2) return false;
+  if (gather_multi_forced(h)) return true;
   if (h->fwd.plan.n_eff < kObsBlockBits || h->opt_obs_kernel == 0) return false;
   if (h->model.n_ops > int(kObsMaxValueOps)) return false;
   if (h->opt_multi_values > 0) return true;
   return h->model.n_ops <= kMultiValueOps && h->fwd.plan.passes.size() > 1 && wide_observables(h);
 }
+
+// Two to four observables through the gather kernel with a value accumulator per observable
+// (apply_observable_kernel<A, OBS_GATHER_MULTI>): ONE launch returns the weighted lambda and every value -- on request only
+// ("gather_multi_values" = 1): the per-observable dot products make that launch VALU-bound at 4 x the single-observable
+// kernel's time.
+bool gather_multi_mode(const qhbm_engine* h) { return gather_multi_forced(h); }
 
 // Forward-only calls: whether the values come from the observable kernel (storing nothing) after lean passes.
 bool forward_values_from_observable(const qhbm_engine* h) {
@@ -790,7 +824,7 @@ int ensure_state_buffers(qhbm_engine* h, uint32_t cs, bool with_lam) {
 }
 
 int run_observable_chunk(qhbm_engine* h, uint32_t s0, uint32_t c, const float* d_upstream, bool value_mode,
-                         hipStream_t stream, bool store_lambda = true);
+                         hipStream_t stream, bool store_lambda = true, bool multi_values = false);
 int run_values_chunk(qhbm_engine* h, uint32_t row0, uint32_t c, hipStream_t stream);
 
 int forward(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_params, float* d_out,
@@ -827,9 +861,21 @@ bool observable_xcd_states(const qhbm_engine* h) {
 
 // lambda = O psi for the chunk in the workspace.  value_mode (a single observable): unweighted, and
 // <psi|O|psi> goes to the fixed-point value accumulators -- the forward sweep measured nothing.
+// multi_values (gather_multi_mode): the gather kernel with a value accumulator per observable -- the weighted lambda (if
+// stored) and every <psi|O_t|psi> from ONE launch.
 int run_observable_chunk(qhbm_engine* h, uint32_t s0, uint32_t c, const float* d_upstream, bool value_mode,
-                         hipStream_t stream, bool store_lambda) {
+                         hipStream_t stream, bool store_lambda, bool multi_values) {
   const uint32_t n_eff = uint32_t(h->fwd.plan.n_eff);
+  if (multi_values) {
+    HIPCHK(h->value_part.reserve(observable_value_parts(n_eff, c) * size_t(h->model.n_ops)));
+    hipEvent_t* ev = timer_begin(h, 2, stream);
+    HIPCHK(launch_apply_observable(h->psi.p, store_lambda ? h->lam.p : nullptr, n_eff, c, h->terms.p,
+                                   uint32_t(h->model.terms.size()), h->obs_groups.p, h->n_obs_groups,
+                                   store_lambda ? d_upstream : nullptr, uint32_t(h->model.n_ops), s0, h->op_scale.p,
+                                   h->vals64.p, h->value_part.p, observable_xcd_states(h), stream, true));
+    timer_end(ev, stream);
+    return 0;
+  }
   if (value_mode)
     HIPCHK(h->value_part.reserve(block_kernel(h) ? observable_blocks_value_parts(n_eff, c, 1u) : observable_value_parts(n_eff, c)));
   hipEvent_t* ev = timer_begin(h, 2, stream);
@@ -853,6 +899,7 @@ int run_observable_chunk(qhbm_engine* h, uint32_t s0, uint32_t c, const float* d
 // nothing stored: one observable through either kernel, several through the block kernel (multi_value_mode).
 int run_values_chunk(qhbm_engine* h, uint32_t row0, uint32_t c, hipStream_t stream) {
   if (h->model.n_ops == 1) return run_observable_chunk(h, row0, c, nullptr, true, stream, false);
+  if (gather_multi_mode(h)) return run_observable_chunk(h, row0, c, nullptr, false, stream, false, true);
   const uint32_t n_eff = uint32_t(h->fwd.plan.n_eff);
   HIPCHK(h->value_part.reserve(observable_blocks_value_parts(n_eff, c, uint32_t(h->model.n_ops))));
   hipEvent_t* ev = timer_begin(h, 2, stream);
@@ -915,9 +962,10 @@ int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_pa
   for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += cs) {
     const uint32_t c = std::min<uint32_t>(cs, uint32_t(U) - s0);
     if (int rc = run_forward_chunk(h, d_bits, s0, c, true, stream, vm || mv)) return rc;
-    if (mv)  // several observables: their values from one launch over the final states, lambda (weighted) from the next
+    const bool gm = mv && gather_multi_mode(h);  // 2..4 observables on the gather kernel: values AND lambda from one launch
+    if (mv && !gm)  // several observables: their values from one launch over the final states, lambda (weighted) from the next
       if (int rc = run_values_chunk(h, s0, c, stream)) return rc;
-    if (int rc = run_observable_chunk(h, s0, c, d_upstream, vm, stream)) return rc;
+    if (int rc = run_observable_chunk(h, s0, c, d_upstream, vm, stream, true, gm)) return rc;
     if (int rc = run_adjoint_chunk(h, d_bits, s0, c, stream)) return rc;
   }
   // value mode ran the sweep on the unweighted lambda: the upstream weight goes onto the gradient rows
@@ -1092,6 +1140,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "observable_xcd_states") h->opt_obs_xcd_states = int(value);
   else if (k == "observable_kernel") { h->opt_obs_kernel = int(value); h->block_choice = -1; }
   else if (k == "multi_observable_values") h->opt_multi_values = int(value);
+  else if (k == "gather_multi_values") h->opt_gather_multi = int(value);
   else if (k == "measure_tile_qubits") { h->opt_meas_tile = int(value); h->plans_valid = false; }
   else if (k == "values_from_observable") h->opt_values_from_obs = int(value);
   else if (k == "cph_wave_bits") { h->opt_cph_wave_bits = int(value); h->plans_valid = false; }
@@ -1527,7 +1576,8 @@ int qhbm_describe_schedule(qhbm_engine* h, char* buf, size_t buf_len) {
   std::string s = describe_plan(h->fwd.plan) + describe_plan(h->adj.plan);
   if (!h->model.terms.empty()) {  // which kernel forms lambda = O psi / the values (bench.py names it in `roofline.kernel`)
     s += std::string("observable kernel: lambda = ") + (block_kernel(h) ? "observable_blocks_kernel" : "apply_observable_kernel");
-    s += std::string(" values = ") + (multi_value_mode(h) || (value_mode(h) && block_kernel(h)) ? "observable_blocks_kernel"
+    s += std::string(" values = ") + (gather_multi_mode(h) ? "apply_observable_kernel (an accumulator per observable)"
+                                      : multi_value_mode(h) || (value_mode(h) && block_kernel(h)) ? "observable_blocks_kernel"
                                       : value_mode(h)                                            ? "apply_observable_kernel"
                                                                                                   : "measured in the passes");
     s += "\n";
@@ -1835,7 +1885,7 @@ int qhbm_traffic_model(qhbm_engine* h, int U, int with_vjp, double* fwd_bytes, d
   if (!with_vjp && from_obs) o = tile_all;  // psi read (gathered through L2), nothing written
   if (with_vjp) {
     o = 2.0 * tile_all;  // psi read (gathered through L2), lambda written
-    if (multi_value_mode(h)) o += tile_all;  // ... and the launch that returns the values of several observables
+    if (multi_value_mode(h) && !gather_multi_mode(h)) o += tile_all;  // ... and the launch that returns the values of several observables
     std::vector<PassArgs> args;
     std::vector<uint32_t> prog, tables;
     fill_args(h->adj.plan, h->model, &args, &prog, &tables);

@@ -26,7 +26,18 @@ struct ObsGroup {
   uint32_t x, end;
   uint32_t has_imag;  // some term of the group has an odd number of Y factors (imaginary weight)
   uint32_t n_h, n_l;
+  // Several observables with a value accumulator each (apply_observable_kernel<A, OBS_GATHER_MULTI>, at most
+  // kObsGatherMultiOps of them): the terms are sorted by (x, observable), a group holds ONE observable's terms of one mask,
+  // and a group whose mask equals the previous group's re-uses its gathered partners (same_x bit 0; bit 1: the array is
+  // in that order at all -- no group may then skip partner pairs as vanishing, its successor may need them).
+  uint32_t op, same_x;
 };
+enum ObsGatherMode : int {
+  OBS_GATHER_LAMBDA = 0,  // lambda = sum_k upstream[s, op_k] c_k P_k psi
+  OBS_GATHER_VALUE = 1,   // one observable: lambda = O psi (unweighted) and <psi|O|psi>
+  OBS_GATHER_MULTI = 2,   // 2..kObsGatherMultiOps observables: the weighted lambda (if asked for) AND every <psi|O_t|psi>
+};
+constexpr uint32_t kObsGatherMultiOps = 4;
 constexpr uint32_t obs_amps_per_thread(uint32_t n) { return n >= 11 ? 8u : 4u; }  // A of apply_observable_kernel<A>
 constexpr uint32_t kObsThreadMask = 0x1feu;                                        // index bits 1..8 = the thread
 constexpr uint32_t obs_slot_mask(uint32_t n) { return 1u | ((obs_amps_per_thread(n) / 2u - 1u) << 9); }  // bit 0 and 9 (, 10)
@@ -98,11 +109,13 @@ hipError_t launch_reduce_tiles(float* tile_grad, uint32_t n_states, uint32_t n_t
                                hipStream_t stream);
 // (value mode, out64 != null: `value_part` holds observable_value_parts(n, n_states) floats of scratch)
 size_t observable_value_parts(uint32_t n, uint32_t n_states);
+// (out64 != null: the values go to the fixed-point accumulators -- one observable, or `multi` (terms and groups in the
+// (x, observable) order of OBS_GATHER_MULTI; value_part then holds observable_value_parts(n, n_states) x n_ops floats))
 hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
                                    const float* op_scale, unsigned long long* out64, float* value_part,
-                                   bool xcd_states, hipStream_t stream);
+                                   bool xcd_states, hipStream_t stream, bool multi = false);
 // Terms measured on the final state in HBM (X-mask wider than a tile); accumulates into out64.
 hipError_t launch_measure_global(const float2* psi, uint32_t n, uint32_t n_states, const DevTerm* terms,
                                  uint32_t n_terms, const float* op_scale, unsigned long long* out64, uint32_t n_ops,

@@ -1752,9 +1752,13 @@ __device__ __forceinline__ void obs_gather(float4 (&buf)[A / 2], const float2* _
 }
 // One group: acc[s] += (signed weight sum of the group's terms at slot s) * psi[j ^ x].  `buf` holds the
 // gathered partners if the mask leaves the block; a mask inside the block reads the block's LDS copy.
-template <int A>
+// MULTI (several observables, OBS_GATHER_MULTI): the staged weights are the bare coefficients of ONE observable (the
+// group's), `upw` its upstream weight for lambda (0 when no lambda is formed), and <psi|O_op|psi> collects
+// sum_a Re(conj(psi_a) * (weight_a * psi[a ^ x])) in `eval`.
+template <int A, bool MULTI = false>
 __device__ __forceinline__ void obs_consume(const ObsGroup& gr, float4 (&buf)[A / 2], const v2f* own, const ObsStage<A>& st,
-                                            uint32_t& k, uint32_t k0, uint32_t tb, v2f (&acc)[A]) {
+                                            uint32_t& k, uint32_t k0, uint32_t tb, v2f (&acc)[A], float upw = 1.f,
+                                            float* eval = nullptr) {
   constexpr int P = A / 2;
   if (gr.x < 256u * A) {  // the mask permutes the workgroup's own block: served from its LDS copy
 #pragma unroll
@@ -1782,8 +1786,17 @@ __device__ __forceinline__ void obs_consume(const ObsGroup& gr, float4 (&buf)[A 
     for (int p = 0; p < P; ++p) {
       const v2f lo = v2f{buf[p].x, buf[p].y}, hi = v2f{buf[p].z, buf[p].w};
       const v2f v0 = odd ? hi : lo, v1 = odd ? lo : hi;
-      acc[2 * p] += v2f{cr[2 * p] * v0.x - ci[2 * p] * v0.y, cr[2 * p] * v0.y + ci[2 * p] * v0.x};
-      acc[2 * p + 1] += v2f{cr[2 * p + 1] * v1.x - ci[2 * p + 1] * v1.y, cr[2 * p + 1] * v1.y + ci[2 * p + 1] * v1.x};
+      const v2f t0 = v2f{cr[2 * p] * v0.x - ci[2 * p] * v0.y, cr[2 * p] * v0.y + ci[2 * p] * v0.x};
+      const v2f t1 = v2f{cr[2 * p + 1] * v1.x - ci[2 * p + 1] * v1.y, cr[2 * p + 1] * v1.y + ci[2 * p + 1] * v1.x};
+      if constexpr (MULTI) {
+        const float4 mine = *reinterpret_cast<const float4*>(&own[tb + 512u * p]);
+        *eval += (mine.x * t0.x + mine.y * t0.y) + (mine.z * t1.x + mine.w * t1.y);
+        acc[2 * p] += upw * t0;
+        acc[2 * p + 1] += upw * t1;
+      } else {
+        acc[2 * p] += t0;
+        acc[2 * p + 1] += t1;
+      }
     }
   } else {  // real weights only (X/Z strings, even Y count): the common case
     float c[A];
@@ -1811,6 +1824,25 @@ __device__ __forceinline__ void obs_consume(const ObsGroup& gr, float4 (&buf)[A 
 #pragma unroll
       for (int a = 0; a < A; ++a) c[a] += __uint_as_float(__float_as_uint(st.flip[k - k0][a]) ^ sg0);
     }
+    if constexpr (MULTI) {  // the value first (bare coefficients), then lambda with the observable's upstream weight
+      float e = 0.f;
+      if (odd) {  // (slot 2p pairs with the partner pair's second amplitude, 2p + 1 with its first)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const float4 mine = *reinterpret_cast<const float4*>(&own[tb + 512u * p]);
+          e += c[2 * p] * (mine.x * buf[p].z + mine.y * buf[p].w) + c[2 * p + 1] * (mine.z * buf[p].x + mine.w * buf[p].y);
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const float4 mine = *reinterpret_cast<const float4*>(&own[tb + 512u * p]);
+          e += c[2 * p] * (mine.x * buf[p].x + mine.y * buf[p].y) + c[2 * p + 1] * (mine.z * buf[p].z + mine.w * buf[p].w);
+        }
+      }
+      *eval += e;
+#pragma unroll
+      for (int a = 0; a < A; ++a) c[a] *= upw;
+    }
     if (odd) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {  // one packed FMA per amplitude
@@ -1830,13 +1862,20 @@ __device__ __forceinline__ void obs_consume(const ObsGroup& gr, float4 (&buf)[A 
 // <psi|O|psi> = sum_j Re(conj(psi_j) lambda_j) leaves as a by-product in the fixed-point accumulator
 // value_part[state, workgroup] (value_parts_kernel) -- the forward sweep then needs no measurement at all, and the caller applies the
 // upstream weight to the state's gradient row (the adjoint sweep is linear in lambda).
-template <int A, bool VALUE>
-__global__ __launch_bounds__(256, 5) void apply_observable_kernel(
+// VM = OBS_GATHER_MULTI: 2..4 observables, one launch for the weighted lambda AND every <psi|O_t|psi> (round 4 took
+// the values from a second launch of the block kernel: config 3 as XX / YY / ZZ sums 64 ms for the two instead of 24).
+// The terms come sorted by (x, observable); a group is one observable's share of a mask, carries the BARE coefficients
+// (the upstream weight of its observable multiplies the group's folded weights when lambda is formed), and a group on
+// the mask of its predecessor re-uses the gathered partners.  No partner run can be skipped as vanishing: XX + YY
+// cancels where the two bits agree, XX alone and YY alone do not.
+template <int A, int VM>
+__global__ __launch_bounds__(256, VM == OBS_GATHER_MULTI ? 4 : 5) void apply_observable_kernel(
     const float2* __restrict__ psi, float2* __restrict__ lam, uint32_t n, const DevTerm* __restrict__ terms,
     uint32_t n_terms, const ObsGroup* __restrict__ groups, uint32_t n_groups,
     const float* __restrict__ upstream, uint32_t n_ops, uint32_t state0, float* __restrict__ value_part,
     uint32_t nb /* workgroups per state */, uint32_t n_states, uint32_t xcd_states) {
   constexpr int P = A / 2;  // adjacent pairs per thread
+  constexpr bool VALUE = VM == OBS_GATHER_VALUE, MULTI = VM == OBS_GATHER_MULTI;
   __shared__ ObsStage<A> st;
   // Workgroups are dealt round-robin to the 8 XCDs (linear id mod 8), each with its own L2.
   //   xcd_states: XCD k works on state 8 g + k, its blocks in index order -- EVERY partner run j ^ x of
@@ -1861,7 +1900,7 @@ __global__ __launch_bounds__(256, 5) void apply_observable_kernel(
   const uint32_t tb = threadIdx.x << 1;                  // thread bits of j
   const float2* ps = psi + (size_t(s_local) << n);
   const uint32_t j0 = jb + tb;                           // the thread's first amplitude
-  const float* up = VALUE ? nullptr : upstream + size_t(state0 + s_local) * n_ops;
+  const float* up = (VALUE || !upstream) ? nullptr : upstream + size_t(state0 + s_local) * n_ops;
   __shared__ __attribute__((aligned(16))) v2f own[256 * A];
   float4 self[P];
 #pragma unroll
@@ -1876,13 +1915,14 @@ __global__ __launch_bounds__(256, 5) void apply_observable_kernel(
   v2f acc[A];
 #pragma unroll
   for (int a = 0; a < A; ++a) acc[a] = v2f{0.f, 0.f};
+  float ev[4] = {0.f, 0.f, 0.f, 0.f};  // MULTI: <psi|O_t|psi> of this thread's amplitudes
   uint32_t g = 0;
   for (uint32_t k0 = 0; k0 < n_terms; k0 += kObsChunk) {
     const uint32_t k1 = min(n_terms, k0 + kObsChunk);
     if (k0) __syncthreads();
     for (uint32_t k = k0 + threadIdx.x; k < k1; k += 256u) {
       const DevTerm tm = terms[k];
-      const float w = VALUE ? tm.coeff : up[tm.op] * tm.coeff;
+      const float w = (VALUE || MULTI) ? tm.coeff : up[tm.op] * tm.coeff;
       const float m = (tm.ny & 2u) ? -w : w;
       // parity of the workgroup-constant part: block bits of j and the x & z overlap (= ny)
       const uint32_t base = (uint32_t(__popc(jb & tm.z)) + tm.ny) & 1u;
@@ -1913,17 +1953,29 @@ __global__ __launch_bounds__(256, 5) void apply_observable_kernel(
       uint32_t pairs = 0;
 #pragma unroll
       for (int p = 0; p < P; ++p) pairs |= ((nz >> (2 * p)) & 3u) ? 1u << p : 0u;
-      if (a == 0) st.live[kb - k0] = (gq.has_imag || gq.n_h != gq.end - kb) ? (1u << P) - 1u : pairs;
+      // ((mask, observable) order -- same_x bit 1 --: a group may feed on its predecessor's partners: every pair is fetched)
+      if (a == 0) st.live[kb - k0] = (MULTI || (gq.same_x & 2u) || gq.has_imag || gq.n_h != gq.end - kb) ? (1u << P) - 1u : pairs;
     }
     __syncthreads();
     uint32_t k = k0;
     uint32_t live_next = st.live[0];  // read one group ahead: the gathers must not wait for it
     while (g < n_groups && gr.end <= k1) {  // gr = groups[g], wave-uniform
       const uint32_t live = uni(live_next);
-      if (gr.x >= 256u * A) obs_gather<A>(cur, ps, j0, gr.x, live);
+      if (gr.x >= 256u * A && !(gr.same_x & 1u)) obs_gather<A>(cur, ps, j0, gr.x, live);
       live_next = st.live[min(gr.end - k0, kObsChunk - 1u)];  // (past the chunk's last group: unused)
-      if (live) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);  // else: the group vanishes on the whole block
-      else k = gr.end;
+      if constexpr (MULTI) {
+        const uint32_t op = uni(gr.op);
+        const float upw = up ? up[op] : 0.f;  // (wave-uniform: a scalar load)
+        float e = 0.f;
+        obs_consume<A, true>(gr, cur, own, st, k, k0, tb, acc, upw, &e);
+        if (op == 0u) ev[0] += e;  // (wave-uniform triangles: a register per observable)
+        if (op == 1u) ev[1] += e;
+        if (op == 2u) ev[2] += e;
+        if (op == 3u) ev[3] += e;
+      } else {
+        if (live) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);  // else: the group vanishes on the whole block
+        else k = gr.end;
+      }
       ++g;
       if (g < n_groups) gr = groups[g];
     }
@@ -1941,6 +1993,21 @@ __global__ __launch_bounds__(256, 5) void apply_observable_kernel(
 #else
       *reinterpret_cast<v4f_nt*>(&ls[tb + 512u * p]) = v;
 #endif
+    }
+  }
+  if constexpr (MULTI) {
+    const float e0 = wave_sum(ev[0]), e1 = wave_sum(ev[1]), e2 = wave_sum(ev[2]), e3 = wave_sum(ev[3]);
+    __syncthreads();  // (the staging area is free now)
+    float* wave_part = reinterpret_cast<float*>(&st.term[0]);  // [4 observables][4 waves]
+    if ((threadIdx.x & 63u) == 0u) {
+      const uint32_t w = threadIdx.x >> 6;
+      wave_part[w] = e0; wave_part[4u + w] = e1; wave_part[8u + w] = e2; wave_part[12u + w] = e3;
+    }
+    __syncthreads();
+    // one partial per (state, logical block, observable): value_parts_multi_kernel adds them in block order
+    if (threadIdx.x < n_ops && threadIdx.x < 4u) {
+      const float* wp = wave_part + 4u * threadIdx.x;
+      value_part[(size_t(s_local) * nb + bx) * n_ops + threadIdx.x] = (wp[0] + wp[1]) + (wp[2] + wp[3]);
     }
   }
   if constexpr (VALUE) {
@@ -1979,6 +2046,23 @@ __global__ __launch_bounds__(256) void value_parts_kernel(const float* __restric
     __syncthreads();
   }
   if (threadIdx.x == 0) out64[state0 + s] += to_fixed(float(part[0]), op_scale[0]);
+}
+
+// ... the same for several observables: value_part[(state, block), op] (apply_observable_kernel<A, OBS_GATHER_MULTI>).
+__global__ __launch_bounds__(256) void value_parts_multi_kernel(const float* __restrict__ value_part, uint32_t n_blocks,
+                                                                uint32_t n_ops, const float* __restrict__ op_scale,
+                                                                unsigned long long* __restrict__ out64, uint32_t state0) {
+  __shared__ double part[256];
+  const uint32_t s = blockIdx.x, t = blockIdx.y;
+  double acc = 0.0;
+  for (uint32_t b = threadIdx.x; b < n_blocks; b += 256u) acc += double(value_part[(size_t(s) * n_blocks + b) * n_ops + t]);
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (int(threadIdx.x) < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out64[size_t(state0 + s) * n_ops + t] += to_fixed(float(part[0]), op_scale[t]);
 }
 
 // ================================================================================
@@ -2820,21 +2904,30 @@ hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, u
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
                                    const float* op_scale, unsigned long long* out64, float* value_part,
-                                   bool xcd_states, hipStream_t stream) {
-  const bool value = out64 != nullptr;  // single observable: unweighted lambda + <psi|O|psi> (see the kernel)
+                                   bool xcd_states, hipStream_t stream, bool multi) {
+  // out64: single observable -- unweighted lambda + <psi|O|psi>; `multi` -- the weighted lambda and every value
+  const int mode = multi ? OBS_GATHER_MULTI : (out64 != nullptr ? OBS_GATHER_VALUE : OBS_GATHER_LAMBDA);
+  if (multi && (n_ops < 2u || n_ops > kObsGatherMultiOps || !out64)) return hipErrorInvalidValue;
   const uint32_t nb = (1u << n) / (256u * obs_amps_per_thread(n));
   const uint32_t xs = xcd_states && nb >= 128u ? 1u : 0u;  // (a state must at least fill an XCD's workgroup slots)
 #define QHBM_OBS(A_, V_)                                                                                          \
   hipLaunchKernelGGL((apply_observable_kernel<A_, V_>), dim3(nb * n_states), dim3(256), 0, stream, psi, lam, n, terms, \
                      n_terms, groups, n_groups, upstream, n_ops, state0, value_part, nb, n_states, xs)
   if (obs_amps_per_thread(n) == 8u) {
-    if (value) QHBM_OBS(8, true); else QHBM_OBS(8, false);
+    if (mode == OBS_GATHER_MULTI) QHBM_OBS(8, OBS_GATHER_MULTI);
+    else if (mode == OBS_GATHER_VALUE) QHBM_OBS(8, OBS_GATHER_VALUE);
+    else QHBM_OBS(8, OBS_GATHER_LAMBDA);
   } else {
-    if (value) QHBM_OBS(4, true); else QHBM_OBS(4, false);
+    if (mode == OBS_GATHER_MULTI) QHBM_OBS(4, OBS_GATHER_MULTI);
+    else if (mode == OBS_GATHER_VALUE) QHBM_OBS(4, OBS_GATHER_VALUE);
+    else QHBM_OBS(4, OBS_GATHER_LAMBDA);
   }
 #undef QHBM_OBS
-  if (value && n_states)
+  if (mode == OBS_GATHER_VALUE && n_states)
     hipLaunchKernelGGL(value_parts_kernel, dim3(n_states), dim3(256), 0, stream, value_part, nb, op_scale, out64, state0);
+  if (mode == OBS_GATHER_MULTI && n_states)
+    hipLaunchKernelGGL(value_parts_multi_kernel, dim3(n_states, n_ops), dim3(256), 0, stream, value_part, nb, n_ops, op_scale,
+                       out64, state0);
   return hipGetLastError();
 }
 

@@ -209,15 +209,15 @@ VARIANTS.update({
 })
 
 
-_OBS_LOOP = "      if (live) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);  // else: the group vanishes on the whole block"
+_OBS_LOOP = "        if (live) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);  // else: the group vanishes on the whole block"
 VARIANTS.update({
     # lambda = O psi (wrong lambda): without the masks that leave the block (no gathers: staging + the masks served
     # from LDS + the block's own read and write), without the masks inside the block, without either
-    "obs_no_far": lambda t: once(t, _OBS_LOOP, "      if (live && gr.x < 256u * A) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);").replace(
-        "      if (gr.x >= 256u * A) obs_gather<A>(cur, ps, j0, gr.x, live);", "", 1),
-    "obs_no_near": lambda t: once(t, _OBS_LOOP, "      if (live && gr.x >= 256u * A) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);"),
-    "obs_no_groups": lambda t: once(t, _OBS_LOOP, "      if (live && gr.x == 0x7fffffffu) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);").replace(
-        "      if (gr.x >= 256u * A) obs_gather<A>(cur, ps, j0, gr.x, live);", "", 1),
+    "obs_no_far": lambda t: once(t, _OBS_LOOP, "        if (live && gr.x < 256u * A) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);").replace(
+        "      if (gr.x >= 256u * A && !(gr.same_x & 1u)) obs_gather<A>(cur, ps, j0, gr.x, live);", "", 1),
+    "obs_no_near": lambda t: once(t, _OBS_LOOP, "        if (live && gr.x >= 256u * A) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);"),
+    "obs_no_groups": lambda t: once(t, _OBS_LOOP, "        if (live && gr.x == 0x7fffffffu) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);").replace(
+        "      if (gr.x >= 256u * A && !(gr.same_x & 1u)) obs_gather<A>(cur, ps, j0, gr.x, live);", "", 1),
 })
 
 

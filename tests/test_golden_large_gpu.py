@@ -65,8 +65,9 @@ def test_c3_values_and_vjp_against_oracle(c3, opts):
     assert opts.get("chunk_states", 0) and opts["chunk_states"] < len(bits)
 
 
-@pytest.mark.parametrize("opts", [{}, {"multi_observable_values": 0}, {"observable_kernel": 0}],
-                         ids=["values-from-the-block-kernel", "measured-in-the-passes", "gather-kernel"])
+@pytest.mark.parametrize("opts", [{}, {"gather_multi_values": 1}, {"multi_observable_values": 0}, {"observable_kernel": 0}],
+                         ids=["values-from-the-block-kernel", "values-and-lambda-from-one-gather-launch", "measured-in-the-passes",
+                              "gather-kernel"])
 def test_c3_three_observables_values_and_vjp_against_oracle(c3, opts):
   """Config 3's circuit with the XXZ chain as THREE observables (XX, YY, ZZ sums) -- several operators per call, the
   reference's normal usage (tests/inference/qnn_test.py:187-190,266-369): lean forward passes + one launch for the
@@ -79,6 +80,8 @@ def test_c3_three_observables_values_and_vjp_against_oracle(c3, opts):
   ops3 = [whole[0::3], whole[1::3], whole[2::3]]
   assert all(x != 0 and z == 0 for _, x, z in ops3[0]) and all(x == z != 0 for _, x, z in ops3[1]) and all(x == 0 for _, x, z in ops3[2])
   eng = _engine(n, gates, len(c3["params"]), ops3, **opts)
+  if opts.get("gather_multi_values"):  # round 5: the gather kernel with a value accumulator per observable (on request)
+    assert "values = apply_observable_kernel (an accumulator per observable)" in eng.describe_schedule()
   bits, params = c3["bits"], c3["params"]
   norm = sum(abs(c) for c, _, _ in whole)
   vals = eng.expectation(bits, params).cpu().numpy()

@@ -157,6 +157,44 @@ def test_three_observables_xxz_split_at_16_qubits_match_the_single_sum(kernel):
   np.testing.assert_allclose(v3.sum(1, keepdims=True), v1, atol=5e-5 * (2 * (n - 1) + 0.5 * (n - 1)), rtol=0)
 
 
+@pytest.mark.parametrize("n_ops,n", [(2, 12), (3, 14), (4, 15)])
+def test_gather_kernel_with_an_accumulator_per_observable_matches_the_oracle(n_ops, n):
+  """Round 5: two to four observables through apply_observable_kernel<A, OBS_GATHER_MULTI> -- the weighted lambda AND
+  every <psi|O_t|psi> from one launch ("gather_multi_values" = 1; not the default: measured slower than two launches at
+  config 3's size, profiles/r05_xxz3_gather_multi_ab.txt) -- on random Pauli sums with real and imaginary weights (odd Y counts), masks
+  inside and outside the kernel's block, shared masks between observables; values-only calls, VJP calls, the retained
+  pair, chunked batches; against the numpy oracle and bit-identical from call to call."""
+  rng = np.random.default_rng(100 * n_ops + n)
+  gates, names = O.hea_gates(n, 2, "gm")
+  params = rng.uniform(-1, 1, len(names))
+  ops = _random_ops(rng, n, n_ops, 7, p_identity=0.6)
+  ops[1] = ops[1] + [(0.5, x, z ^ 1) for _, x, z in ops[0][:3]]   # masks shared between observables
+  bits = rng.integers(0, 2, size=(9, n)).astype(np.int8)
+  up = rng.normal(size=(9, n_ops))
+  eng = _engine(n, gates, len(names), ops, gather_multi_values=1, tile_qubits=10, adjoint_tile_qubits=10)
+  assert "an accumulator per observable" in eng.describe_schedule()
+  v, g = _check(eng, n, gates, params, bits, ops, up)
+  v2, g2 = eng.expectation_vjp(bits, params, up)
+  np.testing.assert_array_equal(v, v2.cpu().numpy())                # bit-identical from call to call
+  np.testing.assert_array_equal(g, g2.cpu().numpy())
+  fwd = eng.expectation(bits, params).cpu().numpy()
+  np.testing.assert_array_equal(fwd, v2.cpu().numpy())             # values-only launch: the same accumulators
+  eng.expectation(bits, params, retain=True)
+  if eng.retained is not None:
+    g_r = eng.expectation_vjp_retained(bits, params, up).cpu().numpy()
+    np.testing.assert_allclose(g_r, g2.cpu().numpy(), atol=2e-6 * max(1.0, float(np.abs(g_r).max())), rtol=0)
+  chunked = _engine(n, gates, len(names), ops, gather_multi_values=1, tile_qubits=10, adjoint_tile_qubits=10, chunk_states=4)
+  v3, g3 = chunked.expectation_vjp(bits, params, up)
+  assert torch.equal(v2, v3) and torch.equal(g2, g3)
+  # the default path (values from the block kernel's launch, where the state has a block) agrees
+  if n >= 13:
+    old = _engine(n, gates, len(names), ops, multi_observable_values=1, tile_qubits=10, adjoint_tile_qubits=10)
+    assert "an accumulator per observable" not in old.describe_schedule()
+    v4, g4 = old.expectation_vjp(bits, params, up)
+    np.testing.assert_allclose(v4.cpu().numpy(), v2.cpu().numpy(), atol=2e-5 * max(sum(abs(c) for c, _, _ in op) for op in ops), rtol=0)
+    np.testing.assert_allclose(g4.cpu().numpy(), g2.cpu().numpy(), atol=1e-4 * max(1.0, float(g2.abs().max())), rtol=0)
+
+
 def test_parameter_shift_takes_its_values_from_the_block_kernel():
   n = 14
   rng = np.random.default_rng(14)
