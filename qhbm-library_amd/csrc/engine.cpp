@@ -118,7 +118,7 @@ struct qhbm_engine {
   bool terms_by_op = false;  // the uploaded terms / groups are in the (mask, observable) order of gather_multi_mode
   DevBuf<ObsBTerm> obs_bterms;    // the same terms sorted and cut for the block-grouped kernels (observable.hip)
   DevBuf<ObsBGroup> obs_bgroups;
-  uint32_t n_obs_bgroups = 0;
+  uint32_t n_obs_bgroups = 0, n_obs_bdirect = 0;  // (the first n_obs_bdirect groups hold one mask each: kernels.h ObsBGroup)
   int opt_obs_kernel = -1;      // lambda = O psi / values: 0 = one gather per mask (apply_observable_kernel), 1 = partner blocks through
                                 // LDS (observable_blocks_kernel), -1 = whichever the fitted cost model prices lower (block_kernel())
   mutable int block_choice = -1;  // cached verdict of block_kernel() (-1: not computed for the installed model / options)
@@ -559,7 +559,16 @@ int upload_model(qhbm_engine* h) {
         }
         units.swap(ordered);
       }
+      // DIRECT units first (round 5): a unit of ONE mask is applied by one half-workgroup from partner rows it loads
+      // straight into registers (observable.hip phase A) -- staging 64 KiB in LDS for one mask to read back was the
+      // dearest way to apply it.  QHBM_OBS_DIRECT_TERMS: the most terms such a unit may hold (0 = none go direct).
+      static const size_t direct_cap = std::getenv("QHBM_OBS_DIRECT_TERMS") ? size_t(std::max(0, std::atoi(std::getenv("QHBM_OBS_DIRECT_TERMS")))) : 4;
+      std::stable_partition(units.begin(), units.end(), [](const Unit& u) { return u.masks.size() == 1 && u.terms <= direct_cap; });
+      uint32_t n_direct = 0;
+      for (const Unit& u : units) n_direct += (u.masks.size() == 1 && u.terms <= direct_cap) ? 1u : 0u;
+      h->n_obs_bdirect = n_direct;
       for (const Unit& u : units) {
+        const bool direct = groups2.size() < n_direct;
         // the unit's masks dealt to the two half-workgroups by term count, largest first (the halves run in step: a unit
         // costs what its larger half costs)
         std::vector<size_t> order(u.masks.size());
@@ -580,7 +589,7 @@ int upload_model(qhbm_engine* h) {
           std::sort(half[hsel].begin(), half[hsel].end(), [&](size_t a, size_t b) { return u.masks[a].first < u.masks[b].first; });
           for (size_t m : half[hsel])
             for (size_t i = u.masks[m].first; i < u.masks[m].second; ++i)
-              terms2.push_back(obs_block_term(bt[i], i == u.masks[m].first));
+              terms2.push_back(obs_block_term(bt[i], !direct && i == u.masks[m].first));
           if (hsel == 0) g.mid = uint32_t(terms2.size());
         }
         g.end = uint32_t(terms2.size());
@@ -884,7 +893,7 @@ int run_observable_chunk(qhbm_engine* h, uint32_t s0, uint32_t c, const float* d
     HIPCHK(launch_observable_blocks(mode, h->psi.p, store_lambda ? h->lam.p : nullptr, n_eff, c, h->obs_bterms.p,
                                     h->obs_bgroups.p, h->n_obs_bgroups, d_upstream, uint32_t(h->model.n_ops), s0,
                                     h->op_scale.p, value_mode ? h->vals64.p : nullptr, h->value_part.p,
-                                    observable_xcd_states(h), stream));
+                                    observable_xcd_states(h), stream, h->n_obs_bdirect));
   } else {
     HIPCHK(launch_apply_observable(h->psi.p, store_lambda ? h->lam.p : nullptr, n_eff, c, h->terms.p,
                                    uint32_t(h->model.terms.size()), h->obs_groups.p, h->n_obs_groups, d_upstream,
@@ -905,7 +914,7 @@ int run_values_chunk(qhbm_engine* h, uint32_t row0, uint32_t c, hipStream_t stre
   hipEvent_t* ev = timer_begin(h, 2, stream);
   HIPCHK(launch_observable_blocks(OBS_VALUES_MULTI, h->psi.p, nullptr, n_eff, c, h->obs_bterms.p, h->obs_bgroups.p,
                                   h->n_obs_bgroups, nullptr, uint32_t(h->model.n_ops), row0, h->op_scale.p, h->vals64.p,
-                                  h->value_part.p, observable_xcd_states(h), stream));
+                                  h->value_part.p, observable_xcd_states(h), stream, h->n_obs_bdirect));
   timer_end(ev, stream);
   return 0;
 }

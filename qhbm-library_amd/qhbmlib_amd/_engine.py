@@ -308,6 +308,8 @@ class Engine:
   def clock_probe(self):
     """The chip's sustained packed-fp32 rate right now: dict of `ghz` (shader clock during the probe),
     `cycles_per_pk_fma` and `tflops` (include/qhbm_engine.h qhbm_clock_probe).  Synchronises the stream."""
+    if self.device is None:
+      raise EngineError("planning-only engine: no device, no CPU fallback")
     g, c, t = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
     self._check(self._lib.qhbm_clock_probe(self._h, ctypes.byref(g), ctypes.byref(c), ctypes.byref(t), self._stream()))
     return {"ghz": g.value, "cycles_per_pk_fma": c.value, "tflops": t.value}

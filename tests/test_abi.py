@@ -199,6 +199,33 @@ def test_flop_model_counts_the_gate_arithmetic_of_the_plan():
   assert 16.0 * 320 * 2**20 / 4 < f3["bwd_flops"] < (16.0 * 320 + 17.25 * 400) * 2**20
 
 
+def test_op_census_counts_the_micro_ops_the_plan_executes():
+  """qhbm_op_census (ABI v5): executed micro-ops per pass in wave-executions per state -- the weights of the dynamic
+  instruction mix (scripts/instruction_mix.py).  Config 3's circuit: every one of the 320 X gates runs on every live
+  wave; the census agrees with the flop model's count of X work; planning-only engines answer; so does
+  qhbm_plan_builds."""
+  n, layers = 20, 16
+  eng = _planner(n, layers, O.xxz_chain_op(n))
+  fwd, adj = eng.op_census(adjoint=False), eng.op_census(adjoint=True)
+  assert (len(fwd), len(adj)) == eng.num_passes()
+  for row in fwd + adj:
+    assert set(row) == set(E.Engine.CENSUS_COLUMNS) and all(np.isfinite(v) and v >= 0 for v in row.values())
+  assert sum(r["reduce8"] for r in fwd) == 0 and sum(r["reduce8"] for r in adj) > 0
+  # the second forward pass works on the 32 tiles the first one can have reached; full passes on all 256
+  assert fwd[0]["tiles"] == 1 and max(r["tiles"] for r in fwd) == 256
+  # an un-pruned wave executes each of the 320 X gates once: 64 waves per tile-set of a state at most
+  waves_full = 256 * 4
+  x_total = sum(r["x"] + r["x_no_slot"] for r in adj)
+  assert 320 * 0.3 * waves_full < x_total <= 320 * waves_full
+  assert sum(r["x_no_slot"] for r in adj) == 0                      # every parameter trainable
+  frozen = _planner(n, layers, O.xxz_chain_op(n))
+  frozen.set_gradient_mask(np.arange(frozen.n_params) % 2 == 0)
+  assert sum(r["x_no_slot"] for r in frozen.op_census(adjoint=True)) > 0
+  assert eng.plan_builds() == (1, 1) and frozen.plan_builds()[1] >= 1
+  with pytest.raises(E.EngineError):
+    eng.clock_probe()                                               # needs the device: no CPU fallback
+
+
 def test_graft_entry_build_checks_the_header_version():
   """__graft_entry__.build() compares the library's ABI version with the header's (a hard-coded number went stale
   when the ABI moved to v4); its source must not pin a literal."""

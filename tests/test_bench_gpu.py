@@ -37,6 +37,12 @@ def test_bench_single_process_line():
   hbm, comp = line["roofline"]["hbm"], line["roofline"]["compute"]
   assert 0 < hbm["frac"] <= 1.0 and hbm["peak"] == 8000.0 and 0 < comp["frac"] <= 1.0 and comp["peak"] == 157.3
   assert comp["achieved_TFs"] == pytest.approx(comp["frac"] * 157.3) and comp["flops_per_launch"] > 0
+  # the ATTAINABLE compute ceiling is measured in the run (qhbm_clock_probe): sustained packed-fp32 rate at the clock
+  # the chip holds right after the timed region -- below the nominal 157.3, above what the kernel reaches
+  probe = comp["probe"]
+  assert 1.0 < probe["ghz"] <= 2.6 and 3.9 <= probe["cycles_per_pk_fma"] <= 5.0, probe
+  assert comp["attainable_peak"] == pytest.approx(probe["tflops"]) and 60.0 < probe["tflops"] <= 157.3
+  assert comp["attainable_frac"] == pytest.approx(comp["achieved_TFs"] / probe["tflops"])
   assert line["roofline"]["bound"] == ("fp32_valu" if comp["frac"] > hbm["frac"] else "hbm")
   assert line["roofline"]["frac"] == pytest.approx(max(hbm["frac"], comp["frac"]))
   assert "12-qubit TFIM ring" in line["config"]["workload"] and line["config"]["states_total"] == 16
