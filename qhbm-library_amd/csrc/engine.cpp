@@ -118,7 +118,7 @@ struct qhbm_engine {
   bool terms_by_op = false;  // the uploaded terms / groups are in the (mask, observable) order of gather_multi_mode
   DevBuf<ObsBTerm> obs_bterms;    // the same terms sorted and cut for the block-grouped kernels (observable.hip)
   DevBuf<ObsBGroup> obs_bgroups;
-  uint32_t n_obs_bgroups = 0, n_obs_bdirect = 0;  // (the first n_obs_bdirect groups hold one mask each: kernels.h ObsBGroup)
+  uint32_t n_obs_bgroups = 0;
   int opt_obs_kernel = -1;      // lambda = O psi / values: 0 = one gather per mask (apply_observable_kernel), 1 = partner blocks through
                                 // LDS (observable_blocks_kernel), -1 = whichever the fitted cost model prices lower (block_kernel())
   mutable int block_choice = -1;  // cached verdict of block_kernel() (-1: not computed for the installed model / options)
@@ -559,16 +559,7 @@ int upload_model(qhbm_engine* h) {
         }
         units.swap(ordered);
       }
-      // DIRECT units first (round 5): a unit of ONE mask is applied by one half-workgroup from partner rows it loads
-      // straight into registers (observable.hip phase A) -- staging 64 KiB in LDS for one mask to read back was the
-      // dearest way to apply it.  QHBM_OBS_DIRECT_TERMS: the most terms such a unit may hold (0 = none go direct).
-      static const size_t direct_cap = std::getenv("QHBM_OBS_DIRECT_TERMS") ? size_t(std::max(0, std::atoi(std::getenv("QHBM_OBS_DIRECT_TERMS")))) : 4;
-      std::stable_partition(units.begin(), units.end(), [](const Unit& u) { return u.masks.size() == 1 && u.terms <= direct_cap; });
-      uint32_t n_direct = 0;
-      for (const Unit& u : units) n_direct += (u.masks.size() == 1 && u.terms <= direct_cap) ? 1u : 0u;
-      h->n_obs_bdirect = n_direct;
       for (const Unit& u : units) {
-        const bool direct = groups2.size() < n_direct;
         // the unit's masks dealt to the two half-workgroups by term count, largest first (the halves run in step: a unit
         // costs what its larger half costs)
         std::vector<size_t> order(u.masks.size());
@@ -589,7 +580,7 @@ int upload_model(qhbm_engine* h) {
           std::sort(half[hsel].begin(), half[hsel].end(), [&](size_t a, size_t b) { return u.masks[a].first < u.masks[b].first; });
           for (size_t m : half[hsel])
             for (size_t i = u.masks[m].first; i < u.masks[m].second; ++i)
-              terms2.push_back(obs_block_term(bt[i], !direct && i == u.masks[m].first));
+              terms2.push_back(obs_block_term(bt[i], i == u.masks[m].first));
           if (hsel == 0) g.mid = uint32_t(terms2.size());
         }
         g.end = uint32_t(terms2.size());
@@ -893,7 +884,7 @@ int run_observable_chunk(qhbm_engine* h, uint32_t s0, uint32_t c, const float* d
     HIPCHK(launch_observable_blocks(mode, h->psi.p, store_lambda ? h->lam.p : nullptr, n_eff, c, h->obs_bterms.p,
                                     h->obs_bgroups.p, h->n_obs_bgroups, d_upstream, uint32_t(h->model.n_ops), s0,
                                     h->op_scale.p, value_mode ? h->vals64.p : nullptr, h->value_part.p,
-                                    observable_xcd_states(h), stream, h->n_obs_bdirect));
+                                    observable_xcd_states(h), stream));
   } else {
     HIPCHK(launch_apply_observable(h->psi.p, store_lambda ? h->lam.p : nullptr, n_eff, c, h->terms.p,
                                    uint32_t(h->model.terms.size()), h->obs_groups.p, h->n_obs_groups, d_upstream,
@@ -914,7 +905,7 @@ int run_values_chunk(qhbm_engine* h, uint32_t row0, uint32_t c, hipStream_t stre
   hipEvent_t* ev = timer_begin(h, 2, stream);
   HIPCHK(launch_observable_blocks(OBS_VALUES_MULTI, h->psi.p, nullptr, n_eff, c, h->obs_bterms.p, h->obs_bgroups.p,
                                   h->n_obs_bgroups, nullptr, uint32_t(h->model.n_ops), row0, h->op_scale.p, h->vals64.p,
-                                  h->value_part.p, observable_xcd_states(h), stream, h->n_obs_bdirect));
+                                  h->value_part.p, observable_xcd_states(h), stream));
   timer_end(ev, stream);
   return 0;
 }
@@ -1630,8 +1621,9 @@ namespace {
 // in kernels.hip (v_pk_fma_f32 = 4, v_pk_mul_f32 / v_pk_add_f32 = 2 per amplitude pair of lanes):
 //   forward   X**t three shears 6 | PH1 3 (half the amplitudes x (mul + fma)) | PH2 1.5 | FULL table 5.625
 //             | boundary CPH 3 x (share of waves whose predicate is on) | Y 6 | dense 2x2 14 | dense 4x4 32
-//   adjoint   X 16 (psi 6 + lambda 6 + inner product 4) | PH1 8 | PH2 4 | FULL 17.25 (partials 6 + two
-//             tables) | CPH 8 x share | Y 16 | dense 2x2 44 | dense 4x4 on (psi, lambda) + generator 96
+//   adjoint   X 16 (psi 6 + lambda 6 + inner product 4) | PH1 8 | PH2 4 | FULL 15.75 (two tables 11.25 + the ten
+//             partial sums as scalar differences, round 5: 15 x (mul + fma) + 27 adds = 4.5) | CPH 8 x share | Y 16 |
+//             dense 2x2 44 | dense 4x4 on (psi, lambda) + generator 96
 // Rounds whose waves are dead (OP_ROUND word 4) run on 2^-popc(dead mask) of the waves.  Wave
 // reductions, address arithmetic and record decoding are NOT counted: this is the arithmetic the gate
 // set requires of this kernel design, the numerator of a compute roofline against the fp32 vector peak.
@@ -1653,7 +1645,7 @@ double pass_flops_per_amplitude(const Plan& plan, const Pass& p) {
         const uint32_t h0 = rec[0], h1 = rec[1];
         const bool full = (h1 & kFullDiagFlag) != 0;
         f += (adj ? 16.0 : 6.0) * __builtin_popcount(h0 & 0xfu);
-        if (full) f += adj ? 17.25 : 5.625;
+        if (full) f += adj ? 15.75 : 5.625;
         else f += (adj ? 8.0 : 3.0) * __builtin_popcount((h0 >> 8) & 0xfu) + (adj ? 4.0 : 1.5) * __builtin_popcount((h0 >> 16) & 0x3fu);
         for (int k = 0; k < 8; ++k) {
           if (!(h1 >> k & 1u)) continue;

@@ -64,9 +64,6 @@ struct ObsBTerm {  // 32 bytes, one s_load_dwordx8: everything the kernel would 
 };
 constexpr uint32_t kObsSignBit = 1u << 13;
 constexpr uint32_t kObsChunkBytes = 68, kObsPreambleBytes = 12;  // layout of the variant tables (scripts/gen_observable_asm.py)
-// The groups [0, n_direct) of the array hold ONE mask each (DIRECT groups, round 5): a half-workgroup applies such a
-// group from partner rows it loads straight into registers -- no LDS copy of the block, no barrier; their term records
-// carry no kObsNewMask.  The groups from n_direct on go through the LDS pipeline.
 struct ObsBGroup {
   uint32_t xout;  // x >> kObsBlockBits: partner block = block ^ xout
   uint32_t begin, end;  // terms [begin, end) ...
@@ -83,8 +80,7 @@ size_t observable_blocks_value_parts(uint32_t n, uint32_t n_states, uint32_t n_o
 hipError_t launch_observable_blocks(int mode, const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
                                     const ObsBTerm* terms, const ObsBGroup* groups, uint32_t n_groups,
                                     const float* upstream, uint32_t n_ops, uint32_t state0, const float* op_scale,
-                                    unsigned long long* out64, float* value_part, bool xcd_states, hipStream_t stream,
-                                    uint32_t n_direct = 0);
+                                    unsigned long long* out64, float* value_part, bool xcd_states, hipStream_t stream);
 
 size_t fwd_lds_bytes(int K);
 size_t adj_lds_bytes(int K, bool exchange);

@@ -169,20 +169,6 @@ __device__ __forceinline__ void obs_fetch(v4f (&pf)[4], const float2* __restrict
                : "=&v"(pf[0]), "=&v"(pf[1]), "=&v"(pf[2]), "=&v"(pf[3])
                : "v"(t16), "s"(rsi), "s"(o0), "s"(o1), "s"(o2), "s"(o3));
 }
-// DIRECT groups (one mask: round 5): the four partner rows of slot rows `p0 .. p0 + 3` under the mask's row flip `xp`,
-// straight from the partner block at the thread's flipped pair column `t16x` = (t ^ xt) << 4 -- the same 16-byte words
-// obs_rows would read from an LDS copy of the block, without the copy.
-__device__ __forceinline__ void obs_fetch_rows(v4f (&pf)[4], const float2* __restrict__ blk, uint32_t t16x, uint32_t p0, uint32_t xp) {
-  const uint64_t addr = reinterpret_cast<uint64_t>(blk);
-  const v4i rsi = v4i{int(uint32_t(addr)), int(uint32_t(addr >> 32) & 0xffffu), 8 << kObsBlockBits, 0x00020000};
-  const uint32_t o0 = 8192u * (p0 ^ xp), o1 = 8192u * ((p0 + 1u) ^ xp), o2 = 8192u * ((p0 + 2u) ^ xp), o3 = 8192u * ((p0 + 3u) ^ xp);
-  asm volatile("buffer_load_dwordx4 %0, %4, %5, %6 offen" QHBM_OBS_LOAD_MOD "\n\t"
-               "buffer_load_dwordx4 %1, %4, %5, %7 offen" QHBM_OBS_LOAD_MOD "\n\t"
-               "buffer_load_dwordx4 %2, %4, %5, %8 offen" QHBM_OBS_LOAD_MOD "\n\t"
-               "buffer_load_dwordx4 %3, %4, %5, %9 offen" QHBM_OBS_LOAD_MOD
-               : "=&v"(pf[0]), "=&v"(pf[1]), "=&v"(pf[2]), "=&v"(pf[3])
-               : "v"(t16x), "s"(rsi), "s"(o0), "s"(o1), "s"(o2), "s"(o3));
-}
 // Every obs_fetch but the `NEWER` most recent ones has landed (4 loads each).  The set that is about to be staged goes
 // THROUGH the statement ("+v"): its consumers depend on the wait by data flow.  (No "memory" clobber on these asm
 // statements: an asm that may write memory makes the compiler load the term records -- read-only kernel arguments --
@@ -307,7 +293,7 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
     const float2* __restrict__ psi, float2* __restrict__ lam, uint32_t n, const ObsBTerm* __restrict__ terms,
     const ObsBGroup* __restrict__ groups, uint32_t n_groups, const float* __restrict__ upstream, uint32_t n_ops,
     uint32_t state0, float* __restrict__ value_part, uint32_t nb /* blocks per state */, uint32_t n_states,
-    uint32_t xcd_states, uint32_t n_direct /* groups [0, n_direct): one mask each, applied without the LDS copy */) {
+    uint32_t xcd_states) {
   constexpr bool ACC = MODE == OBS_LAMBDA || MODE == OBS_LAMBDA_VALUE;
   constexpr bool HALVE = !ACC;
   constexpr bool MULTI = MODE == OBS_VALUES_MULTI;
@@ -343,7 +329,6 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
   else obs_own_(a, own4, std::make_integer_sequence<int, 8>{});
   if constexpr (MULTI) {
     for (uint32_t i = tid; i < kOWaves * n_ops; i += kOT) cells[i] = 0.f;
-    __syncthreads();  // (the direct groups below may already add to a wave's row)
   }
   v4f r[8], pfa[4], pfb[4];
   obs_rows(r, c.lds, t << 4);  // (defined values before the first mask; never used)
@@ -354,42 +339,8 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
   // the block a group pairs this one with (past the last group: the block itself -- no branch around the registers)
   auto partner = [&](uint32_t g) { return ps + (size_t(bx ^ (g < n_groups ? groups[g].xout : 0u)) << kObsBlockBits); };
 
-  // ---- phase A (round 5): the DIRECT groups -- one mask each (config 4: 104 of its 179 groups hold a single term).
-  // Staging 64 KiB in LDS (a store burst at 79 B/clk, a barrier) so that ONE mask reads 64 KiB back was the dearest way
-  // to apply it: a half-workgroup covers the whole block, so each half takes every other direct group, loads the eight
-  // partner rows of its 16 slots straight into its prefetch registers (the same coalesced 16-byte words, permuted by
-  // the mask), one group ahead, and applies the mask from registers: no LDS, no barrier.
-  {
-    auto next_direct = [&](uint32_t from) { return obs_next_group<HALVE>(groups, n_direct, from, bx, pivot_mask); };
-    auto fetch_direct = [&](uint32_t d) {
-      const ObsBGroup gd = groups[d];
-      const uint32_t xrow = terms[gd.begin].xrow, xp = (xrow >> 13) & 7u;
-      const float2* blk = ps + (size_t(bx ^ gd.xout) << kObsBlockBits);
-      obs_fetch_rows(pfa, blk, t16 ^ (xrow & 0x1ff0u), 0u, xp);
-      obs_fetch_rows(pfb, blk, t16 ^ (xrow & 0x1ff0u), 4u, xp);
-    };
-    asm volatile("s_waitcnt vmcnt(0)");  // (plain vector loads before this point must have landed before the manual counting starts)
-    uint32_t d = next_direct(0u);
-    if (hh && d < n_direct) d = next_direct(d + 1u);  // the second half starts at the second group this block runs
-    if (d < n_direct) fetch_direct(d);
-    while (d < n_direct) {
-      const ObsBGroup gd = groups[d];
-      uint32_t dn = next_direct(d + 1u);
-      if (dn < n_direct) dn = next_direct(dn + 1u);   // (skip the other half's group)
-      obs_wait_older<0>(pfa);
-      obs_wait_older<0>(pfb);
-      r[0] = pfa[0]; r[1] = pfa[1]; r[2] = pfa[2]; r[3] = pfa[3];
-      r[4] = pfb[0]; r[5] = pfb[1]; r[6] = pfb[2]; r[7] = pfb[3];
-      if (dn < n_direct) fetch_direct(dn);            // in flight under this group's arithmetic
-      const float pair_weight = (!ACC && gd.xout != 0u) ? 2.f : 1.f;
-      for (uint32_t k = gd.begin; k < gd.end; ++k)    // (their records carry no kObsNewMask: nothing is read from LDS)
-        obs_one_term<MODE>(c, terms[k], 0u, pair_weight, a, r, d2, cur_op, dq);
-      d = dn;
-    }
-  }
-
-  // groups of the next four steps (the LDS pipeline runs the groups from n_direct on)
-  uint32_t g0 = obs_next_group<HALVE>(groups, n_groups, n_direct, bx, pivot_mask);
+  // groups of the next four steps
+  uint32_t g0 = obs_next_group<HALVE>(groups, n_groups, 0u, bx, pivot_mask);
   uint32_t g1 = obs_next_group<HALVE>(groups, n_groups, g0 + 1u, bx, pivot_mask);
   uint32_t g2 = obs_next_group<HALVE>(groups, n_groups, g1 + 1u, bx, pivot_mask);
   // (plain vector loads before this point -- the block's own amplitudes in the value modes -- must have landed before
@@ -579,8 +530,7 @@ size_t observable_blocks_value_parts(uint32_t n, uint32_t n_states, uint32_t n_o
 hipError_t launch_observable_blocks(int mode, const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
                                     const ObsBTerm* terms, const ObsBGroup* groups, uint32_t n_groups,
                                     const float* upstream, uint32_t n_ops, uint32_t state0, const float* op_scale,
-                                    unsigned long long* out64, float* value_part, bool xcd_states, hipStream_t stream,
-                                    uint32_t n_direct) {
+                                    unsigned long long* out64, float* value_part, bool xcd_states, hipStream_t stream) {
   if (n < uint32_t(kObsBlockBits) || n_states == 0) return n_states ? hipErrorInvalidValue : hipSuccess;
   if (mode == OBS_VALUES_MULTI && n_ops > kObsMaxValueOps) return hipErrorInvalidValue;
   const uint32_t nb = 1u << (n - kObsBlockBits);
@@ -595,7 +545,7 @@ hipError_t launch_observable_blocks(int mode, const float2* psi, float2* lam, ui
     if (e != hipSuccess) return e;                                                                                     \
     const size_t use = 2u * size_t(kOBlock) * 8u + (M_ == OBS_VALUES_MULTI ? size_t(kOWaves) * n_ops * sizeof(float) : 64u); \
     hipLaunchKernelGGL((observable_blocks_kernel<M_>), dim3(nb * n_states), dim3(kOT), use, stream, psi, lam, n, terms, \
-                       groups, n_groups, upstream, n_ops, state0, value_part, nb, n_states, xs, n_direct);            \
+                       groups, n_groups, upstream, n_ops, state0, value_part, nb, n_states, xs);                       \
   }
   switch (mode) {
     case OBS_LAMBDA: QHBM_OBSB(OBS_LAMBDA) break;

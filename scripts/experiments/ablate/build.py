@@ -39,9 +39,10 @@ VARIANTS = {
     "base": lambda t: t,
     "no_reduce": lambda t: once(t, "  float t0, t1, t2, t3, u0, u1, w, x;\n#define QHBM_L1(",
                                 "  if (sv == 0x12345u) return;\n  if (true) return;\n  float t0, t1, t2, t3, u0, u1, w, x;\n#define QHBM_L1("),
-    # the reductions' cross-lane part compiled out: the inputs that exist are added per lane and stored
+    # the reductions' cross-lane part compiled out: the partial sums stay alive (an empty asm consumes them), one of
+    # them is stored -- what is removed is add_slots8's DPP adds, swaps and tail
     "no_butterfly": lambda t: once(t, "  float t0, t1, t2, t3, u0, u1, w, x;\n#define QHBM_L1(",
-                                   "  if (lane >= 0) { float vv = 0.f; if (present & 1u) vv += g0; if (present & 2u) vv += g1; if (present & 4u) vv += g2; if (present & 8u) vv += g3; if (present & 16u) vv += g4; if (present & 32u) vv += g5; if (present & 64u) vv += g6; if (present & 128u) vv += g7; if ((lane & 3) == (G8 & 3) && (lane >> 5) == (G8 >> 2) && sv != 0xffffffffu) cells[sv * NW + wave] = vv; return; }\n  float t0, t1, t2, t3, u0, u1, w, x;\n#define QHBM_L1("),
+                                   "  if (lane >= 0) { asm volatile(\"\" :: \"v\"(g0), \"v\"(g1), \"v\"(g2), \"v\"(g3), \"v\"(g4), \"v\"(g5), \"v\"(g6), \"v\"(g7), \"s\"(present)); if ((lane & 3) == (G8 & 3) && (lane >> 5) == (G8 >> 2) && sv != 0xffffffffu) cells[sv * NW + wave] = g0; return; }\n  float t0, t1, t2, t3, u0, u1, w, x;\n#define QHBM_L1("),
     # record coefficients as compile-time constants (only the two header words are loaded): what the
     # scalar-load latency of the record fields costs
     "const_coefs": lambda t: once(t, "  if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];", "  if constexpr (W >= 2) return 0x3f19999au; else if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];"),

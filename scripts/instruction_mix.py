@@ -78,8 +78,8 @@ def main():
       ("X inner products Im<lam|X|psi>", "no_x_inner", None, c["x"], "16 + 2 (sum of two partials, x - y)"),
       ("FULL tables + their ten partials", "no_full", None, c["full"], "60 (2 x 15 x 2) + 31 scalar mul/fma + 27 scalar adds"),
       ("PH1 / PH2 phases + their sums", "no_ph1_ph2", None, c["ph1"] + c["ph2"], "PH1 8 + 32, PH2 4 + 16"),
-      ("boundary phases (CPH)", "no_cph", None, c["cph_tile_on"] + c["cph_wave_on"] + c["cph_lane"] + c["cph_off"], "8 + 32 where the predicate is on (half)"),
-      ("cross-lane reductions (add_slots8)", "no_butterfly", None, c["reduce8"], "0 (values + pairs DPP adds + 9)"),
+      ("boundary phases (CPH) + their reduction", "no_cph", None, c["cph_tile_on"] + c["cph_wave_on"] + c["cph_lane"], "8 + 32 per execution with the predicate on"),
+      ("cross-lane reductions (add_slots8)", "no_butterfly", None, c["reduce8"], "0 (values + pairs DPP adds + 7)"),
       ("LDS exchange between rounds", "no_exchange", None, c["rounds"], "0 (64 DS ops + 60 v_xor)"),
   ]
   seen_valu = seen_cyc = 0.0
