@@ -1782,10 +1782,9 @@ __device__ __forceinline__ void obs_consume(const ObsGroup& gr, float4 (&buf)[A 
         ci[a] += __uint_as_float(__float_as_uint(t.z) ^ sgn);
       }
     }
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const v2f lo = v2f{buf[p].x, buf[p].y}, hi = v2f{buf[p].z, buf[p].w};
-      const v2f v0 = odd ? hi : lo, v1 = odd ? lo : hi;
+    // (both orders of a pair written out under the scalar branch, as in the real-weight path: `odd ? hi : lo` per
+    // register compiles to sixteen v_cndmask_b32 on VCC, 23 cycles each on gfx950)
+    auto weigh = [&](int p, v2f v0, v2f v1) {
       const v2f t0 = v2f{cr[2 * p] * v0.x - ci[2 * p] * v0.y, cr[2 * p] * v0.y + ci[2 * p] * v0.x};
       const v2f t1 = v2f{cr[2 * p + 1] * v1.x - ci[2 * p + 1] * v1.y, cr[2 * p + 1] * v1.y + ci[2 * p + 1] * v1.x};
       if constexpr (MULTI) {
@@ -1797,6 +1796,15 @@ __device__ __forceinline__ void obs_consume(const ObsGroup& gr, float4 (&buf)[A 
         acc[2 * p] += t0;
         acc[2 * p + 1] += t1;
       }
+    };
+    if (odd) {  // (the asm comments keep the optimiser from folding the two branches back into selects)
+      asm volatile("; imaginary weights, pairs swapped");
+#pragma unroll
+      for (int p = 0; p < P; ++p) weigh(p, v2f{buf[p].z, buf[p].w}, v2f{buf[p].x, buf[p].y});
+    } else {
+      asm volatile("; imaginary weights, pairs in place");
+#pragma unroll
+      for (int p = 0; p < P; ++p) weigh(p, v2f{buf[p].x, buf[p].y}, v2f{buf[p].z, buf[p].w});
     }
   } else {  // real weights only (X/Z strings, even Y count): the common case
     float c[A];
