@@ -604,19 +604,19 @@ __device__ __forceinline__ void add_slot(float* cells, int tid, uint32_t slot, f
 }
 
 // Gradient partials of the EIGHT slots of record slot group G8 (program.h slot_lane8), reduced over the wave together
-// WITHOUT selects, and only as far as the values that exist (`present`, a wave-uniform bit per value: the instance's own
-// micro-op masks).  Value v = (v0, v1, v2) ends up in the lanes whose bits (2, 3, 4) spell v:
+// WITHOUT selects.  Value v = (v0, v1, v2) ends up in the lanes whose bits (2, 3, 4) spell v (`present`: a wave-uniform
+// bit per value that exists -- the instance's own micro-op masks; used by the A/B builds with presence tests only):
 //   level 1  lane bit 2 (adjacent banks of four lanes): value 2k adds its partner bank's share under bank_mask 0x5
-//            (row_shl:4), value 2k + 1 under 0xa (row_shr:4) into the SAME register -- one DPP add per PRESENT value;
+//            (row_shl:4), value 2k + 1 under 0xa (row_shr:4) into the SAME register -- one DPP add per value;
 //   level 2  lane bit 3: pair (2k, 2k + 1) with pair (2k + 2, 2k + 3) under bank masks 0x3 / 0xc (row_shl:8 / row_shr:8)
-//            -- one DPP add per present pair;
+//            -- one DPP add per pair;
 //   level 3  v_permlane16_swap + add: values 0..3 stay in even rows, 4..7 in odd rows (summed over the row pair);
 //   then the sums nobody selects on: two quad butterflies (lane bits 0, 1) and v_permlane32_swap + add (lane bit 5).
 // Round 4's butterfly paid two v_cndmask_b32 (4.2 cycles each on gfx950, as much as a packed FMA:
 // scripts/experiments/micro/valu_cycles.hip) per DPP add and all eight inputs whether they existed or not: 12 selects +
-// 8 DPP + 2 swaps = 105 cycles per call at an average of 2.7 present values; here (values + pairs) DPP adds + a 31-cycle
-// tail = ~51.  An input that does not exist is never read.  One asm statement: the DPP hazards (a VGPR written by the
-// previous VALU instruction needs two wait states before a DPP read) are spelled out, and the branches are scalar.
+// 8 DPP + 2 swaps = 105 cycles per call; here 12 DPP adds + a 31-cycle tail = 81, and no zeroed inputs: an input that
+// does not exist holds whatever its register held, and reaches no stored sum.  One asm statement: the DPP hazards (a VGPR
+// written by the previous VALU instruction needs two wait states before a DPP read) are spelled out.
 // The lanes whose slot-vector word `sv` IS the slot of the value they hold then store into their wave's cells (see
 // add_slot).  (`sv` holds slots LOCAL to the pass; the chain-rule scale of the slot class is folded into slot_factor.)
 template <int CTRL>
@@ -627,16 +627,32 @@ template <int G8, int NW>
 __device__ __forceinline__ void add_slots8(float* cells, int lane, uint32_t wave, uint32_t sv, uint32_t present, float g0,
                                            float g1, float g2, float g3, float g4, float g5, float g6, float g7) {
   float t0, t1, t2, t3, u0, u1, w, x;
+// Presence tests (a scalar bit test + branch around the DPP add of a value or pair that does not exist) were measured
+// and LOSE: a taken branch costs a wave more than the 4.2-cycle DPP add it skips (adjoint 230.9 / 229.7 / 228.5 ms with a
+// test per value and pair / per pair / none, profiles/r05_ab_runs.txt).  0 = none (shipped); 1, 2: A/B builds.
+#ifndef QHBM_RED_TESTS
+#define QHBM_RED_TESTS 0
+#endif
+#if QHBM_RED_TESTS >= 2
 #define QHBM_L1(BIT_, T_, G_, DIR_, BANKS_)                                                        \
   "s_bitcmp1_b32 %[m], " #BIT_ "\n\t"                                                              \
   "s_cbranch_scc0 .Lred%=_a" #BIT_ "\n\t"                                                          \
   "v_add_f32_dpp %[" #T_ "], %[" #G_ "], %[" #G_ "] " DIR_ ":4 row_mask:0xf bank_mask:" BANKS_ "\n" \
   ".Lred%=_a" #BIT_ ":\n\t"
+#else
+#define QHBM_L1(BIT_, T_, G_, DIR_, BANKS_)                                                        \
+  "v_add_f32_dpp %[" #T_ "], %[" #G_ "], %[" #G_ "] " DIR_ ":4 row_mask:0xf bank_mask:" BANKS_ "\n\t"
+#endif
+#if QHBM_RED_TESTS >= 1
 #define QHBM_L2(MASK_, TAG_, U_, T_, DIR_, BANKS_)                                                 \
   "s_and_b32 %[sc], %[m], " MASK_ "\n\t"                                                          \
   "s_cbranch_scc0 .Lred%=_b" #TAG_ "\n\t"                                                         \
   "v_add_f32_dpp %[" #U_ "], %[" #T_ "], %[" #T_ "] " DIR_ ":8 row_mask:0xf bank_mask:" BANKS_ "\n" \
   ".Lred%=_b" #TAG_ ":\n\t"
+#else
+#define QHBM_L2(MASK_, TAG_, U_, T_, DIR_, BANKS_)                                                 \
+  "v_add_f32_dpp %[" #U_ "], %[" #T_ "], %[" #T_ "] " DIR_ ":8 row_mask:0xf bank_mask:" BANKS_ "\n\t"
+#endif
   uint32_t sc;
   asm volatile(
       "s_nop 1\n\t"

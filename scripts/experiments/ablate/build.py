@@ -37,12 +37,12 @@ def in_instance(text, old, new, count=-1):
 
 VARIANTS = {
     "base": lambda t: t,
-    "no_reduce": lambda t: once(t, "  float t0, t1, t2, t3, u0, u1, w, x;\n#define QHBM_L1(",
-                                "  if (sv == 0x12345u) return;\n  if (true) return;\n  float t0, t1, t2, t3, u0, u1, w, x;\n#define QHBM_L1("),
+    "no_reduce": lambda t: once(t, "  float t0, t1, t2, t3, u0, u1, w, x;\n",
+                                "  if (sv == 0x12345u) return;\n  if (true) return;\n  float t0, t1, t2, t3, u0, u1, w, x;\n"),
     # the reductions' cross-lane part compiled out: the partial sums stay alive (an empty asm consumes them), one of
     # them is stored -- what is removed is add_slots8's DPP adds, swaps and tail
-    "no_butterfly": lambda t: once(t, "  float t0, t1, t2, t3, u0, u1, w, x;\n#define QHBM_L1(",
-                                   "  if (lane >= 0) { asm volatile(\"\" :: \"v\"(g0), \"v\"(g1), \"v\"(g2), \"v\"(g3), \"v\"(g4), \"v\"(g5), \"v\"(g6), \"v\"(g7), \"s\"(present)); if ((lane & 3) == (G8 & 3) && (lane >> 5) == (G8 >> 2) && sv != 0xffffffffu) cells[sv * NW + wave] = g0; return; }\n  float t0, t1, t2, t3, u0, u1, w, x;\n#define QHBM_L1("),
+    "no_butterfly": lambda t: once(t, "  float t0, t1, t2, t3, u0, u1, w, x;\n",
+                                   "  if (lane >= 0) { asm volatile(\"\" :: \"v\"(g0), \"v\"(g1), \"v\"(g2), \"v\"(g3), \"v\"(g4), \"v\"(g5), \"v\"(g6), \"v\"(g7), \"s\"(present)); if ((lane & 3) == (G8 & 3) && (lane >> 5) == (G8 >> 2) && sv != 0xffffffffu) cells[sv * NW + wave] = g0; return; }\n  float t0, t1, t2, t3, u0, u1, w, x;\n"),
     # record coefficients as compile-time constants (only the two header words are loaded): what the
     # scalar-load latency of the record fields costs
     "const_coefs": lambda t: once(t, "  if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];", "  if constexpr (W >= 2) return 0x3f19999au; else if constexpr (QHBM_SCALAR_RECORDS) return rb.p[W];"),
@@ -203,6 +203,9 @@ VARIANTS.update({
 VARIANTS.update({
     # round 5: the paired forward kernel at FIVE waves per SIMD (its LDS -- one 32-KiB exchange tile -- admits five
     # workgroups per CU; 96 registers instead of 111: the compiler spills 16 in the tile prologue)
+    # round 5: the reductions with presence tests -- a scalar test + branch per pair / per value and pair (shipped: none)
+    "red_tests_pairs": lambda t: once(t, "#define QHBM_RED_TESTS 0\n", "#define QHBM_RED_TESTS 1\n"),
+    "red_tests_values": lambda t: once(t, "#define QHBM_RED_TESTS 0\n", "#define QHBM_RED_TESTS 2\n"),
     "fwd2_five_waves": lambda t: once(t,
         "template <int K>\n__global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_kernel(",
         "constexpr int fwd2_min_waves(int K) { return clampi(wg_per_cu(8 << K) * (1 << (K - 4)) / 256, 1, 5); }\n"
