@@ -217,6 +217,13 @@ void fill_args(const Plan& plan, const Model& m, std::vector<PassArgs>* args, st
     for (size_t i = 0; i < p.nonlocal_phys.size(); ++i) a.nonlocal_pos[i] = uint8_t(p.nonlocal_phys[i]);
     for (size_t i = 0; i < p.local_phys.size(); ++i) a.local_pos[i] = uint8_t(p.local_phys[i]);
     for (size_t bit = 0; bit < 32; ++bit) a.phys_of[bit] = uint8_t(bit < p.phys_of.size() ? p.phys_of[bit] : int(bit));
+    for (size_t bit = 0; bit < 32; ++bit) a.log_of[a.phys_of[bit]] = uint8_t(bit);
+    for (size_t i = 0; i < p.nonlocal_phys.size(); ++i) a.nonlocal_mask |= 1u << p.nonlocal_phys[i];
+    for (uint32_t I = 0; I < 8; ++I) {  // (the pass kernels give a thread eight float4 of its tile: kernels.hip prefetch_tile)
+      const uint32_t l = p.K >= 3 ? I << (p.K - 3) : 0u, hi = l >> a.c;
+      a.row_off[I] = (l & ((1u << a.c) - 1u)) |
+                     (a.spread_shift != 0xffffffffu ? hi << a.spread_shift : (hi < p.spread.size() ? p.spread[hi] : 0u));
+    }
     a.frozen_old_local = p.frozen_old_local;
     prog->insert(prog->end(), p.prog.begin(), p.prog.end());
     tables->insert(tables->end(), p.spread.begin(), p.spread.end());

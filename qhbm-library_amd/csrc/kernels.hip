@@ -360,12 +360,13 @@ struct TileCtx {
   uint32_t c;
   const uint32_t* spread;
   uint32_t shift;  // ~0u: look the high part up in `spread`
+  uint32_t ro[8];  // tile_offset(I << (K - 3)), I = 0..7: the rows of a thread's eight float4 (PassArgs::row_off)
 };
 
 // Local index -> global index WITHOUT the tile's own bits.  Both forms are bitwise (OR-decomposable):
 // f(a | b) = f(a) | f(b) for disjoint a, b.  A thread's eight float4 sit at l = 2 * tid + (I << (K - 3)):
-// f(2 * tid) is computed once per thread, f(I << (K - 3)) is wave-uniform (scalar arithmetic or a
-// scalar table load) and goes into the base pointer, so the eight accesses of a tile share one
+// f(2 * tid) is computed once per thread, f(I << (K - 3)) is the same for every workgroup of the pass (the host
+// computes it: PassArgs::row_off) and goes into the base pointer, so the eight accesses of a tile share one
 // 32-bit VGPR offset and cost no VALU address arithmetic (global_load ... v_off, s[base]).
 // (local bits above c contiguous from bit `shift`: no table lookup in front of the global access)
 __device__ __forceinline__ uint32_t tile_offset(const TileCtx& t, uint32_t l) {
@@ -384,7 +385,7 @@ __device__ __forceinline__ void store_tile(const float2* __restrict__ tile, floa
     const uint32_t g1 = g0 | tile_offset(t, 1u);
 #define QHBM_ST(I)                                                                                     \
   {                                                                                                    \
-    float2* sb = st + (t.tile_base | uni(tile_offset(t, uint32_t(I) << (K - 3))));                     \
+    float2* sb = st + (t.tile_base | t.ro[I]);                     \
     const uint32_t s = s0 ^ swz(uint32_t(I) << (K - 3));                                               \
     sb[g0] = tile[s];                                                                                  \
     sb[g1] = tile[s ^ 1u];                                                                             \
@@ -395,7 +396,7 @@ __device__ __forceinline__ void store_tile(const float2* __restrict__ tile, floa
   }
 #define QHBM_ST(I)                                                                                     \
   {                                                                                                    \
-    float2* sb = st + (t.tile_base | uni(tile_offset(t, uint32_t(I) << (K - 3))));                     \
+    float2* sb = st + (t.tile_base | t.ro[I]);                     \
     const uint32_t s = s0 ^ swz(uint32_t(I) << (K - 3));                                               \
     const float2 a = tile[s], b = tile[s ^ 1u];                                                        \
     *reinterpret_cast<float4*>(sb + g0) = make_float4(a.x, a.y, b.x, b.y);                             \
@@ -418,7 +419,7 @@ __device__ __forceinline__ void prefetch_tile(TileRegs& r, const float2* __restr
     const uint32_t g1 = g0 | tile_offset(t, 1u);
 #define QHBM_PF(I)                                                                                       \
   {                                                                                                      \
-    const float2* sb = st + (t.tile_base | uni(tile_offset(t, uint32_t(I) << (K - 3))));                 \
+    const float2* sb = st + (t.tile_base | t.ro[I]);                 \
     const float2 a = sb[g0], b = sb[g1];                                                                 \
     r.p##I = make_float4(a.x, a.y, b.x, b.y);                                                            \
   }
@@ -428,7 +429,7 @@ __device__ __forceinline__ void prefetch_tile(TileRegs& r, const float2* __restr
   }
 #define QHBM_PF(I)                                                                                       \
   {                                                                                                      \
-    const float2* sb = st + (t.tile_base | uni(tile_offset(t, uint32_t(I) << (K - 3))));                 \
+    const float2* sb = st + (t.tile_base | t.ro[I]);                 \
     r.p##I = *reinterpret_cast<const float4*>(sb + g0);                                                  \
   }
   QHBM_PF(0) QHBM_PF(1) QHBM_PF(2) QHBM_PF(3) QHBM_PF(4) QHBM_PF(5) QHBM_PF(6) QHBM_PF(7)
@@ -447,15 +448,42 @@ __device__ __forceinline__ void commit_tile(float2* __restrict__ tile, const Til
 #undef QHBM_CM
 }
 
-__device__ __forceinline__ TileCtx make_tile_ctx(const PassArgs& a, const uint32_t* tables, uint32_t tile_id) {
+// ---- what a workgroup derives from its block index, the pass and the input bitstring ------------------
+// PassArgs' per-bit tables are bytes in the kernel-argument segment: a loop over one compiles to a vector load PER
+// ITERATION, each waited for -- written as loops, the adjoint kernel ran n_user + n + 2 n_nonlocal + K dependent
+// memory round trips (38 at config 3) before it could issue its first tile load.  Here every table is read one
+// element per LANE (all loads in flight together, one wait) and the bit permutations are ballots.
+__device__ __forceinline__ uint32_t ballot32(bool p) { return uint32_t(__builtin_amdgcn_ballot_w64(p)); }
+
+// The input bitstring as an index in the layout this pass loads: bit n_user-1-q of the logical index = row[q],
+// logical bit b sits on physical position phys_of[b] (identity unless the adjoint plan relabels).
+__device__ __forceinline__ uint32_t input_index(const PassArgs& a, const int8_t* __restrict__ row, int n_user, int lane) {
+  const uint32_t L = uint32_t(lane);
+  const uint32_t src = a.log_of[L & 31u];
+  const int8_t r = row[min(L, uint32_t(n_user) - 1u)];  // (no branch around the load: both tables in flight together)
+  const uint32_t logical = __brev(ballot32((L < uint32_t(n_user)) & (r != 0))) >> (32u - uint32_t(n_user));
+  return ballot32((L < a.n) & (((logical >> src) & 1u) != 0u));
+}
+// ... its bits on the K local positions of the tile.
+template <int K>
+__device__ __forceinline__ uint32_t local_bits(const PassArgs& a, uint32_t idx, int lane) {
+  const uint32_t L = uint32_t(lane);
+  const uint32_t pos = a.local_pos[L & 15u];
+  return ballot32((L < uint32_t(K)) & (((idx >> pos) & 1u) != 0u));
+}
+
+__device__ __forceinline__ TileCtx make_tile_ctx(const PassArgs& a, const uint32_t* tables, uint32_t tile_id, int lane) {
   TileCtx t;
-  uint32_t tb = 0;
-  for (uint32_t i = 0; i < a.n_nonlocal; ++i) tb |= ((tile_id >> i) & 1u) << a.nonlocal_pos[i];
-  t.tile_base = tb;
+  // tile-id bit i goes to the i-th nonlocal position (ascending): lane p deposits the bit of its rank
+  const uint32_t L = uint32_t(lane) & 31u;
+  const uint32_t rank = __popc(a.nonlocal_mask & ((1u << L) - 1u));
+  t.tile_base = ballot32((lane < 32) & ((((a.nonlocal_mask >> L) & (tile_id >> rank)) & 1u) != 0u));
   t.c = a.c;
   t.cmask = (1u << a.c) - 1u;
   t.spread = tables + a.spread_off;
   t.shift = a.spread_shift;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t.ro[i] = a.row_off[i];
   return t;
 }
 
@@ -463,16 +491,16 @@ __device__ __forceinline__ TileCtx make_tile_ctx(const PassArgs& a, const uint32
 // tile `b & (2^n_free - 1)` of the LIVE tiles of state `b >> n_free`; the tile-id bits that belong to index
 // bits of `zero_mask` are those of the input bitstring `idx` (given in the layout the pass loads).  Launching
 // the dead tiles only to return cost 3 - 6 ms per pass at 4096 states (a million workgroups to dispatch).
-__device__ __forceinline__ uint32_t launched_tile(const PassArgs& a, uint32_t block, uint32_t idx) {
-  uint32_t live = block & ((1u << a.n_free) - 1u), tile_id = 0;
-  for (uint32_t i = 0; i < a.n_nonlocal; ++i) {
-    const uint32_t pos = a.nonlocal_pos[i];
-    uint32_t bit;
-    if ((a.zero_mask >> pos) & 1u) bit = (idx >> pos) & 1u;
-    else { bit = live & 1u; live >>= 1; }
-    tile_id |= bit << i;
-  }
-  return tile_id;
+__device__ __forceinline__ uint32_t launched_tile(const PassArgs& a, uint32_t block, uint32_t idx, int lane) {
+  const uint32_t L = uint32_t(lane);
+  const bool valid = L < a.n_nonlocal;
+  const uint32_t pos = a.nonlocal_pos[L & 31u];
+  const bool fixed = (a.zero_mask >> pos) & 1u;                     // this tile-id bit follows the input bitstring
+  const uint32_t free_lanes = ballot32(valid & !fixed);             // the others take the bits of `live` in turn
+  const uint32_t rank = __popc(free_lanes & ((1u << (L & 31u)) - 1u));
+  const uint32_t live = block & ((1u << a.n_free) - 1u);
+  const uint32_t bit = fixed ? (idx >> pos) & 1u : (live >> rank) & 1u;
+  return ballot32(valid & (bit != 0u));
 }
 
 // Round geometry.  Thread `tid` owns the 2^R amplitudes whose local index has
@@ -549,11 +577,6 @@ __device__ __forceinline__ void mat4_apply(const float* __restrict__ u, const fl
   }
 }
 
-__device__ __forceinline__ uint32_t basis_index(const int8_t* __restrict__ row, int n_user) {
-  uint32_t idx = 0;
-  for (int q = 0; q < n_user; ++q) idx |= (row[q] ? 1u : 0u) << (n_user - 1 - q);
-  return idx;
-}
 
 // ---- fixed-layout instance records (program.h RecordLayout) -------------------------------
 // rv[i] holds words 64*i .. 64*i+63 of the record, one word per lane.
@@ -908,12 +931,6 @@ __device__ __forceinline__ float meas_sum(const v2f (&w)[1 << R], uint32_t zhi) 
 }
 
 // ---- relabeling adjoint plans (schedule.h Pass, program.h PassArgs) ------------------------------------
-// The input bitstring as an index in the layout this pass loads.
-__device__ __forceinline__ uint32_t physical_index(const PassArgs& a, uint32_t idx) {
-  uint32_t out = 0;
-  for (uint32_t bit = 0; bit < a.n; ++bit) out |= ((idx >> bit) & 1u) << a.phys_of[bit];
-  return out;
-}
 // Index bits finished by EARLIER passes that this tile holds as local bits: where they differ from the
 // input the memory holds stale data (the finishing pass stored the live half only) -- psi is zero there
 // and lambda there is never needed again, so the prefetched amplitudes are cleared.
@@ -1025,17 +1042,16 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
     coef += size_t(q) * a.coef_stride;
   }
   const uint32_t* recs = reinterpret_cast<const uint32_t*>(coef);
-  uint32_t idx = 0;  // the input bitstring as an index: only the passes that prune or initialise read it (n byte loads)
-  if ((a.flags & PASS_INIT_BASIS) | a.zero_mask | a.frozen_old_local) idx = uni(basis_index(bits + size_t(bits_row) * n_user, n_user));
-  const uint32_t tile_id = launched_tile(a, blockIdx.x, idx);
-  const TileCtx t = make_tile_ctx(a, tables, tile_id);
+  uint32_t idx = 0;  // the input bitstring as an index: only the passes that prune or initialise read it
+  if ((a.flags & PASS_INIT_BASIS) | a.zero_mask | a.frozen_old_local) idx = input_index(a, bits + size_t(bits_row) * n_user, n_user, lane);
+  const uint32_t in_local = local_bits<K>(a, idx, lane);
+  const uint32_t tile_id = launched_tile(a, blockIdx.x, idx, lane);
+  const TileCtx t = make_tile_ctx(a, tables, tile_id, lane);
   const uint32_t tile_hi = tile_id << K;  // tile-bit predicates of boundary phases (cph_*): bit K + i = tile-id bit i
   float2* st = psi + (size_t(s_local) << a.n);
 
   if (a.flags & PASS_INIT_BASIS) {
-    uint32_t nl_mask = 0;
-    for (uint32_t i = 0; i < a.n_nonlocal; ++i) nl_mask |= 1u << a.nonlocal_pos[i];
-    if ((idx & nl_mask) != t.tile_base) {
+    if ((idx & a.nonlocal_mask) != t.tile_base) {
       // The basis amplitude lives in another tile: this one is zero and stays zero under the
       // program (every op is linear), so only its image in HBM has to be written.
       // (PASS_NO_ZERO_FILL: nothing is written -- later passes never read these tiles unmasked, see schedule.cpp)
@@ -1047,20 +1063,12 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
     }
     for (int l = tid; l < (1 << K); l += NT) tile[l] = make_float2(0.f, 0.f);
     __syncthreads();
-    if (tid == 0) {
-      uint32_t l = 0;
-      for (int i = 0; i < K; ++i) l |= ((idx >> a.local_pos[i]) & 1u) << i;
-      tile[swz(l)] = make_float2(1.f, 0.f);
-    }
+    if (tid == 0) tile[swz(in_local)] = make_float2(1.f, 0.f);
   } else {
     // (head of the sweep: the tiles on which psi is identically zero are not launched -- launched_tile)
     TileRegs r;
     prefetch_tile<K, NT>(r, st, t, tid);
-    if (a.frozen_old_local) {  // local bits nothing has acted on yet: their != input half was never written
-      uint32_t in_local = 0;
-      for (int i = 0; i < K; ++i) in_local |= ((idx >> a.local_pos[i]) & 1u) << i;
-      clear_stale<K>(r, tid, in_local, a.frozen_old_local);
-    }
+    if (a.frozen_old_local) clear_stale<K>(r, tid, in_local, a.frozen_old_local);  // local bits nothing has acted on yet: their != input half was never written
     commit_tile<K, NT>(tile, r, tid);
   }
   for (int i = tid; i < kMaxOps; i += NT) red[i] = 0ull;
@@ -1216,7 +1224,7 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_ker
   const uint32_t tile_id = blockIdx.x & ((1u << a.n_nonlocal) - 1u);
   const uint32_t pair = blockIdx.x >> a.n_nonlocal;
   const uint32_t s_a = 2u * pair, s_b = min(2u * pair + 1u, n_states - 1u);  // (an odd batch: the last state twice)
-  const TileCtx t = make_tile_ctx(a, tables, tile_id);
+  const TileCtx t = make_tile_ctx(a, tables, tile_id, lane);
   const uint32_t tile_hi = tile_id << K;  // tile-bit predicates of boundary phases (cph_*): bit K + i = tile-id bit i
   float2* st_a = psi + (size_t(s_a) << a.n);
   float2* st_b = psi + (size_t(s_b) << a.n);
@@ -1224,13 +1232,8 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_ker
   prefetch_tile<K, NT>(ra, st_a, t, tid);
   prefetch_tile<K, NT>(rb, st_b, t, tid);
   if (a.frozen_old_local) {  // local bits nothing has acted on yet: their != input half was never written (per state)
-    const uint32_t idx_a = uni(basis_index(bits + size_t(state0 + s_a) * n_user, n_user));
-    const uint32_t idx_b = uni(basis_index(bits + size_t(state0 + s_b) * n_user, n_user));
-    uint32_t in_a = 0, in_b = 0;
-    for (int i = 0; i < K; ++i) {
-      in_a |= ((idx_a >> a.local_pos[i]) & 1u) << i;
-      in_b |= ((idx_b >> a.local_pos[i]) & 1u) << i;
-    }
+    const uint32_t in_a = local_bits<K>(a, input_index(a, bits + size_t(state0 + s_a) * n_user, n_user, lane), lane);
+    const uint32_t in_b = local_bits<K>(a, input_index(a, bits + size_t(state0 + s_b) * n_user, n_user, lane), lane);
     clear_stale<K>(ra, tid, in_a, a.frozen_old_local);
     clear_stale<K>(rb, tid, in_b, a.frozen_old_local);
   }
@@ -1469,17 +1472,16 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   const uint32_t* recs = reinterpret_cast<const uint32_t*>(coef);
   const uint32_t s_local = blockIdx.x >> a.n_free;
   // (the input bitstring in the layout this pass loads: relabeling plans move finished bits)
-  const uint32_t idx = uni(physical_index(a, basis_index(bits + size_t(state0 + s_local) * n_user, n_user)));
+  const uint32_t idx = input_index(a, bits + size_t(state0 + s_local) * n_user, n_user, lane);
   // tail of the sweep: the tiles on which psi is identically zero are not launched (launched_tile)
-  const uint32_t tile_id = launched_tile(a, blockIdx.x, idx);
-  const TileCtx t = make_tile_ctx(a, tables, tile_id);
+  const uint32_t tile_id = launched_tile(a, blockIdx.x, idx, lane);
+  const TileCtx t = make_tile_ctx(a, tables, tile_id, lane);
   const uint32_t tile_hi = tile_id << K;  // tile-bit predicates of boundary phases (cph_*): bit K + i = tile-id bit i
   float* grow = tile_grad + size_t(blockIdx.x) * a.n_slots;
   const uint32_t* prog = prog_base + a.prog_off;
   uint32_t w0 = uni(prog[0]);
   const bool skip = (w0 & 0xffu) != OP_ROUND;  // (an empty program: nothing to un-apply)
-  uint32_t in_local = 0;  // the input bitstring on the tile's local bits (OP_ROUND word 4: dead waves)
-  for (int i = 0; i < K; ++i) in_local |= ((idx >> a.local_pos[i]) & 1u) << i;
+  const uint32_t in_local = local_bits<K>(a, idx, lane);  // the input bitstring on the tile's local bits (OP_ROUND word 4: dead waves)
   if (skip) {
     for (uint32_t i = tid; i < a.n_slots; i += NT) grow[i] = 0.f;
     return;
@@ -1604,8 +1606,8 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
   const uint32_t s_local = blockIdx.x >> a.n_free;
   // tail of the sweep: the tiles on which psi is identically zero are not launched (launched_tile; these plans
   // never relabel: logical = physical index bits)
-  const uint32_t tile_id = launched_tile(a, blockIdx.x, uni(basis_index(bits + size_t(state0 + s_local) * n_user, n_user)));
-  const TileCtx t = make_tile_ctx(a, tables, tile_id);
+  const uint32_t tile_id = launched_tile(a, blockIdx.x, input_index(a, bits + size_t(state0 + s_local) * n_user, n_user, lane), lane);
+  const TileCtx t = make_tile_ctx(a, tables, tile_id, lane);
   const uint32_t tile_hi = tile_id << K;  // tile-bit predicates of boundary phases (cph_*): bit K + i = tile-id bit i
   float* grow = tile_grad + size_t(blockIdx.x) * a.n_slots;
   float2* sp = psi + (size_t(s_local) << a.n);
