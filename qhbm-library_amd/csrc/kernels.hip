@@ -374,18 +374,34 @@ __device__ __forceinline__ uint32_t tile_offset(const TileCtx& t, uint32_t l) {
 }
 __device__ __forceinline__ uint32_t global_index(const TileCtx& t, uint32_t l) { return t.tile_base | tile_offset(t, l); }
 
-// (C0: the pass may have no index bit 0 among its local bits -- adjoint tail passes only)
-template <int K, int NT, bool C0 = false>
+// (ROWS: adjoint tail passes may have no index bit 0 among their local bits -- the two amplitudes of a float4 are
+// then 8 bytes each.  ROWS16: never; ROWS8: always (the exchange kernel is instantiated for both: a run-time test
+// lets the compiler merge the two paths into THREE accesses per row); ROWS_TEST: tested at run time)
+enum TileRows : int { ROWS16 = 0, ROWS_TEST = 1, ROWS8 = 2 };
+// A thread's offsets inside its rows (a table lookup when the tile's high local bits are scattered): computed
+// ONCE for the tiles a workgroup loads -- per call, the lookup of the second tile waited (vmcnt is in order) for
+// the first tile's eight loads to return before its own could be issued.
+struct ThreadOff {
+  uint32_t g0, g1;  // of local index 2 tid, and of 2 tid + 1 when that is not the next address (ROWS8)
+};
+template <int ROWS = ROWS16>
+__device__ __forceinline__ ThreadOff thread_offsets(const TileCtx& t, int tid) {
+  ThreadOff o;
+  o.g0 = tile_offset(t, 2u * uint32_t(tid));
+  o.g1 = (ROWS == ROWS8 || (ROWS == ROWS_TEST && t.c == 0)) ? (o.g0 | tile_offset(t, 1u)) : o.g0 + 1u;
+  return o;
+}
+template <int K, int NT, int ROWS = ROWS16>
 __device__ __forceinline__ void store_tile(const float2* __restrict__ tile, float2* __restrict__ st,
-                                           const TileCtx& t, int tid) {
+                                           const TileCtx& t, const ThreadOff& o, int tid) {
   static_assert((1 << (K - 1)) / NT == 8, "a thread owns eight float4 of its tile");
-  const uint32_t g0 = tile_offset(t, 2u * uint32_t(tid));
+  const uint32_t g0 = o.g0;
   const uint32_t s0 = swz(2u * uint32_t(tid));
-  if (C0 && t.c == 0) {  // index bit 0 is not local (tail passes of the adjoint sweep): two 8-byte stores
-    const uint32_t g1 = g0 | tile_offset(t, 1u);
+  if (ROWS == ROWS8 || (ROWS == ROWS_TEST && t.c == 0)) {  // index bit 0 is not local (tail passes of the adjoint sweep): two 8-byte stores
+    const uint32_t g1 = o.g1;
 #define QHBM_ST(I)                                                                                     \
   {                                                                                                    \
-    float2* sb = st + (t.tile_base | t.ro[I]);                     \
+    float2* sb = st + (t.tile_base | t.ro[I]);                                                         \
     const uint32_t s = s0 ^ swz(uint32_t(I) << (K - 3));                                               \
     sb[g0] = tile[s];                                                                                  \
     sb[g1] = tile[s ^ 1u];                                                                             \
@@ -396,7 +412,7 @@ __device__ __forceinline__ void store_tile(const float2* __restrict__ tile, floa
   }
 #define QHBM_ST(I)                                                                                     \
   {                                                                                                    \
-    float2* sb = st + (t.tile_base | t.ro[I]);                     \
+    float2* sb = st + (t.tile_base | t.ro[I]);                                                         \
     const uint32_t s = s0 ^ swz(uint32_t(I) << (K - 3));                                               \
     const float2 a = tile[s], b = tile[s ^ 1u];                                                        \
     *reinterpret_cast<float4*>(sb + g0) = make_float4(a.x, a.y, b.x, b.y);                             \
@@ -411,15 +427,15 @@ __device__ __forceinline__ void store_tile(const float2* __restrict__ tile, floa
 struct TileRegs {
   float4 p0, p1, p2, p3, p4, p5, p6, p7;
 };
-template <int K, int NT, bool C0 = false>
-__device__ __forceinline__ void prefetch_tile(TileRegs& r, const float2* __restrict__ st, const TileCtx& t, int tid) {
+template <int K, int NT, int ROWS = ROWS16>
+__device__ __forceinline__ void prefetch_tile(TileRegs& r, const float2* __restrict__ st, const TileCtx& t, const ThreadOff& o) {
   static_assert((1 << (K - 1)) / NT == 8, "a thread owns eight float4 of its tile");
-  const uint32_t g0 = tile_offset(t, 2u * uint32_t(tid));
-  if (C0 && t.c == 0) {  // index bit 0 is not local: the two amplitudes of a float4 are 8-byte loads
-    const uint32_t g1 = g0 | tile_offset(t, 1u);
+  const uint32_t g0 = o.g0;
+  if (ROWS == ROWS8 || (ROWS == ROWS_TEST && t.c == 0)) {  // index bit 0 is not local: the two amplitudes of a float4 are 8-byte loads
+    const uint32_t g1 = o.g1;
 #define QHBM_PF(I)                                                                                       \
   {                                                                                                      \
-    const float2* sb = st + (t.tile_base | t.ro[I]);                 \
+    const float2* sb = st + (t.tile_base | t.ro[I]);                                                     \
     const float2 a = sb[g0], b = sb[g1];                                                                 \
     r.p##I = make_float4(a.x, a.y, b.x, b.y);                                                            \
   }
@@ -429,7 +445,7 @@ __device__ __forceinline__ void prefetch_tile(TileRegs& r, const float2* __restr
   }
 #define QHBM_PF(I)                                                                                       \
   {                                                                                                      \
-    const float2* sb = st + (t.tile_base | t.ro[I]);                 \
+    const float2* sb = st + (t.tile_base | t.ro[I]);                                                     \
     r.p##I = *reinterpret_cast<const float4*>(sb + g0);                                                  \
   }
   QHBM_PF(0) QHBM_PF(1) QHBM_PF(2) QHBM_PF(3) QHBM_PF(4) QHBM_PF(5) QHBM_PF(6) QHBM_PF(7)
@@ -472,12 +488,11 @@ __device__ __forceinline__ uint32_t local_bits(const PassArgs& a, uint32_t idx, 
   return ballot32((L < uint32_t(K)) & (((idx >> pos) & 1u) != 0u));
 }
 
-__device__ __forceinline__ TileCtx make_tile_ctx(const PassArgs& a, const uint32_t* tables, uint32_t tile_id, int lane) {
+// The part of a tile's context that every workgroup of the pass shares (a kernel starts with it, so that the table
+// lookup of thread_offsets travels with the per-bit tables), then the tile's own bits.
+__device__ __forceinline__ TileCtx pass_tile_ctx(const PassArgs& a, const uint32_t* tables) {
   TileCtx t;
-  // tile-id bit i goes to the i-th nonlocal position (ascending): lane p deposits the bit of its rank
-  const uint32_t L = uint32_t(lane) & 31u;
-  const uint32_t rank = __popc(a.nonlocal_mask & ((1u << L) - 1u));
-  t.tile_base = ballot32((lane < 32) & ((((a.nonlocal_mask >> L) & (tile_id >> rank)) & 1u) != 0u));
+  t.tile_base = 0;
   t.c = a.c;
   t.cmask = (1u << a.c) - 1u;
   t.spread = tables + a.spread_off;
@@ -485,6 +500,12 @@ __device__ __forceinline__ TileCtx make_tile_ctx(const PassArgs& a, const uint32
 #pragma unroll
   for (int i = 0; i < 8; ++i) t.ro[i] = a.row_off[i];
   return t;
+}
+__device__ __forceinline__ uint32_t tile_base_of(const PassArgs& a, uint32_t tile_id, int lane) {
+  // tile-id bit i goes to the i-th nonlocal position (ascending): lane p deposits the bit of its rank
+  const uint32_t L = uint32_t(lane) & 31u;
+  const uint32_t rank = __popc(a.nonlocal_mask & ((1u << L) - 1u));
+  return ballot32((lane < 32) & ((((a.nonlocal_mask >> L) & (tile_id >> rank)) & 1u) != 0u));
 }
 
 // Only the tiles that can hold a non-zero amplitude are launched (PassArgs::n_free): block b of the grid is
@@ -1042,11 +1063,13 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
     coef += size_t(q) * a.coef_stride;
   }
   const uint32_t* recs = reinterpret_cast<const uint32_t*>(coef);
+  TileCtx t = pass_tile_ctx(a, tables);
+  const ThreadOff toff = thread_offsets(t, tid);
   uint32_t idx = 0;  // the input bitstring as an index: only the passes that prune or initialise read it
   if ((a.flags & PASS_INIT_BASIS) | a.zero_mask | a.frozen_old_local) idx = input_index(a, bits + size_t(bits_row) * n_user, n_user, lane);
   const uint32_t in_local = local_bits<K>(a, idx, lane);
   const uint32_t tile_id = launched_tile(a, blockIdx.x, idx, lane);
-  const TileCtx t = make_tile_ctx(a, tables, tile_id, lane);
+  t.tile_base = tile_base_of(a, tile_id, lane);
   const uint32_t tile_hi = tile_id << K;  // tile-bit predicates of boundary phases (cph_*): bit K + i = tile-id bit i
   float2* st = psi + (size_t(s_local) << a.n);
 
@@ -1067,7 +1090,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
   } else {
     // (head of the sweep: the tiles on which psi is identically zero are not launched -- launched_tile)
     TileRegs r;
-    prefetch_tile<K, NT>(r, st, t, tid);
+    prefetch_tile<K, NT>(r, st, t, toff);
     if (a.frozen_old_local) clear_stale<K>(r, tid, in_local, a.frozen_old_local);  // local bits nothing has acted on yet: their != input half was never written
     commit_tile<K, NT>(tile, r, tid);
   }
@@ -1194,7 +1217,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
       if (v) atomicAdd(&out64[size_t(out_row) * a.n_ops + i], v);
     }
   }
-  if (a.flags & PASS_STORE) store_tile<K, NT>(tile, st, t, tid);
+  if (a.flags & PASS_STORE) store_tile<K, NT>(tile, st, t, thread_offsets(t, tid), tid);
 }
 
 // ================================================================================
@@ -1224,22 +1247,16 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_ker
   const uint32_t tile_id = blockIdx.x & ((1u << a.n_nonlocal) - 1u);
   const uint32_t pair = blockIdx.x >> a.n_nonlocal;
   const uint32_t s_a = 2u * pair, s_b = min(2u * pair + 1u, n_states - 1u);  // (an odd batch: the last state twice)
-  const TileCtx t = make_tile_ctx(a, tables, tile_id, lane);
+  TileCtx t = pass_tile_ctx(a, tables);
+  const ThreadOff toff = thread_offsets(t, tid);
+  t.tile_base = tile_base_of(a, tile_id, lane);
   const uint32_t tile_hi = tile_id << K;  // tile-bit predicates of boundary phases (cph_*): bit K + i = tile-id bit i
   float2* st_a = psi + (size_t(s_a) << a.n);
   float2* st_b = psi + (size_t(s_b) << a.n);
-  TileRegs ra, rb;
-  prefetch_tile<K, NT>(ra, st_a, t, tid);
-  prefetch_tile<K, NT>(rb, st_b, t, tid);
-  if (a.frozen_old_local) {  // local bits nothing has acted on yet: their != input half was never written (per state)
-    const uint32_t in_a = local_bits<K>(a, input_index(a, bits + size_t(state0 + s_a) * n_user, n_user, lane), lane);
-    const uint32_t in_b = local_bits<K>(a, input_index(a, bits + size_t(state0 + s_b) * n_user, n_user, lane), lane);
-    clear_stale<K>(ra, tid, in_a, a.frozen_old_local);
-    clear_stale<K>(rb, tid, in_b, a.frozen_old_local);
-  }
   const uint32_t* prog = prog_base + a.prog_off;
   uint32_t w0 = uni(prog[0]);
   if ((w0 & 0xffu) != OP_ROUND) return;  // nothing to apply (measurement-only programs never come here)
+  // (the first record and the first round's thread table are requested BEFORE the tiles: one latency, not two)
   constexpr RecordLayout L(R, false);
   uint32_t pc = 0;
   uint32_t cur[1], nxt[1];
@@ -1247,6 +1264,15 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_ker
   rec_load<1>(recs, rec_off, lane, cur);
   const uint32_t* tlt = tables + a.tl_off + uint32_t(tid);
   uint32_t DB[R], T, TL = tlt[uni(prog[3])];
+  TileRegs ra, rb;
+  prefetch_tile<K, NT>(ra, st_a, t, toff);
+  prefetch_tile<K, NT>(rb, st_b, t, toff);
+  if (a.frozen_old_local) {  // local bits nothing has acted on yet: their != input half was never written (per state)
+    const uint32_t in_a = local_bits<K>(a, input_index(a, bits + size_t(state0 + s_a) * n_user, n_user, lane), lane);
+    const uint32_t in_b = local_bits<K>(a, input_index(a, bits + size_t(state0 + s_b) * n_user, n_user, lane), lane);
+    clear_stale<K>(ra, tid, in_a, a.frozen_old_local);
+    clear_stale<K>(rb, tid, in_b, a.frozen_old_local);
+  }
   round_geometry<K, R>(uni(prog[1]), TL, DB, &T);
   v2f p[NR], q[NR];
   commit_tile<K, NT>(xt, ra, tid);
@@ -1292,11 +1318,12 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_ker
   if (a.flags & PASS_STORE) {
     round_store<R>(xt, T, DB, p);
     __syncthreads();
-    store_tile<K, NT>(xt, st_a, t, tid);
+    const ThreadOff o = thread_offsets(t, tid);
+    store_tile<K, NT>(xt, st_a, t, o, tid);
     __syncthreads();
     round_store<R>(xt, T, DB, q);
     __syncthreads();
-    if (s_b != s_a) store_tile<K, NT>(xt, st_b, t, tid);
+    if (s_b != s_a) store_tile<K, NT>(xt, st_b, t, o, tid);
   }
 }
 
@@ -1453,7 +1480,7 @@ __device__ __forceinline__ void store_tile_relabeled(const float2* __restrict__ 
 // workgroups per CU).  A round boundary whose waves keep their amplitudes needs no barrier at all;
 // otherwise three (store psi | load psi | store lambda | load lambda): a wave always writes the
 // region it last read, so nothing else can race.
-template <int K>
+template <int K, int ROWS>
 __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_kernel(
     PassArgs a, float2* __restrict__ psi, float2* __restrict__ lam, const int8_t* __restrict__ bits, int n_user,
     const uint32_t* __restrict__ prog_base, const uint32_t* __restrict__ tables,
@@ -1472,10 +1499,12 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   const uint32_t* recs = reinterpret_cast<const uint32_t*>(coef);
   const uint32_t s_local = blockIdx.x >> a.n_free;
   // (the input bitstring in the layout this pass loads: relabeling plans move finished bits)
+  TileCtx t = pass_tile_ctx(a, tables);
+  const ThreadOff toff = thread_offsets<ROWS>(t, tid);
   const uint32_t idx = input_index(a, bits + size_t(state0 + s_local) * n_user, n_user, lane);
   // tail of the sweep: the tiles on which psi is identically zero are not launched (launched_tile)
   const uint32_t tile_id = launched_tile(a, blockIdx.x, idx, lane);
-  const TileCtx t = make_tile_ctx(a, tables, tile_id, lane);
+  t.tile_base = tile_base_of(a, tile_id, lane);
   const uint32_t tile_hi = tile_id << K;  // tile-bit predicates of boundary phases (cph_*): bit K + i = tile-id bit i
   float* grow = tile_grad + size_t(blockIdx.x) * a.n_slots;
   const uint32_t* prog = prog_base + a.prog_off;
@@ -1488,15 +1517,7 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   }
   float2* sp = psi + (size_t(s_local) << a.n);
   float2* sl = lam + (size_t(s_local) << a.n);
-  TileRegs rp, rl;
-  prefetch_tile<K, NT, true>(rp, sp, t, tid);
-  prefetch_tile<K, NT, true>(rl, sl, t, tid);
-  if (a.frozen_old_local) {
-    clear_stale<K>(rp, tid, in_local, a.frozen_old_local);
-    clear_stale<K>(rl, tid, in_local, a.frozen_old_local);
-  }
-  for (uint32_t i = tid; i < a.n_slots * NW; i += NT) cells[i] = 0.f;
-
+  // (the first record, its slot words and the first round's thread table are requested BEFORE the tiles: one latency)
   constexpr RecordLayout L(R, true);
   uint32_t pc = 0;
   uint32_t cur[1], nxt[1], sv[1], svn[1];
@@ -1505,6 +1526,14 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   rec_load<1>(recs, rec_off + L.slot0(), lane, sv);
   const uint32_t* tlt = tables + a.tl_off + uint32_t(tid);
   uint32_t DB[R], T, TL = tlt[uni(prog[3])];
+  TileRegs rp, rl;
+  prefetch_tile<K, NT, ROWS>(rp, sp, t, toff);
+  prefetch_tile<K, NT, ROWS>(rl, sl, t, toff);
+  if (a.frozen_old_local) {
+    clear_stale<K>(rp, tid, in_local, a.frozen_old_local);
+    clear_stale<K>(rl, tid, in_local, a.frozen_old_local);
+  }
+  for (uint32_t i = tid; i < a.n_slots * NW; i += NT) cells[i] = 0.f;
   round_geometry<K, R>(uni(prog[1]), TL, DB, &T);
   v2f p[NR], l[NR];
   commit_tile<K, NT>(xt, rp, tid);
@@ -1570,13 +1599,14 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
     __syncthreads();
     store_tile_relabeled<K, NT>(xt, sl, a, tables, t.tile_base, in_local, tid);
   } else if (a.flags & PASS_STORE) {
+    const ThreadOff o = thread_offsets<ROWS>(t, tid);
     round_store<R>(xt, T, DB, p);
     __syncthreads();
-    store_tile<K, NT, true>(xt, sp, t, tid);
+    store_tile<K, NT, ROWS>(xt, sp, t, o, tid);
     __syncthreads();
     round_store<R>(xt, T, DB, l);
     __syncthreads();
-    store_tile<K, NT, true>(xt, sl, t, tid);
+    store_tile<K, NT, ROWS>(xt, sl, t, o, tid);
   } else {
     __syncthreads();  // the cells of every wave are complete
   }
@@ -1607,15 +1637,17 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
   // tail of the sweep: the tiles on which psi is identically zero are not launched (launched_tile; these plans
   // never relabel: logical = physical index bits)
   const uint32_t tile_id = launched_tile(a, blockIdx.x, input_index(a, bits + size_t(state0 + s_local) * n_user, n_user, lane), lane);
-  const TileCtx t = make_tile_ctx(a, tables, tile_id, lane);
+  TileCtx t = pass_tile_ctx(a, tables);
+  t.tile_base = tile_base_of(a, tile_id, lane);
   const uint32_t tile_hi = tile_id << K;  // tile-bit predicates of boundary phases (cph_*): bit K + i = tile-id bit i
   float* grow = tile_grad + size_t(blockIdx.x) * a.n_slots;
   float2* sp = psi + (size_t(s_local) << a.n);
   float2* sl = lam + (size_t(s_local) << a.n);
   {
     TileRegs rp, rl;
-    prefetch_tile<K, NT, true>(rp, sp, t, tid);
-    prefetch_tile<K, NT, true>(rl, sl, t, tid);
+    const ThreadOff o = thread_offsets<ROWS_TEST>(t, tid);
+    prefetch_tile<K, NT, ROWS_TEST>(rp, sp, t, o);
+    prefetch_tile<K, NT, ROWS_TEST>(rl, sl, t, o);
     commit_tile<K, NT>(tp, rp, tid);
     commit_tile<K, NT>(tl, rl, tid);
   }
@@ -1692,8 +1724,9 @@ __global__ __launch_bounds__(1 << (K - 4), adj_min_waves(K)) void pass_adj_kerne
   __syncthreads();
   flush_cells<NT, NW>(cells, grow, a.n_slots, tid);
   if (a.flags & PASS_STORE) {
-    store_tile<K, NT, true>(tp, sp, t, tid);
-    store_tile<K, NT, true>(tl, sl, t, tid);
+    const ThreadOff o = thread_offsets<ROWS_TEST>(t, tid);
+    store_tile<K, NT, ROWS_TEST>(tp, sp, t, o, tid);
+    store_tile<K, NT, ROWS_TEST>(tl, sl, t, o, tid);
   }
 }
 
@@ -2442,17 +2475,25 @@ static hipError_t launch_adj_t(const PassArgs& a, uint32_t n_states, float2* psi
   return hipGetLastError();
 }
 
+template <int K, int ROWS>
+static hipError_t launch_adjx_rows(const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
+                                   const int8_t* bits, int n_user, const uint32_t* prog, const uint32_t* tables,
+                                   const float* coef, float* tile_grad, uint32_t state0, hipStream_t stream) {
+  const size_t lds = adj_lds_bytes(K, true);
+  static bool attr_done[kMaxDevices] = {};
+  if (hipError_t e = opt_in_lds(&pass_adjx_kernel<K, ROWS>, attr_done, lds); e != hipSuccess) return e;
+  const uint32_t grid = n_states << a.n_free;
+  hipLaunchKernelGGL((pass_adjx_kernel<K, ROWS>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, lam, bits,
+                     n_user, prog, tables, coef, tile_grad, state0);
+  return hipGetLastError();
+}
 template <int K>
 static hipError_t launch_adjx_t(const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
                                 const int8_t* bits, int n_user, const uint32_t* prog, const uint32_t* tables,
                                 const float* coef, float* tile_grad, uint32_t state0, hipStream_t stream) {
-  const size_t lds = adj_lds_bytes(K, true);
-  static bool attr_done[kMaxDevices] = {};
-  if (hipError_t e = opt_in_lds(&pass_adjx_kernel<K>, attr_done, lds); e != hipSuccess) return e;
-  const uint32_t grid = n_states << a.n_free;
-  hipLaunchKernelGGL((pass_adjx_kernel<K>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, lam, bits,
-                     n_user, prog, tables, coef, tile_grad, state0);
-  return hipGetLastError();
+  // (tail passes whose tiles hold no index bit 0 move their rows as 8-byte halves: the other instantiation)
+  return a.c == 0 ? launch_adjx_rows<K, ROWS8>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, tile_grad, state0, stream)
+                  : launch_adjx_rows<K, ROWS16>(a, n_states, psi, lam, bits, n_user, prog, tables, coef, tile_grad, state0, stream);
 }
 
 hipError_t launch_pass_adj(int K, bool exchange, const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
