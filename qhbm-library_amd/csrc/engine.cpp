@@ -239,12 +239,25 @@ void fill_args(const Plan& plan, const Model& m, std::vector<PassArgs>* args, st
       uint32_t n_live = 0;
       for (int i = 0; i < p.K; ++i) n_live += !(p.frozen_new_local >> i & 1u);
       if (n_live < 1) a.relabel_pairs = 0;
+      std::memset(a.fz_src, 0xff, sizeof(a.fz_src));
       for (int i = 0; i < p.K; ++i)
         if (p.frozen_new_local >> i & 1u) {
           a.fz_local_bit[a.n_fz] = uint8_t(i);
           a.fz_out_pos[a.n_fz] = uint8_t(p.store_local_phys[size_t(i)]);
+          a.fz_src[p.store_local_phys[size_t(i)]] = uint8_t(i);
           ++a.n_fz;
         }
+      // (kernels.hip store_tile_relabeled: a thread's out-indices are (tid + i * threads) [* 2 for pairs])
+      const uint32_t threads = 1u << (p.K - 4), entries = uint32_t(p.relabel_tab.size() / 2);
+      const uint32_t count = a.relabel_pairs ? entries / 2 : entries;
+      uint32_t shift = uint32_t(p.K - 4) + (a.relabel_pairs ? 1u : 0u);
+      a.relabel_iters = (count + threads - 1) / threads;
+      a.relabel_l1 = entries > 1 ? p.relabel_tab[2] : 0u;
+      for (uint32_t i = 0; i < 16; ++i) {
+        const uint64_t o = uint64_t(i) << shift;
+        a.relabel_hi[i][0] = o < entries ? p.relabel_tab[2 * size_t(o)] : 0u;
+        a.relabel_hi[i][1] = o < entries ? p.relabel_tab[2 * size_t(o) + 1] : 0u;
+      }
     }
     args->push_back(a);
   }

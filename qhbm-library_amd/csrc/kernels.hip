@@ -1449,26 +1449,49 @@ __device__ __forceinline__ void flush_cells(const float* cells, float* __restric
 // The relabeling store: only the amplitudes whose newly finished bits equal the input bitstring, in
 // the order of their NEW addresses (finished bits moved to the highest positions the tile owns):
 // whole 128-byte lines of live data, nothing written for the dead half.
+// Live out-index o -> (local index with the finished bits clear, offset in the state) is a table
+// (tables[relabel_off + 2 o]) that is OR-decomposable in o: a thread looks up the entry of ITS low part of o once
+// for both tiles (relabel_lookup) and ORs the entry of the iteration's high part, which the host put into the pass
+// arguments -- as a loop over table entries, every iteration of both stores waited for its own table load.
+struct RelabelCtx {
+  uint32_t l_mine, off_mine;  // the thread's own entry
+  uint32_t fz_addr;           // where the finished bits go in the address, carrying the input bits
+  uint32_t fz_local;          // the finished bits of the live amplitudes, local index space
+  uint32_t count;             // out-indices (pairs of them when relabel_pairs) the store covers
+};
+template <int K>
+__device__ __forceinline__ RelabelCtx relabel_lookup(const PassArgs& a, const uint32_t* __restrict__ tables, uint32_t in_local,
+                                                     int tid, int lane) {
+  RelabelCtx r;
+  const uint32_t n_live = uint32_t(K) - a.n_fz;
+  r.count = a.relabel_pairs ? 1u << (n_live - 1u) : 1u << n_live;
+  const uint32_t mine = min(uint32_t(tid), r.count - 1u) << (a.relabel_pairs ? 1 : 0);
+  const uint2 e = *reinterpret_cast<const uint2*>(tables + a.relabel_off + 2u * mine);
+  const uint32_t src = a.fz_src[uint32_t(lane) & 31u];
+  r.fz_addr = ballot32((lane < 32) & (src != 0xffu) & (((in_local >> (src & 31u)) & 1u) != 0u));
+  r.fz_local = in_local & a.frozen_new_local;
+  r.l_mine = e.x;
+  r.off_mine = e.y;
+  return r;
+}
 template <int K, int NT>
 __device__ __forceinline__ void store_tile_relabeled(const float2* __restrict__ tile, float2* __restrict__ st,
-                                                     const PassArgs& a, const uint32_t* __restrict__ tables,
-                                                     uint32_t tile_base, uint32_t in_local, int tid) {
-  const uint32_t* tab = tables + a.relabel_off;
-  const uint32_t fz_local = in_local & a.frozen_new_local;  // the finished bits of the live amplitudes, local index space
-  uint32_t fz_addr = 0;                                     // ... and where they go in the address
-  for (uint32_t k = 0; k < a.n_fz; ++k) fz_addr |= ((in_local >> a.fz_local_bit[k]) & 1u) << a.fz_out_pos[k];
-  float2* sb = st + (tile_base | fz_addr);
-  const uint32_t n_live = uint32_t(K) - a.n_fz;
+                                                     const PassArgs& a, const RelabelCtx& r, uint32_t tile_base, int tid) {
+  float2* sb = st + (tile_base | r.fz_addr);
   if (a.relabel_pairs) {
-    for (uint32_t j = uint32_t(tid); j < (1u << (n_live - 1u)); j += uint32_t(NT)) {
-      const uint4 e = *reinterpret_cast<const uint4*>(tab + 4u * j);  // (l0, off0, l1, off1): off1 = off0 + 1
-      const float2 v0 = tile[swz(e.x | fz_local)], v1 = tile[swz(e.z | fz_local)];
-      *reinterpret_cast<float4*>(sb + e.y) = make_float4(v0.x, v0.y, v1.x, v1.y);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (uint32_t(i) < a.relabel_iters && uint32_t(tid) + uint32_t(i * NT) < r.count) {
+        const uint32_t l0 = r.l_mine | a.relabel_hi[i][0] | r.fz_local;
+        const float2 v0 = tile[swz(l0)], v1 = tile[swz(l0 | a.relabel_l1)];
+        *reinterpret_cast<float4*>(sb + (r.off_mine | a.relabel_hi[i][1])) = make_float4(v0.x, v0.y, v1.x, v1.y);
+      }
     }
   } else {
-    for (uint32_t o = uint32_t(tid); o < (1u << n_live); o += uint32_t(NT)) {
-      const uint2 e = *reinterpret_cast<const uint2*>(tab + 2u * o);
-      sb[e.y] = tile[swz(e.x | fz_local)];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (uint32_t(i) < a.relabel_iters && uint32_t(tid) + uint32_t(i * NT) < r.count)
+        sb[r.off_mine | a.relabel_hi[i][1]] = tile[swz(r.l_mine | a.relabel_hi[i][0] | r.fz_local)];
     }
   }
 }
@@ -1591,13 +1614,14 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
     w0 = w1;
   }
   if (a.flags & PASS_RELABEL) {
+    const RelabelCtx rc = relabel_lookup<K>(a, tables, in_local, tid, lane);  // (in flight under the exchange below)
     round_store<R>(xt, T, DB, p);
     __syncthreads();
-    store_tile_relabeled<K, NT>(xt, sp, a, tables, t.tile_base, in_local, tid);
+    store_tile_relabeled<K, NT>(xt, sp, a, rc, t.tile_base, tid);
     __syncthreads();
     round_store<R>(xt, T, DB, l);
     __syncthreads();
-    store_tile_relabeled<K, NT>(xt, sl, a, tables, t.tile_base, in_local, tid);
+    store_tile_relabeled<K, NT>(xt, sl, a, rc, t.tile_base, tid);
   } else if (a.flags & PASS_STORE) {
     const ThreadOff o = thread_offsets<ROWS>(t, tid);
     round_store<R>(xt, T, DB, p);

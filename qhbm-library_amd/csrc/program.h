@@ -200,6 +200,14 @@ struct PassArgs {
   uint8_t log_of[32];
   uint32_t nonlocal_mask;
   uint32_t row_off[8];
+  // PASS_RELABEL, the same way: the relabel table is OR-decomposable in the out-index o, so a thread looks up ONE
+  // entry (its own low part of o) and adds the entries of the high parts from here: (local index, offset) of
+  // o = i << relabel_hi_shift for the relabel_iters iterations of the store; the local index of o = 1 (the upper
+  // amplitude of a 16-byte pair); fz_src[p] = the local bit whose input value lands on address position p (0xff: none).
+  uint32_t relabel_hi[16][2];
+  uint32_t relabel_iters;
+  uint32_t relabel_l1;
+  uint8_t fz_src[32];
 };
 
 }  // namespace qhbm
