@@ -18,6 +18,8 @@
 // v_xor per LDS address.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
+#include <cstring>
 
 #include <utility>
 
@@ -1496,6 +1498,16 @@ __device__ __forceinline__ void store_tile_relabeled(const float2* __restrict__ 
   }
 }
 
+#ifdef QHBM_ADJ_TIMING  // diagnostic build (scripts/experiments/ablate/build.py adj_timing; never shipped): the cycles a
+// wave of the exchange adjoint kernel spends per phase, summed over the waves of a launch, printed by the launcher
+__device__ unsigned long long g_adj_phase[8 * 64];
+#define QHBM_TICK() __builtin_readcyclecounter()
+#define QHBM_PHASE(k, v) if (lane == 0) atomicAdd(&g_adj_phase[(k) * 64 + (blockIdx.x & 63u)], (unsigned long long)(v))
+#else
+#define QHBM_TICK() 0ull
+#define QHBM_PHASE(k, v)
+#endif
+
 // ---- exchange layout (default for passes without Y / dense gates) ---------------------------------
 // The (psi, lambda) tile pair lives in REGISTERS for the whole pass; LDS holds one tile-sized
 // exchange buffer through which psi, then lambda, change geometry between rounds.  Half the LDS
@@ -1521,6 +1533,8 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   const uint32_t wave = uni(uint32_t(tid) >> 6);
   const uint32_t* recs = reinterpret_cast<const uint32_t*>(coef);
   const uint32_t s_local = blockIdx.x >> a.n_free;
+  [[maybe_unused]] const unsigned long long tk0 = QHBM_TICK();  // (QHBM_ADJ_TIMING builds only: 0 otherwise)
+  [[maybe_unused]] unsigned long long tk_inst = 0, tk_xchg = 0;
   // (the input bitstring in the layout this pass loads: relabeling plans move finished bits)
   TileCtx t = pass_tile_ctx(a, tables);
   const ThreadOff toff = thread_offsets<ROWS>(t, tid);
@@ -1552,6 +1566,7 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   TileRegs rp, rl;
   prefetch_tile<K, NT, ROWS>(rp, sp, t, toff);
   prefetch_tile<K, NT, ROWS>(rl, sl, t, toff);
+  [[maybe_unused]] const unsigned long long tk1 = QHBM_TICK();
   if (a.frozen_old_local) {
     clear_stale<K>(rp, tid, in_local, a.frozen_old_local);
     clear_stale<K>(rl, tid, in_local, a.frozen_old_local);
@@ -1566,6 +1581,8 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   commit_tile<K, NT>(xt, rl, tid);
   __syncthreads();
   round_load<R>(xt, T, DB, l);
+  [[maybe_unused]] const unsigned long long tk2 = QHBM_TICK();
+  [[maybe_unused]] unsigned long long tk_r = tk2;
   for (;;) {
     const uint32_t n_inst = (w0 & ~kRoundNoBarrier) >> 8;
     // A wave whose (wave-index) bits differ from the input bitstring on a bit that no non-diagonal gate
@@ -1587,6 +1604,7 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
       }
     }
     pc += kRoundWords;
+    { [[maybe_unused]] const unsigned long long now = QHBM_TICK(); tk_inst += now - tk_r; tk_r = now; }
     const uint32_t w1 = uni(prog[pc]);
     if ((w1 & 0xffu) != OP_ROUND) break;
     // ---- change of geometry through the exchange buffer ----
@@ -1612,6 +1630,7 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
     T = Tn;
     TL = TLn;
     w0 = w1;
+    { [[maybe_unused]] const unsigned long long now = QHBM_TICK(); tk_xchg += now - tk_r; tk_r = now; }
   }
   if (a.flags & PASS_RELABEL) {
     const RelabelCtx rc = relabel_lookup<K>(a, tables, in_local, tid, lane);  // (in flight under the exchange below)
@@ -1635,6 +1654,18 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
     __syncthreads();  // the cells of every wave are complete
   }
   flush_cells<NT, NW>(cells, grow, a.n_slots, tid);
+#ifdef QHBM_ADJ_TIMING
+  {
+    const unsigned long long tk4 = QHBM_TICK();
+    QHBM_PHASE(0, tk1 - tk0);   // entry -> both tiles requested
+    QHBM_PHASE(1, tk2 - tk1);   // tiles arrive, staged through LDS into the first round's geometry
+    QHBM_PHASE(2, tk_inst);     // instances
+    QHBM_PHASE(3, tk_xchg);     // changes of geometry between rounds
+    QHBM_PHASE(4, tk4 - tk_r);  // stores, gradient row
+    QHBM_PHASE(5, tk4 - tk0);   // the wave's life
+    QHBM_PHASE(6, 1);
+  }
+#endif
 }
 
 // ---- two-tile layout: both tiles resident in LDS (programs with Y / dense 2x2 / dense two-qubit
@@ -2509,6 +2540,19 @@ static hipError_t launch_adjx_rows(const PassArgs& a, uint32_t n_states, float2*
   const uint32_t grid = n_states << a.n_free;
   hipLaunchKernelGGL((pass_adjx_kernel<K, ROWS>), dim3(grid), dim3(1 << (K - 4)), lds, stream, a, psi, lam, bits,
                      n_user, prog, tables, coef, tile_grad, state0);
+#ifdef QHBM_ADJ_TIMING
+  {
+    unsigned long long h[8 * 64], sum[8] = {};
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_adj_phase), sizeof(h));
+    for (int k = 0; k < 8; ++k) for (int i = 0; i < 64; ++i) sum[k] += h[k * 64 + i];
+    const double w = double(sum[6] ? sum[6] : 1);
+    std::fprintf(stderr, "adj_timing K=%d grid=%u slots=%u waves=%llu cycles/wave: to_loads %.0f load+stage %.0f instances %.0f rounds %.0f store %.0f life %.0f\n",
+                 K, grid, a.n_slots, sum[6], sum[0] / w, sum[1] / w, sum[2] / w, sum[3] / w, sum[4] / w, sum[5] / w);
+    std::memset(h, 0, sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_adj_phase), h, sizeof(h));
+  }
+#endif
   return hipGetLastError();
 }
 template <int K>

@@ -59,7 +59,7 @@ VARIANTS = {
     # from / stored to HBM in the prefetch layout -- wrong amplitudes, same traffic): the upper bound of
     # loading and storing in the first / last round's geometry directly
     "adj_no_staging": lambda t: once(once(once(t,
-        "template <int K>\n__global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_kernel(",
+        "template <int K, int ROWS>\n__global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_kernel(",
         """__device__ __forceinline__ void regs_from_tile(v2f (&a)[16], const TileRegs& r) {
   a[0] = v2f{r.p0.x, r.p0.y}; a[1] = v2f{r.p0.z, r.p0.w}; a[2] = v2f{r.p1.x, r.p1.y}; a[3] = v2f{r.p1.z, r.p1.w};
   a[4] = v2f{r.p2.x, r.p2.y}; a[5] = v2f{r.p2.z, r.p2.w}; a[6] = v2f{r.p3.x, r.p3.y}; a[7] = v2f{r.p3.z, r.p3.w};
@@ -69,15 +69,15 @@ VARIANTS = {
 template <int K, int NT>
 __device__ __forceinline__ void regs_to_global(const v2f (&a)[16], float2* __restrict__ st, const TileCtx& t, int tid) {
   const uint32_t g0 = tile_offset(t, 2u * uint32_t(tid));
-#define QHBM_RG(I) { float2* sb = st + (t.tile_base | uni(tile_offset(t, uint32_t(I) << (K - 3)))); *reinterpret_cast<float4*>(sb + g0) = make_float4(a[2 * I].x, a[2 * I].y, a[2 * I + 1].x, a[2 * I + 1].y); }
+#define QHBM_RG(I) { float2* sb = st + (t.tile_base | t.ro[I]); *reinterpret_cast<float4*>(sb + g0) = make_float4(a[2 * I].x, a[2 * I].y, a[2 * I + 1].x, a[2 * I + 1].y); }
   QHBM_RG(0) QHBM_RG(1) QHBM_RG(2) QHBM_RG(3) QHBM_RG(4) QHBM_RG(5) QHBM_RG(6) QHBM_RG(7)
 #undef QHBM_RG
 }
-template <int K>
+template <int K, int ROWS>
 __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_kernel("""),
         "  commit_tile<K, NT>(xt, rp, tid);\n  __syncthreads();\n  round_load<R>(xt, T, DB, p);\n  __syncthreads();\n  commit_tile<K, NT>(xt, rl, tid);\n  __syncthreads();\n  round_load<R>(xt, T, DB, l);\n",
         "  regs_from_tile(p, rp);\n  regs_from_tile(l, rl);\n  __syncthreads();\n"),
-        "    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT, true>(xt, sp, t, tid);\n    __syncthreads();\n    round_store<R>(xt, T, DB, l);\n    __syncthreads();\n    store_tile<K, NT, true>(xt, sl, t, tid);\n",
+        "    const ThreadOff o = thread_offsets<ROWS>(t, tid);\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT, ROWS>(xt, sp, t, o, tid);\n    __syncthreads();\n    round_store<R>(xt, T, DB, l);\n    __syncthreads();\n    store_tile<K, NT, ROWS>(xt, sl, t, o, tid);\n",
         "    regs_to_global<K, NT>(p, sp, t, tid);\n    regs_to_global<K, NT>(l, sl, t, tid);\n    __syncthreads();\n"),
     "no_x_inner": lambda t: in_instance(t, "g[J] = im_lam_x_psi<R, J>(p, l);", "g[J] = p[0].x;"),
     "no_x_on_lambda": lambda t: in_instance(t, "          apply_x<R, J>(l, cs);\n", ""),
@@ -126,13 +126,13 @@ VARIANTS.update({
     "fwd_no_full": lambda t: in_fwd_instance(t, "if (h1 & kFullDiagFlag) apply_full<NV>(a, rv, rb, false);", "if ((h1 & kFullDiagFlag) && lane == 77) apply_full<NV>(a, rv, rb, false);"),
     "fwd_no_cph": lambda t: in_fwd_instance(t, "  if (h1 & 0xffu) {", "  if ((h1 & 0xffu) && lane == 77) {"),
     # forward without its HBM traffic (tile neither loaded nor stored): what the memory phase adds to the compute
-    "fwd_no_tile_io": lambda t: once(once(t, "    TileRegs r;\n    prefetch_tile<K, NT>(r, st, t, tid);\n    if (a.frozen_old_local) clear_stale",
+    "fwd_no_tile_io": lambda t: once(once(t, "    TileRegs r;\n    prefetch_tile<K, NT>(r, st, t, toff);\n    if (a.frozen_old_local) clear_stale",
                                           "    TileRegs r = TileRegs{};\n    if (a.frozen_old_local) clear_stale"),
-                                     "  if (a.flags & PASS_STORE) store_tile<K, NT>(tile, st, t, tid);\n}\n", "  if ((a.flags & PASS_STORE) && tid == 1000) store_tile<K, NT>(tile, st, t, tid);\n}\n"),
+                                     "  if (a.flags & PASS_STORE) store_tile<K, NT>(tile, st, t, thread_offsets(t, tid), tid);\n}\n", "  if ((a.flags & PASS_STORE) && tid == 1000) store_tile<K, NT>(tile, st, t, thread_offsets(t, tid), tid);\n}\n"),
     "fwd_const_no_trips": lambda t: VARIANTS["const_coefs"](VARIANTS["fwd_no_round_trips"](t)),
     # stagger the first generation of forward workgroups (by hardware wave slot) to break lock step
-    "fwd_stagger": lambda t: once(t, "    TileRegs r;\n    prefetch_tile<K, NT>(r, st, t, tid);\n    if (a.frozen_old_local) clear_stale",
-                                  "    if (blockIdx.x < 1024u) { const uint32_t slot = __builtin_amdgcn_s_getreg(0x1804) & 3u; for (uint32_t i = 0; i < slot * 2u; ++i) __builtin_amdgcn_s_sleep(127); }\n    TileRegs r;\n    prefetch_tile<K, NT>(r, st, t, tid);\n    if (a.frozen_old_local) clear_stale"),
+    "fwd_stagger": lambda t: once(t, "    TileRegs r;\n    prefetch_tile<K, NT>(r, st, t, toff);\n    if (a.frozen_old_local) clear_stale",
+                                  "    if (blockIdx.x < 1024u) { const uint32_t slot = __builtin_amdgcn_s_getreg(0x1804) & 3u; for (uint32_t i = 0; i < slot * 2u; ++i) __builtin_amdgcn_s_sleep(127); }\n    TileRegs r;\n    prefetch_tile<K, NT>(r, st, t, toff);\n    if (a.frozen_old_local) clear_stale"),
     "fwd_no_barriers": lambda t: once(t, "      if (!(w0 & kRoundNoBarrier)) __syncthreads();  // else the next round's waves read only their own writes\n      pc += kRoundWords;\n    } else if (opc == OP_GATE2) {",
                                       "      pc += kRoundWords;\n    } else if (opc == OP_GATE2) {"),
     "fwd_no_round_trips": lambda t: once(once(t, "      round_load<R>(tile, T, DB, amp);\n      for (uint32_t i = 0; i < n_inst; ++i) {", "      if (pc == 0) round_load<R>(tile, T, DB, amp);\n      for (uint32_t i = 0; i < n_inst; ++i) {"),
@@ -179,10 +179,10 @@ VARIANTS.update({
     # 128-byte lines are moved for a half / quarter / ... of their amplitudes): their loads and stores
     # compiled out -- the time a compacted state layout could approach
     "adj_no_io_pruned": lambda t: once(once(t,
-        "  prefetch_tile<K, NT, true>(rp, sp, t, tid);\n  prefetch_tile<K, NT, true>(rl, sl, t, tid);\n  if (a.frozen_old_local) {",
-        "  if (!a.zero_mask) {\n  prefetch_tile<K, NT, true>(rp, sp, t, tid);\n  prefetch_tile<K, NT, true>(rl, sl, t, tid);\n  } else { rp = TileRegs{}; rl = TileRegs{}; rp.p0.x = 1e-3f; rl.p0.y = 1e-3f; }\n  if (a.frozen_old_local) {"),
-        "  } else if (a.flags & PASS_STORE) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT, true>(xt, sp, t, tid);",
-        "  } else if ((a.flags & PASS_STORE) && !a.zero_mask) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT, true>(xt, sp, t, tid);"),
+        "  prefetch_tile<K, NT, ROWS>(rp, sp, t, toff);\n  prefetch_tile<K, NT, ROWS>(rl, sl, t, toff);\n",
+        "  if (!a.zero_mask) {\n  prefetch_tile<K, NT, ROWS>(rp, sp, t, toff);\n  prefetch_tile<K, NT, ROWS>(rl, sl, t, toff);\n  } else { rp = TileRegs{}; rl = TileRegs{}; rp.p0.x = 1e-3f; rl.p0.y = 1e-3f; }\n"),
+        "  } else if (a.flags & PASS_STORE) {\n    const ThreadOff o = thread_offsets<ROWS>(t, tid);",
+        "  } else if ((a.flags & PASS_STORE) && !a.zero_mask) {\n    const ThreadOff o = thread_offsets<ROWS>(t, tid);"),
 })
 
 
@@ -191,12 +191,12 @@ VARIANTS.update({
     # and exchange time of a pass alone -- with `no_instances` (the I/O and the exchange alone) it says how much of a pass
     # is the sum of the two and how much their maximum (round 4: pass 0 of config 3)
     "adj_no_io": lambda t: once(once(once(t,
-        "  prefetch_tile<K, NT, true>(rp, sp, t, tid);\n  prefetch_tile<K, NT, true>(rl, sl, t, tid);\n  if (a.frozen_old_local) {",
-        "  rp = TileRegs{}; rl = TileRegs{}; rp.p0.x = 1e-3f; rl.p0.y = 1e-3f;\n  if (a.frozen_old_local) {"),
-        "  if (a.flags & PASS_RELABEL) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile_relabeled<K, NT>(xt, sp, a, tables, t.tile_base, in_local, tid);",
-        "  if ((a.flags & PASS_RELABEL) && tid == 100000) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile_relabeled<K, NT>(xt, sp, a, tables, t.tile_base, in_local, tid);"),
-        "  } else if (a.flags & PASS_STORE) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT, true>(xt, sp, t, tid);",
-        "  } else if ((a.flags & PASS_STORE) && tid == 100000) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT, true>(xt, sp, t, tid);"),
+        "  prefetch_tile<K, NT, ROWS>(rp, sp, t, toff);\n  prefetch_tile<K, NT, ROWS>(rl, sl, t, toff);\n",
+        "  rp = TileRegs{}; rl = TileRegs{}; rp.p0.x = 1e-3f; rl.p0.y = 1e-3f;\n"),
+        "  if (a.flags & PASS_RELABEL) {\n    const RelabelCtx rc = relabel_lookup<K>(a, tables, in_local, tid, lane);  // (in flight under the exchange below)",
+        "  if ((a.flags & PASS_RELABEL) && tid == 100000) {\n    const RelabelCtx rc = relabel_lookup<K>(a, tables, in_local, tid, lane);"),
+        "  } else if (a.flags & PASS_STORE) {\n    const ThreadOff o = thread_offsets<ROWS>(t, tid);",
+        "  } else if ((a.flags & PASS_STORE) && tid == 100000) {\n    const ThreadOff o = thread_offsets<ROWS>(t, tid);"),
 })
 
 
@@ -210,6 +210,13 @@ VARIANTS.update({
         "template <int K>\n__global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_kernel(",
         "constexpr int fwd2_min_waves(int K) { return clampi(wg_per_cu(8 << K) * (1 << (K - 4)) / 256, 1, 5); }\n"
         "template <int K>\n__global__ __launch_bounds__(1 << (K - 4), fwd2_min_waves(K)) void pass_fwd2_kernel("),
+})
+
+
+VARIANTS.update({
+    # round 5: the adjoint kernel's phases timed with s_memtime (-DQHBM_ADJ_TIMING: the launcher prints cycles per wave and
+    # phase after every launch; results stay correct)
+    "adj_timing": lambda t: once(t, "#include <hip/hip_runtime.h>\n", "#define QHBM_ADJ_TIMING 1\n#include <hip/hip_runtime.h>\n"),
 })
 
 
