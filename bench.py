@@ -213,6 +213,21 @@ def self_launch(args):
   raise SystemExit(subprocess.call(cmd))
 
 
+def kernel_sources_sha16():
+  """sha256 of the engine's sources (csrc/*.hip, *.inc, *.cpp, *.h, in name order): stored with every profile, so that a
+  bench line can say when its stored counters were taken on OTHER kernels than the ones it ran."""
+  csrc = os.path.join(ROOT, "qhbm-library_amd", "csrc")
+  h = hashlib.sha256()
+  try:
+    for name in sorted(os.listdir(csrc)):
+      if name.endswith((".hip", ".inc", ".cpp", ".h")) and not name.startswith("_"):
+        with open(os.path.join(csrc, name), "rb") as f:
+          h.update(name.encode() + b"\0" + f.read())
+  except OSError:
+    return None
+  return h.hexdigest()[:16]
+
+
 def stored_profile(name, n, layers, hamiltonian, mode):
   """profiles/<name>.json if it was taken on this workload (same circuit, observable, mode)."""
   path = os.path.join(ROOT, "profiles", name)
@@ -478,6 +493,11 @@ def main():
     vj = stored_profile("valu.json", n, layers, args.hamiltonian, args.mode)
     if family(vj):
       valu = dict(vj[family(vj)], source=f"stored profile profiles/valu.json (git {vj.get('git_head', '?')})")
+    #  the stored counters go stale with every kernel change: say so in the line when they were taken on
+    # other engine sources than the ones in this tree
+    src_sha = kernel_sources_sha16()
+    stale = [nm for nm, pj in (("traffic.json", tj), ("valu.json", vj))
+             if family(pj) and pj.get("kernel_sources_sha16") not in (None, src_sha)]
     with open(os.path.abspath(__file__), "rb") as f:
       bench_sha = hashlib.sha256(f.read()).hexdigest()[:16]
     mode_name = {"vqt": "VQT step = values + adjoint VJP", "forward": "forward values only",
@@ -530,7 +550,7 @@ def main():
                                             4 * (total_states * n_params
                                                  if (args.reduction == "ordered" and args.mode in ("vqt", "qmhl")) else n_params))),
             "forward_passes": fwd_passes, "adjoint_passes": bwd_passes,
-            "bench_py_sha16": bench_sha, "engine_options": args.engine_option,
+            "bench_py_sha16": bench_sha, "kernel_sources_sha16": kernel_sources_sha16(), "engine_options": args.engine_option,
         },
         "vqt_step_ms": ms_per_step if args.mode == "vqt" else None,
         "qmhl_step_ms": ms_per_step if args.mode == "qmhl" else None,
@@ -563,6 +583,8 @@ def main():
                                             ("apply_observable", fm["obs_flops"], "obs_ms"),
                                             ("adjoint", fm["bwd_flops"], "bwd_ms"))}},
             "traffic": traffic, "traffic_source": traffic_src,
+            **({"stored_profile_warning": "STALE: " + ", ".join(stale) + " taken on other engine sources than this tree's "
+                                          f"(kernel_sources_sha16 {src_sha}): re-run scripts/profile_bench.sh"} if stale else {}),
             "avg_launch_ms": avg_ms, "launches_per_step": per_step_launches,
             "bytes_per_launch": bytes_per_launch,
             "bytes_definition": (

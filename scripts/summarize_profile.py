@@ -42,7 +42,7 @@ with open(os.path.join(DST, f"{tag}_bench_line.json"), "w") as f:
 head = open(os.path.join(SRC, "git_head")).read().strip()
 cfg = line["config"]
 meta = {"command": open(os.path.join(SRC, "command")).read().strip() + " (under rocprofv3)", "git_head": head,
-        "bench_py_sha16": cfg.get("bench_py_sha16"), "n_qubits": cfg["n_qubits"], "layers": cfg["layers"],
+        "bench_py_sha16": cfg.get("bench_py_sha16"), "kernel_sources_sha16": cfg.get("kernel_sources_sha16"), "n_qubits": cfg["n_qubits"], "layers": cfg["layers"],
         "hamiltonian": cfg.get("hamiltonian"), "mode": cfg["mode"], "states_per_gpu": cfg["states_per_gpu"]}
 
 per = {}

@@ -40,3 +40,23 @@ def test_the_block_observable_kernels_compile_without_register_spills():
     assert field("VGPRs Spill") == 0 and field("SGPRs Spill") == 0 and field("ScratchSize") == 0, b[:400]
     assert field("VGPRs") <= 128 and field("Occupancy") >= 4, b[:400]
   assert seen == 4
+
+
+def test_published_counter_profiles_carry_the_hash_of_the_kernels_they_were_taken_on():
+  """profiles/traffic.json and valu.json are stored values that bench.py prints next to its own measurements: they carry
+  the hash of the engine sources they were taken on, and bench.py flags a mismatch in its line (`stored_profile_warning`).
+  A mismatch here is reported as a warning, not a failure: the kernels may have moved on after the last profile."""
+  import json
+  import sys
+  import warnings
+  sys.path.insert(0, ROOT)
+  import bench
+  sha = bench.kernel_sources_sha16()
+  assert sha and len(sha) == 16 and sha == bench.kernel_sources_sha16()
+  for name in ("traffic.json", "valu.json"):
+    with open(os.path.join(ROOT, "profiles", name)) as f:
+      stored = json.load(f)
+    assert len(stored.get("kernel_sources_sha16") or "") == 16, f"profiles/{name} does not say which kernels it was taken on"
+    if stored["kernel_sources_sha16"] != sha:
+      warnings.warn(f"profiles/{name} was taken on other engine sources ({stored['kernel_sources_sha16']}) than this tree's "
+                    f"({sha}): bench.py will say so in its line; re-run scripts/r05_profiles.sh + summarize_profile.py --publish")
