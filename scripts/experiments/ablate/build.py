@@ -220,6 +220,26 @@ VARIANTS.update({
 })
 
 
+VARIANTS.update({
+    # round 5: the PAIRED forward kernel (pass_fwd2_kernel) without its instances / without its tile traffic / without the
+    # exchange between rounds: what the skeleton, the I/O and the LDS round trips cost the forward sweep
+    "fwd2_no_instances": lambda t: once(t, "      instance_fwd_pair<R, 1>(cur, recs, rec_off, p, q, TL | tile_hi);",
+                                        "      if (lane == 77) instance_fwd_pair<R, 1>(cur, recs, rec_off, p, q, TL | tile_hi);"),
+    "fwd2_no_io": lambda t: once(once(t, "  prefetch_tile<K, NT>(ra, st_a, t, toff);\n  prefetch_tile<K, NT>(rb, st_b, t, toff);\n",
+                                      "  ra = TileRegs{}; rb = TileRegs{}; ra.p0.x = 1e-3f; rb.p0.y = 1e-3f;\n"),
+                                 "  if (a.flags & PASS_STORE) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    const ThreadOff o = thread_offsets(t, tid);\n    store_tile<K, NT>(xt, st_a, t, o, tid);",
+                                 "  if ((a.flags & PASS_STORE) && tid == 100000) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    const ThreadOff o = thread_offsets(t, tid);\n    store_tile<K, NT>(xt, st_a, t, o, tid);"),
+    "fwd2_no_exchange": lambda t: once(t, """    round_store<R>(xt, T, DB, p);
+    if (sync) __syncthreads();
+    round_load<R>(xt, Tn, DBn, p);
+    if (sync) __syncthreads();
+    round_store<R>(xt, T, DB, q);
+    if (sync) __syncthreads();
+    round_load<R>(xt, Tn, DBn, q);
+""", ""),
+})
+
+
 _OBS_LOOP = "        if (live) obs_consume<A>(gr, cur, own, st, k, k0, tb, acc);  // else: the group vanishes on the whole block"
 VARIANTS.update({
     # lambda = O psi (wrong lambda): without the masks that leave the block (no gathers: staging + the masks served
