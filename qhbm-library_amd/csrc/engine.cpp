@@ -403,7 +403,9 @@ int build_plans(qhbm_engine* h) {
     Plan wide;
     std::string err2;
     double wide_seconds = 0.0;
-    if (plan_adjoint(13, &wide, &wide_seconds, &err2) && wide.K == 13 && wide_seconds < 0.98 * adj_seconds)
+    // (tiles of 2^13 run 3 - 4 % slower against 2^12 than the model says -- two workgroups of eight waves per CU overlap
+    // their tile I/O worse than four of four; seven shapes, profiles/r05_adjoint_tile_choice.txt: they must win by that)
+    if (plan_adjoint(13, &wide, &wide_seconds, &err2) && wide.K == 13 && wide_seconds < 0.966 * adj_seconds)
       h->adj.plan = std::move(wide);
   }
   h->adj.uploaded = false;
@@ -1594,6 +1596,11 @@ int qhbm_describe_schedule(qhbm_engine* h, char* buf, size_t buf_len) {
   if (!h || !buf || !buf_len) return 1;
   if (int rc = build_plans(h)) return rc;
   std::string s = describe_plan(h->fwd.plan) + describe_plan(h->adj.plan);
+  {  // what the chooser of the adjoint tile and pass order compares (adjoint_plan_seconds)
+    char line[96];
+    std::snprintf(line, sizeof(line), "adjoint time model: %.2f us per state\n", 1e6 * adjoint_plan_seconds(h->adj.plan, h->model));
+    s += line;
+  }
   if (!h->model.terms.empty()) {  // which kernel forms lambda = O psi / the values (bench.py names it in `roofline.kernel`)
     s += std::string("observable kernel: lambda = ") + (block_kernel(h) ? "observable_blocks_kernel" : "apply_observable_kernel");
     s += std::string(" values = ") + (gather_multi_mode(h) ? "apply_observable_kernel (an accumulator per observable)"
