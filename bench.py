@@ -214,15 +214,20 @@ def self_launch(args):
 
 
 def kernel_sources_sha16():
-  """sha256 of the engine's sources (csrc/*.hip, *.inc, *.cpp, *.h, in name order): stored with every profile, so that a
-  bench line can say when its stored counters were taken on OTHER kernels than the ones it ran."""
+  """sha256 of the engine's sources (csrc/*.hip, *.inc, *.cpp, *.h, in name order) WITHOUT their comments and white space:
+  stored with every profile, so that a bench line can say when its stored counters were taken on OTHER code than the code
+  it ran (an edited comment does not count)."""
+  import re  # pylint: disable=import-outside-toplevel
   csrc = os.path.join(ROOT, "qhbm-library_amd", "csrc")
   h = hashlib.sha256()
   try:
     for name in sorted(os.listdir(csrc)):
       if name.endswith((".hip", ".inc", ".cpp", ".h")) and not name.startswith("_"):
-        with open(os.path.join(csrc, name), "rb") as f:
-          h.update(name.encode() + b"\0" + f.read())
+        with open(os.path.join(csrc, name), "r", encoding="utf-8", errors="replace") as f:
+          text = f.read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)   # block comments
+        text = re.sub(r"//[^\n]*", " ", text)                 # line comments (no source string holds "//")
+        h.update(name.encode() + b"\0" + "".join(text.split()).encode())
   except OSError:
     return None
   return h.hexdigest()[:16]

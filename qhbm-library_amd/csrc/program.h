@@ -194,7 +194,7 @@ struct PassArgs {
   uint8_t fz_local_bit[16];
   uint8_t fz_out_pos[16];
   // The per-bit tables above in the forms a workgroup can use WITHOUT walking them (kernels.hip input_index,
-  // launched_tile, make_tile_ctx: one table element per lane and a ballot instead of a loop of dependent byte
+  // launched_tile, tile_base_of, pass_tile_ctx: one table element per lane and a ballot instead of a loop of dependent byte
   // loads): the inverse of phys_of (log_of[p] = the logical bit on physical position p), the nonlocal positions
   // as a mask, and the index offsets of a thread's eight float4 rows, tile_offset(I << (K - 3)) for I = 0..7.
   uint8_t log_of[32];
