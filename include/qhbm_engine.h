@@ -161,7 +161,12 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
  * observables; 0 = always measured in the passes; 1 = always from the kernel, up to 256 observables),
  * "gather_multi_values" (2..4 observables: 1 = the gather kernel forms lambda AND carries a value accumulator per
  * observable -- one launch instead of two; 0 (default) = the values from the block kernel's own launch: the one-launch
- * form measured SLOWER, 103 against 64.7 ms on BASELINE config 3 split into its XX / YY / ZZ sums).
+ * form measured SLOWER, 103 against 64.7 ms on BASELINE config 3 split into its XX / YY / ZZ sums),
+ * "observable_far_windows" (gather kernel, one observable or lambda alone: the masks that flip only bits of a seven-bit
+ * window of far index bits (and bits 0..3) are applied by an extra launch per window that works in the index space with
+ * that window swapped into bits 4..10 -- no partner run of theirs crosses the fabric.  0 (default) = never: measured NOT
+ * faster at 28 qubits (65.0 ms in one launch, 66.2 in three); 1 = always, any window that holds a mask; -1 = from 26
+ * qubits up, windows with three masks or more).
  */
 int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value);
 

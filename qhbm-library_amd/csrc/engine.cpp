@@ -130,6 +130,24 @@ struct qhbm_engine {
                                 // qubits or needs a measurement-only pass, at most kMultiValueOps observables)
   DevBuf<float> value_part;  // value mode: one partial of <psi|O|psi> per workgroup of apply_observable_kernel
   uint32_t n_obs_groups = 0;
+  uint32_t n_gather_terms = 0;  // terms of the gather kernel's FIRST launch (all of them unless far windows took some)
+  // Two-level lambda = O psi (>= 26 qubits, gather kernel, single-observable modes): every mask that leaves a
+  // workgroup's block makes it read a partner run from the fabric -- at 28 qubits the 17 single flips of a TFIM cost
+  // 12.6 reads of the whole 2-GiB state.  Masks that flip only bits of a seven-bit WINDOW [far_hi, far_hi + 7) (and bits
+  // 0..3) go to a FAR launch instead, which works in the index space where the window has changed places with bits
+  // [4, 11): there they permute the workgroup's own block (LDS copy, no gather).  A far launch reads psi and reads and
+  // writes lambda once (3 state-sized transfers) whatever the number of its masks.
+  struct FarWindow {
+    DevBuf<DevTerm> terms;
+    DevBuf<ObsGroup> groups;
+    uint32_t n_terms = 0, n_groups = 0, far_hi = 0;
+  };
+  FarWindow far[3];
+  int n_far = 0;
+  int opt_far_windows = 0;   // 0 (default): never -- measured: config 5 (28 qubits, 17 far single flips) 65.0 ms in one launch,
+                             // 66.2 in three: the far launches move 3 state-sized transfers each as scattered 128-byte runs at about
+                             // half the rate of the streaming first launch; 1: always (any window with a mask); -1: from 26 qubits up,
+                             // windows with >= 3 masks
   DevBuf<float2> psi, lam;
   DevBuf<float> state_grad, slot_factor, vals_tmp, upstream_tmp, phase_cs;
   DevBuf<ShiftPhase> shift_phases;  // gates with a cirq global_shift (qhbm_statevector restores their phases)
@@ -177,7 +195,8 @@ size_t own_bytes(const qhbm_engine* h) {
          buf_bytes(h->value_part) + buf_bytes(h->upstream_tmp) + buf_bytes(h->vals_tmp) + buf_bytes(h->prog_acc) +
          buf_bytes(h->shift_vals) + buf_bytes(h->shift_weight) + buf_bytes(h->shift_gates) + buf_bytes(h->shift_param) +
          buf_bytes(h->slot_factor) + buf_bytes(h->phase_cs) + buf_bytes(h->shift_phases) + buf_bytes(h->terms) +
-         buf_bytes(h->global_terms) + buf_bytes(h->obs_groups) + buf_bytes(h->obs_bterms) + buf_bytes(h->obs_bgroups) + buf_bytes(h->op_scale) + buf_bytes(h->op_inv_scale) +
+         buf_bytes(h->global_terms) + buf_bytes(h->obs_groups) + buf_bytes(h->far[0].terms) + buf_bytes(h->far[0].groups) +
+         buf_bytes(h->far[1].terms) + buf_bytes(h->far[1].groups) + buf_bytes(h->far[2].terms) + buf_bytes(h->far[2].groups) + buf_bytes(h->obs_bterms) + buf_bytes(h->obs_bgroups) + buf_bytes(h->op_scale) + buf_bytes(h->op_inv_scale) +
          buf_bytes(h->param_slot_begin) + buf_bytes(h->param_slots) + plan_bytes(h->fwd) + plan_bytes(h->adj) + [&] {
            size_t cached = 0;  // backward plans of other gradient masks, kept with their device copies (adj_cache)
            for (const auto& kv : h->adj_cache) cached += plan_bytes(*kv.second);
@@ -478,23 +497,25 @@ int upload_model(qhbm_engine* h) {
     // one observable's share of a mask and re-uses the partners its predecessor gathered when the mask is the same)
     const bool by_op = gather_multi_mode(h);
     h->terms_by_op = by_op;
-    std::stable_sort(t.begin(), t.end(), [by_op](const DevTerm& a, const DevTerm& b) {
-      return a.x != b.x ? a.x < b.x : (by_op && a.op < b.op);
-    });
-    std::vector<ObsGroup> groups;
-    for (size_t k = 0; k < t.size(); ++k) {
-      const bool new_mask = k == 0 || t[k].x != t[k - 1].x;
-      if (new_mask || (by_op && t[k].op != t[k - 1].op) || k % (kObsTermChunk / 2) == 0) {
-        groups.push_back(ObsGroup{t[k].x, 0, 0, 0, 0, t[k].op, (new_mask ? 0u : 1u) | (by_op ? 2u : 0u)});
+    // the gather kernel's tables of a term list: sorted by mask (then observable), cut into groups, sign classes in order
+    auto gather_tables = [&](std::vector<DevTerm>& t, std::vector<ObsGroup>* groups) {
+      std::stable_sort(t.begin(), t.end(), [by_op](const DevTerm& a, const DevTerm& b) {
+        return a.x != b.x ? a.x < b.x : (by_op && a.op < b.op);
+      });
+      groups->clear();
+      for (size_t k = 0; k < t.size(); ++k) {
+        const bool new_mask = k == 0 || t[k].x != t[k - 1].x;
+        if (new_mask || (by_op && t[k].op != t[k - 1].op) || k % (kObsTermChunk / 2) == 0) {
+          groups->push_back(ObsGroup{t[k].x, 0, 0, 0, 0, t[k].op, (new_mask ? 0u : 1u) | (by_op ? 2u : 0u)});
+        }
+        groups->back().end = uint32_t(k + 1);
+        groups->back().has_imag |= t[k].ny & 1u;
       }
-      groups.back().end = uint32_t(k + 1);
-      groups.back().has_imag |= t[k].ny & 1u;
-    }
-    {  // order the terms of every real-weight group by sign class (kernels.h ObsGroup)
+      // order the terms of every real-weight group by sign class (kernels.h ObsGroup)
       const uint32_t smask = obs_slot_mask(uint32_t(h->fwd.plan.n_eff));
       auto cls = [&](const DevTerm& d) { return (d.z & kObsThreadMask) == 0 ? 0 : ((d.z & smask) == 0 ? 1 : 2); };
       size_t begin = 0;
-      for (ObsGroup& g : groups) {
+      for (ObsGroup& g : *groups) {
         if (!g.has_imag) {
           std::stable_sort(t.begin() + begin, t.begin() + g.end,
                            [&](const DevTerm& a, const DevTerm& b) { return cls(a) < cls(b); });
@@ -505,12 +526,55 @@ int upload_model(qhbm_engine* h) {
         }
         begin = g.end;
       }
+    };
+    std::vector<DevTerm> full = t;  // (every term, in the gather order: what the block-grouped tables below start from)
+    {
+      std::vector<ObsGroup> unused;
+      gather_tables(full, &unused);
     }
+    // far windows of the two-level sweep (qhbm_engine::FarWindow): top seven bits first
+    h->n_far = 0;
+    const int n_eff = h->fwd.plan.n_eff;
+    const bool far_on = !by_op && obs_amps_per_thread(uint32_t(n_eff)) == 8u &&
+                        (h->opt_far_windows > 0 || (h->opt_far_windows < 0 && n_eff >= 26));
+    if (far_on) {
+      for (int hi = n_eff - 7; hi >= 11 && h->n_far < 3; hi -= 7) {
+        const uint32_t window = 0x7fu << hi;
+        auto takes = [&](const DevTerm& d) { return (d.x & window) != 0u && (d.x & ~(window | 0xfu)) == 0u; };
+        std::vector<uint32_t> masks;
+        for (const DevTerm& d : t) if (takes(d)) masks.push_back(d.x);
+        std::sort(masks.begin(), masks.end());
+        masks.erase(std::unique(masks.begin(), masks.end()), masks.end());
+        if (masks.size() < (h->opt_far_windows > 0 ? 1u : 3u)) continue;  // (three state-sized transfers must buy something)
+        auto virt = [&](uint32_t v) {  // physical -> virtual index bits: the window changes places with bits [4, 11)
+          const uint32_t lo = (v >> 4) & 0x7fu, top = (v >> hi) & 0x7fu;
+          return (v & ~((0x7fu << 4) | window)) | (top << 4) | (lo << hi);
+        };
+        std::vector<DevTerm> ft, rest;
+        for (const DevTerm& d : t) {
+          if (takes(d)) ft.push_back(DevTerm{d.coeff, virt(d.x), virt(d.z), d.ny, d.op});
+          else rest.push_back(d);
+        }
+        t.swap(rest);
+        std::vector<ObsGroup> fg;
+        gather_tables(ft, &fg);
+        qhbm_engine::FarWindow& w = h->far[h->n_far++];
+        HIPCHK(w.terms.upload(ft));
+        HIPCHK(w.groups.upload(fg));
+        w.n_terms = uint32_t(ft.size());
+        w.n_groups = uint32_t(fg.size());
+        w.far_hi = uint32_t(hi);
+      }
+    }
+    std::vector<ObsGroup> groups;
+    gather_tables(t, &groups);
+    if (t.empty()) t.push_back(DevTerm{0.f, 0u, 0u, 0u, 0u});  // (every term went to a far window: the first launch still writes lambda = 0)
     HIPCHK(h->terms.upload(t));
     HIPCHK(h->obs_groups.upload(groups));
     h->n_obs_groups = uint32_t(groups.size());
+    h->n_gather_terms = uint32_t(groups.empty() ? 0u : groups.back().end);
     {  // block-grouped order (kernels.h ObsBTerm): by partner block x >> 13, then by mask, then by observable
-      std::vector<DevTerm> bt = t;
+      std::vector<DevTerm> bt = full;
       std::stable_sort(bt.begin(), bt.end(), [](const DevTerm& a, const DevTerm& b) {
         const uint32_t ao = a.x >> kObsBlockBits, bo = b.x >> kObsBlockBits;
         if (ao != bo) return ao < bo;
@@ -892,7 +956,7 @@ int run_observable_chunk(qhbm_engine* h, uint32_t s0, uint32_t c, const float* d
     HIPCHK(h->value_part.reserve(observable_value_parts(n_eff, c) * size_t(h->model.n_ops)));
     hipEvent_t* ev = timer_begin(h, 2, stream);
     HIPCHK(launch_apply_observable(h->psi.p, store_lambda ? h->lam.p : nullptr, n_eff, c, h->terms.p,
-                                   uint32_t(h->model.terms.size()), h->obs_groups.p, h->n_obs_groups,
+                                   h->n_gather_terms, h->obs_groups.p, h->n_obs_groups,
                                    store_lambda ? d_upstream : nullptr, uint32_t(h->model.n_ops), s0, h->op_scale.p,
                                    h->vals64.p, h->value_part.p, observable_xcd_states(h), stream, true));
     timer_end(ev, stream);
@@ -908,10 +972,13 @@ int run_observable_chunk(qhbm_engine* h, uint32_t s0, uint32_t c, const float* d
                                     h->op_scale.p, value_mode ? h->vals64.p : nullptr, h->value_part.p,
                                     observable_xcd_states(h), stream));
   } else {
+    ObsFarLaunch far[3];
+    for (int f = 0; f < h->n_far; ++f)
+      far[f] = ObsFarLaunch{h->far[f].terms.p, h->far[f].n_terms, h->far[f].groups.p, h->far[f].n_groups, h->far[f].far_hi};
     HIPCHK(launch_apply_observable(h->psi.p, store_lambda ? h->lam.p : nullptr, n_eff, c, h->terms.p,
-                                   uint32_t(h->model.terms.size()), h->obs_groups.p, h->n_obs_groups, d_upstream,
+                                   h->n_gather_terms, h->obs_groups.p, h->n_obs_groups, d_upstream,
                                    uint32_t(h->model.n_ops), s0, h->op_scale.p, value_mode ? h->vals64.p : nullptr,
-                                   h->value_part.p, observable_xcd_states(h), stream));
+                                   h->value_part.p, observable_xcd_states(h), stream, false, far, h->n_far));
   }
   timer_end(ev, stream);
   return 0;
@@ -1163,6 +1230,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "observable_kernel") { h->opt_obs_kernel = int(value); h->block_choice = -1; }
   else if (k == "multi_observable_values") h->opt_multi_values = int(value);
   else if (k == "gather_multi_values") h->opt_gather_multi = int(value);
+  else if (k == "observable_far_windows") { h->opt_far_windows = int(value); h->terms.release(); h->model_uploaded = false; }
   else if (k == "measure_tile_qubits") { h->opt_meas_tile = int(value); h->plans_valid = false; }
   else if (k == "values_from_observable") h->opt_values_from_obs = int(value);
   else if (k == "cph_wave_bits") { h->opt_cph_wave_bits = int(value); h->plans_valid = false; }

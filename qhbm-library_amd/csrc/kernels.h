@@ -38,6 +38,16 @@ enum ObsGatherMode : int {
   OBS_GATHER_MULTI = 2,   // 2..kObsGatherMultiOps observables: the weighted lambda (if asked for) AND every <psi|O_t|psi>
 };
 constexpr uint32_t kObsGatherMultiOps = 4;
+// A far launch of the two-level lambda = O psi sweep (engine.cpp far_windows, kernels.hip obs_phys): the terms whose masks
+// flip only index bits [far_hi, far_hi + 7) (and bits 0..3), with x and z given in the VIRTUAL index space in which that
+// window has changed places with bits [4, 11).
+struct ObsFarLaunch {
+  const DevTerm* terms;
+  uint32_t n_terms;
+  const ObsGroup* groups;
+  uint32_t n_groups;
+  uint32_t far_hi;
+};
 constexpr uint32_t obs_amps_per_thread(uint32_t n) { return n >= 11 ? 8u : 4u; }  // A of apply_observable_kernel<A>
 constexpr uint32_t kObsThreadMask = 0x1feu;                                        // index bits 1..8 = the thread
 constexpr uint32_t obs_slot_mask(uint32_t n) { return 1u | ((obs_amps_per_thread(n) / 2u - 1u) << 9); }  // bit 0 and 9 (, 10)
@@ -115,7 +125,8 @@ hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, u
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
                                    const float* op_scale, unsigned long long* out64, float* value_part,
-                                   bool xcd_states, hipStream_t stream, bool multi = false);
+                                   bool xcd_states, hipStream_t stream, bool multi = false,
+                                   const struct ObsFarLaunch* far = nullptr, int n_far = 0);
 // Terms measured on the final state in HBM (X-mask wider than a tile); accumulates into out64.
 hipError_t launch_measure_global(const float2* psi, uint32_t n, uint32_t n_states, const DevTerm* terms,
                                  uint32_t n_terms, const float* op_scale, unsigned long long* out64, uint32_t n_ops,

@@ -1848,13 +1848,23 @@ template <int A> __device__ __forceinline__ constexpr uint32_t obs_slot_bits(int
 // pair of qubits is zero where the two bits are equal --, and where the mask's qubits are block or slot bits the
 // whole workgroup sees weight 0 for those slots (config 3: half of the partner runs).  A pair that is not
 // fetched holds the thread's own amplitudes instead and is multiplied by exactly 0.
-template <int A>
+// FAR launches (two-level lambda = O psi at >= 26 qubits, engine.cpp far_windows): the kernel works on a VIRTUAL index in
+// which seven far index bits [far_hi, far_hi + 7) have changed places with bits [4, 11) -- the masks that flip only those
+// far bits then permute a workgroup's own block (served from its LDS copy, no gather) while its amplitudes still come
+// as 128-byte runs (bits 0..3 stay).  obs_phys: virtual -> physical index.
+template <bool FAR>
+__device__ __forceinline__ uint32_t obs_phys(uint32_t v, uint32_t far_hi) {
+  if constexpr (!FAR) return v;
+  const uint32_t lo = (v >> 4) & 0x7fu, hi = (v >> far_hi) & 0x7fu;
+  return (v & ~((0x7fu << 4) | (0x7fu << far_hi))) | (hi << 4) | (lo << far_hi);
+}
+template <int A, bool FAR = false>
 __device__ __forceinline__ void obs_gather(float4 (&buf)[A / 2], const float2* __restrict__ ps, uint32_t j0, uint32_t x,
-                                           uint32_t live) {
+                                           uint32_t live, uint32_t far_hi = 0) {
   if (live == 0) return;
 #pragma unroll
   for (int p = 0; p < A / 2; ++p)  // (no branch per pair: a dead one re-reads the thread's own pair, a hit in the nearest cache)
-    buf[p] = *reinterpret_cast<const float4*>(&ps[(j0 + 512u * p) ^ ((live >> p) & 1u ? x & ~1u : 0u)]);
+    buf[p] = *reinterpret_cast<const float4*>(&ps[obs_phys<FAR>((j0 + 512u * p) ^ ((live >> p) & 1u ? x & ~1u : 0u), far_hi)]);
 }
 // One group: acc[s] += (signed weight sum of the group's terms at slot s) * psi[j ^ x].  `buf` holds the
 // gathered partners if the mask leaves the block; a mask inside the block reads the block's LDS copy.
@@ -1982,12 +1992,14 @@ __device__ __forceinline__ void obs_consume(const ObsGroup& gr, float4 (&buf)[A 
 // (the upstream weight of its observable multiplies the group's folded weights when lambda is formed), and a group on
 // the mask of its predecessor re-uses the gathered partners.  No partner run can be skipped as vanishing: XX + YY
 // cancels where the two bits agree, XX alone and YY alone do not.
-template <int A, int VM>
+// FAR = true: a far launch of the two-level sweep (obs_phys): virtual indices, lambda and the value partials ACCUMULATED
+// onto what the first launch left.
+template <int A, int VM, bool FAR = false>
 __global__ __launch_bounds__(256, VM == OBS_GATHER_MULTI ? 4 : 5) void apply_observable_kernel(
     const float2* __restrict__ psi, float2* __restrict__ lam, uint32_t n, const DevTerm* __restrict__ terms,
     uint32_t n_terms, const ObsGroup* __restrict__ groups, uint32_t n_groups,
     const float* __restrict__ upstream, uint32_t n_ops, uint32_t state0, float* __restrict__ value_part,
-    uint32_t nb /* workgroups per state */, uint32_t n_states, uint32_t xcd_states) {
+    uint32_t nb /* workgroups per state */, uint32_t n_states, uint32_t xcd_states, uint32_t far_hi) {
   constexpr int P = A / 2;  // adjacent pairs per thread
   constexpr bool VALUE = VM == OBS_GATHER_VALUE, MULTI = VM == OBS_GATHER_MULTI;
   __shared__ ObsStage<A> st;
@@ -2018,7 +2030,7 @@ __global__ __launch_bounds__(256, VM == OBS_GATHER_MULTI ? 4 : 5) void apply_obs
   __shared__ __attribute__((aligned(16))) v2f own[256 * A];
   float4 self[P];
 #pragma unroll
-  for (int p = 0; p < P; ++p) self[p] = *reinterpret_cast<const float4*>(&ps[j0 + 512u * p]);
+  for (int p = 0; p < P; ++p) self[p] = *reinterpret_cast<const float4*>(&ps[obs_phys<FAR>(j0 + 512u * p, far_hi)]);
   // gathers of the first group that leaves the block (if the first group does): in flight during the staging
   ObsGroup gr = n_groups ? groups[0] : ObsGroup{0u, 0u, 0u, 0u, 0u};
   float4 cur[P];
@@ -2075,7 +2087,7 @@ __global__ __launch_bounds__(256, VM == OBS_GATHER_MULTI ? 4 : 5) void apply_obs
     uint32_t live_next = st.live[0];  // read one group ahead: the gathers must not wait for it
     while (g < n_groups && gr.end <= k1) {  // gr = groups[g], wave-uniform
       const uint32_t live = uni(live_next);
-      if (gr.x >= 256u * A && !(gr.same_x & 1u)) obs_gather<A>(cur, ps, j0, gr.x, live);
+      if (gr.x >= 256u * A && !(gr.same_x & 1u)) obs_gather<A, FAR>(cur, ps, j0, gr.x, live, far_hi);
       live_next = st.live[min(gr.end - k0, kObsChunk - 1u)];  // (past the chunk's last group: unused)
       if constexpr (MULTI) {
         const uint32_t op = uni(gr.op);
@@ -2095,17 +2107,24 @@ __global__ __launch_bounds__(256, VM == OBS_GATHER_MULTI ? 4 : 5) void apply_obs
     }
   }
   if (lam) {  // (null: a forward-only call that wants <psi|O|psi> alone)
-    float2* ls = lam + (size_t(s_local) << n) + jb;
+    float2* ls = lam + (size_t(s_local) << n);
+    typedef float v4f_nt __attribute__((ext_vector_type(4)));
+    [[maybe_unused]] v4f_nt old[P];
+    if constexpr (FAR) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) old[p] = *reinterpret_cast<const v4f_nt*>(&ls[obs_phys<FAR>(j0 + 512u * p, far_hi)]);
+    }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       // streamed past the L2 (QHBM_OBS_NT_STORE): lambda is not read again in this launch, and every line it would
       // occupy there is a line of psi that another workgroup is about to gather
-      typedef float v4f_nt __attribute__((ext_vector_type(4)));
-      const v4f_nt v = {acc[2 * p].x, acc[2 * p].y, acc[2 * p + 1].x, acc[2 * p + 1].y};
+      v4f_nt v = {acc[2 * p].x, acc[2 * p].y, acc[2 * p + 1].x, acc[2 * p + 1].y};
+      if constexpr (FAR) v += old[p];
+      v4f_nt* dst = reinterpret_cast<v4f_nt*>(&ls[obs_phys<FAR>(j0 + 512u * p, far_hi)]);
 #if QHBM_OBS_NT_STORE
-      __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(&ls[tb + 512u * p]));
+      __builtin_nontemporal_store(v, dst);
 #else
-      *reinterpret_cast<v4f_nt*>(&ls[tb + 512u * p]) = v;
+      *dst = v;
 #endif
     }
   }
@@ -2139,8 +2158,11 @@ __global__ __launch_bounds__(256, VM == OBS_GATHER_MULTI ? 4 : 5) void apply_obs
     __syncthreads();
     // one partial per workgroup (512 atomics per state on ONE address cost a quarter of the kernel);
     // value_parts_kernel adds a state's partials in block order
-    if (threadIdx.x == 0)
-      value_part[size_t(s_local) * nb + bx] = (wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3]);  // logical block: the sum order does not depend on the XCD map
+    if (threadIdx.x == 0) {  // logical block: the sum order does not depend on the XCD map
+      const float part = (wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3]);
+      float* dst = &value_part[size_t(s_local) * nb + bx];
+      *dst = FAR ? *dst + part : part;  // (a far launch adds its share of <psi|O|psi> to the first launch's partial)
+    }
   }
 }
 
@@ -3039,7 +3061,7 @@ hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, u
                                    const DevTerm* terms, uint32_t n_terms, const ObsGroup* groups,
                                    uint32_t n_groups, const float* upstream, uint32_t n_ops, uint32_t state0,
                                    const float* op_scale, unsigned long long* out64, float* value_part,
-                                   bool xcd_states, hipStream_t stream, bool multi) {
+                                   bool xcd_states, hipStream_t stream, bool multi, const ObsFarLaunch* far, int n_far) {
   // out64: single observable -- unweighted lambda + <psi|O|psi>; `multi` -- the weighted lambda and every value
   const int mode = multi ? OBS_GATHER_MULTI : (out64 != nullptr ? OBS_GATHER_VALUE : OBS_GATHER_LAMBDA);
   if (multi && (n_ops < 2u || n_ops > kObsGatherMultiOps || !out64)) return hipErrorInvalidValue;
@@ -3047,7 +3069,7 @@ hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, u
   const uint32_t xs = xcd_states && nb >= 128u ? 1u : 0u;  // (a state must at least fill an XCD's workgroup slots)
 #define QHBM_OBS(A_, V_)                                                                                          \
   hipLaunchKernelGGL((apply_observable_kernel<A_, V_>), dim3(nb * n_states), dim3(256), 0, stream, psi, lam, n, terms, \
-                     n_terms, groups, n_groups, upstream, n_ops, state0, value_part, nb, n_states, xs)
+                     n_terms, groups, n_groups, upstream, n_ops, state0, value_part, nb, n_states, xs, 0u)
   if (obs_amps_per_thread(n) == 8u) {
     if (mode == OBS_GATHER_MULTI) QHBM_OBS(8, OBS_GATHER_MULTI);
     else if (mode == OBS_GATHER_VALUE) QHBM_OBS(8, OBS_GATHER_VALUE);
@@ -3058,6 +3080,19 @@ hipError_t launch_apply_observable(const float2* psi, float2* lam, uint32_t n, u
     else QHBM_OBS(4, OBS_GATHER_LAMBDA);
   }
 #undef QHBM_OBS
+  // the far launches of the two-level sweep (single-observable modes, eight amplitudes per thread): lambda and the value
+  // partials accumulate onto the first launch's
+  for (int f = 0; f < n_far; ++f) {
+    if (multi || obs_amps_per_thread(n) != 8u || far[f].far_hi < 11u || far[f].far_hi + 7u > n) return hipErrorInvalidValue;
+    if (mode == OBS_GATHER_VALUE)
+      hipLaunchKernelGGL((apply_observable_kernel<8, OBS_GATHER_VALUE, true>), dim3(nb * n_states), dim3(256), 0, stream, psi, lam, n,
+                         far[f].terms, far[f].n_terms, far[f].groups, far[f].n_groups, upstream, n_ops, state0, value_part, nb,
+                         n_states, xs, far[f].far_hi);
+    else
+      hipLaunchKernelGGL((apply_observable_kernel<8, OBS_GATHER_LAMBDA, true>), dim3(nb * n_states), dim3(256), 0, stream, psi, lam, n,
+                         far[f].terms, far[f].n_terms, far[f].groups, far[f].n_groups, upstream, n_ops, state0, value_part, nb,
+                         n_states, xs, far[f].far_hi);
+  }
   if (mode == OBS_GATHER_VALUE && n_states)
     hipLaunchKernelGGL(value_parts_kernel, dim3(n_states), dim3(256), 0, stream, value_part, nb, op_scale, out64, state0);
   if (mode == OBS_GATHER_MULTI && n_states)

@@ -768,11 +768,15 @@ class Builder {
     static_assert(kRoundBits == 4, "OP_MEASURE_WHT has 16 register classes");
     for (int gi : all) {
       const MeasGroup& g = groups[gi];
-      const bool wht = g.x == 0 && g.terms.size() >= kWhtMinTerms && R_ == kRoundBits && K_ - R_ >= 6 &&
-                       size_t(m_.n_ops) * 8 + (size_t(4) << (K_ - R_)) <= size_t(8) * kMaxOps && !std::getenv("QHBM_NO_WHT");
+      // (the PASS's tile, not this builder's: the wide last pass of a forward plan is measured by the plan's builder --
+      // classes cut at K_ - R_ = 8 bits for a kernel that cuts them at 9 gave wrong values for every plan whose
+      // measuring pass is the wide one, e.g. 38 Z-string shards at 19 qubits)
+      const int Kp = p->K;
+      const bool wht = g.x == 0 && g.terms.size() >= kWhtMinTerms && R_ == kRoundBits && Kp - R_ >= 6 &&
+                       size_t(m_.n_ops) * 8 + (size_t(4) << (Kp - R_)) <= size_t(8) * kMaxOps && !std::getenv("QHBM_NO_WHT");
       if (!wht) { which.push_back(gi); continue; }
       std::vector<std::pair<uint32_t, int>> order;  // (class, term)
-      for (int ti : g.terms) order.push_back({to_local(*p, m_.terms[ti].z & S) >> (K_ - R_), ti});
+      for (int ti : g.terms) order.push_back({to_local(*p, m_.terms[ti].z & S) >> (Kp - R_), ti});
       std::stable_sort(order.begin(), order.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
       p->prog.push_back(OP_MEASURE_WHT | (uint32_t(order.size()) << 8));
       for (uint32_t c = 0; c < 16u; ++c) {

@@ -227,6 +227,14 @@ static void check_plan(const Model& m, const Plan& plan) {
         uint32_t prev = 0;
         for (int cidx = 0; cidx < 16; ++cidx) { const uint32_t e = p.prog[pc + 1 + cidx]; CHECK(e >= prev && e <= n_terms, "class_end"); prev = e; }
         for (size_t t = 0; t < n_terms; ++t) CHECK(p.prog[pc + kWhtHeaderWords + t * kMeasTermWords + 3] < uint32_t(m.n_ops), "wht op index");
+        // a term sits in the class the KERNEL of this pass reads it from: its local z mask cut at the pass's K - 4
+        // (the wide last pass of a forward plan was cut at the plan's K: wrong values at 19 qubits, round 5)
+        for (size_t t = 0; t < n_terms; ++t) {
+          const uint32_t zl = p.prog[pc + kWhtHeaderWords + t * kMeasTermWords];
+          uint32_t cls = 0;
+          while (cls < 15u && t >= p.prog[pc + 1 + cls]) ++cls;
+          CHECK((zl >> K) == 0 && (zl >> (K - 4)) == cls, "wht term %zu: z mask %x in class %u of a tile of 2^%d", t, zl, cls, K);
+        }
         pc += size_t(kWhtHeaderWords) + n_terms * kMeasTermWords;
       } else if (opc == OP_MEASURE) {
         CHECK(!plan.adjoint, "measurement in an adjoint plan");

@@ -1078,3 +1078,26 @@ def test_alternating_gradient_masks_swap_cached_backward_plans():
   eng.set_gradient_mask(masks[2])
   with pytest.raises(E.EngineError):
     eng.state_gradients(3)
+
+
+@pytest.mark.parametrize("case", ["38 shards", "2 x 19 ring", "4 x 10 low", "Z and ZZ"])
+def test_many_diagonal_terms_measured_in_the_wide_last_pass_at_19_qubits(case):
+  """Round 5 regression: at 19 qubits the forward plan's measuring pass is the WIDE last pass (a tile of 2^13), and >= 32
+  diagonal terms go through its Walsh-Hadamard transform.  The scheduler cut the terms' classes at the plan's tile (2^12)
+  instead of the pass's: every such value was wrong (found while testing another option; tests/sanitize/plan_fuzz.cpp now
+  checks the class of every term against the pass's own K)."""
+  n = 19
+  rng = np.random.default_rng(1900)
+  gates, names = O.hea_gates(n, 2, "wht19")
+  params = rng.uniform(-1, 1, len(names))
+  bits = rng.integers(0, 2, size=(2, n)).astype(np.int8)
+  zz = lambda qs: [(float(rng.normal()), 0, (1 << q) | (1 << ((q + 1) % n))) for q in qs]
+  ops = {"38 shards": [[t] for t in zz(range(n)) + zz(range(n))],
+         "2 x 19 ring": [zz(range(n)), zz(range(n))],
+         "4 x 10 low": [zz(range(10)) for _ in range(4)],
+         "Z and ZZ": [zz(range(n)), [(float(rng.normal()), 0, 1 << q) for q in range(n)]]}[case]
+  want = O.expectation(n, gates, params, bits, ops)   # (values only: a Jacobian at 19 qubits costs minutes)
+  eng = _engine(n, gates, len(names), ops)
+  assert "K=13" in eng.describe_schedule()
+  got = eng.expectation(bits, params).cpu().numpy()
+  np.testing.assert_allclose(got, want, atol=5e-5 * max(1.0, _op_norm(ops).max()), rtol=0)

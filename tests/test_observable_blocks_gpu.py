@@ -133,6 +133,35 @@ def test_many_masks_at_19_qubits_values_lambda_and_both_xcd_maps(xcd):
   _check(eng, n, gates, params, bits, ops, up)
 
 
+@pytest.mark.parametrize("n_ops", [1, 3])
+def test_two_level_sweep_far_windows_of_the_gather_kernel_against_the_oracle(n_ops):
+  """Round 5: masks that flip only far index bits go to FAR launches of apply_observable_kernel (virtual index space
+  with the window swapped into bits 4..10, lambda and value partials accumulated onto the first launch's).  Forced at
+  18 qubits (window = bits 11..17): single flips on every qubit, ZZ pairs, Y terms on far bits (imaginary weights),
+  masks that mix window bits with bits 0..3 (taken) and with bits 4..10 (left to the first launch)."""
+  n = 18
+  rng = np.random.default_rng(180 + n_ops)
+  gates, names = O.hea_gates(n, 2, "far")
+  params = rng.uniform(-1, 1, len(names))
+  def op():
+    terms = [(float(rng.normal()), 1 << q, 0) for q in range(n)]                                  # X_q
+    terms += [(float(rng.normal()), 0, (1 << q) | (1 << ((q + 1) % n))) for q in range(n)]        # Z_q Z_q+1
+    terms += [(float(rng.normal()), 1 << q, 1 << q) for q in (0, 3, 11, 14, 17)]                  # Y_q
+    terms += [(float(rng.normal()), (1 << 12) | (1 << 16), 1 << 12), (float(rng.normal()), (1 << 13) | (1 << 2), (1 << 2) | (1 << 9)),
+              (float(rng.normal()), (1 << 15) | (1 << 6), 1 << 15), (float(rng.normal()), (1 << 17) | (1 << 11) | 1, (1 << 17) | 1),
+              (float(rng.normal()), (1 << 14) | (1 << 10), 0)]
+    return terms
+  ops = [op() for _ in range(n_ops)]
+  bits = rng.integers(0, 2, size=(3, n)).astype(np.int8)
+  up = rng.normal(size=(3, n_ops))
+  eng = _engine(n, gates, len(names), ops, observable_kernel=0, observable_far_windows=1)
+  vals, grad = _check(eng, n, gates, params, bits, ops, up)
+  ref = _engine(n, gates, len(names), ops, observable_kernel=0, observable_far_windows=0)
+  rv, rg = ref.expectation_vjp(bits, params, up)
+  np.testing.assert_allclose(vals, rv.cpu().numpy(), atol=2e-5, rtol=0)
+  np.testing.assert_allclose(grad, rg.cpu().numpy(), atol=2e-5 * max(1.0, np.abs(grad).max()), rtol=0)
+
+
 @pytest.mark.parametrize("kernel", [-1, 1])
 def test_three_observables_xxz_split_at_16_qubits_match_the_single_sum(kernel):
   """XXZ split into its XX, YY and ZZ sums (the reference's normal usage: several operators per call,
