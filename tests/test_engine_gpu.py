@@ -1088,7 +1088,7 @@ def test_many_diagonal_terms_measured_in_the_wide_last_pass_at_19_qubits(case):
   checks the class of every term against the pass's own K)."""
   n = 19
   rng = np.random.default_rng(1900)
-  gates, names = O.hea_gates(n, 2, "wht19")
+  gates, names = O.hea_gates(n, 3, "wht19")
   params = rng.uniform(-1, 1, len(names))
   bits = rng.integers(0, 2, size=(2, n)).astype(np.int8)
   zz = lambda qs: [(float(rng.normal()), 0, (1 << q) | (1 << ((q + 1) % n))) for q in qs]
@@ -1098,6 +1098,8 @@ def test_many_diagonal_terms_measured_in_the_wide_last_pass_at_19_qubits(case):
          "Z and ZZ": [zz(range(n)), [(float(rng.normal()), 0, 1 << q) for q in range(n)]]}[case]
   want = O.expectation(n, gates, params, bits, ops)   # (values only: a Jacobian at 19 qubits costs minutes)
   eng = _engine(n, gates, len(names), ops)
-  assert "K=13" in eng.describe_schedule()
+  forward = eng.describe_schedule().split("adjoint")[0]
+  measuring = [line for line in forward.splitlines() if "meas_terms=" in line and "meas_terms=0" not in line]
+  assert measuring and all("K=13" in line for line in measuring), measuring   # (the case the test is for)
   got = eng.expectation(bits, params).cpu().numpy()
   np.testing.assert_allclose(got, want, atol=5e-5 * max(1.0, _op_norm(ops).max()), rtol=0)
