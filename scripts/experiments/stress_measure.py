@@ -1,6 +1,6 @@
 """Randomised parity stress of the values MEASURED IN THE PASSES under default plan options (wide last pass, measurement-only
 passes, the Walsh-Hadamard path for >= 32 diagonal terms) against the numpy oracle, 15..20 qubits (developer tool; GPU).
-  python scripts/experiments/stress_measure.py [seeds] [first seed]
+  python scripts/experiments/stress_measure.py [seeds] [first seed]      (STRESS_N_BASE / STRESS_N_SPAN: qubit counts, default 15 / 6)
 Round 5 added it after the wide-last-pass / WHT class bug: the fixed-tile stress of stress_parity.py never plans a wide pass."""
 import sys; import os; ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'qhbm-library_amd'))
 import numpy as np
@@ -10,7 +10,7 @@ bad=0
 first=int(sys.argv[2]) if len(sys.argv) > 2 else 0
 for seed in range(first, first+(int(sys.argv[1]) if len(sys.argv) > 1 else 18)):
   rng=np.random.default_rng(5000+seed)
-  n=15+seed%6
+  n=int(os.environ.get('STRESS_N_BASE','15'))+seed%int(os.environ.get('STRESS_N_SPAN','6'))
   gates,names=O.hea_gates(n, 2+seed%3, "sm"); P=len(names)
   params=rng.uniform(-1,1,P)
   k=int(rng.integers(20,90))                      # diagonal terms: below and above the WHT threshold (32)
