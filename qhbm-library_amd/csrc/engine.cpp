@@ -128,6 +128,8 @@ struct qhbm_engine {
                                 // by default, kept selectable (tests, A/B runs)
   int opt_multi_values = -1;    // several observables: values from the block kernel after lean passes (-1: when some term flips >= 2
                                 // qubits or needs a measurement-only pass, at most kMultiValueOps observables)
+  DevBuf<uint64_t> probe_out;  // qhbm_clock_probe's buffers
+  DevBuf<float> probe_sink;
   DevBuf<float> value_part;  // value mode: one partial of <psi|O|psi> per workgroup of apply_observable_kernel
   uint32_t n_obs_groups = 0;
   uint32_t n_gather_terms = 0;  // terms of the gather kernel's FIRST launch (all of them unless far windows took some)
@@ -192,7 +194,7 @@ size_t plan_bytes(const DevicePlan& d) {
 size_t own_bytes(const qhbm_engine* h) {
   return buf_bytes(h->psi) + buf_bytes(h->lam) + buf_bytes(h->state_grad) + buf_bytes(h->tile_grad) +
          buf_bytes(h->vals64) + buf_bytes(h->block_cum) + buf_bytes(h->coef_batch) + buf_bytes(h->vals_batch) +
-         buf_bytes(h->value_part) + buf_bytes(h->upstream_tmp) + buf_bytes(h->vals_tmp) + buf_bytes(h->prog_acc) +
+         buf_bytes(h->value_part) + buf_bytes(h->probe_out) + buf_bytes(h->probe_sink) + buf_bytes(h->upstream_tmp) + buf_bytes(h->vals_tmp) + buf_bytes(h->prog_acc) +
          buf_bytes(h->shift_vals) + buf_bytes(h->shift_weight) + buf_bytes(h->shift_gates) + buf_bytes(h->shift_param) +
          buf_bytes(h->slot_factor) + buf_bytes(h->phase_cs) + buf_bytes(h->shift_phases) + buf_bytes(h->terms) +
          buf_bytes(h->global_terms) + buf_bytes(h->obs_groups) + buf_bytes(h->far[0].terms) + buf_bytes(h->far[0].groups) +
@@ -506,7 +508,10 @@ int upload_model(qhbm_engine* h) {
       for (size_t k = 0; k < t.size(); ++k) {
         const bool new_mask = k == 0 || t[k].x != t[k - 1].x;
         if (new_mask || (by_op && t[k].op != t[k - 1].op) || k % (kObsTermChunk / 2) == 0) {
-          groups->push_back(ObsGroup{t[k].x, 0, 0, 0, 0, t[k].op, (new_mask ? 0u : 1u) | (by_op ? 2u : 0u)});
+          // same_x bit 0 ("re-use the predecessor's partners") only in (mask, observable) order, where bit 1 makes every
+          // group fetch ALL its pairs: in the default order a mask cut at a chunk boundary gathers again, because its first
+          // part may have fetched only the pairs it does not vanish on (or nothing at all)
+          groups->push_back(ObsGroup{t[k].x, 0, 0, 0, 0, t[k].op, by_op ? (new_mask ? 2u : 3u) : 0u});
         }
         groups->back().end = uint32_t(k + 1);
         groups->back().has_imag |= t[k].ny & 1u;
@@ -1845,22 +1850,27 @@ extern "C" int qhbm_clock_probe(qhbm_engine* h, double* ghz, double* cycles_per_
   HIPCHK(hipGetDeviceProperties(&prop, h->device));
   const uint32_t n_cus = uint32_t(prop.multiProcessorCount);
   const uint32_t n_waves = clock_probe_waves(n_cus);
-  DevBuf<uint64_t> out;
-  DevBuf<float> sink;
+  // (the probe's buffers stay with the engine: bench.py probes after every run)
+  DevBuf<uint64_t>& out = h->probe_out;
+  DevBuf<float>& sink = h->probe_sink;
   HIPCHK(out.reserve(size_t(2) * n_waves));
   HIPCHK(sink.reserve(1));
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
+  struct Events {  // destroyed on every exit path
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Events() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+    }
+  } ev;
+  HIPCHK(hipEventCreate(&ev.e0));
+  HIPCHK(hipEventCreate(&ev.e1));
   HIPCHK(launch_clock_probe(out.p, sink.p, n_cus, stream));  // warm-up: code object load, clocks
-  HIPCHK(hipEventRecord(e0, stream));
+  HIPCHK(hipEventRecord(ev.e0, stream));
   HIPCHK(launch_clock_probe(out.p, sink.p, n_cus, stream));
-  HIPCHK(hipEventRecord(e1, stream));
-  HIPCHK(hipEventSynchronize(e1));
+  HIPCHK(hipEventRecord(ev.e1, stream));
+  HIPCHK(hipEventSynchronize(ev.e1));
   float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  HIPCHK(hipEventElapsedTime(&ms, ev.e0, ev.e1));
   std::vector<uint64_t> host(size_t(2) * n_waves);
   HIPCHK(hipMemcpy(host.data(), out.p, host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
   double cyc = 0.0, ticks = 0.0;

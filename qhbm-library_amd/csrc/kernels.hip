@@ -2473,6 +2473,15 @@ static hipError_t opt_in_lds(Kernel kernel, bool (&done)[kMaxDevices], size_t ld
   return hipSuccess;
 }
 
+// Preconditions of the workgroup prologue (input_index, launched_tile, tile_base_of, relabel_lookup): its bit
+// permutations are 64-lane ballots truncated to 32 bits with one table element per lane, which is correct only when
+// every wave is FULL and convergent at the call (K >= 10: at least 2^(K-4) = 64 threads; the dispatch below has no
+// smaller instantiation), 1 <= n_user <= 32 (`>> (32 - n_user)` and `min(L, n_user - 1)` are undefined at 0) and the
+// index has at most 32 bits.  qhbm_set_circuit bounds the qubit count to [1, 31]; this guards the launch itself.
+static bool pass_prologue_ok(int K, const PassArgs& a, int n_user) {
+  return K >= 10 && n_user >= 1 && n_user <= 32 && a.n >= 1u && a.n <= 32u && a.n_nonlocal <= 32u;
+}
+
 template <int K, int R, bool GEN>
 static hipError_t launch_fwd_t(const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
                                int n_user, const uint32_t* prog, const uint32_t* tables,
@@ -2490,6 +2499,7 @@ static hipError_t launch_fwd_t(const PassArgs& a, uint32_t n_states, float2* psi
 hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
                            int n_user, const uint32_t* prog, const uint32_t* tables, const float* coef,
                            const float* op_scale, unsigned long long* out64, uint32_t state0, hipStream_t stream) {
+  if (!pass_prologue_ok(K, a, n_user)) return hipErrorInvalidValue;
 #define QHBM_FWD_CASE(K_, R_)                                                                          \
   if (K == K_ && R == R_)                                                                              \
     return (a.flags & PASS_GENERAL)                                                                    \
@@ -2522,6 +2532,7 @@ bool pass_fwd_pair_supported(int K) { return K >= 10 && K <= 13; }
 hipError_t launch_pass_fwd_pair(int K, const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits, int n_user,
                                 uint32_t state0, const uint32_t* prog, const uint32_t* tables, const float* coef,
                                 hipStream_t stream) {
+  if (!pass_prologue_ok(K, a, n_user)) return hipErrorInvalidValue;
   switch (K) {
     case 10: return launch_fwd2_t<10>(a, n_states, psi, bits, n_user, state0, prog, tables, coef, stream);
     case 11: return launch_fwd2_t<11>(a, n_states, psi, bits, n_user, state0, prog, tables, coef, stream);
@@ -2589,6 +2600,7 @@ static hipError_t launch_adjx_t(const PassArgs& a, uint32_t n_states, float2* ps
 hipError_t launch_pass_adj(int K, bool exchange, const PassArgs& a, uint32_t n_states, float2* psi, float2* lam,
                            const int8_t* bits, int n_user, const uint32_t* prog, const uint32_t* tables,
                            const float* coef, float* tile_grad, uint32_t state0, hipStream_t stream) {
+  if (!pass_prologue_ok(K, a, n_user)) return hipErrorInvalidValue;
 #define QHBM_ADJ_CASE(K_)                                                                                           \
   case K_:                                                                                                          \
     if (a.flags & PASS_GENERAL)                                                                                     \

@@ -6,6 +6,7 @@ streams only.
 """
 import ctypes
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -26,6 +27,8 @@ GATE_ISWAPPOW = 8
 GATE_XXPOW = 9
 GATE_YYPOW = 10
 GATE_ZZPOW = 11
+
+ABI_VERSION = 5  # include/qhbm_engine.h QHBM_ABI_VERSION
 
 GRAD_ADJOINT = 0
 GRAD_PARAMETER_SHIFT = 1
@@ -68,6 +71,16 @@ def load_library():
   lib = ctypes.CDLL(LIB_PATH)
   vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
   lib.qhbm_abi_version.restype = i32
+  found = lib.qhbm_abi_version()
+  if found != ABI_VERSION:
+    # an OLDER library handed in on purpose (QHBM_ENGINE_LIB, the one-box A/B runs of scripts/r05_ab.sh) is tolerated
+    # with a warning: the optional symbols below are skipped; anything else is a stale build
+    if os.environ.get("QHBM_ENGINE_LIB") and found < ABI_VERSION:
+      warnings.warn(f"{LIB_PATH} exports ABI v{found}, this binding is written for v{ABI_VERSION}: newer entry "
+                    "points are unavailable")
+    else:
+      raise EngineError(f"{LIB_PATH} exports ABI v{found}, this binding needs v{ABI_VERSION}: rebuild the engine "
+                        "(python -c 'import __graft_entry__ as g; g.build()')")
   lib.qhbm_create.argtypes = [i32, ctypes.POINTER(vp)]
   lib.qhbm_destroy.argtypes = [vp]
   lib.qhbm_destroy.restype = None
@@ -100,8 +113,8 @@ def load_library():
       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
   lib.qhbm_traffic_model.argtypes = [vp, i32, i32] + [ctypes.POINTER(ctypes.c_double)] * 3
   lib.qhbm_flop_model.argtypes = [vp, i32, i32] + [ctypes.POINTER(ctypes.c_double)] * 3
-  lib.qhbm_op_census.argtypes = [vp, i32, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i32)]
   try:
+    lib.qhbm_op_census.argtypes = [vp, i32, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i32)]
     lib.qhbm_plan_builds.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     lib.qhbm_clock_probe.argtypes = [vp] + [ctypes.POINTER(ctypes.c_double)] * 3 + [vp]
   except AttributeError:  # an older library given through QHBM_ENGINE_LIB (A/B runs): the probe is optional there

@@ -376,6 +376,52 @@ def test_masks_whose_terms_cancel_on_part_of_the_index_space(n, layers):
     np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=1e-4 * max(1.0, np.abs(want_grad).max()))
 
 
+@pytest.mark.parametrize("n,cut", [(13, 256), (13, 512), (16, 256)])
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_a_mask_whose_terms_straddle_a_staging_chunk_of_the_gather_kernel(n, cut, kernel):
+  """The gather kernel stages 256 terms at a time; a mask whose terms straddle a multiple of 256 in the mask-sorted
+  term array is cut into two groups.  The second group must fetch its partners again: the first may have fetched only
+  the slot pairs it does not vanish on, or -- XX + YY on two block bits, where the bits agree -- nothing at all (round
+  5's advisor finding: the second group then consumed stale partners).  `cut - 2` diagonal strings sort in front of
+  XX + YY (+ a Z-dressed XX and YY behind the cut), on masks that leave the block and on one inside it; value mode
+  (forward only), lambda mode (VJP) and several observables; the block kernel on the same operator for comparison."""
+  from oracle import qhbm_cpu as C
+  rng = np.random.default_rng(7 * n + cut)
+  gates, names = O.hea_gates(n, 2, "s")
+  params = rng.uniform(-1, 1, len(names)).astype(np.float32)
+  seen, diag = set(), []
+  while len(diag) < cut - 2:
+    z = int(rng.integers(1, 1 << n))
+    if z not in seen:
+      seen.add(z)
+      diag.append((float(rng.normal()) * 0.05, 0, z))
+  bits = _random_bits(rng, 6, n)
+  for a, b in [(0, 1), (0, n // 2), (n - 3, n - 2)]:
+    # sorted by mask: the diagonal strings (x = 0), then [XX, YY | XXZ, YYZ, XX'] of the one flip mask
+    tail = [O.pauli_term(1.0, [(a, "X"), (b, "X")]), O.pauli_term(1.0, [(a, "Y"), (b, "Y")]),
+            O.pauli_term(0.7, [(a, "X"), (b, "X"), (5, "Z")]), O.pauli_term(-0.4, [(a, "Y"), (b, "Y"), (5, "Z")]),
+            O.pauli_term(0.3, [(a, "X"), (b, "X"), (n - 1, "Z")])]
+    op = diag + tail
+    eng = _engine(n, gates, len(names), [op], observable_kernel=kernel)
+    norm = _op_norm([op])[0]
+    got = eng.expectation(bits, params).cpu().numpy()
+    up = rng.normal(size=(6, 1)).astype(np.float32)
+    want, want_grad = C.expectation_vjp(n, gates, params, bits, [op], up)
+    np.testing.assert_allclose(got, want, atol=2e-5 * norm, err_msg=f"values, pair {(a, b)}")
+    vals, grad = eng.expectation_vjp(bits, params, up)
+    np.testing.assert_allclose(vals.cpu().numpy(), want, atol=2e-5 * norm)
+    np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=1e-4 * max(1.0, np.abs(want_grad).max()),
+                               err_msg=f"gradient, pair {(a, b)}")
+    # two observables (weighted lambda): the second holds the same masks with other weights
+    ops = [op, diag[: cut - 3] + tail[1:] + tail[:1]]
+    eng = _engine(n, gates, len(names), ops, observable_kernel=kernel)
+    up = rng.normal(size=(6, 2)).astype(np.float32)
+    vals, grad = eng.expectation_vjp(bits, params, up)
+    want, want_grad = C.expectation_vjp(n, gates, params, bits, ops, up)
+    np.testing.assert_allclose(vals.cpu().numpy(), want, atol=2e-5 * _op_norm(ops).max())
+    np.testing.assert_allclose(grad.cpu().numpy(), want_grad, atol=1e-4 * max(1.0, np.abs(want_grad).max()))
+
+
 def test_results_are_bit_reproducible_and_independent_of_chunking():
   """No floating-point atomics anywhere: expectation values accumulate in 64-bit fixed point,
   gradient partials go wave -> tile -> state in fixed order.  Two runs, and a run cut into chunks
