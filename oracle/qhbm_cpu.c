@@ -36,6 +36,12 @@ typedef struct {
 typedef float complex cf;
 typedef double complex cd;
 
+/* Threads: across states (TFQ's policy for batches of small circuits), or -- when a call holds fewer states than
+ * threads and the state is large (qo_expectation*: U < threads / 2 and n >= 18), and always from 26 qubits (TFQ's
+ * policy for large circuits [SURVEY.md 8d]) -- INSIDE a state: the same gate-by-gate arithmetic with the sweep over the
+ * amplitudes split over the team (sums of a sweep are double-precision reductions, so only their order changes). */
+static int g_inner = 0;
+
 enum { G_I = 0, G_X, G_Y, G_Z, G_H, G_CZ, G_CNOT, G_SWAP, G_ISWAP, G_XX, G_YY, G_ZZ };
 
 static int two_qubit(int kind) { return kind >= G_CZ; }
@@ -101,18 +107,29 @@ static double exponent_of(const qo_gate* g, const float* params) {
 }
 
 static void apply1(cf* psi, int n, int bit, const cf* m) {
-  const size_t dim = (size_t)1 << n, st = (size_t)1 << bit;
-  for (size_t base = 0; base < dim; base += 2 * st)
-    for (size_t k = base; k < base + st; ++k) {
-      cf a = psi[k], b = psi[k + st];
-      psi[k] = m[0] * a + m[1] * b;
-      psi[k + st] = m[2] * a + m[3] * b;
-    }
+  const size_t dim = (size_t)1 << n, half = dim >> 1, st = (size_t)1 << bit;
+  if (!g_inner) {
+    for (size_t base = 0; base < dim; base += 2 * st)
+      for (size_t k = base; k < base + st; ++k) {
+        cf a = psi[k], b = psi[k + st];
+        psi[k] = m[0] * a + m[1] * b;
+        psi[k + st] = m[2] * a + m[3] * b;
+      }
+    return;
+  }
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < half; ++i) { /* the same pairs, dealt to the team */
+    const size_t k = ((i >> bit) << (bit + 1)) | (i & (st - 1));
+    cf a = psi[k], b = psi[k + st];
+    psi[k] = m[0] * a + m[1] * b;
+    psi[k + st] = m[2] * a + m[3] * b;
+  }
 }
 
 static void apply2(cf* psi, int n, int bit_hi_q0, int bit_q1, const cf* m) {
   /* matrix index = (b_q0 << 1) | b_q1 */
   const size_t dim = (size_t)1 << n, s0 = (size_t)1 << bit_hi_q0, s1 = (size_t)1 << bit_q1;
+#pragma omp parallel for schedule(static) if (g_inner)
   for (size_t k = 0; k < dim; ++k) {
     if (k & (s0 | s1)) continue;
     cf x[4] = {psi[k], psi[k | s1], psi[k | s0], psi[k | s0 | s1]}, y[4];
@@ -138,15 +155,27 @@ static double inner_du(const cf* lam, const cf* psi, int n, const qo_gate* g, co
     const size_t st = (size_t)1 << (n - 1 - g->q0);
     cf m[4];
     for (int i = 0; i < 4; ++i) m[i] = (cf)du[i];
-    for (size_t base = 0; base < dim; base += 2 * st)
-      for (size_t k = base; k < base + st; ++k) {
+    const int bit = n - 1 - g->q0;
+    const size_t half = dim >> 1;
+    if (!g_inner) {
+      for (size_t base = 0; base < dim; base += 2 * st)
+        for (size_t k = base; k < base + st; ++k) {
+          cf a = psi[k], b = psi[k + st];
+          acc += creal(conjf(lam[k]) * (m[0] * a + m[1] * b) + conjf(lam[k + st]) * (m[2] * a + m[3] * b));
+        }
+    } else {
+#pragma omp parallel for schedule(static) reduction(+ : acc)
+      for (size_t i = 0; i < half; ++i) {
+        const size_t k = ((i >> bit) << (bit + 1)) | (i & (st - 1));
         cf a = psi[k], b = psi[k + st];
         acc += creal(conjf(lam[k]) * (m[0] * a + m[1] * b) + conjf(lam[k + st]) * (m[2] * a + m[3] * b));
       }
+    }
   } else {
     const size_t s0 = (size_t)1 << (n - 1 - g->q0), s1 = (size_t)1 << (n - 1 - g->q1);
     cf m[16];
     for (int i = 0; i < 16; ++i) m[i] = (cf)du[i];
+#pragma omp parallel for schedule(static) reduction(+ : acc) if (g_inner)
     for (size_t k = 0; k < dim; ++k) {
       if (k & (s0 | s1)) continue;
       const size_t ix[4] = {k, k | s1, k | s0, k | s0 | s1};
@@ -190,18 +219,32 @@ static void simulate(cf* psi, int n, int n_gates, const qo_gate* gates, const fl
 static double term_expectation(const cf* psi, int n, uint64_t x, uint64_t z, int ny) {
   const size_t dim = (size_t)1 << n;
   double acc = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : acc) if (g_inner)
   for (size_t j = 0; j < dim; ++j) acc += creal(conjf(psi[j ^ x]) * pauli_phase(ny, j, z) * psi[j]);
   return acc;
+}
+
+static int team_size(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+static void choose_threading(int n, int U, int n_threads) {
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+  g_inner = team_size() > 1 && (n >= 26 || (n >= 18 && 2 * U < team_size()));
 }
 
 int qo_expectation(int n, int n_gates, const qo_gate* gates, const float* params, const int8_t* bits, int U,
                    int n_ops, const int32_t* term_offsets, const float* coeffs, const uint64_t* xq,
                    const uint64_t* zq, float* out, int n_threads) {
   const size_t dim = (size_t)1 << n;
-#ifdef _OPENMP
-  if (n_threads > 0) omp_set_num_threads(n_threads);
-#endif
-#pragma omp parallel
+  choose_threading(n, U, n_threads);
+#pragma omp parallel if (!g_inner)
   {
     cf* psi = (cf*)malloc(dim * sizeof(cf));
 #pragma omp for schedule(dynamic, 1)
@@ -228,10 +271,8 @@ int qo_expectation_vjp(int n, int n_gates, const qo_gate* gates, const float* pa
                        float* grad, int n_params, int n_threads) {
   const size_t dim = (size_t)1 << n;
   double* gsum = (double*)calloc((size_t)n_params + 1, sizeof(double));
-#ifdef _OPENMP
-  if (n_threads > 0) omp_set_num_threads(n_threads);
-#endif
-#pragma omp parallel
+  choose_threading(n, U, n_threads);
+#pragma omp parallel if (!g_inner)
   {
     cf* psi = (cf*)malloc(dim * sizeof(cf));
     cf* lam = (cf*)malloc(dim * sizeof(cf));
@@ -248,6 +289,7 @@ int qo_expectation_vjp(int n, int n_gates, const qo_gate* gates, const float* pa
           int ny = __builtin_popcountll(xq[j] & zq[j]);
           e += coeffs[j] * term_expectation(psi, n, x, z, ny);
           const float c = w * coeffs[j];
+#pragma omp parallel for schedule(static) if (g_inner)
           for (size_t i = 0; i < dim; ++i) lam[i] += c * pauli_phase(ny, i ^ x, z) * psi[i ^ x];
         }
         if (out_vals) out_vals[(size_t)u * n_ops + k] = (float)e;
@@ -270,6 +312,17 @@ int qo_expectation_vjp(int n, int n_gates, const qo_gate* gates, const float* pa
   }
   for (int p = 0; p < n_params; ++p) grad[p] = (float)gsum[p];
   free(gsum);
+  return 0;
+}
+
+/* Final states C(params)|x_u>, complex64 [U, 2^n] (the checker of qhbm_statevector at sizes numpy needs minutes for).
+ * Gate records carry no cirq global_shift here: exact for the X / Z / CZ powers of the HEA (global_shift 0). */
+int qo_statevector(int n, int n_gates, const qo_gate* gates, const float* params, const int8_t* bits, int U, cf* out,
+                   int n_threads) {
+  const size_t dim = (size_t)1 << n;
+  choose_threading(n, U, n_threads);
+#pragma omp parallel for schedule(dynamic, 1) if (!g_inner)
+  for (int u = 0; u < U; ++u) simulate(out + (size_t)u * dim, n, n_gates, gates, params, bits + (size_t)u * n);
   return 0;
 }
 

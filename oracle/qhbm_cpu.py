@@ -69,3 +69,15 @@ def expectation_vjp(n, gates, params, bits, ops, upstream, n_threads=0):
                          vp(up.ctypes.data), vp(vals.ctypes.data), vp(grad.ctypes.data),
                          ctypes.c_int(len(p)), ctypes.c_int(n_threads))
   return vals, grad
+
+
+def statevector(n, gates, params, bits, n_threads=0):
+  """complex64 [batch, 2^n] final states (qubit 0 = most significant index bit); cirq's global_shift is not carried:
+  exact for X / Z / CZ powers."""
+  lib = _load()
+  arr, p, b, _, _, _, _ = _pack(n, gates, params, bits, [])
+  out = np.zeros((b.shape[0], 1 << n), np.complex64)
+  vp = ctypes.c_void_p
+  lib.qo_statevector(ctypes.c_int(n), ctypes.c_int(len(gates)), arr, vp(p.ctypes.data), vp(b.ctypes.data),
+                     ctypes.c_int(b.shape[0]), vp(out.ctypes.data), ctypes.c_int(n_threads))
+  return out
