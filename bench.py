@@ -246,6 +246,110 @@ def stored_profile(name, n, layers, hamiltonian, mode):
   return tj if same else None
 
 
+def mirror_bench(args):
+  """`--through-mirror`: one JSON line with `mirror_step_ms` (eager), `captured_step_ms` (hipGraph replay) and the
+  engine's `engine_ms_per_step` on the same unique rows.  Reference of the step: vqt_loss.py:25-55, ebm.py:262-329."""
+  if not torch.cuda.is_available():
+    raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+  from qhbmlib_amd import _engine as E, inference, ir, models, utils  # pylint: disable=import-outside-toplevel
+  torch.cuda.set_device(0)
+  cfg = {"c1": dict(n=4, layers=2, samples=32, ham="tfim", ebm="bernoulli", label="BASELINE configs[0]"),
+         "c2": dict(n=12, layers=8, samples=1024, ham="tfim", ebm="bernoulli", label="BASELINE configs[1]"),
+         "c3": dict(n=20, layers=16, samples=4096, ham="xxz", ebm="kobe2", label="BASELINE configs[2]")}[args.through_mirror]
+  n, layers, samples = cfg["n"], cfg["layers"], cfg["samples"]
+  qubits = ir.GridQubit.rect(1, n)
+  pqc = ir.Circuit()
+  for layer in range(layers):                      # tests/test_util.py:25-67 of the reference
+    for q, qubit in enumerate(qubits):
+      pqc += [ir.X(qubit)**ir.Symbol(f"sx_b_{layer}_{q}"), ir.Z(qubit)**ir.Symbol(f"sz_b_{layer}_{q}")]
+    for k, (q0, q1) in enumerate(zip(qubits[::2], qubits[1::2])):
+      pqc += ir.CZPowGate(ir.Symbol(f"sc_b_{layer}_{2 * k}"))(q0, q1)
+    for k, (q0, q1) in enumerate(zip(qubits[1::2], qubits[2::2])):
+      pqc += ir.CZPowGate(ir.Symbol(f"sc_b_{layer}_{2 * k + 1}"))(q0, q1)
+  torch.manual_seed(1234)
+  circuit = models.DirectQuantumCircuit(pqc, tfq_compat_bit_order=False).to("cuda")
+  with torch.no_grad():
+    circuit.trainable_variables[0].uniform_(-1, 1)
+  energy = (models.BernoulliEnergy(list(range(n))) if cfg["ebm"] == "bernoulli" else models.KOBE(list(range(n)), 2)).to("cuda")
+  with torch.no_grad():
+    energy.post_process[0].kernel.uniform_(-0.1, 0.1)   # high entropy: U close to the sample count (SURVEY.md 8d)
+  e_inf = (inference.BernoulliEnergyInference if cfg["ebm"] == "bernoulli" else inference.AnalyticEnergyInference)(
+      energy, samples, initial_seed=7)
+  qhbm = inference.QHBM(e_inf, inference.AnalyticQuantumInference(circuit))
+  ham = ir.PauliSum()
+  if cfg["ham"] == "tfim":
+    for i, q in enumerate(qubits):
+      ham += -1.0 * ir.PX(q)
+      ham += -1.0 * ir.PZ(q) * ir.PZ(qubits[(i + 1) % n])
+  else:
+    for a, b in zip(qubits, qubits[1:]):
+      ham += ir.PX(a) * ir.PX(b) + ir.PY(a) * ir.PY(b) + 0.5 * ir.PZ(a) * ir.PZ(b)
+  variables = list(energy.parameters()) + circuit.trainable_variables
+  with torch.no_grad():
+    drawn = e_inf.sample(samples).cuda()
+  rows, _, counts = utils.unique_bitstrings_with_counts(drawn)   # the fixed multiset of every timed step
+  n_unique = int(rows.shape[0])
+
+  def eager_step():
+    for v in variables:
+      v.grad = None
+    with e_inf.fixed_samples(rows, counts):
+      loss = inference.vqt(qhbm, [ham], 1.0)
+      loss.backward()
+    return loss.detach()
+
+  def timed(fn):
+    for _ in range(args.warmup):
+      fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / args.steps * 1e3, out
+
+  mirror_ms, loss_eager = timed(eager_step)
+  grads_eager = [v.grad.detach().clone() for v in variables]
+  # the engine's own time on the same rows: values + adjoint VJP (the default line's step)
+  (eng,) = list(qhbm.q_inference._engines._engines.values())   # pylint: disable=protected-access
+  upstream = (counts.float() / counts.sum()).reshape(-1, 1).contiguous()
+  phi = circuit.symbol_values.detach()
+  engine_ms, _ = timed(lambda: eng.expectation_vjp(rows, phi, upstream))
+  # hipGraph replay of the padded step
+  step = inference.CapturedLoss(lambda: inference.vqt(qhbm, [ham], 1.0), [e_inf], variables)
+  loss_padded_eager = step.eager([(rows, counts)]).clone()
+  grads_padded_eager = [v.grad.detach().clone() for v in variables]
+  captured_ms, loss_replay = timed(lambda: step([(rows, counts)]))
+  torch.cuda.synchronize()
+  same_bits = bool(torch.equal(loss_replay, loss_padded_eager)) and all(
+      torch.equal(v.grad, g) for v, g in zip(variables, grads_padded_eager))
+  drift = max([float((loss_replay - loss_eager).abs())] +
+              [float((v.grad - g).abs().max()) for v, g in zip(variables, grads_eager)])
+  replay_only_ms, _ = timed(lambda: step._graph.replay())   # pylint: disable=protected-access
+  with open(os.path.abspath(__file__), "rb") as f:
+    bench_sha = hashlib.sha256(f.read()).hexdigest()[:16]
+  line = {
+      "metric": "VQT step time through the host mirror: inference.vqt(qhbm, H, beta) + backward(), sampler excluded",
+      "value": mirror_ms, "unit": "ms", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+      "ms_per_step": mirror_ms, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+      "data": "synthetic",
+      "config": {"workload": (f"{cfg['label']} through the host mirror: {n}-qubit {cfg['ham'].upper()}, {cfg['ebm']} EBM, HEA depth "
+                              f"{layers}, {samples} samples = {n_unique} unique bitstrings (fixed multiset, sampler excluded)"),
+                 "n_qubits": n, "layers": layers, "samples": samples, "unique_bitstrings": n_unique,
+                 "bench_py_sha16": bench_sha, "kernel_sources_sha16": kernel_sources_sha16()},
+      "mirror_step_ms": mirror_ms,                 # eager: vqt() + backward() on the unique rows
+      "captured_step_ms": captured_ms,             # CapturedLoss: buffers refilled + hipGraph replay, padded to `samples` rows
+      "captured_replay_only_ms": replay_only_ms,   # the graph replay alone
+      "engine_ms_per_step": engine_ms,             # qhbm_expectation_vjp on the same unique rows
+      "mirror_over_engine": mirror_ms / engine_ms, "captured_over_engine": captured_ms / engine_ms,
+      "replay_equals_padded_eager_bitwise": same_bits,
+      "max_abs_diff_replay_vs_unpadded_eager": drift,
+  }
+  print(json.dumps(line), flush=True)
+  if not same_bits or not drift < 1e-4:
+    raise SystemExit(3)
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -280,7 +384,16 @@ def main():
                   help="rank 0 re-evaluates the whole batch alone (outside the timed region) and compares with the "
                        "sharded result; default: on for --gpus N > 1, off for N = 1")
   ap.add_argument("--no-verify", dest="verify", action="store_false")
+  ap.add_argument("--through-mirror", choices=["c1", "c2", "c3"], default=None,
+                  help="a SECOND, separately labelled measurement (the default line is unchanged): the step a user calls -- "
+                       "inference.vqt(qhbm, H, beta) + backward() through the host mirror on a fixed sample multiset (sampler "
+                       "excluded: BASELINE.md section 3 'VQT step time') -- for BASELINE configs[0], [1] or [2], eager and as a "
+                       "replayed hipGraph (inference.CapturedLoss), beside the engine's own time on the same rows")
   args = ap.parse_args()
+  if args.through_mirror:
+    if args.gpus != 1:
+      raise SystemExit("bench.py --through-mirror is a one-GPU measurement")
+    return mirror_bench(args)
 
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
     self_launch(args)

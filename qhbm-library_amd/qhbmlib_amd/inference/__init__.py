@@ -1,5 +1,6 @@
 """Inference (reference: qhbmlib/inference/__init__.py:32-47)."""
 from qhbmlib_amd.inference import ebm  # noqa: F401
+from qhbmlib_amd.inference.captured import CapturedLoss
 from qhbmlib_amd.inference.ebm import (AnalyticEnergyInference, BernoulliEnergyInference,
                                        EnergyInference, EnergyInferenceBase,
                                        GibbsWithGradientsInference)
@@ -12,7 +13,7 @@ from qhbmlib_amd.inference.qnn import (AnalyticQuantumInference, QuantumInferenc
 from qhbmlib_amd.inference.qnn_utils import unitary
 from qhbmlib_amd.inference.vqt_loss import vqt
 
-__all__ = ["AnalyticEnergyInference", "AnalyticQuantumInference", "BernoulliEnergyInference",
+__all__ = ["AnalyticEnergyInference", "AnalyticQuantumInference", "BernoulliEnergyInference", "CapturedLoss",
            "EnergyInference", "EnergyInferenceBase", "GibbsWithGradientsInference", "QHBM", "QuantumInference",
            "SampledQuantumInference", "density_matrix",
            "fidelity", "probabilities", "qmhl", "unitary", "vqt"]

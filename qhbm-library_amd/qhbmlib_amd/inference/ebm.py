@@ -8,6 +8,7 @@ reference distributionally (its tests are statistical), not
 bit-for-bit: TFP's stateless PRNG is not reproduced.
 """
 import abc
+import contextlib
 import itertools
 from typing import Union
 
@@ -43,6 +44,46 @@ class EnergyInferenceBase(torch.nn.Module, abc.ABC):
     self._generator = torch.Generator()
     self._seed = fresh_seed() if initial_seed is None else int(initial_seed)
     self._first_inference = True
+    self._fixed_multiset = None
+    self._device_only = 0
+
+  @contextlib.contextmanager
+  def device_only(self):
+    """Inside the block `_preface_inference` is skipped: no variable is read back to the host to see whether it changed
+    (ebm.py:125-134 compares with a checkpoint), no seed is advanced, nothing is made ready.  For inferences a recorded
+    step (`inference.CapturedLoss`) only asks for EXACT quantities computed from the live variables -- `log_partition` /
+    `entropy` of the analytic and Bernoulli inferences -- and never for samples."""
+    self._device_only += 1
+    try:
+      yield self
+    finally:
+      self._device_only -= 1
+
+  @contextlib.contextmanager
+  def fixed_samples(self, bitstrings: torch.Tensor, counts: torch.Tensor):
+    """Inside the block, sample averages (`expectation`, the gradient of the default `log_partition`) run over the GIVEN
+    multiset -- rows `bitstrings[i]` with multiplicities `counts[i]` (zero-count rows are allowed and contribute nothing)
+    -- instead of drawing `num_expectation_samples` samples and deduplicating them (ebm.py:271-273).  Two uses: timing a
+    step with the sampler excluded (`bench.py --through-mirror`, BASELINE.md section 3 "VQT step time"), and the
+    fixed-shape, synchronisation-free step that `inference.CapturedLoss` records into a hipGraph: no sample is drawn, no
+    variable is read back to the host (`_preface_inference` is skipped), nothing is sorted."""
+    previous = self._fixed_multiset
+    self._fixed_multiset = (bitstrings, counts)
+    try:
+      yield self
+    finally:
+      self._fixed_multiset = previous
+
+  def _unique_samples(self, num_samples):
+    """(unique bitstrings, counts) of `num_samples` model samples (ebm.py:271-273, 402-403), or the fixed multiset."""
+    if self._fixed_multiset is not None:
+      bitstrings, counts = self._fixed_multiset
+      utils.mark_rows_unique(bitstrings)   # (the quantum side must not sort them again; duplicates would only cost time)
+      return bitstrings, counts
+    with torch.no_grad():
+      samples = self.sample(num_samples)
+    bitstrings, _, counts = utils.unique_bitstrings_with_counts(samples)
+    return bitstrings, counts
 
   @property
   def energy(self):
@@ -81,6 +122,8 @@ class EnergyInferenceBase(torch.nn.Module, abc.ABC):
 
   def _preface_inference(self):
     """ebm.py:142-162."""
+    if self._fixed_multiset is not None or self._device_only:
+      return  # (`fixed_samples`: nothing is drawn, so nothing has to be made ready -- and no host read of the variables)
     if self._first_inference:
       self._checkpoint_variables()
       self._ready_inference()
@@ -154,9 +197,7 @@ class EnergyInference(EnergyInferenceBase):
     """Sample average with the gradient of ebm.py:262-329 (eq. A5 of the QHBM paper):
         d<f> = <df> + <f><dE> - <f dE>
     realised with a zero-valued surrogate whose derivative is the score-function term."""
-    with torch.no_grad():
-      samples = self.sample(self.num_expectation_samples)
-    bitstrings, _, counts = utils.unique_bitstrings_with_counts(samples)
+    bitstrings, counts = self._unique_samples(self.num_expectation_samples)
     values = function(bitstrings)
     single = torch.is_tensor(values)
     flat = [values] if single else list(values)
@@ -208,9 +249,7 @@ class _LogPartition(torch.autograd.Function):
     inf, variables = ctx.inference, ctx.variables
     if not variables:
       return (None,)
-    with torch.no_grad():
-      samples = inf.sample(inf.num_expectation_samples)            # ebm.py:402 (model samples)
-    unique_samples, _, counts = utils.unique_bitstrings_with_counts(samples)   # ebm.py:403
+    unique_samples, counts = inf._unique_samples(inf.num_expectation_samples)   # ebm.py:402-403 (model samples)
     with torch.enable_grad():
       unique_energies = inf.energy(unique_samples.to(_device_of(inf.energy)))
       weights = (counts.to(torch.float32) / counts.sum()).to(unique_energies.device)

@@ -176,6 +176,21 @@ def _engine_bits(total_circuit, states):
   return bits
 
 
+class _ContentKey:
+  """A content key of the engine cache with its hash computed once."""
+  __slots__ = ("content", "_hash")
+
+  def __init__(self, content):
+    self.content = content
+    self._hash = hash(content)
+
+  def __hash__(self):
+    return self._hash
+
+  def __eq__(self, other):
+    return self is other or (isinstance(other, _ContentKey) and self._hash == other._hash and self.content == other.content)
+
+
 class _EngineCache:
   """Engines keyed by CONTENT -- (n, flat gate list, n symbols, Pauli masks of every op) -- never
   by object identity: CPython reuses the ids of freed operator lists, and `PauliSum.__iadd__`
@@ -233,6 +248,7 @@ class AnalyticQuantumInference(QuantumInference):
     self.ordered_reduction = ordered_reduction
     self.check_consistency = check_consistency
     self._engines = _EngineCache(max_cached_engines)
+    self._by_identity = {}
 
   def _group(self):
     g = self._process_group
@@ -243,7 +259,18 @@ class AnalyticQuantumInference(QuantumInference):
     return dist.group.WORLD if g is True else g
 
   def _engine_for(self, n_qubits, flat_gates, n_symbols, op_masks):
-    key = (n_qubits, tuple(flat_gates), n_symbols, tuple(tuple(m) for m in op_masks))
+    # `flat_gates` and the mask lists are memoised by the IR (ir.Circuit.flat_gates, ir.PauliSum.masks): while circuit and
+    # operators are unchanged the SAME objects arrive, and an identity lookup finds the engine without hashing ~10^4
+    # numbers per step; anything else is looked up by CONTENT as before.
+    ident = (id(flat_gates), n_qubits, n_symbols) + tuple(map(id, op_masks))
+    seen = self._by_identity.get(ident)
+    if seen is not None:
+      key = seen[0]
+    else:
+      key = _ContentKey((n_qubits, tuple(flat_gates), n_symbols, tuple(tuple(m) for m in op_masks)))
+      if len(self._by_identity) >= 64:
+        self._by_identity.clear()
+      self._by_identity[ident] = (key, flat_gates, list(op_masks))   # (the references keep the ids valid)
 
     def make():
       if not torch.cuda.is_available():

@@ -262,6 +262,18 @@ class Circuit:
     the seventh entry only for gates that have a global shift (rx / ry / rz).
     `qubits` fixes the qubit index (sorted qubit j = engine qubit j);
     `symbol_names[i]` is the symbol whose value sits at params[i]."""
+    # memoised per (gate list, qubit order, symbol order): a training step lowers the same circuit again and again
+    # (0.4 ms at config 2's size, more than the engine's whole step).  The key holds the gate objects themselves
+    # (frozen dataclasses, compared by identity first), so any edit of `self.gates` misses.
+    memo = self.__dict__.get("_flat_memo")
+    if (memo is not None and memo[0] == tuple(self.gates)   # (element-wise `is` before `==`: microseconds when unchanged)
+        and memo[1] == list(qubits) and memo[2] == list(symbol_names)):
+      return memo[3]
+    out = self._lower(qubits, symbol_names)
+    self.__dict__["_flat_memo"] = (tuple(self.gates), list(qubits), list(symbol_names), out)
+    return out
+
+  def _lower(self, qubits, symbol_names):
     qindex = {q: i for i, q in enumerate(qubits)}
     pindex = {s: i for i, s in enumerate(symbol_names)}
     out = []
@@ -376,7 +388,13 @@ class PauliSum:
     return set(q for t in self.terms for q in t.paulis)
 
   def masks(self, qubits: Sequence[GridQubit]):
-    """[(coeff, x_mask, z_mask)] in the C ABI's qubit-space convention."""
+    """[(coeff, x_mask, z_mask)] in the C ABI's qubit-space convention.  Memoised per (term objects, qubit order): the
+    SAME list object comes back while neither changed (the engine cache of `AnalyticQuantumInference` recognises an
+    unchanged operator by identity before it falls back to comparing contents) -- treat it as read-only."""
+    memo = self.__dict__.get("_masks_memo")
+    if (memo is not None and memo[0] == tuple(map(id, self.terms)) and memo[1] == [t.coefficient for t in self.terms]
+        and memo[2] == list(qubits)):
+      return memo[3]
     qindex = {q: i for i, q in enumerate(qubits)}
     out = []
     for t in self.terms:
@@ -387,6 +405,8 @@ class PauliSum:
         if p in ("Z", "Y"):
           z |= 1 << qindex[q]
       out.append((t.coefficient, x, z))
+    self.__dict__["_masks_memo"] = (tuple(map(id, self.terms)), [t.coefficient for t in self.terms], list(qubits), out)
+    self.__dict__["_masks_memo_terms"] = list(self.terms)  # (keeps the ids above alive)
     return out
 
 
@@ -394,7 +414,14 @@ PauliSumLike = Union[PauliSum, PauliString]
 
 
 def as_pauli_sum(op: PauliSumLike) -> PauliSum:
-  return op if isinstance(op, PauliSum) else PauliSum.from_pauli_strings(op)
+  if isinstance(op, PauliSum):
+    return op
+  # (one wrapper per string, kept with it: the wrapper carries the memo of `masks`)
+  wrapped = op.__dict__.get("_as_sum")
+  if wrapped is None or len(wrapped.terms) != 1 or wrapped.terms[0] is not op:
+    wrapped = PauliSum.from_pauli_strings(op)
+    op.__dict__["_as_sum"] = wrapped
+  return wrapped
 
 
 # ---------------------------------------------------------------------------

@@ -139,6 +139,18 @@ class QuantumCircuit(torch.nn.Module):
       raise TypeError
     if set(self.symbol_names) & set(other.symbol_names):
       raise ValueError("Circuits to be summed must not have symbols in common.")
+    # the sum of the same two circuits is asked for on every step (`self.circuit + observables.circuit_dagger`,
+    # qnn.py:68-69): one entry is remembered while neither gate list changed
+    memo = self.__dict__.get("_sum_memo")
+    if (memo is not None and memo[0] is other and memo[1] == tuple(self.pqc.gates) and memo[2] == tuple(other.pqc.gates)
+        and memo[3] == (self.tfq_compat_bit_order, other.tfq_compat_bit_order)):
+      return memo[4]
+    total = self._sum(other)
+    self.__dict__["_sum_memo"] = (other, tuple(self.pqc.gates), tuple(other.pqc.gates),
+                                  (self.tfq_compat_bit_order, other.tfq_compat_bit_order), total)
+    return total
+
+  def _sum(self, other):
     new_qubits = list(set(self.qubits + other.qubits))
     return QuantumCircuit(
         self.pqc + other.pqc, new_qubits, self.symbol_names + other.symbol_names,

@@ -210,6 +210,35 @@ def test_unique_expand_weighted_average():
   assert utils.Squeeze(1)(torch.zeros(3, 1, 2)).shape == (3, 2)
 
 
+def test_device_side_unique_equals_the_host_path():
+  """`utils._unique_on_device` (torch ops on the tensor's own device: what CUDA bitstrings go through) returns the same
+  bits as the numpy path on the reference's own cases (tests/utils_test.py:107-186: `test_short`, `test_long`) and on
+  random, ragged and non-binary inputs; a tensor the function just returned is recognised and not sorted again."""
+  short = [[1], [0], [0], [1], [1], [0], [1], [1]]
+  long_ = [[1, 0, 1], [1, 1, 1], [0, 1, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1], [1, 0, 1], [1, 0, 1]]
+  for rows, want_y, want_idx, want_c in ((short, [[1], [0]], [0, 1, 1, 0, 0, 1, 0, 0], [5, 3]),
+                                         (long_, [[1, 0, 1], [1, 1, 1], [0, 1, 1]], [0, 1, 2, 0, 1, 2, 0, 0], [4, 2, 2])):
+    for fn in (utils.unique_bitstrings_with_counts, lambda t: utils._unique_on_device(t, torch.int32)):
+      y, idx, c = fn(torch.tensor(rows, dtype=torch.int8))
+      assert y.tolist() == want_y and idx.tolist() == want_idx and c.tolist() == want_c
+      assert utils.expand_unique_results(y, idx).tolist() == rows
+  rng = np.random.default_rng(3)
+  for count, n, hi in [(1, 1, 2), (4096, 20, 2), (1024, 12, 2), (700, 5, 2), (300, 4, 5), (100, 70, 2), (64, 62, 2), (9, 63, 2)]:
+    arr = rng.integers(0, hi, size=(count, n)).astype(np.int8)
+    t = torch.from_numpy(arr)
+    host = utils.unique_bitstrings_with_counts(t)
+    dev = utils._unique_on_device(t, torch.int32)
+    want = O.unique_bitstrings_with_counts(arr)
+    for a, b, w in zip(host, dev, want):
+      assert torch.equal(a, b) and np.array_equal(a.numpy(), w) and a.dtype == b.dtype, (count, n, hi)
+  y, idx, c = utils.unique_bitstrings_with_counts(torch.from_numpy(rng.integers(0, 2, size=(50, 4)).astype(np.int8)))
+  again = utils.unique_bitstrings_with_counts(y)
+  assert again[0] is y and again[1].tolist() == list(range(y.shape[0])) and bool((again[2] == 1).all())
+  y.add_(0)                                            # any in-place write voids the mark
+  assert utils.unique_bitstrings_with_counts(y)[0] is not y
+  assert utils.unique_bitstrings_with_counts(y.clone())[0].shape == y.shape
+
+
 def test_analytic_inference_needs_gpu_and_says_so():
   """The product fails loudly without the HIP device -- no CPU fallback."""
   if torch.cuda.is_available():
