@@ -114,27 +114,41 @@ def distinct_bitstrings(n, count, seed):
   return bits
 
 
-def cpu_baseline(n, gates, n_params, ops, params, bits, upstream, mode):
-  """The oracle's C restatement (oracle/qhbm_cpu.c) timed on this host's cores on a bounded sample
-  of the TIMED batch itself (its first K bitstrings, same parameters, same upstream weight) -- a
-  reported baseline, never the product.  Returns the record plus the oracle's values [K, 1] and
-  [P] VJP of those K states, which `parity_check` compares with what the engine produced."""
+def cpu_baseline(n, gates, n_params, ops, params, bits, upstream, mode, checker_states=4):
+  """The CPU baseline BASELINE.md section 3 describes, timed on this host's cores on a bounded sample of the TIMED batch
+  itself (its first K bitstrings, same parameters): oracle/qhbm_cpu_diag.c -- the oracle's fp32 statevector algorithm
+  with merged diagonal runs, an AVX2 one-qubit kernel and fused adjoint steps, one state per thread -- a reported
+  baseline, never the product (`kind: "port+diag"`).  The CHECKER stays the gate-by-gate restatement oracle/qhbm_cpu.c:
+  it runs on the first `checker_states` of those states (threads inside a state), `parity_check` compares the engine
+  with IT, and the record carries how far the timed path is from it on the same states.
+  Returns the record, the checker's values [k, n_ops] and [P] VJP (upstream 1/k) and k."""
   from oracle import qhbm_cpu as C
   cores = min(C.max_threads(), os.cpu_count() or 1)
   states = bits.shape[0]
   up = np.ascontiguousarray(upstream, np.float32)
   t0 = time.perf_counter()
-  if mode == "forward":
-    vals, grad = C.expectation(n, gates, params, bits, ops, n_threads=cores), None
-  else:
-    vals, grad = C.expectation_vjp(n, gates, params, bits, ops, up, n_threads=cores)
+  C.expectation_vjp_diag(n, gates, params, bits, ops, None if mode == "forward" else up, n_threads=cores)
   dt = time.perf_counter() - t0
+  k = max(1, min(checker_states, states))
+  up_k = np.ascontiguousarray(up[:k] * (float(states) / float(k)), np.float32)   # upstream theta / k on the checker's rows
+  t1 = time.perf_counter()
+  if mode == "forward":
+    vals, grad = C.expectation(n, gates, params, bits[:k], ops, n_threads=cores), None
+    fast_vals, fast_grad = C.expectation_vjp_diag(n, gates, params, bits[:k], ops, None, n_threads=cores)
+  else:
+    vals, grad = C.expectation_vjp(n, gates, params, bits[:k], ops, up_k, n_threads=cores)
+    fast_vals, fast_grad = C.expectation_vjp_diag(n, gates, params, bits[:k], ops, up_k, n_threads=cores)
+  dt_check = time.perf_counter() - t1
   return {
       "value": states * sum(len(op) for op in ops) / dt, "unit": "evals/s", "cores": int(min(cores, states)),
-      "kind": "port",
+      "kind": "port+diag",
       "sample": f"the first {states} states of the timed batch ({mode} step, same parameters), one state "
-                f"per thread, {dt:.2f} s wall",
-  }, vals, grad
+                f"per thread, {dt:.2f} s wall (oracle/qhbm_cpu_diag.c: merged diagonal runs, AVX2 one-qubit kernel, fused "
+                f"adjoint steps; no other gate fusion)",
+      "checker": {"what": "oracle/qhbm_cpu.c, gate by gate, threads inside a state", "states": k, "wall_s": dt_check,
+                  "max_diff_values_timed_path_vs_checker": float(np.abs(fast_vals - vals).max()),
+                  "max_diff_grad_timed_path_vs_checker": (float(np.abs(fast_grad - grad).max()) if grad is not None else None)},
+  }, vals, grad, k
 
 
 def parity_check(eng, E, mode, ops, bits_k, params, timed_vals_k, timed_grad_rows_k, rows_scale, upstream_k, oracle_vals,
@@ -760,14 +774,16 @@ def main():
           if os.environ.get("QHBM_BENCH_CORRUPT_PARITY") == "1":   # test hook: the check must be able to fail
             oracle_params = params_np + np.float32(0.05)
           up_k = np.tile(thetas[None, :] / float(k), (k, 1))
-          rec, o_vals, o_grad = cpu_baseline(n, gates, n_params, ops, oracle_params, bits_k, up_k, args.mode)
+          rec, o_vals, o_grad, kc = cpu_baseline(n, gates, n_params, ops, oracle_params, bits_k, up_k, args.mode)
           if o_grad is not None and grad_mask is not None:
             o_grad = np.where(grad_mask, o_grad, 0.0)   # the engine returns 0 for the frozen (data) parameters
           line["cpu_baseline"] = rec if world == 1 else None
-          timed_rows = vals[:k].float().cpu().numpy()   # global rows lo..lo+k are rank 0's own block
-          grad_rows = timed_grad_rows[:k] if timed_grad_rows is not None and timed_grad_rows.shape[0] >= k else None
-          line["parity_check"] = parity_check(eng, E, args.mode, ops, bits_k, params, timed_rows, grad_rows,
-                                              float(total_states) / float(k), up_k, o_vals, o_grad)
+          # the checker (gate by gate) ran on the first kc of the K states, with upstream theta / kc
+          bits_c, up_c = bits_k[:kc], np.tile(thetas[None, :] / float(kc), (kc, 1))
+          timed_rows = vals[:kc].float().cpu().numpy()   # global rows lo..lo+kc are rank 0's own block
+          grad_rows = timed_grad_rows[:kc] if timed_grad_rows is not None and timed_grad_rows.shape[0] >= kc else None
+          line["parity_check"] = parity_check(eng, E, args.mode, ops, bits_c, params, timed_rows, grad_rows,
+                                              float(total_states) / float(kc), up_c, o_vals, o_grad)
           parity_failed = not line["parity_check"]["ok"]
         except Exception as exc:  # pylint: disable=broad-except
           # a check that was requested and could not run is a FAILED check (exit code 3), with the reason on the line

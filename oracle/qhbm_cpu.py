@@ -81,3 +81,22 @@ def statevector(n, gates, params, bits, n_threads=0):
   lib.qo_statevector(ctypes.c_int(n), ctypes.c_int(len(gates)), arr, vp(p.ctypes.data), vp(b.ctypes.data),
                      ctypes.c_int(b.shape[0]), vp(out.ctypes.data), ctypes.c_int(n_threads))
   return out
+
+
+def expectation_vjp_diag(n, gates, params, bits, ops, upstream=None, n_threads=0):
+  """The timed baseline path (oracle/qhbm_cpu_diag.c: merged diagonal runs, AVX2 one-qubit kernel, fused adjoint steps):
+  (values, grad), or (values, None) when `upstream` is None (forward only).  Same contract as `expectation_vjp`."""
+  lib = _load()
+  arr, p, b, off, cf, xm, zm = _pack(n, gates, params, bits, ops)
+  vals = np.zeros((b.shape[0], len(ops)), np.float32)
+  vp = ctypes.c_void_p
+  up = grad = None
+  if upstream is not None:
+    up = np.ascontiguousarray(upstream, dtype=np.float32)
+    grad = np.zeros((len(p),), np.float32)
+  lib.qo_expectation_vjp_diag(ctypes.c_int(n), ctypes.c_int(len(gates)), arr, vp(p.ctypes.data), vp(b.ctypes.data),
+                              ctypes.c_int(b.shape[0]), ctypes.c_int(len(ops)), vp(off.ctypes.data), vp(cf.ctypes.data),
+                              vp(xm.ctypes.data), vp(zm.ctypes.data), vp(up.ctypes.data) if up is not None else None,
+                              vp(vals.ctypes.data), vp(grad.ctypes.data) if grad is not None else None,
+                              ctypes.c_int(len(p)), ctypes.c_int(n_threads))
+  return vals, grad

@@ -46,7 +46,12 @@ def test_bench_single_process_line():
   assert line["roofline"]["bound"] == ("fp32_valu" if comp["frac"] > hbm["frac"] else "hbm")
   assert line["roofline"]["frac"] == pytest.approx(max(hbm["frac"], comp["frac"]))
   assert "12-qubit TFIM ring" in line["config"]["workload"] and line["config"]["states_total"] == 16
-  assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+  # the TIMED CPU path is the diagonal-merging one; the CHECKER of parity_check stays the
+  # gate-by-gate restatement, and the record says how far the two are apart on the checker's states
+  cb = line["cpu_baseline"]
+  assert cb["kind"] == "port+diag" and cb["value"] > 0 and cb["checker"]["states"] == 2
+  assert cb["checker"]["max_diff_values_timed_path_vs_checker"] <= 2e-6
+  assert cb["checker"]["max_diff_grad_timed_path_vs_checker"] <= 1e-5
   assert line["verify"]["ok"], line["verify"]
   pc = line["parity_check"]
   assert pc["ok"] and pc["states"] == 2 and pc["max_err_values"] <= pc["tol_values"]
@@ -76,7 +81,8 @@ def test_bench_config3_timed_batch_against_the_oracle():
   line = _line(out.stdout)
   assert (line["config"]["n_qubits"], line["config"]["layers"], line["config"]["pauli_terms"]) == (20, 16, 57)
   pc = line["parity_check"]
-  assert pc["ok"] and pc["states"] == 8, pc
+  assert pc["ok"] and pc["states"] == 4, pc          # (the gate-by-gate checker runs on the first 4 of the 8 timed CPU states)
+  assert line["cpu_baseline"]["checker"]["max_diff_values_timed_path_vs_checker"] <= 5e-6
   assert pc["max_err_values"] <= pc["tol_values"] == pytest.approx(5e-5 * 47.5)
   assert pc["max_err_grad"] <= pc["tol_grad"] and pc["grad_inf_norm"] > 1e-2
   assert pc["grad_from"].startswith("rows of the last timed step")

@@ -87,3 +87,35 @@ def test_c_threads_inside_a_state_equal_the_serial_sweep():
   np.testing.assert_allclose(v_team, v_one, atol=1e-6)
   np.testing.assert_allclose(g_team, g_one, atol=1e-5 * max(1.0, np.abs(g_one).max()))
   np.testing.assert_allclose(sv_team, sv_one, atol=1e-7)
+
+
+@pytest.mark.parametrize("n", [5, 6, 9, 13])
+def test_timed_baseline_path_equals_the_gate_by_gate_checker(n):
+  """oracle/qhbm_cpu_diag.c ("port+diag": merged diagonal runs, AVX2 one-qubit kernel, fused adjoint steps -- what
+  bench.py times as `cpu_baseline`) against oracle/qhbm_cpu.c on HEA circuits and on random circuits of every gate kind
+  (diagonal runs cut by the straddling-pair limit, generic two-qubit gates, parameter-free gates): values 1e-6 * sum|c|,
+  gradients 1e-5 relative, forward-only mode included."""
+  rng = np.random.default_rng(50 + n)
+  for trial in range(3):
+    if trial == 0:
+      gates, names = O.hea_gates(n, 3, "d")
+      n_params = len(names)
+    else:
+      n_params = 7
+      gates = _random_circuit(rng, n, 70, n_params)
+      if trial == 2:   # long diagonal runs over scattered pairs: more than four straddling high bits
+        for _ in range(40):
+          q0 = int(rng.integers(n)); q1 = int(rng.integers(n - 1)); q1 += q1 >= q0
+          kind = [3, 5, 11][int(rng.integers(3))]
+          gates.append((kind, q0, q1 if kind != 3 else -1, int(rng.integers(n_params)), float(rng.uniform(-1, 1)), 0.1))
+    params = rng.uniform(-1, 1, n_params)
+    ops = [O.xxz_chain_op(n), O.tfim_ring_op(n), O.random_pauli_op(n, 6, trial, 0.5)]
+    bits = rng.integers(0, 2, size=(4, n)).astype(np.int8)
+    up = rng.normal(size=(4, 3))
+    want_v, want_g = C.expectation_vjp(n, gates, params, bits, ops, up)
+    got_v, got_g = C.expectation_vjp_diag(n, gates, params, bits, ops, up)
+    fwd_v, none = C.expectation_vjp_diag(n, gates, params, bits, ops)
+    norm = np.array([sum(abs(c) for c, _, _ in op) for op in ops])
+    assert none is None
+    assert (np.abs(got_v - want_v) <= 1e-6 * norm).all() and (np.abs(fwd_v - want_v) <= 1e-6 * norm).all()
+    np.testing.assert_allclose(got_g, want_g, atol=1e-5 * max(1.0, np.abs(want_g).max()), rtol=0)
