@@ -392,6 +392,10 @@ def main():
                   help="N > 1 gradient exchange: all-reduce of the [P] gradient (engine level), or the host "
                        "mirror's default -- all-gather of the per-state rows [U, P], added in global state order "
                        "(bit-identical for any N; AnalyticQuantumInference(ordered_reduction=True))")
+  ap.add_argument("--balance", choices=["equal", "measured"], default="equal",
+                  help="N > 1, strong scaling: equal row blocks (default), or blocks proportional to every rank's MEASURED "
+                       "speed -- one probing step on the equal blocks, kernel time per state all-gathered once "
+                       "(parallel.measured_weights) -- so that a GPU that sustains a lower clock gets fewer states")
   ap.add_argument("--cpu-sample-states", type=int, default=64)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--verify", dest="verify", action="store_true", default=None,
@@ -518,6 +522,22 @@ def main():
       vals = parallel.all_gather_rows(vals, blocks)
     return vals, grad
 
+  shard_weights = None
+  if args.balance == "measured" and world > 1 and not weak:
+    # one probing step on the equal blocks (after one that builds plans and workspaces): this rank's kernel time per state
+    step()
+    torch.cuda.synchronize()
+    eng.kernel_time_ms(reset=True)
+    step()
+    torch.cuda.synchronize()
+    probe_kt = eng.kernel_time_ms(reset=True)
+    per_state = (probe_kt["fwd_ms"] + probe_kt["bwd_ms"] + probe_kt["obs_ms"]) * 1e-3 / max(1, spg)
+    shard_weights = parallel.measured_weights(per_state if spg > 0 and per_state > 0 else 1.0)
+    blocks = parallel.partition(total_states, world, shard_weights)
+    lo, hi = blocks[rank]
+    spg = hi - lo
+    bits = torch.from_numpy(all_bits[lo:hi]).cuda()
+    upstream = (torch.from_numpy(thetas).cuda() / float(total_states)).repeat(spg, 1).contiguous()
   for _ in range(args.warmup):
     step()
   torch.cuda.synchronize()
@@ -561,6 +581,13 @@ def main():
   if world > 1:
     device_ids = [None] * world
     dist.all_gather_object(device_ids, my_dev)
+
+  # every rank's own kernel time per step (HIP events on its launch stream) and block size: a straggler shows up here
+  my_kernel_ms = (kt["fwd_ms"] + kt["bwd_ms"] + kt["obs_ms"]) / max(1, args.steps)
+  per_rank = [(my_kernel_ms, spg)]
+  if world > 1:
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, (my_kernel_ms, spg))
 
   parity_failed = False
   if rank == 0:
@@ -688,6 +715,12 @@ def main():
         "qmhl_step_ms": ms_per_step if args.mode == "qmhl" else None,
         "kernel_ms_per_step": {"forward": kt["fwd_ms"] / args.steps, "adjoint": kt["bwd_ms"] / args.steps,
                                "apply_observable": kt["obs_ms"] / args.steps},
+        # per rank: kernel time per step and states held -- ranks run in lock step, the slowest one sets the pace
+        "per_rank": {"kernel_ms_per_step": [float(k) for k, _ in per_rank], "states": [int(b) for _, b in per_rank],
+                     "min": float(min(k for k, _ in per_rank)), "max": float(max(k for k, _ in per_rank)),
+                     "argmax": int(max(range(len(per_rank)), key=lambda r: per_rank[r][0])),
+                     "balance": args.balance if world > 1 else None,
+                     "weights": shard_weights},
         "roofline": {
             # the bound is whichever ceiling the dominant kernel sits closer to; achieved / peak / unit /
             # frac are those of that ceiling, and both are spelled out in "hbm" and "compute"

@@ -36,7 +36,7 @@ class _ExpectationFunction(torch.autograd.Function):
   `AnalyticQuantumInference._expectation` verifies that before the call (`check_consistency`)."""
 
   @staticmethod
-  def forward(ctx, symbol_values, engine, bits, method, group, ordered, grad_mask=None):
+  def forward(ctx, symbol_values, engine, bits, method, group, ordered, grad_mask=None, weights=None):
     ctx.engine, ctx.method, ctx.group, ctx.ordered = engine, method, group, ordered
     ctx.rows = None
     # symbols nobody wants a gradient of (a fixed data circuit's): no gradient work, and the backward sweep stops
@@ -45,7 +45,7 @@ class _ExpectationFunction(torch.autograd.Function):
     if ctx.needs_input_grad[0]:
       engine.set_gradient_mask(ctx.grad_mask)
     if group is not None:
-      blocks = parallel.partition(bits.shape[0], dist.get_world_size(group))
+      blocks = parallel.partition(bits.shape[0], dist.get_world_size(group), weights)
       ctx.rows = blocks[dist.get_rank(group)]
       ctx.blocks = blocks
       bits = bits[ctx.rows[0]:ctx.rows[1]]
@@ -85,7 +85,7 @@ class _ExpectationFunction(torch.autograd.Function):
         grad = rows.to(torch.float64).sum(0).to(torch.float32)
       else:
         parallel.all_reduce_sum(grad, ctx.group)
-    return grad.to(symbol_values.device), None, None, None, None, None, None
+    return grad.to(symbol_values.device), None, None, None, None, None, None, None
 
 
 class ResolvedCircuits(tuple):
@@ -231,6 +231,10 @@ class AnalyticQuantumInference(QuantumInference):
   `ordered_reduction=True` gathers the per-state gradient rows [U, P] instead (config 3: 15.5 MB) and adds
   them in global state order in fp64, so losses and gradients are bit-identical for 1, 2, 4 or 8 ranks --
   for regression runs that compare rank counts, not for throughput.
+  `shard_weights`: one positive speed per rank, the same list on every rank (`parallel.measured_weights`, taken once from
+  a warm-up step): the unique rows are then dealt out in blocks PROPORTIONAL to them instead of equal ones -- GPUs of one
+  node differ by 6-8 % in sustained clock and ranks in lock step run at the slowest one's pace.  Not with
+  `ordered_reduction=True`.
   `check_consistency` (default True): before a sharded call the ranks compare a fingerprint of the
   unique bitstrings and the symbol values (8 bytes each) and raise `parallel.ShardMismatchError` if
   they differ -- differently seeded samplers would otherwise shard different sets, silently."""
@@ -240,8 +244,11 @@ class AnalyticQuantumInference(QuantumInference):
   def __init__(self, input_circuit: circuit.QuantumCircuit, name: Union[None, str] = None,
                device: Union[None, int] = None, gradient_method: int = _engine.GRAD_ADJOINT,
                process_group=None, max_cached_engines: int = 4, ordered_reduction: bool = False,
-               check_consistency: bool = True):
+               check_consistency: bool = True, shard_weights=None):
     super().__init__(input_circuit, name)
+    if shard_weights is not None and ordered_reduction:
+      raise ValueError("ordered_reduction=True (regression runs that compare rank counts) uses equal blocks only")
+    self.shard_weights = None if shard_weights is None else [float(w) for w in shard_weights]
     self._device = device
     self.gradient_method = gradient_method
     self._process_group = process_group
@@ -314,7 +321,7 @@ class AnalyticQuantumInference(QuantumInference):
       if grad_mask is not None and len(grad_mask) != len(symbol_names):
         grad_mask = None
       parts.append(_ExpectationFunction.apply(values, eng, bits, self.gradient_method, group, self.ordered_reduction,
-                                              grad_mask))
+                                              grad_mask, self.shard_weights))
     expectations = parts[0] if len(parts) == 1 else torch.cat(parts, 1)
     return post_process(expectations)
 

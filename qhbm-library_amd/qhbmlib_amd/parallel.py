@@ -8,7 +8,7 @@ values and an all-reduce (sum) of the [P] gradient -- KiB-sized messages over
 RCCL/xGMI (latency-bound), nothing else crosses GPUs.
 """
 import hashlib
-from typing import Callable, List, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -19,16 +19,46 @@ class ShardMismatchError(RuntimeError):
   """The ranks of a process group were handed different inputs for one sharded call."""
 
 
-def partition(num_rows: int, world_size: int) -> List[Tuple[int, int]]:
-  """Contiguous [lo, hi) block per rank; the first `num_rows % world_size` ranks get
-  one extra row."""
-  base, extra = divmod(num_rows, world_size)
+def partition(num_rows: int, world_size: int, weights: Optional[Sequence[float]] = None) -> List[Tuple[int, int]]:
+  """Contiguous [lo, hi) block per rank.  Without `weights`: equal blocks, the first `num_rows % world_size` ranks get
+  one extra row.  With `weights` (one positive number per rank, the SAME list on every rank -- `measured_weights`): block
+  sizes proportional to them (largest-remainder rounding, ties to the lower rank), so that ranks whose GPU sustains a
+  lower clock -- boxes differ by 6-8 % (profiles/r05_bench_slowbox_c3.json) and ranks in lock step run at the slowest
+  one's pace -- get fewer states.  Any contiguous partition gives the same results; only the wall time differs."""
+  if weights is None:
+    base, extra = divmod(num_rows, world_size)
+    sizes = [base + (1 if r < extra else 0) for r in range(world_size)]
+  else:
+    w = [float(x) for x in weights]
+    if len(w) != world_size or any(not (x > 0.0) or x != x or x == float("inf") for x in w):
+      raise ValueError(f"partition: {world_size} positive finite weights expected, got {list(weights)!r}")
+    total = sum(w)
+    exact = [num_rows * x / total for x in w]
+    sizes = [int(e) for e in exact]
+    # hand out the rows the floors left over, largest fractional part first (ties: lower rank)
+    order = sorted(range(world_size), key=lambda r: (-(exact[r] - sizes[r]), r))
+    for r in order[:num_rows - sum(sizes)]:
+      sizes[r] += 1
   out, lo = [], 0
-  for r in range(world_size):
-    hi = lo + base + (1 if r < extra else 0)
-    out.append((lo, hi))
-    lo = hi
+  for size in sizes:
+    out.append((lo, lo + size))
+    lo += size
   return out
+
+
+def measured_weights(seconds_per_state: float, group=None) -> List[float]:
+  """Every rank's measured speed (1 / its `seconds_per_state`, e.g. a warm-up step's kernel time divided by its block
+  size, or `Engine.clock_probe()["ghz"]` inverted), all-gathered ONCE: the same list on every rank, ready for
+  `partition(..., weights=...)`.  COLLECTIVE over `group`.  float64 through the exchange, so every rank rounds alike."""
+  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    return [1.0]
+  if not seconds_per_state > 0.0:
+    raise ValueError("measured_weights: a positive time per state is needed")
+  dev = _collective_device(group)
+  mine = torch.tensor([1.0 / float(seconds_per_state)], dtype=torch.float64, device=dev)
+  every = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+  dist.all_gather(every, mine, group=group)
+  return [float(t.cpu().item()) for t in every]
 
 
 def _via_host(group) -> bool:
@@ -179,9 +209,10 @@ class ShardedExpectation:
   """Wraps a single-device `expectation_vjp(bits, params, upstream) -> (vals, grad)`
   (e.g. `Engine.expectation_vjp`) into the same call over the whole process group."""
 
-  def __init__(self, local_expectation_vjp: Callable, group=None):
+  def __init__(self, local_expectation_vjp: Callable, group=None, weights: Optional[Sequence[float]] = None):
     self._local = local_expectation_vjp
     self._group = group
+    self.weights = weights   # per-rank speeds (`measured_weights`), None: equal blocks
 
   def expectation_vjp(self, bits: torch.Tensor, params: torch.Tensor, upstream: torch.Tensor):
     """bits [U, n], upstream [U, T] are the FULL batch on every rank (tiny, host-made);
@@ -190,7 +221,7 @@ class ShardedExpectation:
       return self._local(bits, params, upstream)
     world = dist.get_world_size(self._group)
     rank = dist.get_rank(self._group)
-    blocks = partition(bits.shape[0], world)
+    blocks = partition(bits.shape[0], world, self.weights)
     lo, hi = blocks[rank]
     vals_local, grad = self._local(bits[lo:hi], params, upstream[lo:hi])
     vals = all_gather_rows(vals_local, blocks, self._group)

@@ -134,6 +134,10 @@ def test_bench_two_ranks_as_the_driver_launches_it(reduction):
   # bytes of the step's exchange: values [32] + the [P] gradient, or + the rows [32, P]
   n_params = 2 * (3 * 12 - 1)
   assert line["config"]["exchange_bytes"] == 4 * 32 + 4 * (32 * n_params if reduction == "ordered" else n_params)
+  # every rank's own kernel time and block: what diagnoses a straggler in the driver's scaling run
+  pr = line["per_rank"]
+  assert len(pr["kernel_ms_per_step"]) == 2 and pr["states"] == [16, 16] and pr["balance"] == "equal"
+  assert 0 < pr["min"] <= pr["max"] == pr["kernel_ms_per_step"][pr["argmax"]]
 
 
 def test_bench_eight_ranks_as_the_driver_launches_it():
@@ -160,6 +164,31 @@ def test_bench_eight_ranks_as_the_driver_launches_it():
   assert line["config"]["exchange_bytes"] == 4 * 36 + 4 * n_params
   assert line["verify"]["ok"], line["verify"]                 # on by default for N > 1
   assert line["parity_check"]["ok"], line["parity_check"]
+  pr = line["per_rank"]
+  assert pr["states"] == [5, 5, 5, 5, 4, 4, 4, 4] and len(pr["kernel_ms_per_step"]) == 8 and pr["weights"] is None
+
+
+def test_bench_balance_measured_deals_blocks_by_measured_speed():
+  """`--balance measured` (three gloo ranks sharing the one device): a probing step, every rank's kernel time per state
+  all-gathered once (parallel.measured_weights), blocks proportional to the speeds; the sharded result still equals rank
+  0's own evaluation of the whole batch and the oracle."""
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  env = dict(os.environ, QHBM_BENCH_SHARE_DEVICE="1", QHBM_BENCH_BACKEND="gloo")
+  args = ["--qubits", "12", "--layers", "2", "--states-total", "90", "--steps", "2", "--warmup", "1",
+          "--hamiltonian", "tfim", "--cpu-sample-states", "2", "--balance", "measured"]
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "3"] + args
+  out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+  assert out.returncode == 0, out.stderr[-3000:]
+  line = _line(out.stdout)
+  pr = line["per_rank"]
+  assert pr["balance"] == "measured" and len(pr["weights"]) == 3 and all(w > 0 for w in pr["weights"])
+  assert sum(pr["states"]) == 90 and min(pr["states"]) >= 1
+  total = sum(pr["weights"])
+  assert all(abs(s - 90 * w / total) <= 1.0 for s, w in zip(pr["states"], pr["weights"]))
+  assert line["verify"]["ok"] and line["parity_check"]["ok"]
 
 
 def test_bench_gpus_flag_starts_its_own_ranks_and_shards_a_fixed_total():

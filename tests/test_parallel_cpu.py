@@ -188,3 +188,60 @@ def test_uneven_blocks_of_4096_rows_over_3_5_7_and_8_ranks():
     for rank in range(world):
       same, gsum, mismatch, _ = out[rank]
       assert same and gsum == pytest.approx(world * (world + 1) / 2) and mismatch
+
+
+def test_weighted_partition():
+  """`partition(num_rows, world, weights)`: blocks proportional to the measured speeds, contiguous, complete,
+  deterministic (largest remainder, ties to the lower rank); equal weights reproduce the equal blocks."""
+  import pytest
+  assert parallel.partition(4096, 8, [1.0] * 8) == parallel.partition(4096, 8)
+  assert parallel.partition(10, 4, [1, 1, 1, 1]) == parallel.partition(10, 4)
+  blocks = parallel.partition(4096, 8, [1.0, 1.0, 0.92, 1.0, 1.0, 1.0, 1.06, 1.0])   # one slow, one fast GPU
+  sizes = [h - l for l, h in blocks]
+  assert sum(sizes) == 4096 and blocks[0][0] == 0 and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+  assert sizes[2] == min(sizes) and sizes[6] == max(sizes) and sizes[2] == pytest.approx(4096 * 0.92 / 7.98, abs=1)
+  # times per state follow 1 / weight: the slowest rank's share of the wall time drops to the mean
+  t_equal = max(512 / w for w in [1.0, 1.0, 0.92, 1.0, 1.0, 1.0, 1.06, 1.0])
+  t_weighted = max(s / w for s, w in zip(sizes, [1.0, 1.0, 0.92, 1.0, 1.0, 1.0, 1.06, 1.0]))
+  assert t_weighted < 0.95 * t_equal
+  assert parallel.partition(3, 2, [1.0, 3.0]) == [(0, 1), (1, 3)]
+  assert parallel.partition(1, 3, [1.0, 1.0, 1.0]) == [(0, 1), (1, 1), (1, 1)]
+  assert parallel.partition(0, 2, [2.0, 1.0]) == [(0, 0), (0, 0)]
+  for bad in ([1.0], [1.0, 0.0], [1.0, -2.0], [1.0, float("nan")], [1.0, float("inf")]):
+    with pytest.raises(ValueError):
+      parallel.partition(8, 2, bad)
+  assert parallel.measured_weights(0.5) == [1.0]        # no process group: one rank
+
+
+def _weighted_worker(rank, world, port, out):
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  n, gates, params, bits, ops, up = _problem()
+  # rank r "measured" (r + 1) seconds per state: the exchange gives every rank the same speeds
+  weights = parallel.measured_weights(float(rank + 1))
+  sharded = parallel.ShardedExpectation(_oracle_local(n, gates, ops), weights=weights)
+  vals, grad = sharded.expectation_vjp(torch.from_numpy(bits), torch.from_numpy(params), torch.from_numpy(up))
+  out[rank] = (vals.numpy(), grad.numpy(), weights, parallel.partition(bits.shape[0], world, weights))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_sharded_step_with_skewed_measured_weights_world3():
+  """Blocks proportional to all-gathered speeds (7 rows over ranks of speed 1, 1/2, 1/3 -> 4, 2, 1): same values and
+  gradient as one process."""
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  mgr = mp.Manager()
+  out = mgr.dict()
+  mp.spawn(_weighted_worker, args=(3, port, out), nprocs=3, join=True)
+  n, gates, params, bits, ops, up = _problem()
+  want_vals, want_jac = O.expectation_jacobian(n, gates, params, bits, ops)
+  want_grad = np.einsum("bt,btp->p", up, want_jac)
+  for rank in range(3):
+    vals, grad, weights, blocks = out[rank]
+    assert weights == out[0][2] and blocks == out[0][3] == [(0, 4), (4, 6), (6, 7)]
+    np.testing.assert_allclose(weights, [1.0, 0.5, 1.0 / 3.0])
+    np.testing.assert_allclose(vals, want_vals, atol=1e-6)
+    np.testing.assert_allclose(grad, want_grad, atol=1e-5)
