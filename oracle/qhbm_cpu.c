@@ -132,10 +132,4 @@ int qo_statevector(int n, int n_gates, const qo_gate* gates, const float* params
   return 0;
 }
 
-int qo_max_threads(void) {
-#ifdef _OPENMP
-  return omp_get_max_threads();
-#else
-  return 1;
-#endif
-}
+int qo_max_threads(void) { return team_size(); }

@@ -94,6 +94,7 @@ struct qhbm_engine {
   int opt_adj_plan_search = 1; // adjoint: build the scheduler's best few pass orders and keep the one with the fewest model flops
   int opt_wide_last = -1;      // forward: the last gate pass may take a tile one or two bits wider (-1: unless tile_qubits is set)
   int opt_fwd_pair = 1;        // dense lean forward passes run on pairs of states, tiles in registers (pass_fwd2_kernel)
+  int opt_shift_prefix = 1;    // parameter shift: a shifted program starts at the pass that holds its gate, from the base program's state
   int opt_adj_relabel = 1;     // adjoint plans move finished index bits out of the 128-byte lines (schedule.h Pass)
   int opt_obs_xcd_states = -1; // lambda = O psi: one state per XCD at a time (1), every XCD an eighth of each state (0); -1: by state size
   int opt_adj_exchange = 1;  // lean adjoint passes: register-resident tile pair + one LDS exchange buffer
@@ -157,9 +158,12 @@ struct qhbm_engine {
   // parameter-shift batches: per-program coefficient buffers, shift tables, accumulators
   DevBuf<float> coef_batch, shift_vals, shift_weight, vals_batch;
   DevBuf<int> shift_gates, shift_param;
+  DevBuf<int> shift_dst;             // execution order -> gate order of the shifted programs (prog_acc index)
+  std::vector<uint32_t> shift_group_end;  // programs (execution order) whose shifted gate sits in pass <= i end here
   DevBuf<double> prog_acc;
   size_t coef_batch_programs = 0;  // copies of the forward plan's static words already in coef_batch
   bool shift_ready = false;        // shift tables on the device match the model
+  bool shift_tables_from_obs = false;  // ... and were ordered for values taken from the observable kernel (or in the passes)
   uint32_t shift_programs = 0, shift_gate_count = 0;
   DevBuf<float> tile_grad;              // [chunk states * tiles, slots of one adjoint pass]
   DevBuf<unsigned long long> vals64;    // [U, n_ops] fixed-point accumulators of the expectation values
@@ -195,7 +199,7 @@ size_t own_bytes(const qhbm_engine* h) {
   return buf_bytes(h->psi) + buf_bytes(h->lam) + buf_bytes(h->state_grad) + buf_bytes(h->tile_grad) +
          buf_bytes(h->vals64) + buf_bytes(h->block_cum) + buf_bytes(h->coef_batch) + buf_bytes(h->vals_batch) +
          buf_bytes(h->value_part) + buf_bytes(h->probe_out) + buf_bytes(h->probe_sink) + buf_bytes(h->upstream_tmp) + buf_bytes(h->vals_tmp) + buf_bytes(h->prog_acc) +
-         buf_bytes(h->shift_vals) + buf_bytes(h->shift_weight) + buf_bytes(h->shift_gates) + buf_bytes(h->shift_param) +
+         buf_bytes(h->shift_vals) + buf_bytes(h->shift_weight) + buf_bytes(h->shift_gates) + buf_bytes(h->shift_param) + buf_bytes(h->shift_dst) +
          buf_bytes(h->slot_factor) + buf_bytes(h->phase_cs) + buf_bytes(h->shift_phases) + buf_bytes(h->terms) +
          buf_bytes(h->global_terms) + buf_bytes(h->obs_groups) + buf_bytes(h->far[0].terms) + buf_bytes(h->far[0].groups) +
          buf_bytes(h->far[1].terms) + buf_bytes(h->far[1].groups) + buf_bytes(h->far[2].terms) + buf_bytes(h->far[2].groups) + buf_bytes(h->obs_bterms) + buf_bytes(h->obs_bgroups) + buf_bytes(h->op_scale) + buf_bytes(h->op_inv_scale) +
@@ -1075,6 +1079,55 @@ int check_call(qhbm_engine* h, int U) {
   return upload_model(h);
 }
 
+// Parameter shift with a shared prefix.  A shifted program differs from the base program in the coefficients of ONE gate;
+// the passes in front of the first pass that reads them compute, state by state, the bits the base program computes.
+// first_dependent_pass()[g] = that pass for gate g (the pass count for a gate no record depends on); `first_measuring` =
+// the first pass with a measurement op (a program must not start behind it: a pass measures into the program's own
+// accumulators).  Record ranges come from the pass programs (OP_ROUND: n_instances records from its first record;
+// OP_GATE2: a 4 x 4 matrix), jobs from the plan (CoefJob::gate writes at CoefJob::out_off).
+std::vector<int> first_dependent_pass(const Plan& plan, size_t n_gates, int* first_measuring) {
+  const RecordLayout L(plan.R, false);
+  struct Range { uint32_t lo, hi; int pass; };
+  std::vector<Range> ranges;
+  const int n_pass = int(plan.passes.size());
+  *first_measuring = n_pass;
+  for (int i = 0; i < n_pass; ++i) {
+    const std::vector<uint32_t>& prog = plan.passes[size_t(i)].prog;
+    size_t pc = 0;
+    while (pc < prog.size()) {
+      const uint32_t w0 = prog[pc], opc = w0 & 0xffu;
+      if (opc == OP_END) break;
+      if (opc == OP_ROUND) {
+        const uint32_t n_inst = (w0 & ~kRoundNoBarrier) >> 8, rec = prog[pc + 2];
+        ranges.push_back(Range{rec, rec + n_inst * uint32_t(L.words()), i});
+        pc += kRoundWords;
+      } else if (opc == OP_GATE2) {
+        ranges.push_back(Range{prog[pc + 2], prog[pc + 2] + 32u, i});
+        pc += kGate2Words;
+      } else if (opc == OP_MEASURE_WHT) {
+        *first_measuring = std::min(*first_measuring, i);
+        pc += size_t(kWhtHeaderWords) + size_t(w0 >> 8) * kMeasTermWords;
+      } else if (opc == OP_MEASURE) {
+        const uint32_t n_groups = w0 >> 8;
+        if (n_groups) *first_measuring = std::min(*first_measuring, i);
+        pc += 1;
+        for (uint32_t g = 0; g < n_groups && pc + 1 < prog.size(); ++g) pc += 2u + size_t(prog[pc + 1]) * kMeasTermWords;
+      } else {
+        return std::vector<int>(n_gates, 0);  // an opcode this walk does not know: share nothing
+      }
+    }
+  }
+  std::vector<int> first(n_gates, n_pass);
+  for (const CoefJob& j : plan.jobs) {
+    if (j.gate < 0 || size_t(j.gate) >= n_gates) continue;
+    int pass = 0;  // (a job whose record no pass claims: share nothing for its gate)
+    for (const Range& r : ranges)
+      if (uint32_t(j.out_off) >= r.lo && uint32_t(j.out_off) < r.hi) { pass = r.pass; break; }
+    first[size_t(j.gate)] = std::min(first[size_t(j.gate)], pass);
+  }
+  return first;
+}
+
 }  // namespace
 
 // ================================================================================
@@ -1227,6 +1280,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "adjoint_exchange") { h->opt_adj_exchange = int(value); h->plans_valid = false; }
   else if (k == "adjoint_relabel") { h->opt_adj_relabel = int(value); h->plans_valid = false; }
   else if (k == "forward_pairs") h->opt_fwd_pair = int(value);
+  else if (k == "shift_prefix_sharing") { h->opt_shift_prefix = int(value); h->shift_ready = false; }
   else if (k == "forward_values_from_observable") h->opt_fwd_values_obs = int(value);
   else if (k == "adjoint_stop_early") { h->opt_adj_stop_early = int(value); h->plans_valid = false; }
   else if (k == "adjoint_plan_search") { h->opt_adj_plan_search = int(value); h->plans_valid = false; }
@@ -1535,7 +1589,10 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const floa
   // pairs are the batch: as many programs as the workspace holds run in ONE launch set, each on
   // its own copy of the coefficient buffer (PassArgs::prog_states).
   if (int rc = forward(h, d_bits, U, d_params, d_out_vals, -1, 0.0, s)) return rc;
-  if (!h->shift_ready) {  // shift tables: once per model
+  DevicePlan& d = h->fwd;
+  const bool from_obs = forward_values_from_observable(h);
+  if (!h->shift_ready || h->shift_tables_from_obs != from_obs) {  // shift tables: once per model
+    h->shift_tables_from_obs = from_obs;
     std::vector<int> sg, sp;
     std::vector<float> sv, sw;
     for (size_t g = 0; g < h->model.gates.size(); ++g) {
@@ -1548,9 +1605,36 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const floa
       sp.push_back(G.param_idx);
       sw.push_back(float(1.5707963267948966 * double(G.scalar)));
     }
+    // Execution order: by the first pass that reads the shifted gate's coefficients (first_dependent_pass), gate order
+    // within a pass; the sums of program q land at prog_acc[dst[q]], i.e. in GATE order, so the combination per parameter
+    // adds in the order it always did.  Without sharing every program "starts" at pass 0.
+    const int n_pass = int(d.plan.passes.size());
+    int first_measuring = n_pass;
+    std::vector<int> first(h->model.gates.size(), 0);
+    if (h->opt_shift_prefix) first = first_dependent_pass(d.plan, h->model.gates.size(), &first_measuring);
+    auto start_of = [&](int gate) {
+      int k = std::min(first[size_t(gate)], n_pass - 1);
+      if (!from_obs) k = std::min(k, first_measuring);   // measuring passes write the program's own accumulators
+      return std::max(k, 0);
+    };
+    std::vector<int> order(sg.size());
+    for (size_t q = 0; q < order.size(); ++q) order[q] = int(q);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return start_of(sg[size_t(x)]) < start_of(sg[size_t(y)]); });
+    std::vector<int> sg_exec(sg.size()), dst(sg.size());
+    std::vector<float> sv_exec(sg.size());
+    h->shift_group_end.assign(size_t(std::max(n_pass, 1)), 0u);
+    for (size_t q = 0; q < order.size(); ++q) {
+      sg_exec[q] = sg[size_t(order[q])];
+      sv_exec[q] = sv[size_t(order[q])];
+      dst[q] = order[q];
+      h->shift_group_end[size_t(start_of(sg_exec[q]))] = uint32_t(q + 1);
+    }
+    for (size_t i = 1; i < h->shift_group_end.size(); ++i)
+      h->shift_group_end[i] = std::max(h->shift_group_end[i], h->shift_group_end[i - 1]);
     HIPCHK(hipStreamSynchronize(s));  // synchronous copies into buffers an earlier call on this stream may still read
-    HIPCHK(h->shift_gates.upload(sg));
-    HIPCHK(h->shift_vals.upload(sv));
+    HIPCHK(h->shift_gates.upload(sg_exec));
+    HIPCHK(h->shift_vals.upload(sv_exec));
+    HIPCHK(h->shift_dst.upload(dst));
     HIPCHK(h->shift_param.upload(sp));
     HIPCHK(h->shift_weight.upload(sw));
     h->shift_programs = uint32_t(sg.size());
@@ -1562,18 +1646,20 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const floa
     if (P) HIPCHK(hipMemsetAsync(d_grad, 0, size_t(P) * sizeof(float), s));
     return 0;
   }
-  DevicePlan& d = h->fwd;
   const uint32_t stride = uint32_t((d.plan.coef_init.size() + 64 + 63) / 64 * 64);
-  // batch geometry: Uc states x Pc programs per launch set
+  // batch geometry: Uc states x Pc programs per launch set (+ Uc base states when programs share their prefix)
   size_t cap = std::max<size_t>(1, budget_bytes(h) / state_bytes(h));
   uint32_t max_nl = 0;
   for (const PassArgs& a : d.args) max_nl = std::max(max_nl, a.n_nonlocal);
   cap = std::min<size_t>(cap, (size_t(1) << 30) >> max_nl);  // grid.x = elements << n_nonlocal
   cap = std::min<size_t>(cap, (size_t(2) << 30) / (size_t(stride) * sizeof(float)));  // <= 2 GiB of coefficient copies
   if (h->opt_chunk > 0) cap = std::min<size_t>(cap, size_t(h->opt_chunk));
-  const uint32_t Uc = uint32_t(std::min<size_t>(size_t(U), cap));
-  const uint32_t Pc = uint32_t(std::max<size_t>(1, std::min<size_t>(n_prog, cap / Uc)));
+  // sharing needs a second buffer of Uc base states and at least one pass to skip
+  const bool share = h->opt_shift_prefix != 0 && h->shift_group_end.size() > 1 && h->shift_group_end[0] < n_prog && cap >= 2;
+  const uint32_t Uc = uint32_t(std::min<size_t>(size_t(U), share ? cap / 2 : cap));
+  const uint32_t Pc = uint32_t(std::max<size_t>(1, std::min<size_t>(n_prog, (cap - (share ? Uc : 0)) / Uc)));
   if (int rc = ensure_state_buffers(h, Uc * Pc, false)) return rc;
+  if (share) HIPCHK(h->lam.reserve(size_t(Uc) << d.plan.n_eff, false));   // the base states live where lambda would
   const size_t nvb = size_t(Uc) * Pc * size_t(h->model.n_ops);
   HIPCHK(h->vals64.reserve(nvb));
   HIPCHK(h->vals_batch.reserve(nvb));
@@ -1591,41 +1677,65 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const floa
   // The values of a shifted program come the way a forward-only call takes them: where that is the observable kernel
   // (wide terms: lean passes, then one sweep over the final states, the lower block of every pair only), the
   // shifted programs do the same -- config 4's 480 masks cost 51 measurement passes per program otherwise.
-  const bool from_obs = forward_values_from_observable(h);
+  auto pass_args = [&](size_t i, uint32_t prog_states) {
+    const Pass& p = d.plan.passes[i];
+    PassArgs a = d.args[i];
+    a.flags = p.flags & (PASS_INIT_BASIS | PASS_GENERAL | PASS_NO_ZERO_FILL);
+    if (h->opt_force_general) a.flags |= PASS_GENERAL;
+    if (from_obs) a.flags |= PASS_SKIP_MEASURE;
+    if (!p.is_measure_only && (!p.completes_circuit || measure_only_after || from_obs)) a.flags |= PASS_STORE;
+    a.prog_states = prog_states;
+    a.coef_stride = prog_states ? stride : 0u;
+    return a;
+  };
+  const size_t n_pass = d.plan.passes.size();
   for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += Uc) {
     const uint32_t c = std::min<uint32_t>(Uc, uint32_t(U) - s0);
-    for (uint32_t q0 = 0; q0 < n_prog; q0 += Pc) {
-      const uint32_t nq = std::min<uint32_t>(Pc, n_prog - q0);
-      HIPCHK(launch_prep_coefs_batch(d.jobs.p, int(d.plan.jobs.size()), d_params, h->coef_batch.p, h->shift_gates.p + q0,
-                                     h->shift_vals.p + q0, nq, stride, s));
-      HIPCHK(launch_combine_diag(h->coef_batch.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), nq, stride, s));
-      HIPCHK(hipMemsetAsync(h->vals64.p, 0, size_t(nq) * c * size_t(h->model.n_ops) * sizeof(unsigned long long), s));
-      for (size_t i = 0; i < d.plan.passes.size(); ++i) {
-        const Pass& p = d.plan.passes[i];
-        if (from_obs && p.is_measure_only) continue;
-        PassArgs a = d.args[i];
-        a.flags = p.flags & (PASS_INIT_BASIS | PASS_GENERAL | PASS_NO_ZERO_FILL);
-        if (h->opt_force_general) a.flags |= PASS_GENERAL;
-        if (from_obs) a.flags |= PASS_SKIP_MEASURE;
-        if (!p.is_measure_only && (!p.completes_circuit || measure_only_after || from_obs)) a.flags |= PASS_STORE;
-        a.prog_states = c;
-        a.coef_stride = stride;
+    // k: the pass the programs of this group start at; the base buffer holds the base program's states after passes < k
+    for (size_t k = 0; k < (share ? n_pass : size_t(1)); ++k) {
+      const uint32_t group_begin = share ? (k ? h->shift_group_end[k - 1] : 0u) : 0u;
+      const uint32_t group_end = share ? h->shift_group_end[k] : n_prog;
+      for (uint32_t q0 = group_begin; q0 < group_end; q0 += Pc) {
+        const uint32_t nq = std::min<uint32_t>(Pc, group_end - q0);
+        HIPCHK(launch_prep_coefs_batch(d.jobs.p, int(d.plan.jobs.size()), d_params, h->coef_batch.p, h->shift_gates.p + q0,
+                                       h->shift_vals.p + q0, nq, stride, s));
+        HIPCHK(launch_combine_diag(h->coef_batch.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), nq, stride, s));
+        HIPCHK(hipMemsetAsync(h->vals64.p, 0, size_t(nq) * c * size_t(h->model.n_ops) * sizeof(unsigned long long), s));
+        bool first_pass = true;
+        for (size_t i = k; i < n_pass; ++i) {
+          const Pass& p = d.plan.passes[i];
+          if (from_obs && p.is_measure_only) continue;
+          const PassArgs a = pass_args(i, c);
+          hipEvent_t* ev = timer_begin(h, 0, s);
+          // (the first pass a prefix-sharing program runs loads the base program's state of its bitstring)
+          HIPCHK(launch_pass_fwd(p.K, d.plan.R, a, nq * c, h->psi.p, d_bits, h->model.n, d.prog.p, d.tables.p,
+                                 h->coef_batch.p, h->op_scale.p, h->vals64.p, s0, s,
+                                 (first_pass && k > 0) ? h->lam.p : nullptr));
+          timer_end(ev, s);
+          first_pass = false;
+        }
+        if (from_obs) {
+          if (int rc = run_values_chunk(h, 0u, nq * c, s)) return rc;
+        } else if (!d.plan.global_terms.empty()) {
+          HIPCHK(launch_measure_global(h->psi.p, uint32_t(d.plan.n_eff), nq * c, h->global_terms.p,
+                                       uint32_t(d.plan.global_terms.size()), h->op_scale.p, h->vals64.p,
+                                       uint32_t(h->model.n_ops), 0u, s));
+        }
+        HIPCHK(launch_values_from_fixed(h->vals64.p, h->op_inv_scale.p, h->vals_batch.p,
+                                        nq * c * uint32_t(h->model.n_ops), uint32_t(h->model.n_ops), s));
+        HIPCHK(launch_shift_program_accumulate(h->vals_batch.p, d_upstream, nq, c, uint32_t(h->model.n_ops), s0,
+                                               h->prog_acc.p, s, h->shift_dst.p + q0));
+      }
+      // the base program advances by pass k (its own coefficients: d.coef, prepared by the forward call above) unless
+      // no later program needs it
+      if (share && group_end < n_prog && !(from_obs && d.plan.passes[k].is_measure_only)) {
+        PassArgs a = pass_args(k, 0u);
+        a.flags |= PASS_STORE | PASS_SKIP_MEASURE;   // (its values were taken by the forward call)
         hipEvent_t* ev = timer_begin(h, 0, s);
-        HIPCHK(launch_pass_fwd(p.K, d.plan.R, a, nq * c, h->psi.p, d_bits, h->model.n, d.prog.p, d.tables.p,
-                               h->coef_batch.p, h->op_scale.p, h->vals64.p, s0, s));
+        HIPCHK(launch_pass_fwd(d.plan.passes[k].K, d.plan.R, a, c, h->lam.p, d_bits, h->model.n, d.prog.p, d.tables.p,
+                               d.coef.p, h->op_scale.p, h->vals64.p, s0, s));
         timer_end(ev, s);
       }
-      if (from_obs) {
-        if (int rc = run_values_chunk(h, 0u, nq * c, s)) return rc;
-      } else if (!d.plan.global_terms.empty()) {
-        HIPCHK(launch_measure_global(h->psi.p, uint32_t(d.plan.n_eff), nq * c, h->global_terms.p,
-                                     uint32_t(d.plan.global_terms.size()), h->op_scale.p, h->vals64.p,
-                                     uint32_t(h->model.n_ops), 0u, s));
-      }
-      HIPCHK(launch_values_from_fixed(h->vals64.p, h->op_inv_scale.p, h->vals_batch.p,
-                                      nq * c * uint32_t(h->model.n_ops), uint32_t(h->model.n_ops), s));
-      HIPCHK(launch_shift_program_accumulate(h->vals_batch.p, d_upstream, nq, c, uint32_t(h->model.n_ops), s0,
-                                             h->prog_acc.p + q0, s));
     }
   }
   HIPCHK(launch_shift_combine(h->prog_acc.p, h->shift_param.p, h->shift_weight.p, int(n_shift_gates), d_grad, P, s));

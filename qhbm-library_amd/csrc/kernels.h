@@ -98,7 +98,9 @@ size_t adj_lds_bytes(int K, bool exchange);
 // op_scale[k] = 2^(kValueFracBits - ceil(log2 sum|c|)) of op k; out64 [U, n_ops] fixed-point accumulators.
 hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
                            int n_user, const uint32_t* prog, const uint32_t* tables, const float* coef,
-                           const float* op_scale, unsigned long long* out64, uint32_t state0, hipStream_t stream);
+                           const float* op_scale, unsigned long long* out64, uint32_t state0, hipStream_t stream,
+                           const float2* psi_src = nullptr /* batched programs: element e LOADS the tile of state
+                           e % prog_states of this buffer and stores into its own element of psi */);
 // The same pass on PAIRS of consecutive states, tile pair in registers (kernels.hip pass_fwd2_kernel): only for
 // lean passes that prune nothing, load nothing stale and measure nothing (or whose measurements are ignored).
 bool pass_fwd_pair_supported(int K);
@@ -164,7 +166,8 @@ hipError_t launch_prep_coefs_batch(const CoefJob* jobs, int n_jobs, const float*
 hipError_t launch_replicate(const float* src, float* dst, uint32_t words, uint32_t stride, uint32_t copies,
                             hipStream_t stream);
 hipError_t launch_shift_program_accumulate(const float* vals, const float* upstream, uint32_t n_programs, uint32_t c,
-                                           uint32_t n_ops, uint32_t s0, double* prog_acc, hipStream_t stream);
+                                           uint32_t n_ops, uint32_t s0, double* prog_acc, hipStream_t stream,
+                                           const int* dst_index = nullptr /* program q adds to prog_acc[dst_index[q]] */);
 hipError_t launch_shift_combine(const double* prog_acc, const int* gate_param, const float* gate_weight,
                                 int n_shift_gates, float* grad, int n_params, hipStream_t stream);
 hipError_t launch_reduce_grad(const float* state_grad, uint32_t U, uint32_t n_slots,

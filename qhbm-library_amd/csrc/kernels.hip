@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
     PassArgs a, float2* __restrict__ psi, const int8_t* __restrict__ bits, int n_user,
     const uint32_t* __restrict__ prog_base, const uint32_t* __restrict__ tables,
     const float* __restrict__ coef, const float* __restrict__ op_scale, unsigned long long* __restrict__ out64,
-    uint32_t state0) {
+    uint32_t state0, const float2* __restrict__ psi_src) {
   constexpr int NT = 1 << (K - R);
   constexpr int NR = 1 << R;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1092,7 +1092,10 @@ __global__ __launch_bounds__(1 << (K - R), fwd_min_waves(K, R)) void pass_fwd_ke
   } else {
     // (head of the sweep: the tiles on which psi is identically zero are not launched -- launched_tile)
     TileRegs r;
-    prefetch_tile<K, NT>(r, st, t, toff);
+    // (psi_src: the first pass of a shifted program that shares its prefix with the base program loads the BASE state of
+    // its bitstring -- the passes before it are the same bits for every program -- and stores into its own element)
+    const float2* ld = psi_src ? psi_src + (size_t(bits_row - state0) << a.n) : st;
+    prefetch_tile<K, NT>(r, ld, t, toff);
     if (a.frozen_old_local) clear_stale<K>(r, tid, in_local, a.frozen_old_local);  // local bits nothing has acted on yet: their != input half was never written
     commit_tile<K, NT>(tile, r, tid);
   }
@@ -2486,25 +2489,27 @@ template <int K, int R, bool GEN>
 static hipError_t launch_fwd_t(const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
                                int n_user, const uint32_t* prog, const uint32_t* tables,
                                const float* coef, const float* op_scale, unsigned long long* out64, uint32_t state0,
-                               hipStream_t stream) {
+                               hipStream_t stream, const float2* psi_src) {
   const size_t lds = fwd_lds_bytes(K);
   static bool attr_done[kMaxDevices] = {};
   if (hipError_t e = opt_in_lds(&pass_fwd_kernel<K, R, GEN>, attr_done, lds); e != hipSuccess) return e;
   const uint32_t grid = n_states << a.n_free;
   hipLaunchKernelGGL((pass_fwd_kernel<K, R, GEN>), dim3(grid), dim3(1 << (K - R)), lds, stream, a, psi, bits,
-                     n_user, prog, tables, coef, op_scale, out64, state0);
+                     n_user, prog, tables, coef, op_scale, out64, state0, psi_src);
   return hipGetLastError();
 }
 
 hipError_t launch_pass_fwd(int K, int R, const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits,
                            int n_user, const uint32_t* prog, const uint32_t* tables, const float* coef,
-                           const float* op_scale, unsigned long long* out64, uint32_t state0, hipStream_t stream) {
+                           const float* op_scale, unsigned long long* out64, uint32_t state0, hipStream_t stream,
+                           const float2* psi_src) {
   if (!pass_prologue_ok(K, a, n_user)) return hipErrorInvalidValue;
+  if (psi_src && ((a.flags & PASS_INIT_BASIS) || !a.prog_states)) return hipErrorInvalidValue;  // (batched programs that LOAD)
 #define QHBM_FWD_CASE(K_, R_)                                                                          \
   if (K == K_ && R == R_)                                                                              \
     return (a.flags & PASS_GENERAL)                                                                    \
-               ? launch_fwd_t<K_, R_, true>(a, n_states, psi, bits, n_user, prog, tables, coef, op_scale, out64, state0, stream)   \
-               : launch_fwd_t<K_, R_, false>(a, n_states, psi, bits, n_user, prog, tables, coef, op_scale, out64, state0, stream);
+               ? launch_fwd_t<K_, R_, true>(a, n_states, psi, bits, n_user, prog, tables, coef, op_scale, out64, state0, stream, psi_src)   \
+               : launch_fwd_t<K_, R_, false>(a, n_states, psi, bits, n_user, prog, tables, coef, op_scale, out64, state0, stream, psi_src);
   QHBM_FWD_CASE(10, 4)
   QHBM_FWD_CASE(11, 4)
   QHBM_FWD_CASE(12, 4)
@@ -3156,7 +3161,8 @@ hipError_t launch_replicate(const float* src, float* dst, uint32_t words, uint32
 __global__ __launch_bounds__(256) void shift_program_accumulate_kernel(const float* __restrict__ vals,
                                                                        const float* __restrict__ upstream, uint32_t c,
                                                                        uint32_t n_ops, uint32_t s0,
-                                                                       double* __restrict__ prog_acc) {
+                                                                       double* __restrict__ prog_acc,
+                                                                       const int* __restrict__ dst_index) {
   __shared__ double part[256];
   const float* v = vals + size_t(blockIdx.x) * c * n_ops;
   const float* up = upstream + size_t(s0) * n_ops;
@@ -3168,7 +3174,8 @@ __global__ __launch_bounds__(256) void shift_program_accumulate_kernel(const flo
     if (int(threadIdx.x) < o) part[threadIdx.x] += part[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) prog_acc[blockIdx.x] += part[0];
+  // (dst_index: the programs run sorted by the pass their shifted gate sits in; the sums land in gate order)
+  if (threadIdx.x == 0) prog_acc[dst_index ? uint32_t(dst_index[blockIdx.x]) : blockIdx.x] += part[0];
 }
 // ... and grad[p] = sum over the gates g driven by p (in gate order) of weight_g * (acc[2g] - acc[2g+1]).
 __global__ void shift_combine_kernel(const double* __restrict__ prog_acc, const int* __restrict__ gate_param,
@@ -3182,10 +3189,11 @@ __global__ void shift_combine_kernel(const double* __restrict__ prog_acc, const 
   grad[p] = float(acc);
 }
 hipError_t launch_shift_program_accumulate(const float* vals, const float* upstream, uint32_t n_programs, uint32_t c,
-                                           uint32_t n_ops, uint32_t s0, double* prog_acc, hipStream_t stream) {
+                                           uint32_t n_ops, uint32_t s0, double* prog_acc, hipStream_t stream,
+                                           const int* dst_index) {
   if (!n_programs) return hipSuccess;
   hipLaunchKernelGGL(shift_program_accumulate_kernel, dim3(n_programs), dim3(256), 0, stream, vals, upstream, c, n_ops,
-                     s0, prog_acc);
+                     s0, prog_acc, dst_index);
   return hipGetLastError();
 }
 hipError_t launch_shift_combine(const double* prog_acc, const int* gate_param, const float* gate_weight,

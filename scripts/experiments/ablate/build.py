@@ -126,13 +126,13 @@ VARIANTS.update({
     "fwd_no_full": lambda t: in_fwd_instance(t, "if (h1 & kFullDiagFlag) apply_full<NV>(a, rv, rb, false);", "if ((h1 & kFullDiagFlag) && lane == 77) apply_full<NV>(a, rv, rb, false);"),
     "fwd_no_cph": lambda t: in_fwd_instance(t, "  if (h1 & 0xffu) {", "  if ((h1 & 0xffu) && lane == 77) {"),
     # forward without its HBM traffic (tile neither loaded nor stored): what the memory phase adds to the compute
-    "fwd_no_tile_io": lambda t: once(once(t, "    TileRegs r;\n    prefetch_tile<K, NT>(r, st, t, toff);\n    if (a.frozen_old_local) clear_stale",
-                                          "    TileRegs r = TileRegs{};\n    if (a.frozen_old_local) clear_stale"),
+    "fwd_no_tile_io": lambda t: once(once(t, "    prefetch_tile<K, NT>(r, ld, t, toff);\n    if (a.frozen_old_local) clear_stale",
+                                          "    r = TileRegs{};\n    if (a.frozen_old_local) clear_stale"),
                                      "  if (a.flags & PASS_STORE) store_tile<K, NT>(tile, st, t, thread_offsets(t, tid), tid);\n}\n", "  if ((a.flags & PASS_STORE) && tid == 1000) store_tile<K, NT>(tile, st, t, thread_offsets(t, tid), tid);\n}\n"),
     "fwd_const_no_trips": lambda t: VARIANTS["const_coefs"](VARIANTS["fwd_no_round_trips"](t)),
     # stagger the first generation of forward workgroups (by hardware wave slot) to break lock step
-    "fwd_stagger": lambda t: once(t, "    TileRegs r;\n    prefetch_tile<K, NT>(r, st, t, toff);\n    if (a.frozen_old_local) clear_stale",
-                                  "    if (blockIdx.x < 1024u) { const uint32_t slot = __builtin_amdgcn_s_getreg(0x1804) & 3u; for (uint32_t i = 0; i < slot * 2u; ++i) __builtin_amdgcn_s_sleep(127); }\n    TileRegs r;\n    prefetch_tile<K, NT>(r, st, t, toff);\n    if (a.frozen_old_local) clear_stale"),
+    "fwd_stagger": lambda t: once(t, "    prefetch_tile<K, NT>(r, ld, t, toff);\n    if (a.frozen_old_local) clear_stale",
+                                  "    if (blockIdx.x < 1024u) { const uint32_t slot = __builtin_amdgcn_s_getreg(0x1804) & 3u; for (uint32_t i = 0; i < slot * 2u; ++i) __builtin_amdgcn_s_sleep(127); }\n    prefetch_tile<K, NT>(r, ld, t, toff);\n    if (a.frozen_old_local) clear_stale"),
     "fwd_no_barriers": lambda t: once(t, "      if (!(w0 & kRoundNoBarrier)) __syncthreads();  // else the next round's waves read only their own writes\n      pc += kRoundWords;\n    } else if (opc == OP_GATE2) {",
                                       "      pc += kRoundWords;\n    } else if (opc == OP_GATE2) {"),
     "fwd_no_round_trips": lambda t: once(once(t, "      round_load<R>(tile, T, DB, amp);\n      for (uint32_t i = 0; i < n_inst; ++i) {", "      if (pc == 0) round_load<R>(tile, T, DB, amp);\n      for (uint32_t i = 0; i < n_inst; ++i) {"),

@@ -472,6 +472,52 @@ def test_parameter_shift_batches_states_and_programs():
       np.testing.assert_allclose(eng.expectation(bits, params).cpu().numpy(), want_vals, atol=1e-4)
 
 
+@pytest.mark.parametrize("n,layers,tile,kinds", [(13, 3, 10, "hea"), (14, 2, 10, "all kinds"), (15, 4, 11, "hea"), (16, 2, 0, "hea")])
+def test_parameter_shift_programs_share_the_base_program_s_prefix_bit_for_bit(n, layers, tile, kinds):
+  """A shifted program differs from the base program in ONE gate: it starts at the first pass that reads that gate's
+  coefficients, from the base program's state (`shift_prefix_sharing`, default on; round 5's review, item 2 i).  The
+  passes it skips would have computed the same bits, so gradient and values must EQUAL the unshared run bit for bit --
+  values taken by the observable kernel (a wide random Pauli sum) and measured in the passes (TFIM, shards), tied
+  parameters, a gradient mask, launch sets cut by `chunk_states` -- and agree with the oracle's adjoint VJP."""
+  from oracle import qhbm_cpu as C
+  rng = np.random.default_rng(700 + n)
+  if kinds == "hea":
+    gates, names = O.hea_gates(n, layers, "ps")
+    n_params = len(names)
+    gates = gates + [(O.GATE_XXPOW, 2, n - 3, 3, 0.7, 0.1), (O.GATE_ZZPOW, 0, n - 1, 5, -1.3, 0.0)]   # tied parameters
+  else:
+    n_params = 9
+    gates = random_circuit(rng, n, 60, n_params, kinds=[k for k in range(12) if k != O.GATE_ISWAPPOW])
+  params = rng.uniform(-1, 1, n_params).astype(np.float32)
+  bits = _random_bits(rng, 3, n)
+  layouts = {"wide sum": [O.random_pauli_op(n, 40, n, p_identity=0.6)],
+             "tfim + xxz": [O.tfim_ring_op(n), O.xxz_chain_op(n)],
+             "shards": [[(1.0, 0, 1 << q)] for q in range(n)] + [[(0.5, 0, (1 << q) | (1 << ((q + 5) % n)))] for q in range(n)]}
+  mask = rng.random(n_params) < 0.6
+  for name, ops in layouts.items():
+    up = rng.normal(size=(3, len(ops))).astype(np.float32)
+    want_vals, want = C.expectation_vjp(n, gates, params, bits, ops, up)
+    for use_mask in (False, True):
+      for chunk in (0, 5):
+        results = []
+        for sharing in (0, 1):
+          eng = _engine(n, gates, n_params, ops, tile_qubits=tile, chunk_states=chunk, shift_prefix_sharing=sharing)
+          if use_mask:
+            eng.set_gradient_mask(mask)
+          vals, grad = eng.expectation_vjp(bits, params, up, method=E.GRAD_PARAMETER_SHIFT)
+          results.append((vals.clone(), grad.clone()))
+          if sharing:
+            fwd, _ = eng.num_passes()
+            assert fwd > 1 or tile == 0, "the case is meant to run several forward passes"
+        assert torch.equal(results[0][0], results[1][0]), (name, use_mask, chunk)
+        assert torch.equal(results[0][1], results[1][1]), (name, use_mask, chunk,
+                                                         float((results[0][1] - results[1][1]).abs().max()))
+        wg = np.where(mask, want, 0.0) if use_mask else want
+        np.testing.assert_allclose(results[1][1].cpu().numpy(), wg, atol=3e-4 * max(1.0, float(np.abs(wg).max())), rtol=0,
+                                   err_msg=f"{name} mask={use_mask} chunk={chunk}")
+        np.testing.assert_allclose(results[1][0].cpu().numpy(), want_vals, atol=5e-5 * _op_norm(ops).max())
+
+
 def test_random_circuits_of_every_gate_kind_at_18_qubits_against_c_oracle():
   """The general kernel variants (Y, H, CNOT / SWAP / ISWAP / XX / YY / ZZ powers: dense two-qubit
   ops on the LDS tiles, the two-tile adjoint layout) on multi-pass plans at a size where only the C
