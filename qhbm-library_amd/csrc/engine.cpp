@@ -886,7 +886,7 @@ int run_forward_chunk(qhbm_engine* h, const int8_t* d_bits, uint32_t s0, uint32_
 int values_begin(qhbm_engine* h, int U, hipStream_t stream) {
   const size_t nv = size_t(U) * size_t(std::max(h->model.n_ops, 1));
   HIPCHK(h->vals64.reserve(nv));
-  HIPCHK(hipMemsetAsync(h->vals64.p, 0, nv * sizeof(unsigned long long), stream));
+  HIPCHK(launch_zero_fill(h->vals64.p, nv * sizeof(unsigned long long), stream));
   return 0;
 }
 // ... and are converted to fp32 [U, n_ops] once at the end.
@@ -1053,7 +1053,7 @@ int adjoint_sweep(qhbm_engine* h, const int8_t* d_bits, int U, const float* d_pa
   HIPCHK(launch_combine_diag(b.coef.p, b.rec_offsets.p, int(b.plan.record_offsets.size()), 1u, 0u, stream));
   if (int rc = values_begin(h, U, stream)) return rc;
   HIPCHK(h->state_grad.reserve(size_t(U) * std::max<uint32_t>(n_slots, 1)));
-  HIPCHK(hipMemsetAsync(h->state_grad.p, 0, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), stream));
+  HIPCHK(launch_zero_fill(h->state_grad.p, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), stream));
   const uint32_t cs = adjoint_chunk_states(h, U);
   if (int rc = ensure_state_buffers(h, cs, true)) return rc;
   const bool vm = value_mode(h), mv = multi_value_mode(h);
@@ -1375,7 +1375,7 @@ int qhbm_expectation_vjp_retained(qhbm_engine* h, const int8_t* d_bits, int U, c
   HIPCHK(launch_prep_coefs(b.jobs.p, int(b.plan.jobs.size()), d_params, b.coef.p, -1, 0.0, s));
   HIPCHK(launch_combine_diag(b.coef.p, b.rec_offsets.p, int(b.plan.record_offsets.size()), 1u, 0u, s));
   HIPCHK(h->state_grad.reserve(size_t(U) * std::max<uint32_t>(n_slots, 1)));
-  HIPCHK(hipMemsetAsync(h->state_grad.p, 0, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), s));
+  HIPCHK(launch_zero_fill(h->state_grad.p, size_t(U) * std::max<uint32_t>(n_slots, 1) * sizeof(float), s));
   if (h->retained_mu) {  // lambda = O psi (unweighted) was computed with the values: weight the rows instead
     if (int rc = run_adjoint_chunk(h, d_bits, 0, uint32_t(U), s)) return rc;
     HIPCHK(launch_scale_rows(h->state_grad.p, uint32_t(U), std::max<uint32_t>(n_slots, 1), d_upstream, s));
@@ -1448,7 +1448,7 @@ int qhbm_parity_energy_vjp(const int8_t* d_bits, int64_t n_rows, int n_bits, con
   if (n_rows < 0 || n_terms < 0) return fail(nullptr, "negative size");
   if (n_bits < 1 || n_bits > 64) return fail(nullptr, "n_bits must be in [1, 64]");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = n_terms ? hipMemsetAsync(d_grad, 0, size_t(n_terms) * sizeof(float), s) : hipSuccess;
+  hipError_t e = n_terms ? launch_zero_fill(d_grad, size_t(n_terms) * sizeof(float), s) : hipSuccess;
   if (e == hipSuccess) e = launch_parity_energy_vjp(d_bits, n_rows, n_bits, d_masks, n_terms, d_weights, d_grad, s);
   if (e != hipSuccess) return fail(nullptr, std::string("qhbm_parity_energy_vjp: ") + hipGetErrorString(e));
   return 0;
@@ -1535,7 +1535,7 @@ int qhbm_sample_counts(qhbm_engine* h, const int8_t* d_bits, int U, const float*
     h->coef_batch_programs = Pc;
   }
   if (n_eff > uint32_t(kMinTileBits))
-    HIPCHK(hipMemsetAsync(d_out_counts, 0, ((size_t(n_prog) * size_t(U)) << h->model.n) * sizeof(int32_t), s));
+    HIPCHK(launch_zero_fill(d_out_counts, ((size_t(n_prog) * size_t(U)) << h->model.n) * sizeof(int32_t), s));
   for (uint32_t s0 = 0; s0 < uint32_t(U); s0 += Uc) {
     const uint32_t c = std::min<uint32_t>(Uc, uint32_t(U) - s0);
     for (uint32_t q0 = 0; q0 < n_prog; q0 += Pc) {
@@ -1568,7 +1568,7 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const floa
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int P = h->model.n_params;
   if (U == 0) {
-    if (P) HIPCHK(hipMemsetAsync(d_grad, 0, size_t(P) * sizeof(float), s));
+    if (P) HIPCHK(launch_zero_fill(d_grad, size_t(P) * sizeof(float), s));
     return 0;
   }
   const size_t nv = size_t(U) * h->model.n_ops;
@@ -1643,7 +1643,7 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const floa
   }
   const uint32_t n_prog = h->shift_programs, n_shift_gates = h->shift_gate_count;
   if (n_prog == 0) {
-    if (P) HIPCHK(hipMemsetAsync(d_grad, 0, size_t(P) * sizeof(float), s));
+    if (P) HIPCHK(launch_zero_fill(d_grad, size_t(P) * sizeof(float), s));
     return 0;
   }
   const uint32_t stride = uint32_t((d.plan.coef_init.size() + 64 + 63) / 64 * 64);
@@ -1664,7 +1664,7 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const floa
   HIPCHK(h->vals64.reserve(nvb));
   HIPCHK(h->vals_batch.reserve(nvb));
   HIPCHK(h->prog_acc.reserve(n_prog));
-  HIPCHK(hipMemsetAsync(h->prog_acc.p, 0, size_t(n_prog) * sizeof(double), s));
+  HIPCHK(launch_zero_fill(h->prog_acc.p, size_t(n_prog) * sizeof(double), s));
   if (h->coef_batch_programs < Pc) {
     HIPCHK(h->coef_batch.reserve(size_t(Pc) * stride));
     HIPCHK(launch_replicate(d.coef.p, h->coef_batch.p, uint32_t(d.plan.coef_init.size()), stride, Pc, s));
@@ -1700,7 +1700,7 @@ int qhbm_expectation_vjp(qhbm_engine* h, const int8_t* d_bits, int U, const floa
         HIPCHK(launch_prep_coefs_batch(d.jobs.p, int(d.plan.jobs.size()), d_params, h->coef_batch.p, h->shift_gates.p + q0,
                                        h->shift_vals.p + q0, nq, stride, s));
         HIPCHK(launch_combine_diag(h->coef_batch.p, d.rec_offsets.p, int(d.plan.record_offsets.size()), nq, stride, s));
-        HIPCHK(hipMemsetAsync(h->vals64.p, 0, size_t(nq) * c * size_t(h->model.n_ops) * sizeof(unsigned long long), s));
+        HIPCHK(launch_zero_fill(h->vals64.p, size_t(nq) * c * size_t(h->model.n_ops) * sizeof(unsigned long long), s));
         bool first_pass = true;
         for (size_t i = k; i < n_pass; ++i) {
           const Pass& p = d.plan.passes[i];

@@ -107,6 +107,8 @@ bool pass_fwd_pair_supported(int K);
 hipError_t launch_pass_fwd_pair(int K, const PassArgs& a, uint32_t n_states, float2* psi, const int8_t* bits, int n_user,
                                 uint32_t state0, const uint32_t* prog, const uint32_t* tables, const float* coef,
                                 hipStream_t stream);
+// p[0 .. bytes) = 0 by a kernel (not a memset node: see kernels.hip)
+hipError_t launch_zero_fill(void* p, size_t bytes, hipStream_t stream);
 hipError_t launch_values_from_fixed(const unsigned long long* acc, const float* inv_scale, float* out, uint32_t count,
                                     uint32_t n_ops, hipStream_t stream);
 // tile_grad [n_states * tiles, a.n_slots]: one gradient row per workgroup.  `exchange` selects the

@@ -1635,23 +1635,32 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
     w0 = w1;
     { [[maybe_unused]] const unsigned long long now = QHBM_TICK(); tk_xchg += now - tk_r; tk_r = now; }
   }
+  // (sched_barrier: the epilogue runs once per workgroup -- nothing to gain from interleaving the two tiles' stores, and
+  // hoisting the second tile's LDS reads over the first tile's stores spilled 4 - 13 VGPRs in the ROWS8 / K = 10, 11, 13
+  // instantiations)
   if (a.flags & PASS_RELABEL) {
     const RelabelCtx rc = relabel_lookup<K>(a, tables, in_local, tid, lane);  // (in flight under the exchange below)
     round_store<R>(xt, T, DB, p);
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     store_tile_relabeled<K, NT>(xt, sp, a, rc, t.tile_base, tid);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     round_store<R>(xt, T, DB, l);
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     store_tile_relabeled<K, NT>(xt, sl, a, rc, t.tile_base, tid);
   } else if (a.flags & PASS_STORE) {
     const ThreadOff o = thread_offsets<ROWS>(t, tid);
     round_store<R>(xt, T, DB, p);
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     store_tile<K, NT, ROWS>(xt, sp, t, o, tid);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     round_store<R>(xt, T, DB, l);
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     store_tile<K, NT, ROWS>(xt, sl, t, o, tid);
   } else {
     __syncthreads();  // the cells of every wave are complete
@@ -2545,6 +2554,27 @@ hipError_t launch_pass_fwd_pair(int K, const PassArgs& a, uint32_t n_states, flo
     case 13: return launch_fwd2_t<13>(a, n_states, psi, bits, n_user, state0, prog, tables, coef, stream);
     default: return hipErrorInvalidValue;
   }
+}
+
+// Zero fill as a KERNEL.  hipMemsetAsync becomes a memset NODE when the caller captures the call into a hipGraph, and on this
+// runtime (ROCm 7.0 / gfx950) a graph warmed up on one stream and replayed on another ran its kernels without the
+// memset from the second replay on (values offset by a constant: scripts/tmp/debug_capture6.py, HISTORY round 6); a
+// kernel node is ordered like every other kernel of the call.
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4* __restrict__ p, size_t n16, uint32_t* __restrict__ tail,
+                                                        uint32_t n_tail) {
+  const size_t i = size_t(blockIdx.x) * 256u + threadIdx.x;
+  if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (i < n_tail) tail[i] = 0u;
+}
+hipError_t launch_zero_fill(void* p, size_t bytes, hipStream_t stream) {
+  if (!bytes) return hipSuccess;
+  if ((reinterpret_cast<uintptr_t>(p) & 15u) || (bytes & 3u)) return hipMemsetAsync(p, 0, bytes, stream);  // (never: hipMalloc'ed fp32 / u64 arrays)
+  const size_t n16 = bytes / 16;
+  const uint32_t n_tail = uint32_t((bytes - n16 * 16) / 4);
+  const size_t threads = std::max<size_t>(n16, n_tail);
+  hipLaunchKernelGGL(zero_fill_kernel, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, stream, static_cast<uint4*>(p), n16,
+                     reinterpret_cast<uint32_t*>(static_cast<char*>(p) + n16 * 16), n_tail);
+  return hipGetLastError();
 }
 
 hipError_t launch_values_from_fixed(const unsigned long long* acc, const float* inv_scale, float* out, uint32_t count,

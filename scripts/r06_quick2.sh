@@ -1,0 +1,24 @@
+#!/bin/bash
+set -u
+ulimit -c 0
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/r06_quick2
+mkdir -p "$OUT"
+cd "$R"
+(time timeout 1500 python -m pytest tests/test_captured_gpu.py tests/test_engine_gpu.py tests/test_sample_gpu.py tests/test_ebm_gpu.py -q --durations=15 -x) > "$OUT/pytest.log" 2>&1
+tail -30 "$OUT/pytest.log"
+for c in c1 c2 c3; do
+  timeout 600 python bench.py --through-mirror $c --steps 20 --warmup 5 > "$OUT/mirror_$c.json" 2> "$OUT/mirror_$c.err"
+  python - "$OUT/mirror_$c.json" <<'PY'
+import json,sys
+try:
+  d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+  print(sys.argv[1].split('/')[-1], {k: (round(v,4) if isinstance(v,float) else v) for k,v in d.items() if k.endswith("_ms") or k.endswith("_step") or "over_engine" in k or "bitwise" in k or "diff" in k})
+except Exception as e: print(sys.argv[1], "FAILED", e); print(open(sys.argv[1][:-5]+".err").read()[-1500:])
+PY
+done
+timeout 600 python bench.py --steps 5 --warmup 2 > "$OUT/c3.json" 2> "$OUT/c3.err"
+python - "$OUT/c3.json" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print("c3", round(d["ms_per_step"],2), {k:round(v,2) for k,v in d["kernel_ms_per_step"].items()}, d["parity_check"]["ok"], d["cpu_baseline"])
+PY

@@ -570,6 +570,48 @@ def test_a_compute_call_is_asynchronous_and_graph_capturable():
   np.testing.assert_allclose(vals.cpu().numpy(), want, atol=1e-4)
 
 
+@pytest.mark.parametrize("mode", ["forward", "vjp", "retained pair"])
+def test_a_captured_call_replays_correctly_on_another_stream_than_it_was_warmed_up_on(mode):
+  """Round 6: the engine used to zero its accumulators with hipMemsetAsync, which a capture turns into a memset NODE;
+  a graph warmed up on a side stream (the `torch.cuda.graph` recipe) and replayed on the default stream then returned
+  values offset by a constant from the SECOND replay on (the first was right).  The zero fills are kernels now
+  (kernels.hip launch_zero_fill): every replay, on either stream, equals the eager call bit for bit."""
+  rng = np.random.default_rng(6)
+  n, layers = 6, 2
+  gates, names = O.hea_gates(n, layers, "cg")
+  eng = _engine(n, gates, len(names), [O.tfim_ring_op(n)])
+  bits = torch.from_numpy(_random_bits(rng, 32, n)).cuda()
+  params = torch.from_numpy(rng.uniform(-1, 1, len(names)).astype(np.float32)).cuda()
+  up = torch.full((32, 1), 1.0 / 32, device="cuda")
+
+  def call():
+    if mode == "forward":
+      return eng.expectation(bits, params), torch.zeros(1, device="cuda")
+    if mode == "vjp":
+      return eng.expectation_vjp(bits, params, up)
+    vals = eng.expectation(bits, params, retain=True)
+    return vals, eng.expectation_vjp_retained(bits, params, up)
+
+  side = torch.cuda.Stream()
+  side.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(side):
+    for _ in range(2):
+      want_vals, want_grad = (t.clone() for t in call())
+  torch.cuda.current_stream().wait_stream(side)
+  torch.cuda.synchronize()
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph):
+    got_vals, got_grad = call()
+  for replay in range(4):
+    if replay == 2:
+      with torch.cuda.stream(side):
+        graph.replay()
+    else:
+      graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got_vals, want_vals) and torch.equal(got_grad, want_grad), (mode, replay)
+
+
 def test_x_exponents_far_outside_one_period():
   """X**t is applied as three shears of the exponent reduced to one period (kernels.hip x_pair4,
   prep_coefs_kernel): values, Jacobian and the exported state (global phase included) must not

@@ -60,3 +60,15 @@ def test_published_counter_profiles_carry_the_hash_of_the_kernels_they_were_take
     if stored["kernel_sources_sha16"] != sha:
       warnings.warn(f"profiles/{name} was taken on other engine sources ({stored['kernel_sources_sha16']}) than this tree's "
                     f"({sha}): bench.py will say so in its line; re-run scripts/r05_profiles.sh + summarize_profile.py --publish")
+
+
+def test_no_register_spills_in_the_kernels_the_default_planner_selects():
+  """scripts/kernel_resources.py on the shipped sources (hipcc cross-compiles: no GPU): a kernel the planner can pick
+  without options spills NO VGPR (round 5 shipped 4 - 13 in `pass_adjx_kernel<10, *>`, `<11, 0>`, `<12, 2>`, `<13, 2>`:
+  the store epilogue's two tiles were interleaved by the scheduler) and spills / reloads no SGPR inside its instance loop
+  (the 8 - 12 SGPR lane spills of the exchange adjoint kernel sit in the workgroup's prologue and store epilogue)."""
+  spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "scripts", "kernel_resources.py"))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  assert mod.default_selectable("pass_adjx_kernel<12, 0>") and not mod.default_selectable("pass_adj_kernel<12, true>")
+  assert mod.check() == []
