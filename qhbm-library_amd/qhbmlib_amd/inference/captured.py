@@ -11,8 +11,8 @@ EBM's parity kernel, weighted averages, autograd bookkeeping) issues dozens of s
     (`EnergyInferenceBase.fixed_samples`), so shapes never change and nothing synchronises;
   * the engine's compute calls are asynchronous on the caller's stream and capturable: the
     retained forward and the adjoint sweep from the retained states land in the same graph;
-  * gradients arrive in the `.grad` of the given variables (static tensors, rewritten by every replay -- the
-    whole-network capture idiom of `torch.cuda.graph`).
+  * gradients are taken with `torch.autograd.grad` inside the graph and copied into static buffers, which every call
+    installs as the `.grad` of the given variables (rewritten by every replay).
 
 The replayed step runs the same kernels on the same inputs as the eager step over the same padded multiset, so it returns
 the same bits (tests/test_captured_gpu.py); against the unpadded eager step it differs only by the order of the sample
@@ -62,6 +62,11 @@ class CapturedLoss:
     self._graph: Optional[torch.cuda.CUDAGraph] = None
     self._loss: Optional[torch.Tensor] = None
     self.last_unique_rows = []
+    # The gradients are taken with torch.autograd.grad and COPIED into these buffers by kernels of the recorded stream.
+    # (`loss.backward()` would hand them to the leaves' AccumulateGrad nodes, which run on the stream each node was first
+    # created on: a cross-stream edge inside the graph -- on this runtime the `.grad` of the circuit parameters came back
+    # wrong from the second replay on at 18 qubits and more, while the engine's own output was right.)
+    self._static_grads = [torch.zeros_like(v) for v in self._variables]
 
   # ---- the multisets ---------------------------------------------------------------------------------
   def _fill(self, inf, multiset):
@@ -99,7 +104,15 @@ class CapturedLoss:
         cm.__enter__()
         stack.append(cm)
       loss = self._loss_fn()
-      loss.backward()
+      grads = torch.autograd.grad(loss, self._variables, allow_unused=True)
+      for buf, g in zip(self._static_grads, grads):
+        # (element-wise KERNELS on purpose: `copy_` of a contiguous tensor is a device-to-device memcpy, which a capture
+        # records as a memcpy NODE -- and memcpy / memset nodes of a graph warmed up on one stream and replayed on
+        # another were dropped from the second replay on by this runtime; see kernels.hip launch_zero_fill)
+        if g is None:
+          buf.fill_(0.0)
+        else:
+          torch.mul(g, 1.0, out=buf)
     finally:
       for cm in reversed(stack):
         cm.__exit__(None, None, None)
@@ -108,9 +121,14 @@ class CapturedLoss:
   def eager(self, multisets=None):
     """The same padded step WITHOUT the graph (what the replay is compared with bit for bit)."""
     self._prepare(multisets)
-    for v in self._variables:
-      v.grad = None
-    return self._run().detach()
+    loss = self._run().detach()
+    self._publish()
+    return loss
+
+  def _publish(self):
+    for v, buf in zip(self._variables, self._static_grads):
+      if v.grad is not buf:
+        v.grad = buf
 
   def _prepare(self, multisets):
     if multisets is None:
@@ -120,32 +138,37 @@ class CapturedLoss:
     self.last_unique_rows = [self._fill(inf, ms) for inf, ms in zip(self._inferences, multisets)]
 
   def _capture(self):
-    side = torch.cuda.Stream(device=self.device)
-    side.wait_stream(torch.cuda.current_stream(self.device))
-    with torch.cuda.stream(side):           # warm-up on a side stream: allocations, plans, engine workspaces
+    # Warm-up, capture AND every replay run on ONE side stream of this object (ordered against the caller's stream with
+    # events): torch ops inside the step may still record memcpy / memset nodes (`clone`, `zero_`), and those are
+    # reliable on this runtime only when the graph replays on the stream it was warmed up and captured on.
+    self._stream = torch.cuda.Stream(device=self.device)
+    self._stream.wait_stream(torch.cuda.current_stream(self.device))
+    with torch.cuda.stream(self._stream):   # warm-up: allocations, plans, engine workspaces
       for _ in range(max(1, self._warmup)):
-        for v in self._variables:
-          v.grad = None
         self._run()
-    torch.cuda.current_stream(self.device).wait_stream(side)
     torch.cuda.synchronize(self.device)
-    for v in self._variables:
-      v.grad = None                         # backward() inside the capture allocates the static .grad tensors
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-      loss = self._run()
+    with torch.cuda.stream(self._stream):
+      with torch.cuda.graph(graph, stream=self._stream):
+        loss = self._run()
+    torch.cuda.synchronize(self.device)
     self._graph, self._loss = graph, loss.detach()
-    self._grads = [v.grad for v in self._variables]
 
   def __call__(self, multisets=None):
     self._prepare(multisets)
+    return self.replay()
+
+  def replay(self):
+    """The recorded step on whatever the multiset buffers hold (recording it first if need be)."""
     if self._graph is None:
       with torch.cuda.device(self.device):
         self._capture()
-    for v, g in zip(self._variables, self._grads):
-      if g is not None and v.grad is not g:                   # (an optimiser's zero_grad(set_to_none=True) drops them: put the static ones back)
-        v.grad = g
-    self._graph.replay()
+    caller = torch.cuda.current_stream(self.device)
+    self._stream.wait_stream(caller)          # the multiset buffers and the variables as the caller's stream left them
+    with torch.cuda.stream(self._stream):
+      self._graph.replay()
+    caller.wait_stream(self._stream)          # loss and gradients are the caller's to read
+    self._publish()
     return self._loss
 
   @property

@@ -1,7 +1,9 @@
 """`inference.CapturedLoss`: a whole VQT / QMHL step -- loss and backward -- recorded into ONE hipGraph and replayed.
 
 The replay runs the same kernels on the same inputs as the eager step over the same padded multiset, so it must return the
-SAME BITS (loss and every gradient, atol = 0); against the plain eager step over the unpadded multiset it may differ by the
+SAME BITS (loss and every gradient, atol = 0) on EVERY replay -- round 6 found the second and later replays wrong while the
+first was right (memset / memcpy nodes of a graph replayed on another stream than it was warmed up on; 18 qubits and more
+showed it in the circuit gradient); against the plain eager step over the unpadded multiset it may differ by the
 summation order of the sample averages only (<= 1e-6).  Reference of the step: /root/reference/qhbmlib/inference/
 vqt_loss.py:25-55, qmhl_loss.py:21-34, ebm.py:262-329 (the sample average and its score-function gradient).
 """
@@ -49,7 +51,8 @@ def _grads(variables):
   return [v.grad.detach().clone() for v in variables]
 
 
-@pytest.mark.parametrize("n,layers,samples,kind", [(4, 2, 32, "bernoulli"), (12, 3, 256, "bernoulli"), (10, 2, 128, "kobe")])
+@pytest.mark.parametrize("n,layers,samples,kind", [(4, 2, 32, "bernoulli"), (12, 3, 256, "bernoulli"), (10, 2, 128, "kobe"),
+                                                   (18, 6, 1024, "kobe")])
 def test_replayed_vqt_step_returns_the_bits_of_the_eager_step(n, layers, samples, kind):
   qubits, qhbm, variables = _model(n, layers, samples, kind, 11, "cv")
   e_inf, ham = qhbm.e_inference, _tfim(qubits)
