@@ -108,7 +108,7 @@ static cf pauli_phase(int ny, uint64_t src, uint64_t z) {
 /* The team the caller asked for (n_threads > 0) or the machine offers -- remembered, because a call that threads INSIDE
  * a state shrinks OpenMP's team for itself: splitting a sweep of 2^18 amplitudes over 256 threads costs more in forks
  * and spinning than the sweep (measured on the GPU box's 256 hardware threads: 19 qubits inside a state 400 x slower than
- * 17 qubits across states), so a sweep gets one thread per 2^17 amplitudes, at most 64 (memory bandwidth is spent by then). */
+ * 17 qubits across states), so a sweep gets one thread per 2^15 amplitudes, at most 64 (memory bandwidth is spent by then). */
 static int g_full_team = 0;
 
 static int team_size(void) {
@@ -125,7 +125,7 @@ static void choose_threading(int n, int U, int n_threads) {
   if (n_threads > 0) g_full_team = n_threads;
 #endif
   const int team = team_size();
-  int inner = (int)(((size_t)1 << n) >> 17);
+  int inner = (int)(((size_t)1 << n) >> 15);
   if (inner > 64) inner = 64;
   if (inner > team) inner = team;
   g_inner = inner > 1 && (n >= 26 || (n >= 18 && 2 * U < team));
