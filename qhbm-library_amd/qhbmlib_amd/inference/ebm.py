@@ -113,9 +113,10 @@ class EnergyInferenceBase(torch.nn.Module, abc.ABC):
 
   @property
   def variables_updated(self):
-    """True if tracked variables differ from the checkpointed values (ebm.py:125-134)."""
-    return any(not torch.equal(v.detach().cpu(), c.cpu())
-               for v, c in zip(self._tracked_variables, self._checkpoint))
+    """True if tracked variables differ from the checkpointed values (ebm.py:125-134): compared by VALUE, as the
+    reference does (a version counter would miss writes through `.data`), where the variable lives -- one boolean comes
+    back to the host per variable, not the variable."""
+    return any(not torch.equal(v.detach(), c.to(v.device)) for v, c in zip(self._tracked_variables, self._checkpoint))
 
   def _checkpoint_variables(self):
     self._checkpoint = [v.detach().clone() for v in self._tracked_variables]
