@@ -114,7 +114,7 @@ def distinct_bitstrings(n, count, seed):
   return bits
 
 
-def cpu_baseline(n, gates, n_params, ops, params, bits, upstream, mode, checker_states=4):
+def cpu_baseline(n, gates, n_params, ops, params, bits, upstream, mode, checker_states=2):
   """The CPU baseline BASELINE.md section 3 describes, timed on this host's cores on a bounded sample of the TIMED batch
   itself (its first K bitstrings, same parameters): oracle/qhbm_cpu_diag.c -- the oracle's fp32 statevector algorithm
   with merged diagonal runs, an AVX2 one-qubit kernel and fused adjoint steps, one state per thread -- a reported
@@ -337,6 +337,8 @@ def mirror_bench(args):
   torch.cuda.synchronize()
   same_bits = bool(torch.equal(loss_replay, loss_padded_eager)) and all(
       torch.equal(v.grad, g) for v, g in zip(variables, grads_padded_eager))
+  replay_vs_padded = [float((loss_replay - loss_padded_eager).abs())] + [
+      float((v.grad - g).abs().max()) for v, g in zip(variables, grads_padded_eager)]
   drift = max([float((loss_replay - loss_eager).abs())] +
               [float((v.grad - g).abs().max()) for v, g in zip(variables, grads_eager)])
   replay_only_ms, _ = timed(step.replay)
@@ -357,6 +359,7 @@ def mirror_bench(args):
       "engine_ms_per_step": engine_ms,             # qhbm_expectation_vjp on the same unique rows
       "mirror_over_engine": mirror_ms / engine_ms, "captured_over_engine": captured_ms / engine_ms,
       "replay_equals_padded_eager_bitwise": same_bits,
+      "replay_vs_padded_eager_abs_diffs": replay_vs_padded,   # [loss, grad of every variable]
       "max_abs_diff_replay_vs_unpadded_eager": drift,
   }
   print(json.dumps(line), flush=True)

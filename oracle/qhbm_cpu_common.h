@@ -22,10 +22,9 @@ typedef struct {
 typedef float complex cf;
 typedef double complex cd;
 
-/* Threads: across states (TFQ's policy for batches of small circuits), or -- when a call holds fewer states than
- * threads and the state is large (qo_expectation*: U < threads / 2 and n >= 18), and always from 26 qubits (TFQ's
- * policy for large circuits [SURVEY.md 8d]) -- INSIDE a state: the same gate-by-gate arithmetic with the sweep over the
- * amplitudes split over the team (sums of a sweep are double-precision reductions, so only their order changes). */
+/* Threads: across states (TFQ's policy for batches of small circuits) or INSIDE a state (choose_threading below):
+ * the same gate-by-gate arithmetic with the sweep over the amplitudes split over the team (sums of a sweep are
+ * double-precision reductions, so only their order changes). */
 static int g_inner = 0;
 
 enum { G_I = 0, G_X, G_Y, G_Z, G_H, G_CZ, G_CNOT, G_SWAP, G_ISWAP, G_XX, G_YY, G_ZZ };
@@ -106,9 +105,12 @@ static cf pauli_phase(int ny, uint64_t src, uint64_t z) {
 }
 
 /* The team the caller asked for (n_threads > 0) or the machine offers -- remembered, because a call that threads INSIDE
- * a state shrinks OpenMP's team for itself: splitting a sweep of 2^18 amplitudes over 256 threads costs more in forks
- * and spinning than the sweep (measured on the GPU box's 256 hardware threads: 19 qubits inside a state 400 x slower than
- * 17 qubits across states), so a sweep gets one thread per 2^15 amplitudes, at most 64 (memory bandwidth is spent by then). */
+ * a state shrinks OpenMP's team for itself.  Threads go ACROSS states (one state per thread) unless the call holds very few
+ * large states: inside a state the speed-up is modest (a sweep of 2^20 amplitudes gains ~5 x from 8 threads and LOSES from
+ * 32: forks and spinning; measured on the GPU box's 256 hardware threads, where 19 qubits inside a state on the whole team
+ * ran 400 x slower than 17 qubits across states), so 40 states of 20 qubits are faster across 40 threads.  Inside a state: from
+ * 26 qubits always (TFQ's policy), from 22 qubits for at most 8 states, from 18 qubits for at most 2; one thread per 2^17
+ * amplitudes, at most 64 (memory bandwidth is spent by then). */
 static int g_full_team = 0;
 
 static int team_size(void) {
@@ -125,10 +127,10 @@ static void choose_threading(int n, int U, int n_threads) {
   if (n_threads > 0) g_full_team = n_threads;
 #endif
   const int team = team_size();
-  int inner = (int)(((size_t)1 << n) >> 15);
+  int inner = (int)(((size_t)1 << n) >> 17);
   if (inner > 64) inner = 64;
   if (inner > team) inner = team;
-  g_inner = inner > 1 && (n >= 26 || (n >= 18 && 2 * U < team));
+  g_inner = inner > 1 && U < team && (n >= 26 || (n >= 22 && U <= 8) || (n >= 18 && U <= 2));
 #ifdef _OPENMP
   omp_set_num_threads(g_inner ? inner : team);
 #endif

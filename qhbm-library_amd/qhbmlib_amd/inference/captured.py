@@ -39,8 +39,15 @@ class CapturedLoss:
 
   def __init__(self, loss_fn: Callable[[], torch.Tensor], e_inferences: Sequence["ebm.EnergyInference"],
                variables: Sequence[torch.Tensor], warmup: int = 2,
-               exact_inferences: Sequence["ebm.EnergyInferenceBase"] = ()):
+               exact_inferences: Sequence["ebm.EnergyInferenceBase"] = (), synchronize: bool = True):
     self._loss_fn = loss_fn
+    # `synchronize` (default): a call returns when its replay has FINISHED.  torch records memset nodes of its own into
+    # the graph (the semaphores of a multi-block reduction: `logsumexp` over the 2^20 energies of an analytic EBM), and on
+    # this runtime a graph whose replays interleave with other work on the caller's stream that the host never waits for
+    # -- even one unrelated element-wise kernel per step -- came back with a wrong log-partition value after about ten
+    # steps, and stayed wrong (the engine's own outputs inside the same graph were right; round 6, HISTORY.md).  Waiting
+    # for the caller's stream after every replay removes the overlap; a step this class is meant for is launch-bound, so
+    # the wait costs microseconds.
     self._inferences = list(e_inferences)
     # inferences the loss only asks for exact, device-side quantities (qmhl's log Z of the model): `device_only`
     self._exact = [inf for inf in exact_inferences if all(inf is not other for other in self._inferences)]
@@ -54,6 +61,7 @@ class CapturedLoss:
           f"(found {sorted(str(d) for d in devices)}); a host-resident parameter would be copied inside the graph")
     self.device = next(iter(devices))
     self._warmup = int(warmup)
+    self.synchronize = bool(synchronize)
     self._buffers: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
     for inf in self._inferences:
       cap, n = int(inf.num_expectation_samples), int(inf.energy.num_bits)
@@ -168,6 +176,8 @@ class CapturedLoss:
     with torch.cuda.stream(self._stream):
       self._graph.replay()
     caller.wait_stream(self._stream)          # loss and gradients are the caller's to read
+    if self.synchronize:
+      caller.synchronize()
     self._publish()
     return self._loss
 

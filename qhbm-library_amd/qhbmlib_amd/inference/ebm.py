@@ -231,6 +231,26 @@ class EnergyInference(EnergyInferenceBase):
             torch.logsumexp(-1.0 * energies, 0))
 
 
+def _as_rows(x):
+  """A 1-D tensor of 2^n entries as [rows, columns] with columns <= 2^10: reductions along the columns, then over the
+  rows, are each the work of ONE thread block per output -- no multi-block reduction with global semaphores, whose
+  zero-fill a hipGraph capture records as a memset node (see `inference.CapturedLoss`).  The values are the same sums in
+  another association order (a gradient flows through both stages)."""
+  n = x.numel()
+  cols = 1
+  while cols < 1024 and n % (cols * 2) == 0:
+    cols *= 2
+  return x.reshape(n // cols, cols)
+
+
+def _logsumexp_rows(x):
+  return torch.logsumexp(torch.logsumexp(_as_rows(x), 1), 0)
+
+
+def _sum_rows(x):
+  return _as_rows(x).sum(1).sum(0)
+
+
 def _device_of(module):
   return next(iter(module.parameters()), torch.zeros(())).device
 
@@ -309,11 +329,12 @@ class AnalyticEnergyInference(EnergyInference):
 
   def _entropy(self):
     logits = -self.all_energies
-    logp = logits - torch.logsumexp(logits, 0)
-    return -(torch.exp(logp) * logp).sum()
+    logp = logits - _logsumexp_rows(logits)
+    plogp = torch.exp(logp) * logp
+    return -_sum_rows(plogp)
 
   def _log_partition(self):
-    return torch.logsumexp(-self.all_energies, 0)
+    return _logsumexp_rows(-self.all_energies)
 
   def _sample(self, num_samples: int):
     probs = torch.softmax(self._logits.to(torch.float64), 0)

@@ -81,7 +81,7 @@ def test_bench_config3_timed_batch_against_the_oracle():
   line = _line(out.stdout)
   assert (line["config"]["n_qubits"], line["config"]["layers"], line["config"]["pauli_terms"]) == (20, 16, 57)
   pc = line["parity_check"]
-  assert pc["ok"] and pc["states"] == 4, pc          # (the gate-by-gate checker runs on the first 4 of the 8 timed CPU states)
+  assert pc["ok"] and pc["states"] == 2, pc          # (the gate-by-gate checker runs on the first 2 of the 8 timed CPU states)
   assert line["cpu_baseline"]["checker"]["max_diff_values_timed_path_vs_checker"] <= 5e-6
   assert pc["max_err_values"] <= pc["tol_values"] == pytest.approx(5e-5 * 47.5)
   assert pc["max_err_grad"] <= pc["tol_grad"] and pc["grad_inf_norm"] > 1e-2
@@ -241,7 +241,7 @@ def test_bench_qmhl_mode_checks_the_masked_gradient_of_the_timed_step():
   assert cfg["mode"] == "qmhl" and cfg["observables"] == 13 + 13 * 12 // 2 and cfg["hamiltonian"] == "kobe2_shards"
   assert line["qmhl_step_ms"] == line["ms_per_step"] and line["vqt_step_ms"] is None
   pc = line["parity_check"]
-  assert pc["ok"] and pc["states"] == 4 and pc["grad_from"].startswith("rows of the last timed step"), pc
+  assert pc["ok"] and pc["states"] == 2 and pc["grad_from"].startswith("rows of the last timed step"), pc
   assert pc["max_err_values"] <= pc["tol_values"] == pytest.approx(5e-5) and pc["grad_inf_norm"] > 1e-3
 
 

@@ -91,6 +91,34 @@ def test_replayed_vqt_step_returns_the_bits_of_the_eager_step(n, layers, samples
   assert torch.isfinite(loss) and 1 <= step.last_unique_rows[0] <= samples
 
 
+@pytest.mark.parametrize("synchronize", [True, False])
+def test_thirty_replays_interleaved_with_other_work_on_the_caller_s_stream(synchronize):
+  """Round 6: with the log partition of an analytic EBM taken by ONE `logsumexp` over its 2^n energies (a multi-block
+  reduction: torch zeroes its semaphores with a memset, a memset NODE under capture), a graph whose replays interleaved with
+  unrelated kernels on the caller's stream returned a wrong log Z after about ten steps and stayed wrong.  The analytic
+  inference reduces in two single-block stages now (`ebm._logsumexp_rows`), and `CapturedLoss(synchronize=True)` waits for
+  every replay; both settings must hold the eager bits through thirty such steps."""
+  n, samples = 18, 512
+  qubits, qhbm, variables = _model(n, 3, samples, "kobe", 5, "il")
+  e_inf, ham = qhbm.e_inference, _tfim(qubits)
+  step = inference.CapturedLoss(lambda: inference.vqt(qhbm, [ham], 1.0), [e_inf], variables, synchronize=synchronize)
+  multiset = _multiset(e_inf, samples)
+  want_loss = step.eager([multiset]).clone()
+  want = _grads(variables)
+  other = torch.zeros(4096, device="cuda")
+  for _ in range(30):
+    got = step([multiset])
+    other.add_(1.0)                                     # (the caller's own work, never waited for)
+  torch.cuda.synchronize()
+  assert float(other[0]) == 30.0
+  assert torch.equal(got, want_loss) and all(torch.equal(v.grad, w) for v, w in zip(variables, want))
+  # the same two-stage reductions outside a graph: log Z and entropy against the one-shot forms
+  energies = e_inf.all_energies.detach()
+  np.testing.assert_allclose(float(e_inf.log_partition()), float(torch.logsumexp(-energies.double(), 0)), rtol=1e-6)
+  logp = -energies.double() - torch.logsumexp(-energies.double(), 0)
+  np.testing.assert_allclose(float(e_inf.entropy()), float(-(logp.exp() * logp).sum()), rtol=1e-5)
+
+
 def test_replayed_qmhl_step_with_two_sample_averages():
   """qmhl(data, model) = <K_model>_data + log Z_model (qmhl_loss.py:33-34): the data QHBM's sample average over ITS
   multiset, the model's modular Hamiltonian measured behind U_data U_model^dagger, gradients for the model only."""

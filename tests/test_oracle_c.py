@@ -66,8 +66,8 @@ def test_c_statevector_matches_numpy():
 
 
 def test_c_threads_inside_a_state_equal_the_serial_sweep():
-  """From 18 qubits a call with fewer states than threads splits every sweep over the team (from 26 always: TFQ's
-  policy for large circuits); the arithmetic per amplitude is the same, sums are double-precision reductions."""
+  """A call that holds very few large states (here one of 22 qubits; from 26 qubits always: TFQ's policy for large
+  circuits) splits every sweep over a team; the arithmetic per amplitude is the same, sums are double-precision reductions."""
   team = C.max_threads()
   if team < 4:
     pytest.skip("needs a team of at least four threads")
