@@ -146,19 +146,17 @@ class CapturedLoss:
     self.last_unique_rows = [self._fill(inf, ms) for inf, ms in zip(self._inferences, multisets)]
 
   def _capture(self):
-    # Warm-up, capture AND every replay run on ONE side stream of this object (ordered against the caller's stream with
-    # events): torch ops inside the step may still record memcpy / memset nodes (`clone`, `zero_`), and those are
-    # reliable on this runtime only when the graph replays on the stream it was warmed up and captured on.
-    self._stream = torch.cuda.Stream(device=self.device)
-    self._stream.wait_stream(torch.cuda.current_stream(self.device))
-    with torch.cuda.stream(self._stream):   # warm-up: allocations, plans, engine workspaces
-      for _ in range(max(1, self._warmup)):
-        self._run()
+    # Warm-up AND every replay run on ONE stream, the caller's at the time of recording (`_home`); only the capture itself
+    # needs a side stream.  (A graph warmed up on one stream and replayed on another lost its memset / memcpy nodes from
+    # the second replay on -- round 6; a caller that later arrives on a different stream is ordered against `_home` with
+    # events instead.)
+    self._home = torch.cuda.current_stream(self.device)
+    for _ in range(max(1, self._warmup)):   # allocations, plans, engine workspaces
+      self._run()
     torch.cuda.synchronize(self.device)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.stream(self._stream):
-      with torch.cuda.graph(graph, stream=self._stream):
-        loss = self._run()
+    with torch.cuda.graph(graph):
+      loss = self._run()
     torch.cuda.synchronize(self.device)
     self._graph, self._loss = graph, loss.detach()
 
@@ -172,10 +170,13 @@ class CapturedLoss:
       with torch.cuda.device(self.device):
         self._capture()
     caller = torch.cuda.current_stream(self.device)
-    self._stream.wait_stream(caller)          # the multiset buffers and the variables as the caller's stream left them
-    with torch.cuda.stream(self._stream):
+    if caller == self._home:
       self._graph.replay()
-    caller.wait_stream(self._stream)          # loss and gradients are the caller's to read
+    else:
+      self._home.wait_stream(caller)          # the multiset buffers and the variables as the caller's stream left them
+      with torch.cuda.stream(self._home):
+        self._graph.replay()
+      caller.wait_stream(self._home)          # loss and gradients are the caller's to read
     if self.synchronize:
       caller.synchronize()
     self._publish()

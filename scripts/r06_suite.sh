@@ -41,4 +41,3 @@ except Exception as e: print(sys.argv[1], "FAILED", e); print(open(sys.argv[1][:
 PY
 done
 run c4_shift_noshare --qubits 24 --layers 16 --states-total 2 --hamiltonian random512 --mode shift --steps 1 --warmup 0 --no-cpu-baseline --engine-option shift_prefix_sharing=0
-bash scripts/r05_ab.sh r06_c3 2 "--steps 5 --warmup 2" scripts/tmp/lib_r05.so head
