@@ -77,7 +77,7 @@ template <int K, int ROWS>
 __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_kernel("""),
         "  commit_tile<K, NT>(xt, rp, tid);\n  __syncthreads();\n  round_load<R>(xt, T, DB, p);\n  __syncthreads();\n  commit_tile<K, NT>(xt, rl, tid);\n  __syncthreads();\n  round_load<R>(xt, T, DB, l);\n",
         "  regs_from_tile(p, rp);\n  regs_from_tile(l, rl);\n  __syncthreads();\n"),
-        "    const ThreadOff o = thread_offsets<ROWS>(t, tid);\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    store_tile<K, NT, ROWS>(xt, sp, t, o, tid);\n    __syncthreads();\n    round_store<R>(xt, T, DB, l);\n    __syncthreads();\n    store_tile<K, NT, ROWS>(xt, sl, t, o, tid);\n",
+        "    const ThreadOff o = thread_offsets<ROWS>(t, tid);\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    __builtin_amdgcn_sched_barrier(0);\n    store_tile<K, NT, ROWS>(xt, sp, t, o, tid);\n    __builtin_amdgcn_sched_barrier(0);\n    __syncthreads();\n    round_store<R>(xt, T, DB, l);\n    __syncthreads();\n    __builtin_amdgcn_sched_barrier(0);\n    store_tile<K, NT, ROWS>(xt, sl, t, o, tid);\n",
         "    regs_to_global<K, NT>(p, sp, t, tid);\n    regs_to_global<K, NT>(l, sl, t, tid);\n    __syncthreads();\n"),
     "no_x_inner": lambda t: in_instance(t, "g[J] = im_lam_x_psi<R, J>(p, l);", "g[J] = p[0].x;"),
     "no_x_on_lambda": lambda t: in_instance(t, "          apply_x<R, J>(l, cs);\n", ""),
