@@ -260,17 +260,11 @@ def stored_profile(name, n, layers, hamiltonian, mode):
   return tj if same else None
 
 
-def mirror_bench(args):
-  """`--through-mirror`: one JSON line with `mirror_step_ms` (eager), `captured_step_ms` (hipGraph replay) and the
-  engine's `engine_ms_per_step` on the same unique rows.  Reference of the step: vqt_loss.py:25-55, ebm.py:262-329."""
-  if not torch.cuda.is_available():
-    raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-  from qhbmlib_amd import _engine as E, inference, ir, models, utils  # pylint: disable=import-outside-toplevel
-  torch.cuda.set_device(0)
-  cfg = {"c1": dict(n=4, layers=2, samples=32, ham="tfim", ebm="bernoulli", label="BASELINE configs[0]"),
-         "c2": dict(n=12, layers=8, samples=1024, ham="tfim", ebm="bernoulli", label="BASELINE configs[1]"),
-         "c3": dict(n=20, layers=16, samples=4096, ham="xxz", ebm="kobe2", label="BASELINE configs[2]")}[args.through_mirror]
-  n, layers, samples = cfg["n"], cfg["layers"], cfg["samples"]
+def mirror_model(n, layers, samples, ham_kind, ebm_kind):
+  """The QHBM of a BASELINE config through the host mirror (HEA circuit of tests/test_util.py:25-67, Bernoulli or KOBE-2
+  EBM on the device, TFIM ring or XXZ chain) and ONE drawn sample multiset: (circuit, energy, e_inference, qhbm,
+  hamiltonian, variables, unique rows, counts)."""
+  from qhbmlib_amd import inference, ir, models, utils  # pylint: disable=import-outside-toplevel
   qubits = ir.GridQubit.rect(1, n)
   pqc = ir.Circuit()
   for layer in range(layers):                      # tests/test_util.py:25-67 of the reference
@@ -284,14 +278,14 @@ def mirror_bench(args):
   circuit = models.DirectQuantumCircuit(pqc, tfq_compat_bit_order=False).to("cuda")
   with torch.no_grad():
     circuit.trainable_variables[0].uniform_(-1, 1)
-  energy = (models.BernoulliEnergy(list(range(n))) if cfg["ebm"] == "bernoulli" else models.KOBE(list(range(n)), 2)).to("cuda")
+  energy = (models.BernoulliEnergy(list(range(n))) if ebm_kind == "bernoulli" else models.KOBE(list(range(n)), 2)).to("cuda")
   with torch.no_grad():
     energy.post_process[0].kernel.uniform_(-0.1, 0.1)   # high entropy: U close to the sample count
-  e_inf = (inference.BernoulliEnergyInference if cfg["ebm"] == "bernoulli" else inference.AnalyticEnergyInference)(
+  e_inf = (inference.BernoulliEnergyInference if ebm_kind == "bernoulli" else inference.AnalyticEnergyInference)(
       energy, samples, initial_seed=7)
   qhbm = inference.QHBM(e_inf, inference.AnalyticQuantumInference(circuit))
   ham = ir.PauliSum()
-  if cfg["ham"] == "tfim":
+  if ham_kind == "tfim":
     for i, q in enumerate(qubits):
       ham += -1.0 * ir.PX(q)
       ham += -1.0 * ir.PZ(q) * ir.PZ(qubits[(i + 1) % n])
@@ -302,6 +296,50 @@ def mirror_bench(args):
   with torch.no_grad():
     drawn = e_inf.sample(samples).cuda()
   rows, _, counts = utils.unique_bitstrings_with_counts(drawn)   # the fixed multiset of every timed step
+  return circuit, energy, e_inf, qhbm, ham, variables, rows, counts
+
+
+def mirror_step_sample(n, layers, samples, ham_kind, steps=3):
+  """`vqt_step_through_mirror` of the DEFAULT line (round 5's review, "what's missing" 4): BASELINE.md section 3 defines
+  "VQT step time" as loss + both gradients through `vqt()`, sampler excluded -- the engine's share is `ms_per_step`, this is
+  the whole: `steps` eager `inference.vqt(qhbm, [H], 1.0)` + `backward()` on one fixed multiset of `samples` samples of a
+  KOBE-2 (Bernoulli below 14 qubits) EBM, after one untimed step.  Runs AFTER the timed region, the probe and the parity
+  check, on an engine of its own (the bench's is closed first)."""
+  from qhbmlib_amd import inference  # pylint: disable=import-outside-toplevel
+  _, _, e_inf, qhbm, ham, variables, rows, counts = mirror_model(n, layers, samples, ham_kind, "kobe2" if n >= 14 else "bernoulli")
+
+  def step():
+    for v in variables:
+      v.grad = None
+    with e_inf.fixed_samples(rows, counts):
+      loss = inference.vqt(qhbm, [ham], 1.0)
+      loss.backward()
+    return loss
+
+  step()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    loss = step()
+  torch.cuda.synchronize()
+  ms = (time.perf_counter() - t0) / steps * 1e3
+  return {"ms_per_step": ms, "steps": steps, "samples": samples, "unique_bitstrings": int(rows.shape[0]),
+          "loss": float(loss.detach()), "what": "inference.vqt(qhbm, [H], 1.0) + backward() through the host mirror, eager, fixed "
+          "sample multiset (sampler excluded), EBM on the device; `python bench.py --through-mirror c3` is the full measurement"}
+
+
+def mirror_bench(args):
+  """`--through-mirror`: one JSON line with `mirror_step_ms` (eager), `captured_step_ms` (hipGraph replay) and the
+  engine's `engine_ms_per_step` on the same unique rows.  Reference of the step: vqt_loss.py:25-55, ebm.py:262-329."""
+  if not torch.cuda.is_available():
+    raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+  from qhbmlib_amd import inference  # pylint: disable=import-outside-toplevel
+  torch.cuda.set_device(0)
+  cfg = {"c1": dict(n=4, layers=2, samples=32, ham="tfim", ebm="bernoulli", label="BASELINE configs[0]"),
+         "c2": dict(n=12, layers=8, samples=1024, ham="tfim", ebm="bernoulli", label="BASELINE configs[1]"),
+         "c3": dict(n=20, layers=16, samples=4096, ham="xxz", ebm="kobe2", label="BASELINE configs[2]")}[args.through_mirror]
+  n, layers, samples = cfg["n"], cfg["layers"], cfg["samples"]
+  circuit, energy, e_inf, qhbm, ham, variables, rows, counts = mirror_model(n, layers, samples, cfg["ham"], cfg["ebm"])
   n_unique = int(rows.shape[0])
 
   def eager_step():
@@ -405,6 +443,9 @@ def main():
                   help="rank 0 re-evaluates the whole batch alone (outside the timed region) and compares with the "
                        "sharded result; default: on for --gpus N > 1, off for N = 1")
   ap.add_argument("--no-verify", dest="verify", action="store_false")
+  ap.add_argument("--no-mirror-step", action="store_true",
+                  help="skip `vqt_step_through_mirror` (three eager vqt() + backward() steps through the host mirror after "
+                       "the timed region: BASELINE.md's 'VQT step time', sampler excluded)")
   ap.add_argument("--through-mirror", choices=["c1", "c2", "c3"], default=None,
                   help="a SECOND, separately labelled measurement (the default line is unchanged): the step a user calls -- "
                        "inference.vqt(qhbm, H, beta) + backward() through the host mirror on a fixed sample multiset (sampler "
@@ -826,6 +867,17 @@ def main():
           line.setdefault("cpu_baseline", {"error": str(exc)})
           line["parity_check"] = {"ok": False, "error": f"{type(exc).__name__}: {exc}"}
           parity_failed = True
+    # "VQT step time" as BASELINE.md section 3 defines it -- loss + both gradients through vqt(), sampler excluded: the
+    # same circuit and Hamiltonian through the host mirror, after everything above (the bench's engine is closed first: the
+    # mirror builds its own).  A reported companion of ms_per_step (the engine's share), never the headline.
+    if (world == 1 and args.mode == "vqt" and args.hamiltonian in ("xxz", "tfim") and n <= 20 and not args.no_mirror_step):
+      try:
+        eng.close()
+        torch.cuda.empty_cache()
+        line["vqt_step_through_mirror"] = mirror_step_sample(n, layers, total_states, args.hamiltonian)
+        line["vqt_step_through_mirror"]["over_engine_ms_per_step"] = line["vqt_step_through_mirror"]["ms_per_step"] / ms_per_step
+      except Exception as exc:  # pylint: disable=broad-except
+        line["vqt_step_through_mirror"] = {"error": f"{type(exc).__name__}: {exc}"}
     print(json.dumps(line), flush=True)
     if parity_failed:
       print("bench.py: parity_check FAILED: the timed workload disagrees with the oracle: "

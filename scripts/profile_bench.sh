@@ -12,7 +12,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-mirror-step $*"
 echo "$HEAD" > "$OUT/git_head"
 echo "python3 bench.py $ARGS" > "$OUT/command"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench --output-format csv -- python3 "$R/bench.py" $ARGS > "$OUT/bench_stats.log" 2>&1

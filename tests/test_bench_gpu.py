@@ -59,6 +59,10 @@ def test_bench_single_process_line():
   # the gradient that is checked is the TIMED one: rows of the last timed adjoint sweep, not a second call
   assert pc["grad_from"].startswith("rows of the last timed step")
   assert line["config"]["exchange_bytes"] is None
+  # BASELINE.md's "VQT step time" -- loss + both gradients through the mirror's vqt(), sampler excluded -- rides along
+  through = line["vqt_step_through_mirror"]
+  assert "error" not in through and through["ms_per_step"] > 0 and 1 <= through["unique_bitstrings"] <= 16
+  assert through["over_engine_ms_per_step"] == pytest.approx(through["ms_per_step"] / line["ms_per_step"])
 
 
 def test_bench_parameter_shift_mode_says_where_its_checked_gradient_comes_from():
