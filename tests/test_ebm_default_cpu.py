@@ -154,3 +154,42 @@ def test_gibbs_with_gradients_log_partition_gradient_matches_analytic():
   got = torch.autograd.grad(gwg.log_partition(), list(energy.parameters()))
   for a, e in zip(got, want):
     np.testing.assert_allclose(a.numpy(), e.numpy(), atol=4e-2)
+
+
+def test_fixed_samples_average_over_a_given_multiset_and_ignore_zero_count_rows():
+  """`EnergyInferenceBase.fixed_samples(bitstrings, counts)`: the sample average of ebm.py:262-329 and its score-function
+  gradient over a GIVEN multiset (what `inference.CapturedLoss` records and `bench.py --through-mirror` times); rows with
+  count 0 -- the padding of a fixed-capacity buffer -- change nothing; no sample is drawn, no seed advances."""
+  import torch
+  from qhbmlib_amd import inference, models, utils
+  torch.manual_seed(3)
+  energy = models.KOBE(list(range(5)), 2)
+  with torch.no_grad():
+    energy.post_process[0].kernel.uniform_(-0.7, 0.7)
+  e_inf = inference.AnalyticEnergyInference(energy, 64, initial_seed=9)
+  drawn = e_inf.sample(64)
+  rows, _, counts = utils.unique_bitstrings_with_counts(drawn)
+  seed_before = e_inf.seed
+  f = lambda b: (b.to(torch.float32) * torch.arange(1.0, 6.0)).sum(1)
+  theta = energy.post_process[0].kernel
+
+  def value_and_grad(r, c):
+    with e_inf.fixed_samples(r, c):
+      out = e_inf.expectation(f)
+    (g,) = torch.autograd.grad(out, [theta])
+    return out.detach(), g
+
+  got, grad = value_and_grad(rows, counts)
+  w = counts.to(torch.float32) / counts.sum()
+  np.testing.assert_allclose(float(got), float((w * f(rows)).sum()), rtol=1e-6)
+  # d<f> = <f><dE> - <f dE> with dE/dtheta_k = the parity features of the rows
+  from oracle import qhbm_oracle as O
+  feats = torch.from_numpy(O.parities(rows.numpy(), O.parity_indices(5, 2)).astype(np.float32))   # [U, 15] = dE/dtheta
+  want = (w * f(rows)).sum() * (w[:, None] * feats).sum(0) - (w[:, None] * f(rows)[:, None] * feats).sum(0)
+  np.testing.assert_allclose(grad.numpy(), want.numpy(), atol=1e-5)
+  padded_rows = torch.cat([rows, rows[:1].expand(7, -1)])
+  padded_counts = torch.cat([counts, torch.zeros(7, dtype=counts.dtype)])
+  got_p, grad_p = value_and_grad(padded_rows, padded_counts)
+  np.testing.assert_allclose(float(got_p), float(got), rtol=1e-6)
+  np.testing.assert_allclose(grad_p.numpy(), grad.numpy(), atol=1e-6)
+  assert e_inf.seed == seed_before and e_inf._fixed_multiset is None
