@@ -156,6 +156,11 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
  * 64 MiB and more are shared), "observable_kernel" (lambda = O psi and <psi|O|psi>: 0 = one L2 gather per X-mask and
  * block of 2^11 amplitudes, 1 = partner blocks of 2^13 amplitudes staged in LDS once per group of masks that share them
  * (states of >= 13 qubits), -1 = whichever a fitted cost model prefers: the block kernel for operators with many masks),
+ * "observable_block_bits" (shape of that block kernel: 13 (default) = blocks of 2^13 amplitudes under ONE workgroup of 1024
+ * threads per CU whose two halves split a group's masks; 12 = blocks of 2^12 under TWO independent workgroups of 512 threads
+ * per CU, every mask of a group applied by the one workgroup -- measured SLOWER, 94.4 against 51.2 ms for lambda on BASELINE
+ * config 4: the co-resident workgroups drift apart and the window of partner blocks leaves the L2, hit rate 0.27 against
+ * 0.77; kept for A/B runs),
  * "multi_observable_values" (several observables: -1 = their values come from ONE launch of the block kernel over the
  * final states, after lean measurement-free passes, when some term flips two or more qubits and there are at most 64
  * observables; 0 = always measured in the passes; 1 = always from the kernel, up to 256 observables),

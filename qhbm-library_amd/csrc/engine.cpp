@@ -120,6 +120,7 @@ struct qhbm_engine {
   DevBuf<ObsBTerm> obs_bterms;    // the same terms sorted and cut for the block-grouped kernels (observable.hip)
   DevBuf<ObsBGroup> obs_bgroups;
   uint32_t n_obs_bgroups = 0;
+  int opt_obs_block_bits = kObsBlockBits;  // shape of the block-grouped kernels (kernels.h): 13 or 12
   int opt_obs_kernel = -1;      // lambda = O psi / values: 0 = one gather per mask (apply_observable_kernel), 1 = partner blocks through
                                 // LDS (observable_blocks_kernel), -1 = whichever the fitted cost model prices lower (block_kernel())
   mutable int block_choice = -1;  // cached verdict of block_kernel() (-1: not computed for the installed model / options)
@@ -460,18 +461,19 @@ int upload_plan(qhbm_engine* h, DevicePlan* d) {
   return 0;
 }
 
-// One term of the block-grouped kernels (kernels.h ObsBTerm): slot bits of the block layout are index bits 0, 10, 11, 12.
-ObsBTerm obs_block_term(const DevTerm& d, bool new_mask) {
-  const uint32_t xin = d.x & ((1u << kObsBlockBits) - 1u);
-  const uint32_t zs = (d.z & 1u) | (((d.z >> 10) & 7u) << 1);
+// One term of the block-grouped kernels (kernels.h ObsBTerm): slot bits of the block layout are index bits 0, 10, 11, 12
+// (blocks of 2^12: 0, 10, 11).
+ObsBTerm obs_block_term(const DevTerm& d, bool new_mask, int bb) {
+  const uint32_t xin = d.x & ((1u << bb) - 1u), rows = (1u << (bb - 10)) - 1u;
+  const uint32_t zs = (d.z & 1u) | (((d.z >> 10) & rows) << 1);
   // variant (scripts/gen_observable_asm.py): Z bits of the three low slot bits | base sign << 3 | odd x << 4 | imaginary << 5
   const uint32_t variant = (zs & 7u) | ((xin & 1u) << 4) | ((d.ny & 1u) << 5);
   const uint32_t chunk = kObsChunkBytes, preamble = kObsPreambleBytes;
   ObsBTerm t;
   t.coeff = d.coeff;
   t.zt = (d.z >> 1) & 511u;
-  t.zb = d.z >> kObsBlockBits;
-  t.xrow = (((xin >> 1) & 511u) << 4) | (((xin >> 10) & 7u) << 13);
+  t.zb = d.z >> bb;
+  t.xrow = (((xin >> 1) & 511u) << 4) | (((xin >> 10) & rows) << 13);
   t.off0 = variant * chunk + preamble;
   t.off1 = (variant | (zs & 8u)) * chunk + preamble;
   // sign at the own index: (-1)^ny from the x & z overlap, and i^2 = -1 once ny >= 2
@@ -582,10 +584,11 @@ int upload_model(qhbm_engine* h) {
     HIPCHK(h->obs_groups.upload(groups));
     h->n_obs_groups = uint32_t(groups.size());
     h->n_gather_terms = uint32_t(groups.empty() ? 0u : groups.back().end);
-    {  // block-grouped order (kernels.h ObsBTerm): by partner block x >> 13, then by mask, then by observable
+    {  // block-grouped order (kernels.h ObsBTerm): by partner block x >> block bits, then by mask, then by observable
+      const int bb = h->opt_obs_block_bits;
       std::vector<DevTerm> bt = full;
-      std::stable_sort(bt.begin(), bt.end(), [](const DevTerm& a, const DevTerm& b) {
-        const uint32_t ao = a.x >> kObsBlockBits, bo = b.x >> kObsBlockBits;
+      std::stable_sort(bt.begin(), bt.end(), [bb](const DevTerm& a, const DevTerm& b) {
+        const uint32_t ao = a.x >> bb, bo = b.x >> bb;
         if (ao != bo) return ao < bo;
         if (a.x != b.x) return a.x < b.x;
         return a.op < b.op;
@@ -607,9 +610,9 @@ int upload_model(qhbm_engine* h) {
       struct Unit { uint32_t xo; std::vector<std::pair<size_t, size_t>> masks; size_t terms = 0; };
       std::vector<Unit> units;
       for (size_t k = 0; k < bt.size();) {
-        const uint32_t xo = bt[k].x >> kObsBlockBits;
+        const uint32_t xo = bt[k].x >> bb;
         size_t e = k;
-        while (e < bt.size() && (bt[e].x >> kObsBlockBits) == xo) ++e;
+        while (e < bt.size() && (bt[e].x >> bb) == xo) ++e;
         std::vector<std::pair<size_t, size_t>> masks;  // the masks of the group [k, e) and their term ranges
         for (size_t i = k; i < e;) {
           size_t j = i;
@@ -632,10 +635,11 @@ int upload_model(qhbm_engine* h) {
         k = e;
       }
       if (interleave) {  // inside every window: the heaviest unit while the running load is behind the average, else the lightest
+        const int window = 5 + (kObsBlockBits - bb);  // (2 MiB of partner blocks)
         std::vector<Unit> ordered;
         for (size_t a = 0; a < units.size();) {
           size_t b = a;
-          while (b < units.size() && (units[b].xo >> 5) == (units[a].xo >> 5)) ++b;
+          while (b < units.size() && (units[b].xo >> window) == (units[a].xo >> window)) ++b;
           std::vector<Unit> win(std::make_move_iterator(units.begin() + long(a)), std::make_move_iterator(units.begin() + long(b)));
           std::stable_sort(win.begin(), win.end(), [](const Unit& x, const Unit& y) { return x.terms > y.terms; });
           double total = 0.0;
@@ -665,7 +669,7 @@ int upload_model(qhbm_engine* h) {
         std::vector<size_t> half[2];
         size_t load[2] = {0, 0};
         for (size_t m : order) {
-          const int hsel = load[1] < load[0] ? 1 : 0;
+          const int hsel = bb == kObsBlockBits && load[1] < load[0] ? 1 : 0;  // (blocks of 2^12: one workgroup, every mask)
           half[hsel].push_back(m);
           load[hsel] += u.masks[m].second - u.masks[m].first;
         }
@@ -675,7 +679,7 @@ int upload_model(qhbm_engine* h) {
           std::sort(half[hsel].begin(), half[hsel].end(), [&](size_t a, size_t b) { return u.masks[a].first < u.masks[b].first; });
           for (size_t m : half[hsel])
             for (size_t i = u.masks[m].first; i < u.masks[m].second; ++i)
-              terms2.push_back(obs_block_term(bt[i], i == u.masks[m].first));
+              terms2.push_back(obs_block_term(bt[i], i == u.masks[m].first, bb));
           if (hsel == 0) g.mid = uint32_t(terms2.size());
         }
         g.end = uint32_t(terms2.size());
@@ -797,7 +801,7 @@ bool block_kernel(const qhbm_engine* h) {
   std::vector<uint32_t> outs;
   for (uint32_t x : xs) {
     leaving += x >= gather_block ? 1.0 : 0.0;
-    outs.push_back(x >> kObsBlockBits);
+    outs.push_back(x >> h->opt_obs_block_bits);
   }
   std::sort(outs.begin(), outs.end());
   const double groups = double(std::unique(outs.begin(), outs.end()) - outs.begin());
@@ -972,11 +976,11 @@ int run_observable_chunk(qhbm_engine* h, uint32_t s0, uint32_t c, const float* d
     return 0;
   }
   if (value_mode)
-    HIPCHK(h->value_part.reserve(block_kernel(h) ? observable_blocks_value_parts(n_eff, c, 1u) : observable_value_parts(n_eff, c)));
+    HIPCHK(h->value_part.reserve(block_kernel(h) ? observable_blocks_value_parts(n_eff, c, 1u, h->opt_obs_block_bits) : observable_value_parts(n_eff, c)));
   hipEvent_t* ev = timer_begin(h, 2, stream);
   if (block_kernel(h)) {
     const int mode = !value_mode ? OBS_LAMBDA : (store_lambda ? OBS_LAMBDA_VALUE : OBS_VALUES);
-    HIPCHK(launch_observable_blocks(mode, h->psi.p, store_lambda ? h->lam.p : nullptr, n_eff, c, h->obs_bterms.p,
+    HIPCHK(launch_observable_blocks(mode, h->opt_obs_block_bits, h->psi.p, store_lambda ? h->lam.p : nullptr, n_eff, c, h->obs_bterms.p,
                                     h->obs_bgroups.p, h->n_obs_bgroups, d_upstream, uint32_t(h->model.n_ops), s0,
                                     h->op_scale.p, value_mode ? h->vals64.p : nullptr, h->value_part.p,
                                     observable_xcd_states(h), stream));
@@ -999,9 +1003,9 @@ int run_values_chunk(qhbm_engine* h, uint32_t row0, uint32_t c, hipStream_t stre
   if (h->model.n_ops == 1) return run_observable_chunk(h, row0, c, nullptr, true, stream, false);
   if (gather_multi_mode(h)) return run_observable_chunk(h, row0, c, nullptr, false, stream, false, true);
   const uint32_t n_eff = uint32_t(h->fwd.plan.n_eff);
-  HIPCHK(h->value_part.reserve(observable_blocks_value_parts(n_eff, c, uint32_t(h->model.n_ops))));
+  HIPCHK(h->value_part.reserve(observable_blocks_value_parts(n_eff, c, uint32_t(h->model.n_ops), h->opt_obs_block_bits)));
   hipEvent_t* ev = timer_begin(h, 2, stream);
-  HIPCHK(launch_observable_blocks(OBS_VALUES_MULTI, h->psi.p, nullptr, n_eff, c, h->obs_bterms.p, h->obs_bgroups.p,
+  HIPCHK(launch_observable_blocks(OBS_VALUES_MULTI, h->opt_obs_block_bits, h->psi.p, nullptr, n_eff, c, h->obs_bterms.p, h->obs_bgroups.p,
                                   h->n_obs_bgroups, nullptr, uint32_t(h->model.n_ops), row0, h->op_scale.p, h->vals64.p,
                                   h->value_part.p, observable_xcd_states(h), stream));
   timer_end(ev, stream);
@@ -1139,6 +1143,8 @@ int qhbm_create(int device, qhbm_engine** out) {
   if (!out) return fail(nullptr, "out is NULL");
   std::unique_ptr<qhbm_engine> h(new qhbm_engine());
   h->device = device;
+  if (const char* bb = std::getenv("QHBM_OBS_BLOCK_BITS"))  // (A/B runs of whole programs: the option's default)
+    if (std::atoi(bb) == kObsBlockBits || std::atoi(bb) == kObsBlockBitsSmall) h->opt_obs_block_bits = std::atoi(bb);
   if (device >= 0) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -1287,6 +1293,10 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "wide_last_pass") { h->opt_wide_last = int(value); h->plans_valid = false; }
   else if (k == "observable_xcd_states") h->opt_obs_xcd_states = int(value);
   else if (k == "observable_kernel") { h->opt_obs_kernel = int(value); h->block_choice = -1; }
+  else if (k == "observable_block_bits") {
+    if (value != kObsBlockBits && value != kObsBlockBitsSmall) return fail(h, "observable_block_bits: 12 or 13");
+    h->opt_obs_block_bits = int(value); h->block_choice = -1; h->terms.release(); h->model_uploaded = false;
+  }
   else if (k == "multi_observable_values") h->opt_multi_values = int(value);
   else if (k == "gather_multi_values") h->opt_gather_multi = int(value);
   else if (k == "observable_far_windows") { h->opt_far_windows = int(value); h->terms.release(); h->model_uploaded = false; }

@@ -59,25 +59,30 @@ constexpr uint32_t kObsTermChunk = 512;  // 2 x the terms staged in LDS at a tim
 // the block) pairs the block with the partner block b ^ x_out: the terms come sorted by x_out and cut into GROUPS of
 // equal x_out, the partner block of a group is fetched ONCE into LDS and every mask of the group reads it from there at
 // l ^ x_in (config 4: 173 fetches per block instead of 453 gathers).
-constexpr int kObsBlockBits = 13;
+// Two shapes of the same kernel (observable.hip): blocks of 2^13 under ONE workgroup of 1024 threads per CU whose two halves
+// split a group's masks, or blocks of 2^12 under TWO independent workgroups of 512 threads per CU that apply every mask of
+// their groups (engine option "observable_block_bits").
+constexpr int kObsBlockBits = 13;      // the larger shape: what the engine requires of a state before it picks these kernels
+constexpr int kObsBlockBitsSmall = 12;
 constexpr uint32_t kObsNewMask = 1u << 12;   // ObsBTerm::meta: the term's x differs from the previous term's
 constexpr uint32_t kObsMaxValueOps = 256;    // per-op value cells of a workgroup (one row per wave: 16 KiB) must fit LDS
 struct ObsBTerm {  // 32 bytes, one s_load_dwordx8: everything the kernel would otherwise derive per term with scalar ALU work
   float coeff;
   uint32_t zt;     // Z mask on the thread bits: (z >> 1) & 511
-  uint32_t zb;     // Z mask on the block bits: z >> kObsBlockBits
+  uint32_t zb;     // Z mask on the block bits: z >> block bits
   uint32_t xrow;   // byte-address XOR of the partner rows in the LDS buffer: ((x >> 1) & 511) << 4 | ((x >> 10) & 7) << 13
+                   // (blocks of 2^12: four rows, (x >> 10) & 3)
   uint32_t off0;   // jump-table offset of the variant for slots 0..7 (observable_variants.inc) ...
-  uint32_t off1;   // ... and for slots 8..15 (base sign flipped when z holds the highest slot bit)
+  uint32_t off1;   // ... and for slots 8..15 (base sign flipped when z holds the highest slot bit; blocks of 2^12: unused)
   uint32_t meta;   // op (bits 0..9) | kObsNewMask | kObsSignBit when i^ny (-1)^ny contributes a minus sign
   uint32_t pad;
 };
 constexpr uint32_t kObsSignBit = 1u << 13;
 constexpr uint32_t kObsChunkBytes = 68, kObsPreambleBytes = 12;  // layout of the variant tables (scripts/gen_observable_asm.py)
 struct ObsBGroup {
-  uint32_t xout;  // x >> kObsBlockBits: partner block = block ^ xout
+  uint32_t xout;  // x >> block bits: partner block = block ^ xout
   uint32_t begin, end;  // terms [begin, end) ...
-  uint32_t mid;         // ... of which [begin, mid) are the first half-workgroup's masks, [mid, end) the second's
+  uint32_t mid;         // ... of which [begin, mid) are the first half-workgroup's masks, [mid, end) the second's (blocks of 2^12: = end)
 };
 enum ObsBlocksMode : int {
   OBS_LAMBDA = 0,        // lambda = sum_k upstream[s, op_k] c_k P_k psi
@@ -86,8 +91,9 @@ enum ObsBlocksMode : int {
   OBS_VALUES_MULTI = 3,  // n_ops <= kObsMaxValueOps observables: <psi|O_t|psi> for every t (nothing stored)
 };
 // value modes: value_part holds observable_blocks_value_parts(n, n_states, n_ops) floats of scratch
-size_t observable_blocks_value_parts(uint32_t n, uint32_t n_states, uint32_t n_ops);
-hipError_t launch_observable_blocks(int mode, const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
+size_t observable_blocks_value_parts(uint32_t n, uint32_t n_states, uint32_t n_ops, int block_bits);
+// `block_bits`: kObsBlockBits or kObsBlockBitsSmall -- the one the tables `terms` / `groups` were built for
+hipError_t launch_observable_blocks(int mode, int block_bits, const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
                                     const ObsBTerm* terms, const ObsBGroup* groups, uint32_t n_groups,
                                     const float* upstream, uint32_t n_ops, uint32_t state0, const float* op_scale,
                                     unsigned long long* out64, float* value_part, bool xcd_states, hipStream_t stream);

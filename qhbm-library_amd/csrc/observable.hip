@@ -27,6 +27,9 @@
 // distinct windows predicts.  (Two workgroups SHARING a block and taking alternate groups drift apart by whole windows
 // -- 0.13; a resident grid walking the blocks with a stride loses the compact sliding window -- both measured, both
 // dropped.)  The halves of one workgroup are kept in step by its barrier.
+// (Round 6, BB = 12 below: blocks of 2^12 under two INDEPENDENT workgroups of 512 threads per CU -- the same 2-MiB footprint
+// per XCD, one workgroup's store burst under the other's masks -- measured 94.4 against 51.2 ms: co-resident workgroups
+// drift apart by whole windows, hit rate 0.27, 20 GB of fabric reads.  profiles/r06_obs_block_bits.txt; option-only.)
 // Pipeline per group: the block of group s + 1 goes from registers to the OTHER of two 64-KiB LDS buffers while the
 // masks of group s are applied from the first; the blocks of groups s + 2 and s + 3 are in flight in the two
 // four-row prefetch sets of every thread (128 KiB per CU); ONE barrier per group.  The two halves do the store burst
@@ -57,13 +60,20 @@ namespace qhbm {
 
 namespace {
 
-constexpr uint32_t kOH = 512;                                // threads of one half: one per eight adjacent pairs
-constexpr uint32_t kOT = 2 * kOH;                            // threads per workgroup
-constexpr uint32_t kOP = 8;                                  // adjacent pairs per thread
-constexpr uint32_t kOBlock = 1u << kObsBlockBits;            // amplitudes per block
-constexpr uint32_t kOWaves = kOT / 64;
-constexpr uint32_t kOBuf = kOBlock / 2;                      // 16-byte words of one LDS block buffer
-static_assert(kOH * kOP * 2 == kOBlock, "512 threads x 8 pairs = one block");
+constexpr uint32_t kOH = 512;                                // threads of one half: one per column of adjacent pairs
+// The two shapes (kernels.h): BB = 13 -- one workgroup of two halves per CU, eight pairs per thread; BB = 12 -- two
+// independent workgroups of 512 threads per CU, four pairs per thread, every mask of a group applied by the one "half".
+template <int BB>
+struct ObsShape {
+  static_assert(BB == kObsBlockBits || BB == kObsBlockBitsSmall, "two shapes");
+  static constexpr bool kHalves = BB == kObsBlockBits;
+  static constexpr uint32_t kThreads = kHalves ? 2 * kOH : kOH;   // per workgroup
+  static constexpr uint32_t kPairs = kHalves ? 8 : 4;             // adjacent pairs per thread
+  static constexpr uint32_t kBlock = 1u << BB;                    // amplitudes per block
+  static constexpr uint32_t kWaves = kThreads / 64;
+  static constexpr uint32_t kBuf = kBlock / 2;                    // 16-byte words of one LDS block buffer
+  static_assert(kOH * kPairs * 2 == kBlock, "512 threads x their pairs = one block");
+};
 
 // 16-byte words as a NATIVE vector type: copies of HIP's v4f struct become memcpy calls between address spaces,
 // which keep the register arrays below in scratch memory
@@ -120,6 +130,18 @@ __device__ __forceinline__ void obs_term(v2f (&a)[16], const v4f (&r)[8], v2f w,
   }
 }
 
+// blocks of 2^12: eight slots, four rows
+template <bool ACC>
+__device__ __forceinline__ void obs_term(v2f (&a)[8], const v4f (&r)[4], v2f w, v2f (&s)[4], uint32_t off0, uint32_t) {
+  if constexpr (ACC) {
+    obs_fma8(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], lo_half(r[0]), hi_half(r[0]), lo_half(r[1]), hi_half(r[1]),
+             lo_half(r[2]), hi_half(r[2]), lo_half(r[3]), hi_half(r[3]), w, off0);
+  } else {
+    obs_dot8(s[0], s[1], s[2], s[3], a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], lo_half(r[0]), hi_half(r[0]),
+             lo_half(r[1]), hi_half(r[1]), lo_half(r[2]), hi_half(r[2]), lo_half(r[3]), hi_half(r[3]), off0);
+  }
+}
+
 #ifdef QHBM_OBS_TIMING  // diagnostic build: cycles of one workgroup's waves per phase, printed (never shipped)
 #define OBS_T(slot) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); tacc[slot] += now_ - tlast; tlast = now_; }
 #else
@@ -136,31 +158,39 @@ __device__ __forceinline__ void obs_term(v2f (&a)[16], const v4f (&r)[8], v2f w,
 // (Measured and dropped: the rows as immediate ds_read offsets behind an 8-way jump table like the term variants --
 // 15 vector instructions fewer per term, the LDS wait inside the asm statement -- 51.4 -> 52.5 ms on config 4: the mask
 // phase is bound by the LDS reads themselves, 8 KiB per wave and term, not by VALU issue.)
-template <int... P>
-__device__ __forceinline__ void obs_rows_(v4f (&r)[8], const char* lds, uint32_t base, std::integer_sequence<int, P...>) {
+template <int N, int... P>
+__device__ __forceinline__ void obs_rows_(v4f (&r)[N], const char* lds, uint32_t base, std::integer_sequence<int, P...>) {
   ((r[P] = *reinterpret_cast<const v4f*>(lds + (base ^ uint32_t(P << 13)))), ...);
 }
-__device__ __forceinline__ void obs_rows(v4f (&r)[8], const char* lds, uint32_t base) {
-  obs_rows_(r, lds, base, std::make_integer_sequence<int, 8>{});
+template <int N>
+__device__ __forceinline__ void obs_rows(v4f (&r)[N], const char* lds, uint32_t base) {
+  obs_rows_(r, lds, base, std::make_integer_sequence<int, N>{});
 }
 // (register arrays are only ever indexed by compile-time constants: integer_sequence folds, never loops)
 // One block (64 KiB) into the thread's prefetch registers: row P at `blk` + 8192 P + 16 tid, as BUFFER loads -- the
 // block is the buffer (a wave-uniform descriptor in four SGPRs), the row a scalar offset, and the eight loads share
 // ONE 32-bit offset register; flat global loads need eight 64-bit address pairs, which the register file of
 // accumulators + partner rows + prefetch rows has no room for (18 spilled registers).
+#ifndef QHBM_OBS_ADDTID
+#define QHBM_OBS_ADDTID 0
+#endif
+#if !QHBM_OBS_ADDTID
+typedef v4f ObsSet[4];   // one prefetch set: the thread's 16-byte word of four rows
 typedef int v4i __attribute__((ext_vector_type(4)));
-// A thread fetches and stages FOUR of its pair column's eight rows: rows 4 hh .. 4 hh + 3 for half hh (wave-uniform).
+// A thread fetches and stages FOUR rows of its pair column: rows 4 hh .. 4 hh + 3 for half hh (wave-uniform) of the eight of
+// a block of 2^13, all four of a block of 2^12.
 // The loads are volatile asm with MANUAL s_waitcnt: two prefetch sets are in flight across the loop's back edge, and
 // the compiler's own wait insertion, exact inside straight-line code, gives up at the loop header -- it waited for
 // vmcnt(0), i.e. for the set issued one step ago as well, which halves the prefetch distance (measured).  The
 // compiler does not know these registers are pending: nothing may touch a set between obs_fetch and obs_wait_older
 // (the sets are written and read by unconditional straight-line code only -- no phi, hence no copy).
 typedef int v4i __attribute__((ext_vector_type(4)));
+template <int BB>
 __device__ __forceinline__ void obs_fetch(v4f (&pf)[4], const float2* __restrict__ blk, uint32_t t16, uint32_t row0) {
   // 0x00020000: the raw-buffer word 3 of gfx90a / gfx942 / gfx950 (32-bit data format, no swizzle)
   // (descriptor words: base[31:0] | base[47:32], stride 0 | bytes of the block | word 3)
   const uint64_t addr = reinterpret_cast<uint64_t>(blk);
-  const v4i rsi = v4i{int(uint32_t(addr)), int(uint32_t(addr >> 32) & 0xffffu), 8 << kObsBlockBits, 0x00020000};
+  const v4i rsi = v4i{int(uint32_t(addr)), int(uint32_t(addr >> 32) & 0xffffu), 8 << BB, 0x00020000};
   const uint32_t o0 = 8192u * row0, o1 = o0 + 8192u, o2 = o0 + 16384u, o3 = o0 + 24576u;
   asm volatile("buffer_load_dwordx4 %0, %4, %5, %6 offen" QHBM_OBS_LOAD_MOD "\n\t"
                "buffer_load_dwordx4 %1, %4, %5, %7 offen" QHBM_OBS_LOAD_MOD "\n\t"
@@ -186,6 +216,63 @@ __device__ __forceinline__ void obs_stage_(v4f* dst, const v4f (&pf)[4], std::in
 __device__ __forceinline__ void obs_stage(v4f* dst, const v4f (&pf)[4]) {   // dst = buffer + t + 512 row0
   obs_stage_(dst, pf, std::make_integer_sequence<int, 4>{});
 }
+#else
+// The same pipeline with the block staged dword by dword: a wave loads its 1-KiB segment of a row as four
+// buffer_load_dword (lane l: byte 256 j + 4 l -- two full 128-byte lines per instruction) and stores it with four
+// ds_write_addtid_b32 (address = M0 + immediate + 4 l, no address register: 2 cycles per wave-instruction, 128 B/clk/CU
+// against the 79 of ds_write_b128 -- MI355X_MICROARCH.md, LDS).  The LDS image is the same linear block.
+typedef float ObsSet[16];   // one prefetch set: dword j of row p in [4 p + j]
+typedef int v4i __attribute__((ext_vector_type(4)));
+// `lane_off` = 1024 x (wave of the half) + 4 x lane
+template <int BB>
+__device__ __forceinline__ void obs_fetch(ObsSet& pf, const float2* __restrict__ blk, uint32_t lane_off, uint32_t row0) {
+  const uint64_t addr = reinterpret_cast<uint64_t>(blk);
+  const v4i rsi = v4i{int(uint32_t(addr)), int(uint32_t(addr >> 32) & 0xffffu), 8 << BB, 0x00020000};
+  const uint32_t o0 = 8192u * row0, o1 = o0 + 8192u, o2 = o0 + 16384u, o3 = o0 + 24576u;
+#define OBS_LD4(R0_, R1_, R2_, R3_, O_)                                             \
+  "buffer_load_dword %" #R0_ ", %16, %17, %" #O_ " offen" QHBM_OBS_LOAD_MOD "\n\t"            \
+  "buffer_load_dword %" #R1_ ", %16, %17, %" #O_ " offen offset:256" QHBM_OBS_LOAD_MOD "\n\t" \
+  "buffer_load_dword %" #R2_ ", %16, %17, %" #O_ " offen offset:512" QHBM_OBS_LOAD_MOD "\n\t" \
+  "buffer_load_dword %" #R3_ ", %16, %17, %" #O_ " offen offset:768" QHBM_OBS_LOAD_MOD "\n\t"
+  asm volatile(OBS_LD4(0, 1, 2, 3, 18) OBS_LD4(4, 5, 6, 7, 19) OBS_LD4(8, 9, 10, 11, 20) OBS_LD4(12, 13, 14, 15, 21)
+               : "=&v"(pf[0]), "=&v"(pf[1]), "=&v"(pf[2]), "=&v"(pf[3]), "=&v"(pf[4]), "=&v"(pf[5]), "=&v"(pf[6]), "=&v"(pf[7]),
+                 "=&v"(pf[8]), "=&v"(pf[9]), "=&v"(pf[10]), "=&v"(pf[11]), "=&v"(pf[12]), "=&v"(pf[13]), "=&v"(pf[14]), "=&v"(pf[15])
+               : "v"(lane_off), "s"(rsi), "s"(o0), "s"(o1), "s"(o2), "s"(o3));
+#undef OBS_LD4
+}
+#define OBS_SET_RW(pf) "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]), "+v"(pf[6]), "+v"(pf[7]), \
+                       "+v"(pf[8]), "+v"(pf[9]), "+v"(pf[10]), "+v"(pf[11]), "+v"(pf[12]), "+v"(pf[13]), "+v"(pf[14]), "+v"(pf[15])
+template <int NEWER>
+__device__ __forceinline__ void obs_wait_older(ObsSet& pf) {
+  static_assert(NEWER == 0 || NEWER == 1, "two sets");
+  if constexpr (NEWER == 1) asm volatile("s_waitcnt vmcnt(16)" : OBS_SET_RW(pf));
+  else asm volatile("s_waitcnt vmcnt(0)" : OBS_SET_RW(pf));
+}
+// Byte address of a store = M0[15:0] + immediate (16 bits) + 4 lane, the second buffer of a block of 2^13 starts at 64 KiB:
+// its base is split X in M0 + (64 Ki - X) in the immediate, X such that both stay below 64 Ki
+// (M0 <= X + 32 Ki (rows 4..7) + 7 Ki (wave); immediate <= 64 Ki - X + 24 Ki (row) + 768).
+template <int BB> constexpr uint32_t obs_m0_part() { return BB == kObsBlockBits ? 25348u : 0u; }
+// `m0` = obs_m0_part x buffer + 8192 x row0 + 1024 x (wave of the half); BUF: 0 / 1.  M0 is a reserved register the
+// compiler loads right before the few instructions that read it (none in this kernel), so it is not on the clobber list.
+#define OBS_ST4(R0_, R1_, R2_, R3_, BASE_, ROW_)                                     \
+  "ds_write_addtid_b32 %" #R0_ " offset:" #BASE_ "+8192*" #ROW_ "\n\t"               \
+  "ds_write_addtid_b32 %" #R1_ " offset:" #BASE_ "+8192*" #ROW_ "+256\n\t"           \
+  "ds_write_addtid_b32 %" #R2_ " offset:" #BASE_ "+8192*" #ROW_ "+512\n\t"           \
+  "ds_write_addtid_b32 %" #R3_ " offset:" #BASE_ "+8192*" #ROW_ "+768\n\t"
+#define OBS_ST16(BASE_) "s_mov_b32 m0, %16\n\t" OBS_ST4(0, 1, 2, 3, BASE_, 0) OBS_ST4(4, 5, 6, 7, BASE_, 1) \
+                        OBS_ST4(8, 9, 10, 11, BASE_, 2) OBS_ST4(12, 13, 14, 15, BASE_, 3)
+#define OBS_SET_R(pf) "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]), "v"(pf[6]), "v"(pf[7]), \
+                      "v"(pf[8]), "v"(pf[9]), "v"(pf[10]), "v"(pf[11]), "v"(pf[12]), "v"(pf[13]), "v"(pf[14]), "v"(pf[15])
+template <int BB, int BUF>
+__device__ __forceinline__ void obs_stage(const ObsSet& pf, uint32_t m0) {
+  // (the asm statement writes memory the compiler does not see: the reads of this buffer are behind the workgroup's
+  // barrier, and obs_stores_done() before that barrier waits for the stores)
+  if constexpr (BUF == 0) asm volatile(OBS_ST16(0) : : OBS_SET_R(pf), "s"(m0));
+  else if constexpr (BB == kObsBlockBits) asm volatile(OBS_ST16(40188) : : OBS_SET_R(pf), "s"(m0));   // 65536 - 25348
+  else asm volatile(OBS_ST16(32768) : : OBS_SET_R(pf), "s"(m0));
+}
+__device__ __forceinline__ void obs_stores_done() { asm volatile("s_waitcnt lgkmcnt(0)"); }
+#endif
 // the second half hands its accumulators to the first through an LDS buffer
 template <int... P>
 __device__ __forceinline__ void obs_acc_out_(v4f* dst, const v2f (&a)[16], std::integer_sequence<int, P...>) {
@@ -195,17 +282,17 @@ template <int... P>
 __device__ __forceinline__ void obs_acc_in_(v2f (&a)[16], const v4f* src, std::integer_sequence<int, P...>) {
   (([&] { const v4f o = src[512 * P]; a[2 * P] += v2f{o.x, o.y}; a[2 * P + 1] += v2f{o.z, o.w}; }()), ...);
 }
-template <int... P>
-__device__ __forceinline__ void obs_own_(v2f (&a)[16], const v4f* __restrict__ src, std::integer_sequence<int, P...>) {
+template <int N, int... P>
+__device__ __forceinline__ void obs_own_(v2f (&a)[N], const v4f* __restrict__ src, std::integer_sequence<int, P...>) {
   (([&] { const v4f o = src[512 * P]; a[2 * P] = v2f{o.x, o.y}; a[2 * P + 1] = v2f{o.z, o.w}; }()), ...);
 }
-template <int... P>
-__device__ __forceinline__ void obs_store_(v4f* __restrict__ dst, const v2f (&a)[16], std::integer_sequence<int, P...>) {
+template <int N, int... P>
+__device__ __forceinline__ void obs_store_(v4f* __restrict__ dst, const v2f (&a)[N], std::integer_sequence<int, P...>) {
   // (non-temporal: lambda is read next by another kernel -- it must not displace the partner blocks in L2)
   ((__builtin_nontemporal_store(v4f{a[2 * P].x, a[2 * P].y, a[2 * P + 1].x, a[2 * P + 1].y}, dst + 512 * P)), ...);
 }
-template <int... P>
-__device__ __forceinline__ float obs_energy_(const v4f* __restrict__ src, const v2f (&a)[16], std::integer_sequence<int, P...>) {
+template <int N, int... P>
+__device__ __forceinline__ float obs_energy_(const v4f* __restrict__ src, const v2f (&a)[N], std::integer_sequence<int, P...>) {
   float e = 0.f;
   (([&] {
      const v4f o = src[512 * P];
@@ -213,8 +300,8 @@ __device__ __forceinline__ float obs_energy_(const v4f* __restrict__ src, const 
    }()), ...);
   return e;
 }
-template <int... I>
-__device__ __forceinline__ void obs_zero_(v2f (&a)[16], std::integer_sequence<int, I...>) { ((a[I] = v2f{0.f, 0.f}), ...); }
+template <int N, int... I>
+__device__ __forceinline__ void obs_zero_(v2f (&a)[N], std::integer_sequence<int, I...>) { ((a[I] = v2f{0.f, 0.f}), ...); }
 
 // first group at or after g that this block runs: value modes skip a pair's upper block
 template <bool HALVE>
@@ -244,10 +331,10 @@ struct ObsCtx {
   uint32_t n_ops, bx, t, tid;
 };
 
-// One term on the thread's 16 slots, from its 32-byte record.
-template <int MODE>
+// One term on the thread's slots (2 NP of them: NP rows of adjacent pairs), from its 32-byte record.
+template <int MODE, int NP>
 __device__ __forceinline__ void obs_one_term(const ObsCtx<MODE>& c, const ObsBTerm t, uint32_t cur_bytes, float pair_weight,
-                                             v2f (&a)[16], v4f (&r)[8], v2f& d2, uint32_t& cur_op, v2f (&dq)[4]) {
+                                             v2f (&a)[2 * NP], v4f (&r)[NP], v2f& d2, uint32_t& cur_op, v2f (&dq)[4]) {
   constexpr bool ACC = MODE == OBS_LAMBDA || MODE == OBS_LAMBDA_VALUE;
   constexpr bool MULTI = MODE == OBS_VALUES_MULTI;
   if (t.meta & kObsNewMask) obs_rows(r, c.lds, ((c.t << 4) | cur_bytes) ^ t.xrow);
@@ -288,8 +375,8 @@ __device__ __forceinline__ void obs_one_term(const ObsCtx<MODE>& c, const ObsBTe
   }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
+template <int MODE, int BB>
+__global__ __launch_bounds__(ObsShape<BB>::kThreads, 4) void observable_blocks_kernel(
     const float2* __restrict__ psi, float2* __restrict__ lam, uint32_t n, const ObsBTerm* __restrict__ terms,
     const ObsBGroup* __restrict__ groups, uint32_t n_groups, const float* __restrict__ upstream, uint32_t n_ops,
     uint32_t state0, float* __restrict__ value_part, uint32_t nb /* blocks per state */, uint32_t n_states,
@@ -297,7 +384,11 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
   constexpr bool ACC = MODE == OBS_LAMBDA || MODE == OBS_LAMBDA_VALUE;
   constexpr bool HALVE = !ACC;
   constexpr bool MULTI = MODE == OBS_VALUES_MULTI;
-  extern __shared__ v4f lds4[];  // two block buffers of 4096 16-byte words; then the value cells
+  using Shape = ObsShape<BB>;
+  constexpr bool HALVES = Shape::kHalves;
+  constexpr int NP = int(Shape::kPairs);
+  constexpr uint32_t kOT = Shape::kThreads, kOWaves = Shape::kWaves, kOBuf = Shape::kBuf, kOBlock = Shape::kBlock;
+  extern __shared__ v4f lds4[];  // two block buffers of kOBuf 16-byte words; then the value cells
   float* cells = reinterpret_cast<float*>(lds4 + 2 * kOBuf);
   // Workgroup -> (state, block).  Workgroups are dealt round-robin to the 8 XCDs (linear id mod 8), each with its own L2:
   //   xcd_states: XCD k works on state 8 g + k, its blocks in index order;
@@ -317,27 +408,40 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
       bx = (nb & 7u) ? b : (b & 7u) * (nb >> 3) + (b >> 3);
     }
   }
-  const uint32_t tid = threadIdx.x, t = tid & (kOH - 1u), hh = uni(tid >> 9);
+  const uint32_t tid = threadIdx.x, t = tid & (kOH - 1u), hh = HALVES ? uni(tid >> 9) : 0u;
   const float2* ps = psi + (size_t(s_local) << n);
-  const v4f* own4 = reinterpret_cast<const v4f*>(ps + (size_t(bx) << kObsBlockBits)) + t;
+  const v4f* own4 = reinterpret_cast<const v4f*>(ps + (size_t(bx) << BB)) + t;
   ObsCtx<MODE> c;
   c.terms = terms; c.lds = reinterpret_cast<const char*>(lds4); c.cells = cells; c.n_ops = n_ops; c.bx = bx; c.t = t; c.tid = tid;
   c.up = MODE == OBS_LAMBDA ? upstream + size_t(state0 + s_local) * n_ops : nullptr;
 
-  v2f a[16];
-  if constexpr (ACC) obs_zero_(a, std::make_integer_sequence<int, 16>{});
-  else obs_own_(a, own4, std::make_integer_sequence<int, 8>{});
+  v2f a[2 * NP];
+  if constexpr (ACC) obs_zero_(a, std::make_integer_sequence<int, 2 * NP>{});
+  else obs_own_(a, own4, std::make_integer_sequence<int, NP>{});
   if constexpr (MULTI) {
     for (uint32_t i = tid; i < kOWaves * n_ops; i += kOT) cells[i] = 0.f;
   }
-  v4f r[8], pfa[4], pfb[4];
+  v4f r[NP];
+  ObsSet pfa, pfb;
   obs_rows(r, c.lds, t << 4);  // (defined values before the first mask; never used)
   v2f d2 = v2f{0.f, 0.f};  // value modes: sum_k W_k (own . partner), both halves
   uint32_t cur_op = ~0u;  // (several observables: the one d2 is collecting, none yet)
   v2f dq[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
-  const uint32_t t16 = t << 4, row0 = 4u * hh;
+  const uint32_t row0 = 4u * hh;
+#if QHBM_OBS_ADDTID
+  const uint32_t t16 = ((t >> 6) << 10) | ((t & 63u) << 2);   // the lane's dword of its wave's 1-KiB row segment
+  const uint32_t m0a = uni(8192u * row0 + ((t >> 6) << 10)), m0b = m0a + obs_m0_part<BB>();
+  auto stage_a = [&] { obs_stage<BB, 0>(pfa, m0a); };
+  auto stage_b = [&] { obs_stage<BB, 1>(pfb, m0b); };
+  auto stores_done = [] { obs_stores_done(); };
+#else
+  const uint32_t t16 = t << 4;
+  auto stage_a = [&] { obs_stage(lds4 + t + 512u * row0, pfa); };
+  auto stage_b = [&] { obs_stage(lds4 + kOBuf + t + 512u * row0, pfb); };
+  auto stores_done = [] {};   // (the compiler counts its own stores)
+#endif
   // the block a group pairs this one with (past the last group: the block itself -- no branch around the registers)
-  auto partner = [&](uint32_t g) { return ps + (size_t(bx ^ (g < n_groups ? groups[g].xout : 0u)) << kObsBlockBits); };
+  auto partner = [&](uint32_t g) { return ps + (size_t(bx ^ (g < n_groups ? groups[g].xout : 0u)) << BB); };
 
   // groups of the next four steps
   uint32_t g0 = obs_next_group<HALVE>(groups, n_groups, 0u, bx, pivot_mask);
@@ -346,29 +450,30 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
   // (plain vector loads before this point -- the block's own amplitudes in the value modes -- must have landed before
   // the manual counting starts)
   asm volatile("s_waitcnt vmcnt(0)");
-  obs_fetch(pfa, partner(g0), t16, row0);
-  obs_fetch(pfb, partner(g1), t16, row0);
+  obs_fetch<BB>(pfa, partner(g0), t16, row0);
+  obs_fetch<BB>(pfb, partner(g1), t16, row0);
   obs_wait_older<1>(pfa);
-  obs_stage(lds4 + t + 512u * row0, pfa);
-  obs_fetch(pfa, partner(g2), t16, row0);
+  stage_a();
+  obs_fetch<BB>(pfa, partner(g2), t16, row0);
+  stores_done();
   __syncthreads();
   // Two steps per iteration (the prefetch sets alternate; a run-time choice between them would make the compiler copy
   // them).  Step: the block of g1 moves from its set to the buffer nobody reads in this step, the set is refilled
   // with the block of g3, the masks of g0 (this half's share) are applied from the other buffer; one barrier.
   auto terms_of = [&](const ObsBGroup gr, uint32_t cur_bytes) {
     const float pair_weight = (!ACC && gr.xout != 0u) ? 2.f : 1.f;
-    uint32_t k = hh ? gr.mid : gr.begin;
-    const uint32_t k1 = hh ? gr.end : gr.mid;  // this half's masks
+    uint32_t k = HALVES && hh ? gr.mid : gr.begin;
+    const uint32_t k1 = HALVES && !hh ? gr.mid : gr.end;  // this half's masks (blocks of 2^12: all of them)
     // two records in flight: the scalar load of the next one runs behind the arithmetic of the current one (the
     // array is padded by one record)
     if (k < k1) {
       ObsBTerm ta = terms[k];
       for (;;) {
         const ObsBTerm tb = terms[k + 1u];
-        obs_one_term<MODE>(c, ta, cur_bytes, pair_weight, a, r, d2, cur_op, dq);
+        obs_one_term<MODE, NP>(c, ta, cur_bytes, pair_weight, a, r, d2, cur_op, dq);
         if (++k >= k1) break;
         ta = terms[k + 1u];
-        obs_one_term<MODE>(c, tb, cur_bytes, pair_weight, a, r, d2, cur_op, dq);
+        obs_one_term<MODE, NP>(c, tb, cur_bytes, pair_weight, a, r, d2, cur_op, dq);
         if (++k >= k1) break;
       }
     }
@@ -377,7 +482,7 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
   // then applies its masks, half 1 applies its masks first.  All sixteen waves storing at once is a burst the LDS
   // takes 830 cycles for (ds_write_b128: 79 B/clk) with the vector units idle; this way each half's stores run under
   // the other half's arithmetic.  (-DQHBM_OBS_SKEW=0: both halves store first, for A/B measurements.)
-  const bool skew = QHBM_OBS_SKEW && hh;
+  const bool skew = QHBM_OBS_SKEW && HALVES && hh;
 #ifdef QHBM_OBS_TIMING
   uint64_t tacc[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
@@ -385,16 +490,16 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
     OBS_T(4)
     obs_wait_older<1>(pfa);
     OBS_T(0)
-    obs_stage(lds4 + t + 512u * row0, pfa);
-    obs_fetch(pfa, partner(g3), t16, row0);
+    stage_a();
+    obs_fetch<BB>(pfa, partner(g3), t16, row0);
     OBS_T(1)
   };
   auto refill_b = [&](uint32_t g3) {
     OBS_T(4)
     obs_wait_older<1>(pfb);
     OBS_T(0)
-    obs_stage(lds4 + kOBuf + t + 512u * row0, pfb);
-    obs_fetch(pfb, partner(g3), t16, row0);
+    stage_b();
+    obs_fetch<BB>(pfb, partner(g3), t16, row0);
     OBS_T(1)
   };
   while (g0 < n_groups) {
@@ -407,6 +512,7 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
       OBS_T(2)
       if (skew) refill_b(g3);
       OBS_T(4)
+      stores_done();
       __syncthreads();
       OBS_T(3)
       g0 = g1; g1 = g2; g2 = g3;
@@ -421,6 +527,7 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
       OBS_T(2)
       if (skew) refill_a(g3);
       OBS_T(4)
+      stores_done();
       __syncthreads();
       OBS_T(3)
       g0 = g1; g1 = g2; g2 = g3;
@@ -436,15 +543,15 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
 
   v4f* const buf0 = lds4;
   if constexpr (ACC) {
-    // the second half's accumulators join the first half's through an LDS buffer (every wave is past its last read)
-    if (hh) obs_acc_out_(buf0 + t, a, std::make_integer_sequence<int, 8>{});
-    __syncthreads();
-    if (!hh) {
-      obs_acc_in_(a, buf0 + t, std::make_integer_sequence<int, 8>{});
-      if (lam)
-        obs_store_(reinterpret_cast<v4f*>(lam + (size_t(s_local) << n) + (size_t(bx) << kObsBlockBits)) + t, a,
-                   std::make_integer_sequence<int, 8>{});
+    if constexpr (HALVES) {
+      // the second half's accumulators join the first half's through an LDS buffer (every wave is past its last read)
+      if (hh) obs_acc_out_(buf0 + t, a, std::make_integer_sequence<int, 8>{});
+      __syncthreads();
+      if (!hh) obs_acc_in_(a, buf0 + t, std::make_integer_sequence<int, 8>{});
     }
+    if (!hh && lam)
+      obs_store_(reinterpret_cast<v4f*>(lam + (size_t(s_local) << n) + (size_t(bx) << BB)) + t, a,
+                 std::make_integer_sequence<int, NP>{});
   }
   if constexpr (MODE == OBS_LAMBDA) return;
   if constexpr (MULTI) {
@@ -473,7 +580,7 @@ __global__ __launch_bounds__(1024, 4) void observable_blocks_kernel(
   } else {
     float e;
     if constexpr (MODE == OBS_LAMBDA_VALUE) {  // <psi|O|psi> = sum_j Re(conj(psi_j) lambda_j): the first half holds lambda
-      e = hh ? 0.f : obs_energy_(own4, a, std::make_integer_sequence<int, 8>{});
+      e = hh ? 0.f : obs_energy_(own4, a, std::make_integer_sequence<int, NP>{});
     } else {
       e = d2.x + d2.y;
     }
@@ -523,28 +630,33 @@ hipError_t obs_opt_in(Kernel kernel, bool (&done)[kMaxDev], size_t lds) {
 
 }  // namespace
 
-size_t observable_blocks_value_parts(uint32_t n, uint32_t n_states, uint32_t n_ops) {
-  return size_t(n_states) * (size_t(1) << (n - kObsBlockBits)) * std::max<uint32_t>(n_ops, 1u);
+size_t observable_blocks_value_parts(uint32_t n, uint32_t n_states, uint32_t n_ops, int block_bits) {
+  return size_t(n_states) * (size_t(1) << (n - uint32_t(block_bits))) * std::max<uint32_t>(n_ops, 1u);
 }
 
-hipError_t launch_observable_blocks(int mode, const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
+namespace {
+template <int BB>
+hipError_t launch_observable_blocks_shape(int mode, const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
                                     const ObsBTerm* terms, const ObsBGroup* groups, uint32_t n_groups,
                                     const float* upstream, uint32_t n_ops, uint32_t state0, const float* op_scale,
                                     unsigned long long* out64, float* value_part, bool xcd_states, hipStream_t stream) {
-  if (n < uint32_t(kObsBlockBits) || n_states == 0) return n_states ? hipErrorInvalidValue : hipSuccess;
+  using Shape = ObsShape<BB>;
+  constexpr uint32_t kOBlock = Shape::kBlock, kOWaves = Shape::kWaves, kOT = Shape::kThreads;
+  if (n < uint32_t(BB) || n_states == 0) return n_states ? hipErrorInvalidValue : hipSuccess;
   if (mode == OBS_VALUES_MULTI && n_ops > kObsMaxValueOps) return hipErrorInvalidValue;
-  const uint32_t nb = 1u << (n - kObsBlockBits);
-  const uint32_t xs = xcd_states && nb >= 64u ? 1u : 0u;  // (a state must at least fill an XCD's workgroup slots)
+  const uint32_t nb = 1u << (n - uint32_t(BB));
+  // (a state must at least fill an XCD's workgroup slots: 32 CUs x the workgroups of a CU)
+  const uint32_t xs = xcd_states && nb >= (Shape::kHalves ? 64u : 128u) ? 1u : 0u;
   // the largest cell area any mode uses, so that every instantiation is opted in once for the same size
   const size_t lds = 2u * size_t(kOBlock) * 8u + size_t(kOWaves) * kObsMaxValueOps * sizeof(float);
   static bool done[4][kMaxDev];
   hipError_t e = hipSuccess;
 #define QHBM_OBSB(M_)                                                                                                   \
   {                                                                                                                    \
-    e = obs_opt_in(observable_blocks_kernel<M_>, done[M_], lds);                                                        \
+    e = obs_opt_in(observable_blocks_kernel<M_, BB>, done[M_], lds);                                                    \
     if (e != hipSuccess) return e;                                                                                     \
     const size_t use = 2u * size_t(kOBlock) * 8u + (M_ == OBS_VALUES_MULTI ? size_t(kOWaves) * n_ops * sizeof(float) : 64u); \
-    hipLaunchKernelGGL((observable_blocks_kernel<M_>), dim3(nb * n_states), dim3(kOT), use, stream, psi, lam, n, terms, \
+    hipLaunchKernelGGL((observable_blocks_kernel<M_, BB>), dim3(nb * n_states), dim3(kOT), use, stream, psi, lam, n, terms, \
                        groups, n_groups, upstream, n_ops, state0, value_part, nb, n_states, xs);                       \
   }
   switch (mode) {
@@ -564,6 +676,20 @@ hipError_t launch_observable_blocks(int mode, const float2* psi, float2* lam, ui
     e = hipGetLastError();
   }
   return e;
+}
+}  // namespace
+
+hipError_t launch_observable_blocks(int mode, int block_bits, const float2* psi, float2* lam, uint32_t n, uint32_t n_states,
+                                    const ObsBTerm* terms, const ObsBGroup* groups, uint32_t n_groups,
+                                    const float* upstream, uint32_t n_ops, uint32_t state0, const float* op_scale,
+                                    unsigned long long* out64, float* value_part, bool xcd_states, hipStream_t stream) {
+  if (block_bits == kObsBlockBits)
+    return launch_observable_blocks_shape<kObsBlockBits>(mode, psi, lam, n, n_states, terms, groups, n_groups, upstream, n_ops,
+                                                         state0, op_scale, out64, value_part, xcd_states, stream);
+  if (block_bits == kObsBlockBitsSmall)
+    return launch_observable_blocks_shape<kObsBlockBitsSmall>(mode, psi, lam, n, n_states, terms, groups, n_groups, upstream,
+                                                              n_ops, state0, op_scale, out64, value_part, xcd_states, stream);
+  return hipErrorInvalidValue;
 }
 
 }  // namespace qhbm

@@ -128,12 +128,15 @@ def spill_sites(body):
 def default_selectable(name):
   """Kernels the planner picks WITHOUT options: lean pass kernels (every gate kind is lowered to X powers and phases, so
   the GENERAL variants -- `<..., true>` -- run only under `force_general_kernels`), tiles of 2^10 .. 2^14, both row modes of
-  the exchange adjoint kernel, and the observable kernels but the far launches of the two-level sweep."""
+  the exchange adjoint kernel, and the observable kernels but the far launches of the two-level sweep and the block kernel's
+  shape for blocks of 2^12."""
   if name.startswith("pass_fwd_kernel") or name.startswith("pass_adj_kernel"):
     return name.endswith("false>")
   if name.startswith("apply_observable_kernel"):
     return name.endswith("false>")   # (`<..., true>`: the far launches of the two-level sweep, `observable_far_windows`, default off)
-  return name.startswith(("pass_fwd2_kernel", "pass_adjx_kernel", "observable_blocks_kernel"))
+  if name.startswith("observable_blocks_kernel"):
+    return name.endswith(", 13>")    # (`<..., 12>`: the two-workgroups-per-CU shape, option "observable_block_bits" = 12)
+  return name.startswith(("pass_fwd2_kernel", "pass_adjx_kernel"))
 
 
 def report():

@@ -155,6 +155,9 @@ def test_schedule_options_and_errors():
   assert fwd > 1 and bwd > 1
   with pytest.raises(E.EngineError):
     E.Engine(device=None).set_option("no_such_option", 1)
+  with pytest.raises(E.EngineError):
+    E.Engine(device=None).set_option("observable_block_bits", 11)   # 12 or 13 (include/qhbm_engine.h)
+  E.Engine(device=None).set_option("observable_block_bits", 12)
   bad = E.Engine(device=None)
   with pytest.raises(E.EngineError):
     bad.set_circuit(3, [(O.GATE_CZPOW, 0, 0, -1, 0.0, 1.0)], 0)  # q1 == q0

@@ -69,9 +69,10 @@ def _check(eng, n, gates, params, bits, ops, up):
   return vals.cpu().numpy(), grad.cpu().numpy()
 
 
+@pytest.mark.parametrize("block_bits", [13, 12])   # the shipped shape, and two independent workgroups per CU (option-only)
 @pytest.mark.parametrize("n", [13, 15])
 @pytest.mark.parametrize("n_ops", [1, 3])
-def test_random_pauli_sums_block_kernel_against_oracle(n, n_ops):
+def test_random_pauli_sums_block_kernel_against_oracle(n, n_ops, block_bits):
   rng = np.random.default_rng(100 * n + n_ops)
   gates, names = O.hea_gates(n, 2, "blk")
   params = rng.uniform(-1, 1, len(names))
@@ -79,7 +80,7 @@ def test_random_pauli_sums_block_kernel_against_oracle(n, n_ops):
   bits = rng.integers(0, 2, size=(5, n)).astype(np.int8)
   up = rng.normal(size=(5, n_ops))
   eng = _engine(n, gates, len(names), ops, tile_qubits=10, adjoint_tile_qubits=10, observable_kernel=1,
-                multi_observable_values=1)
+                multi_observable_values=1, observable_block_bits=block_bits)
   v_blk, g_blk = _check(eng, n, gates, params, bits, ops, up)
   # the gather kernel on the same inputs (the values of several observables are then measured in the passes)
   ref = _engine(n, gates, len(names), ops, tile_qubits=10, adjoint_tile_qubits=10, observable_kernel=0)
@@ -88,9 +89,10 @@ def test_random_pauli_sums_block_kernel_against_oracle(n, n_ops):
   np.testing.assert_allclose(g_blk, g_ref.cpu().numpy(), atol=1e-4 * max(1.0, float(np.abs(g_blk).max())), rtol=0)
 
 
-def test_every_sign_half_and_imaginary_variant_one_term_at_a_time():
+@pytest.mark.parametrize("block_bits", [13, 12])
+def test_every_sign_half_and_imaginary_variant_one_term_at_a_time(block_bits):
   """One observable per (slot Z bits, odd x, Y parity) combination at 13 qubits, i.e. one term per jump-table chunk:
-  slot bits of the block layout are index bits 0, 10, 11, 12 = qubits 12, 2, 1, 0."""
+  slot bits of the block layout are index bits 0, 10, 11, 12 = qubits 12, 2, 1, 0 (blocks of 2^12: bit 12 is a block bit)."""
   n = 13
   rng = np.random.default_rng(7)
   gates, names = O.hea_gates(n, 2, "var")
@@ -118,14 +120,15 @@ def test_every_sign_half_and_imaginary_variant_one_term_at_a_time():
         assert (bin(x & z).count("1") & 1) == imag
         ops.append([(float(rng.uniform(0.5, 1.5)), x, z)])
   eng = _engine(n, gates, len(names), ops, tile_qubits=10, adjoint_tile_qubits=10, observable_kernel=1,
-                multi_observable_values=1)
+                multi_observable_values=1, observable_block_bits=block_bits)
   up = rng.normal(size=(3, len(ops)))
   _check(eng, n, gates, params, bits, ops, up)
 
 
+@pytest.mark.parametrize("block_bits", [13, 12])
 @pytest.mark.parametrize("xcd", [0, 1])
-def test_many_masks_at_19_qubits_values_lambda_and_both_xcd_maps(xcd):
-  """64 blocks per state: partner blocks of other workgroups, the pair-halving of the value modes, the XCD maps."""
+def test_many_masks_at_19_qubits_values_lambda_and_both_xcd_maps(xcd, block_bits):
+  """64 (128) blocks per state: partner blocks of other workgroups, the pair-halving of the value modes, the XCD maps."""
   n = 19
   rng = np.random.default_rng(19 + xcd)
   gates, names = O.hea_gates(n, 3, "m19")
@@ -133,7 +136,7 @@ def test_many_masks_at_19_qubits_values_lambda_and_both_xcd_maps(xcd):
   ops = _random_ops(rng, n, 1, 96, p_identity=0.75)
   bits = rng.integers(0, 2, size=(9, n)).astype(np.int8)   # 9: one group of eight states and a remainder
   up = rng.normal(size=(9, 1))
-  eng = _engine(n, gates, len(names), ops, observable_kernel=1, observable_xcd_states=xcd)
+  eng = _engine(n, gates, len(names), ops, observable_kernel=1, observable_xcd_states=xcd, observable_block_bits=block_bits)
   _check(eng, n, gates, params, bits, ops, up)
 
 
