@@ -171,10 +171,6 @@ __device__ __forceinline__ void obs_rows(v4f (&r)[N], const char* lds, uint32_t 
 // block is the buffer (a wave-uniform descriptor in four SGPRs), the row a scalar offset, and the eight loads share
 // ONE 32-bit offset register; flat global loads need eight 64-bit address pairs, which the register file of
 // accumulators + partner rows + prefetch rows has no room for (18 spilled registers).
-#ifndef QHBM_OBS_ADDTID
-#define QHBM_OBS_ADDTID 0
-#endif
-#if !QHBM_OBS_ADDTID
 typedef v4f ObsSet[4];   // one prefetch set: the thread's 16-byte word of four rows
 typedef int v4i __attribute__((ext_vector_type(4)));
 // A thread fetches and stages FOUR rows of its pair column: rows 4 hh .. 4 hh + 3 for half hh (wave-uniform) of the eight of
@@ -216,63 +212,6 @@ __device__ __forceinline__ void obs_stage_(v4f* dst, const v4f (&pf)[4], std::in
 __device__ __forceinline__ void obs_stage(v4f* dst, const v4f (&pf)[4]) {   // dst = buffer + t + 512 row0
   obs_stage_(dst, pf, std::make_integer_sequence<int, 4>{});
 }
-#else
-// The same pipeline with the block staged dword by dword: a wave loads its 1-KiB segment of a row as four
-// buffer_load_dword (lane l: byte 256 j + 4 l -- two full 128-byte lines per instruction) and stores it with four
-// ds_write_addtid_b32 (address = M0 + immediate + 4 l, no address register: 2 cycles per wave-instruction, 128 B/clk/CU
-// against the 79 of ds_write_b128 -- MI355X_MICROARCH.md, LDS).  The LDS image is the same linear block.
-typedef float ObsSet[16];   // one prefetch set: dword j of row p in [4 p + j]
-typedef int v4i __attribute__((ext_vector_type(4)));
-// `lane_off` = 1024 x (wave of the half) + 4 x lane
-template <int BB>
-__device__ __forceinline__ void obs_fetch(ObsSet& pf, const float2* __restrict__ blk, uint32_t lane_off, uint32_t row0) {
-  const uint64_t addr = reinterpret_cast<uint64_t>(blk);
-  const v4i rsi = v4i{int(uint32_t(addr)), int(uint32_t(addr >> 32) & 0xffffu), 8 << BB, 0x00020000};
-  const uint32_t o0 = 8192u * row0, o1 = o0 + 8192u, o2 = o0 + 16384u, o3 = o0 + 24576u;
-#define OBS_LD4(R0_, R1_, R2_, R3_, O_)                                             \
-  "buffer_load_dword %" #R0_ ", %16, %17, %" #O_ " offen" QHBM_OBS_LOAD_MOD "\n\t"            \
-  "buffer_load_dword %" #R1_ ", %16, %17, %" #O_ " offen offset:256" QHBM_OBS_LOAD_MOD "\n\t" \
-  "buffer_load_dword %" #R2_ ", %16, %17, %" #O_ " offen offset:512" QHBM_OBS_LOAD_MOD "\n\t" \
-  "buffer_load_dword %" #R3_ ", %16, %17, %" #O_ " offen offset:768" QHBM_OBS_LOAD_MOD "\n\t"
-  asm volatile(OBS_LD4(0, 1, 2, 3, 18) OBS_LD4(4, 5, 6, 7, 19) OBS_LD4(8, 9, 10, 11, 20) OBS_LD4(12, 13, 14, 15, 21)
-               : "=&v"(pf[0]), "=&v"(pf[1]), "=&v"(pf[2]), "=&v"(pf[3]), "=&v"(pf[4]), "=&v"(pf[5]), "=&v"(pf[6]), "=&v"(pf[7]),
-                 "=&v"(pf[8]), "=&v"(pf[9]), "=&v"(pf[10]), "=&v"(pf[11]), "=&v"(pf[12]), "=&v"(pf[13]), "=&v"(pf[14]), "=&v"(pf[15])
-               : "v"(lane_off), "s"(rsi), "s"(o0), "s"(o1), "s"(o2), "s"(o3));
-#undef OBS_LD4
-}
-#define OBS_SET_RW(pf) "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]), "+v"(pf[6]), "+v"(pf[7]), \
-                       "+v"(pf[8]), "+v"(pf[9]), "+v"(pf[10]), "+v"(pf[11]), "+v"(pf[12]), "+v"(pf[13]), "+v"(pf[14]), "+v"(pf[15])
-template <int NEWER>
-__device__ __forceinline__ void obs_wait_older(ObsSet& pf) {
-  static_assert(NEWER == 0 || NEWER == 1, "two sets");
-  if constexpr (NEWER == 1) asm volatile("s_waitcnt vmcnt(16)" : OBS_SET_RW(pf));
-  else asm volatile("s_waitcnt vmcnt(0)" : OBS_SET_RW(pf));
-}
-// Byte address of a store = M0[15:0] + immediate (16 bits) + 4 lane, the second buffer of a block of 2^13 starts at 64 KiB:
-// its base is split X in M0 + (64 Ki - X) in the immediate, X such that both stay below 64 Ki
-// (M0 <= X + 32 Ki (rows 4..7) + 7 Ki (wave); immediate <= 64 Ki - X + 24 Ki (row) + 768).
-template <int BB> constexpr uint32_t obs_m0_part() { return BB == kObsBlockBits ? 25348u : 0u; }
-// `m0` = obs_m0_part x buffer + 8192 x row0 + 1024 x (wave of the half); BUF: 0 / 1.  M0 is a reserved register the
-// compiler loads right before the few instructions that read it (none in this kernel), so it is not on the clobber list.
-#define OBS_ST4(R0_, R1_, R2_, R3_, BASE_, ROW_)                                     \
-  "ds_write_addtid_b32 %" #R0_ " offset:" #BASE_ "+8192*" #ROW_ "\n\t"               \
-  "ds_write_addtid_b32 %" #R1_ " offset:" #BASE_ "+8192*" #ROW_ "+256\n\t"           \
-  "ds_write_addtid_b32 %" #R2_ " offset:" #BASE_ "+8192*" #ROW_ "+512\n\t"           \
-  "ds_write_addtid_b32 %" #R3_ " offset:" #BASE_ "+8192*" #ROW_ "+768\n\t"
-#define OBS_ST16(BASE_) "s_mov_b32 m0, %16\n\t" OBS_ST4(0, 1, 2, 3, BASE_, 0) OBS_ST4(4, 5, 6, 7, BASE_, 1) \
-                        OBS_ST4(8, 9, 10, 11, BASE_, 2) OBS_ST4(12, 13, 14, 15, BASE_, 3)
-#define OBS_SET_R(pf) "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]), "v"(pf[6]), "v"(pf[7]), \
-                      "v"(pf[8]), "v"(pf[9]), "v"(pf[10]), "v"(pf[11]), "v"(pf[12]), "v"(pf[13]), "v"(pf[14]), "v"(pf[15])
-template <int BB, int BUF>
-__device__ __forceinline__ void obs_stage(const ObsSet& pf, uint32_t m0) {
-  // (the asm statement writes memory the compiler does not see: the reads of this buffer are behind the workgroup's
-  // barrier, and obs_stores_done() before that barrier waits for the stores)
-  if constexpr (BUF == 0) asm volatile(OBS_ST16(0) : : OBS_SET_R(pf), "s"(m0));
-  else if constexpr (BB == kObsBlockBits) asm volatile(OBS_ST16(40188) : : OBS_SET_R(pf), "s"(m0));   // 65536 - 25348
-  else asm volatile(OBS_ST16(32768) : : OBS_SET_R(pf), "s"(m0));
-}
-__device__ __forceinline__ void obs_stores_done() { asm volatile("s_waitcnt lgkmcnt(0)"); }
-#endif
 // the second half hands its accumulators to the first through an LDS buffer
 template <int... P>
 __device__ __forceinline__ void obs_acc_out_(v4f* dst, const v2f (&a)[16], std::integer_sequence<int, P...>) {
@@ -428,18 +367,9 @@ __global__ __launch_bounds__(ObsShape<BB>::kThreads, 4) void observable_blocks_k
   uint32_t cur_op = ~0u;  // (several observables: the one d2 is collecting, none yet)
   v2f dq[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
   const uint32_t row0 = 4u * hh;
-#if QHBM_OBS_ADDTID
-  const uint32_t t16 = ((t >> 6) << 10) | ((t & 63u) << 2);   // the lane's dword of its wave's 1-KiB row segment
-  const uint32_t m0a = uni(8192u * row0 + ((t >> 6) << 10)), m0b = m0a + obs_m0_part<BB>();
-  auto stage_a = [&] { obs_stage<BB, 0>(pfa, m0a); };
-  auto stage_b = [&] { obs_stage<BB, 1>(pfb, m0b); };
-  auto stores_done = [] { obs_stores_done(); };
-#else
   const uint32_t t16 = t << 4;
   auto stage_a = [&] { obs_stage(lds4 + t + 512u * row0, pfa); };
   auto stage_b = [&] { obs_stage(lds4 + kOBuf + t + 512u * row0, pfb); };
-  auto stores_done = [] {};   // (the compiler counts its own stores)
-#endif
   // the block a group pairs this one with (past the last group: the block itself -- no branch around the registers)
   auto partner = [&](uint32_t g) { return ps + (size_t(bx ^ (g < n_groups ? groups[g].xout : 0u)) << BB); };
 
@@ -455,7 +385,6 @@ __global__ __launch_bounds__(ObsShape<BB>::kThreads, 4) void observable_blocks_k
   obs_wait_older<1>(pfa);
   stage_a();
   obs_fetch<BB>(pfa, partner(g2), t16, row0);
-  stores_done();
   __syncthreads();
   // Two steps per iteration (the prefetch sets alternate; a run-time choice between them would make the compiler copy
   // them).  Step: the block of g1 moves from its set to the buffer nobody reads in this step, the set is refilled
@@ -512,8 +441,7 @@ __global__ __launch_bounds__(ObsShape<BB>::kThreads, 4) void observable_blocks_k
       OBS_T(2)
       if (skew) refill_b(g3);
       OBS_T(4)
-      stores_done();
-      __syncthreads();
+          __syncthreads();
       OBS_T(3)
       g0 = g1; g1 = g2; g2 = g3;
     }
@@ -527,8 +455,7 @@ __global__ __launch_bounds__(ObsShape<BB>::kThreads, 4) void observable_blocks_k
       OBS_T(2)
       if (skew) refill_a(g3);
       OBS_T(4)
-      stores_done();
-      __syncthreads();
+          __syncthreads();
       OBS_T(3)
       g0 = g1; g1 = g2; g2 = g3;
     }
