@@ -1,7 +1,8 @@
 """Randomised parity stress of the block-grouped Pauli-sum kernels against the numpy oracle (developer tool; GPU):
 qubit counts 13..18, 1..4 observables, sparse and dense strings, 1..11 states (whole groups of eight AND leftovers:
 both XCD maps and both pivot rules of the value modes), values / VJP / retained backward.
-    python scripts/experiments/stress_observable_blocks.py [seeds [first seed]]"""
+    python scripts/experiments/stress_observable_blocks.py [seeds [first seed]]
+(QHBM_OBS_BLOCK_BITS=12 in the environment: the same sweep on the kernel's second shape, option "observable_block_bits".)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "qhbm-library_amd"))
