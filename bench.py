@@ -118,7 +118,7 @@ def cpu_baseline(n, gates, n_params, ops, params, bits, upstream, mode, checker_
   """The CPU baseline BASELINE.md section 3 describes, timed on this host's cores on a bounded sample of the TIMED batch
   itself (its first K bitstrings, same parameters): oracle/qhbm_cpu_diag.c -- the oracle's fp32 statevector algorithm
   with merged diagonal runs, an AVX2 one-qubit kernel and fused adjoint steps, one state per thread -- a reported
-  baseline, never the product (`kind: "port+diag"`).  The CHECKER stays the gate-by-gate restatement oracle/qhbm_cpu.c:
+  baseline, never the product (`kind: "port"`, `variant: "port+diag"`).  The CHECKER stays the gate-by-gate restatement oracle/qhbm_cpu.c:
   it runs on the first `checker_states` of those states (threads inside a state), `parity_check` compares the engine
   with IT, and the record carries how far the timed path is from it on the same states.
   Returns the record, the checker's values [k, n_ops] and [P] VJP (upstream 1/k) and k."""
@@ -141,7 +141,7 @@ def cpu_baseline(n, gates, n_params, ops, params, bits, upstream, mode, checker_
   dt_check = time.perf_counter() - t1
   return {
       "value": states * sum(len(op) for op in ops) / dt, "unit": "evals/s", "cores": int(min(cores, states)),
-      "kind": "port+diag",
+      "kind": "port", "variant": "port+diag",   # (kind: the contract's "reference" | "port"; the variant names WHICH port)
       "sample": f"the first {states} states of the timed batch ({mode} step, same parameters), one state "
                 f"per thread, {dt:.2f} s wall (oracle/qhbm_cpu_diag.c: merged diagonal runs, AVX2 one-qubit kernel, fused "
                 f"adjoint steps; no other gate fusion)",

@@ -49,7 +49,7 @@ def test_bench_single_process_line():
   # the TIMED CPU path is the diagonal-merging one; the CHECKER of parity_check stays the
   # gate-by-gate restatement, and the record says how far the two are apart on the checker's states
   cb = line["cpu_baseline"]
-  assert cb["kind"] == "port+diag" and cb["value"] > 0 and cb["checker"]["states"] == 2
+  assert cb["kind"] == "port" and cb["variant"] == "port+diag" and cb["value"] > 0 and cb["checker"]["states"] == 2
   assert cb["checker"]["max_diff_values_timed_path_vs_checker"] <= 2e-6
   assert cb["checker"]["max_diff_grad_timed_path_vs_checker"] <= 1e-5
   assert line["verify"]["ok"], line["verify"]
