@@ -538,6 +538,13 @@ int upload_model(qhbm_engine* h) {
         begin = g.end;
       }
     };
+    // (the kernel skips a group's gather on same_x bit 0 and trusts that the predecessor fetched EVERY pair, which only bit 1
+    // guarantees: round 5's wrong-value bug was a table with bit 0 alone)
+    auto tables_ok = [](const std::vector<ObsGroup>& groups) {
+      for (const ObsGroup& g : groups)
+        if ((g.same_x & 1u) && !(g.same_x & 2u)) return false;
+      return true;
+    };
     std::vector<DevTerm> full = t;  // (every term, in the gather order: what the block-grouped tables below start from)
     {
       std::vector<ObsGroup> unused;
@@ -569,6 +576,7 @@ int upload_model(qhbm_engine* h) {
         t.swap(rest);
         std::vector<ObsGroup> fg;
         gather_tables(ft, &fg);
+        if (!tables_ok(fg)) return fail(h, "observable tables: a group re-uses partners its predecessor need not have fetched");
         qhbm_engine::FarWindow& w = h->far[h->n_far++];
         HIPCHK(w.terms.upload(ft));
         HIPCHK(w.groups.upload(fg));
@@ -579,6 +587,7 @@ int upload_model(qhbm_engine* h) {
     }
     std::vector<ObsGroup> groups;
     gather_tables(t, &groups);
+    if (!tables_ok(groups)) return fail(h, "observable tables: a group re-uses partners its predecessor need not have fetched");
     if (t.empty()) t.push_back(DevTerm{0.f, 0u, 0u, 0u, 0u});  // (every term went to a far window: the first launch still writes lambda = 0)
     HIPCHK(h->terms.upload(t));
     HIPCHK(h->obs_groups.upload(groups));
