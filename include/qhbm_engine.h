@@ -160,7 +160,9 @@ int qhbm_set_observables(qhbm_engine* h, int n_ops, const int32_t* term_offsets,
  * threads per CU whose two halves split a group's masks; 12 = blocks of 2^12 under TWO independent workgroups of 512 threads
  * per CU, every mask of a group applied by the one workgroup -- measured SLOWER, 94.4 against 51.2 ms for lambda on BASELINE
  * config 4: the co-resident workgroups drift apart and the window of partner blocks leaves the L2, hit rate 0.27 against
- * 0.77; kept for A/B runs),
+ * 0.77; kept for A/B runs), "observable_split_rows" (blocks of 2^13: 1 = the two halves of the workgroup split the block's
+ * ROWS and each applies every mask of a group, instead of splitting the group's masks -- measured SLOWER, 57.6 against 51.3 ms:
+ * twice the instructions per term; 0 = default),
  * "multi_observable_values" (several observables: -1 = their values come from ONE launch of the block kernel over the
  * final states, after lean measurement-free passes, when some term flips two or more qubits and there are at most 64
  * observables; 0 = always measured in the passes; 1 = always from the kernel, up to 256 observables),

@@ -121,6 +121,7 @@ struct qhbm_engine {
   DevBuf<ObsBGroup> obs_bgroups;
   uint32_t n_obs_bgroups = 0;
   int opt_obs_block_bits = kObsBlockBits;  // shape of the block-grouped kernels (kernels.h): 13 or 12
+  int opt_obs_split_rows = 0;              // blocks of 2^13: the halves of the workgroup split the block's rows, not a group's masks
   int opt_obs_kernel = -1;      // lambda = O psi / values: 0 = one gather per mask (apply_observable_kernel), 1 = partner blocks through
                                 // LDS (observable_blocks_kernel), -1 = whichever the fitted cost model prices lower (block_kernel())
   mutable int block_choice = -1;  // cached verdict of block_kernel() (-1: not computed for the installed model / options)
@@ -796,6 +797,9 @@ bool gather_multi_forced(const qhbm_engine* h) {
   return h->opt_gather_multi > 0 && h->model.n_ops >= 2 && h->model.n_ops <= int(kObsGatherMultiOps) &&
          h->opt_values_from_obs != 0 && h->opt_multi_values != 0;
 }
+int obs_block_shape(const qhbm_engine* h) {
+  return h->opt_obs_block_bits == kObsBlockBits && h->opt_obs_split_rows ? kObsShapeRows : h->opt_obs_block_bits;
+}
 bool block_kernel(const qhbm_engine* h) {
   if (gather_multi_forced(h)) return false;
   if (h->fwd.plan.n_eff < kObsBlockBits || h->opt_obs_kernel == 0) return false;
@@ -989,7 +993,7 @@ int run_observable_chunk(qhbm_engine* h, uint32_t s0, uint32_t c, const float* d
   hipEvent_t* ev = timer_begin(h, 2, stream);
   if (block_kernel(h)) {
     const int mode = !value_mode ? OBS_LAMBDA : (store_lambda ? OBS_LAMBDA_VALUE : OBS_VALUES);
-    HIPCHK(launch_observable_blocks(mode, h->opt_obs_block_bits, h->psi.p, store_lambda ? h->lam.p : nullptr, n_eff, c, h->obs_bterms.p,
+    HIPCHK(launch_observable_blocks(mode, obs_block_shape(h), h->psi.p, store_lambda ? h->lam.p : nullptr, n_eff, c, h->obs_bterms.p,
                                     h->obs_bgroups.p, h->n_obs_bgroups, d_upstream, uint32_t(h->model.n_ops), s0,
                                     h->op_scale.p, value_mode ? h->vals64.p : nullptr, h->value_part.p,
                                     observable_xcd_states(h), stream));
@@ -1014,7 +1018,7 @@ int run_values_chunk(qhbm_engine* h, uint32_t row0, uint32_t c, hipStream_t stre
   const uint32_t n_eff = uint32_t(h->fwd.plan.n_eff);
   HIPCHK(h->value_part.reserve(observable_blocks_value_parts(n_eff, c, uint32_t(h->model.n_ops), h->opt_obs_block_bits)));
   hipEvent_t* ev = timer_begin(h, 2, stream);
-  HIPCHK(launch_observable_blocks(OBS_VALUES_MULTI, h->opt_obs_block_bits, h->psi.p, nullptr, n_eff, c, h->obs_bterms.p, h->obs_bgroups.p,
+  HIPCHK(launch_observable_blocks(OBS_VALUES_MULTI, obs_block_shape(h), h->psi.p, nullptr, n_eff, c, h->obs_bterms.p, h->obs_bgroups.p,
                                   h->n_obs_bgroups, nullptr, uint32_t(h->model.n_ops), row0, h->op_scale.p, h->vals64.p,
                                   h->value_part.p, observable_xcd_states(h), stream));
   timer_end(ev, stream);
@@ -1152,8 +1156,9 @@ int qhbm_create(int device, qhbm_engine** out) {
   if (!out) return fail(nullptr, "out is NULL");
   std::unique_ptr<qhbm_engine> h(new qhbm_engine());
   h->device = device;
-  if (const char* bb = std::getenv("QHBM_OBS_BLOCK_BITS"))  // (A/B runs of whole programs: the option's default)
+  if (const char* bb = std::getenv("QHBM_OBS_BLOCK_BITS"))  // (A/B runs of whole programs: the options' defaults)
     if (std::atoi(bb) == kObsBlockBits || std::atoi(bb) == kObsBlockBitsSmall) h->opt_obs_block_bits = std::atoi(bb);
+  if (const char* sr = std::getenv("QHBM_OBS_SPLIT_ROWS")) h->opt_obs_split_rows = std::atoi(sr) != 0;
   if (device >= 0) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -1302,6 +1307,7 @@ int qhbm_set_option(qhbm_engine* h, const char* name, int64_t value) {
   else if (k == "wide_last_pass") { h->opt_wide_last = int(value); h->plans_valid = false; }
   else if (k == "observable_xcd_states") h->opt_obs_xcd_states = int(value);
   else if (k == "observable_kernel") { h->opt_obs_kernel = int(value); h->block_choice = -1; }
+  else if (k == "observable_split_rows") h->opt_obs_split_rows = value != 0;
   else if (k == "observable_block_bits") {
     if (value != kObsBlockBits && value != kObsBlockBitsSmall) return fail(h, "observable_block_bits: 12 or 13");
     h->opt_obs_block_bits = int(value); h->block_choice = -1; h->terms.release(); h->model_uploaded = false;

@@ -64,6 +64,7 @@ constexpr uint32_t kObsTermChunk = 512;  // 2 x the terms staged in LDS at a tim
 // their groups (engine option "observable_block_bits").
 constexpr int kObsBlockBits = 13;      // the larger shape: what the engine requires of a state before it picks these kernels
 constexpr int kObsBlockBitsSmall = 12;
+constexpr int kObsShapeRows = 113;     // launch_observable_blocks `block_bits`: blocks of 2^13 (the tables of 13), the halves split the ROWS
 constexpr uint32_t kObsNewMask = 1u << 12;   // ObsBTerm::meta: the term's x differs from the previous term's
 constexpr uint32_t kObsMaxValueOps = 256;    // per-op value cells of a workgroup (one row per wave: 16 KiB) must fit LDS
 struct ObsBTerm {  // 32 bytes, one s_load_dwordx8: everything the kernel would otherwise derive per term with scalar ALU work

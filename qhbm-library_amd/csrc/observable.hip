@@ -30,6 +30,10 @@
 // (Round 6, BB = 12 below: blocks of 2^12 under two INDEPENDENT workgroups of 512 threads per CU -- the same 2-MiB footprint
 // per XCD, one workgroup's store burst under the other's masks -- measured 94.4 against 51.2 ms: co-resident workgroups
 // drift apart by whole windows, hit rate 0.27, 20 GB of fabric reads.  profiles/r06_obs_block_bits.txt; option-only.)
+// (Round 6, BB = kObsShapeRows: this workgroup, the halves splitting the block's ROWS instead of a group's masks -- every mask
+// on both halves, four pairs per thread, no idle half, no merge, 72 - 96 registers: 57.6 against 51.3 ms; with the spare
+// registers holding the partner rows of a second mask, two masks per LDS wait: 67.2.  The mask phase is bound by instruction
+// issue, not by a wave's LDS latency: what halves the work per instruction or adds branches loses.  Option-only.)
 // Pipeline per group: the block of group s + 1 goes from registers to the OTHER of two 64-KiB LDS buffers while the
 // masks of group s are applied from the first; the blocks of groups s + 2 and s + 3 are in flight in the two
 // four-row prefetch sets of every thread (128 KiB per CU); ONE barrier per group.  The two halves do the store burst
@@ -63,16 +67,22 @@ namespace {
 constexpr uint32_t kOH = 512;                                // threads of one half: one per column of adjacent pairs
 // The two shapes (kernels.h): BB = 13 -- one workgroup of two halves per CU, eight pairs per thread; BB = 12 -- two
 // independent workgroups of 512 threads per CU, four pairs per thread, every mask of a group applied by the one "half".
+// BB = kObsShapeRows: the block of 2^13 and the one workgroup of the first shape, but the halves split the block's ROWS (half hh
+// owns rows 4 hh .. 4 hh + 3 of every pair column: four pairs per thread) and each applies EVERY mask of a group to its
+// rows -- no idle half in a group of one mask, no merge at the end, and half the accumulator and partner registers.
 template <int BB>
 struct ObsShape {
-  static_assert(BB == kObsBlockBits || BB == kObsBlockBitsSmall, "two shapes");
-  static constexpr bool kHalves = BB == kObsBlockBits;
+  static_assert(BB == kObsBlockBits || BB == kObsBlockBitsSmall || BB == kObsShapeRows, "three shapes");
+  static constexpr int kBits = BB == kObsBlockBitsSmall ? kObsBlockBitsSmall : kObsBlockBits;
+  static constexpr bool kHalves = BB != kObsBlockBitsSmall;       // a workgroup of two halves
+  static constexpr bool kByTerms = BB == kObsBlockBits;           // the halves split a group's MASKS (else: the rows, or nothing)
+  static constexpr bool kByRows = BB == kObsShapeRows;
   static constexpr uint32_t kThreads = kHalves ? 2 * kOH : kOH;   // per workgroup
-  static constexpr uint32_t kPairs = kHalves ? 8 : 4;             // adjacent pairs per thread
-  static constexpr uint32_t kBlock = 1u << BB;                    // amplitudes per block
+  static constexpr uint32_t kPairs = kByTerms ? 8 : 4;            // adjacent pairs per thread
+  static constexpr uint32_t kBlock = 1u << kBits;                 // amplitudes per block
   static constexpr uint32_t kWaves = kThreads / 64;
   static constexpr uint32_t kBuf = kBlock / 2;                    // 16-byte words of one LDS block buffer
-  static_assert(kOH * kPairs * 2 == kBlock, "512 threads x their pairs = one block");
+  static_assert(kOH * kPairs * 2 * (kByRows ? 2 : 1) == kBlock, "512 threads x their pairs (x 2 halves of rows) = one block");
 };
 
 // 16-byte words as a NATIVE vector type: copies of HIP's v4f struct become memcpy calls between address spaces,
@@ -150,6 +160,9 @@ __device__ __forceinline__ void obs_term(v2f (&a)[8], const v4f (&r)[4], v2f w, 
 #ifndef QHBM_OBS_SKEW
 #define QHBM_OBS_SKEW 1
 #endif
+#ifndef QHBM_OBS_ROWS_PAIRED
+#define QHBM_OBS_ROWS_PAIRED 0   // (rows shape, 1: the partner rows of two masks per LDS wait -- measured slower: 67.2 against 57.6 ms)
+#endif
 #ifndef QHBM_OBS_LOAD_MOD
 #define QHBM_OBS_LOAD_MOD ""  // cache-policy bits of the partner-block loads (A/B builds: " nt", " sc1", ...)
 #endif
@@ -186,7 +199,7 @@ __device__ __forceinline__ void obs_fetch(v4f (&pf)[4], const float2* __restrict
   // 0x00020000: the raw-buffer word 3 of gfx90a / gfx942 / gfx950 (32-bit data format, no swizzle)
   // (descriptor words: base[31:0] | base[47:32], stride 0 | bytes of the block | word 3)
   const uint64_t addr = reinterpret_cast<uint64_t>(blk);
-  const v4i rsi = v4i{int(uint32_t(addr)), int(uint32_t(addr >> 32) & 0xffffu), 8 << BB, 0x00020000};
+  const v4i rsi = v4i{int(uint32_t(addr)), int(uint32_t(addr >> 32) & 0xffffu), 8 << ObsShape<BB>::kBits, 0x00020000};
   const uint32_t o0 = 8192u * row0, o1 = o0 + 8192u, o2 = o0 + 16384u, o3 = o0 + 24576u;
   asm volatile("buffer_load_dwordx4 %0, %4, %5, %6 offen" QHBM_OBS_LOAD_MOD "\n\t"
                "buffer_load_dwordx4 %1, %4, %5, %7 offen" QHBM_OBS_LOAD_MOD "\n\t"
@@ -268,15 +281,29 @@ struct ObsCtx {
   const char* lds;   // the workgroup's LDS (byte address 0 of the dynamic array)
   float* cells;
   uint32_t n_ops, bx, t, tid;
+  uint32_t row_bytes;   // LDS byte offset of the thread's first row (rows split between the halves: 0 or 4 x 8192)
+  bool second;          // the thread's slots are 8..15 of the block layout (variant offset off1)
 };
 
 // One term on the thread's slots (2 NP of them: NP rows of adjacent pairs), from its 32-byte record.
 template <int MODE, int NP>
+__device__ __forceinline__ void obs_term_rows(const ObsCtx<MODE>& c, const ObsBTerm& t, uint32_t cur_bytes, v4f (&r)[NP]) {
+  obs_rows(r, c.lds, ((c.t << 4) | c.row_bytes | cur_bytes) ^ t.xrow);
+}
+template <int MODE, int NP>
+__device__ __forceinline__ void obs_term_math(const ObsCtx<MODE>& c, const ObsBTerm t, float pair_weight,
+                                              v2f (&a)[2 * NP], v4f (&r)[NP], v2f& d2, uint32_t& cur_op, v2f (&dq)[4]);
+template <int MODE, int NP>
 __device__ __forceinline__ void obs_one_term(const ObsCtx<MODE>& c, const ObsBTerm t, uint32_t cur_bytes, float pair_weight,
                                              v2f (&a)[2 * NP], v4f (&r)[NP], v2f& d2, uint32_t& cur_op, v2f (&dq)[4]) {
+  if (t.meta & kObsNewMask) obs_term_rows<MODE, NP>(c, t, cur_bytes, r);
+  obs_term_math<MODE, NP>(c, t, pair_weight, a, r, d2, cur_op, dq);
+}
+template <int MODE, int NP>
+__device__ __forceinline__ void obs_term_math(const ObsCtx<MODE>& c, const ObsBTerm t, float pair_weight,
+                                              v2f (&a)[2 * NP], v4f (&r)[NP], v2f& d2, uint32_t& cur_op, v2f (&dq)[4]) {
   constexpr bool ACC = MODE == OBS_LAMBDA || MODE == OBS_LAMBDA_VALUE;
   constexpr bool MULTI = MODE == OBS_VALUES_MULTI;
-  if (t.meta & kObsNewMask) obs_rows(r, c.lds, ((c.t << 4) | cur_bytes) ^ t.xrow);
   const uint32_t op = t.meta & 1023u;
   float wv = t.coeff * pair_weight;
   if constexpr (MODE == OBS_LAMBDA) wv *= c.up[op];
@@ -286,7 +313,7 @@ __device__ __forceinline__ void obs_one_term(const ObsCtx<MODE>& c, const ObsBTe
   const float wp = __uint_as_float(__float_as_uint(wv) ^ (sg << 31));
   const v2f w = v2f{wp, -wp};
   v2f s[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
-  obs_term<ACC>(a, r, w, s, t.off0, t.off1);
+  obs_term<ACC>(a, r, w, s, c.second ? t.off1 : t.off0, t.off1);
   if constexpr (!ACC) {
     const v2f inc = wp * ((s[0] + s[1]) + (s[2] + s[3]));
     if constexpr (MULTI) {
@@ -324,8 +351,8 @@ __global__ __launch_bounds__(ObsShape<BB>::kThreads, 4) void observable_blocks_k
   constexpr bool HALVE = !ACC;
   constexpr bool MULTI = MODE == OBS_VALUES_MULTI;
   using Shape = ObsShape<BB>;
-  constexpr bool HALVES = Shape::kHalves;
-  constexpr int NP = int(Shape::kPairs);
+  constexpr bool HALVES = Shape::kHalves, BYTERMS = Shape::kByTerms, BYROWS = Shape::kByRows;
+  constexpr int NP = int(Shape::kPairs), BITS = Shape::kBits;
   constexpr uint32_t kOT = Shape::kThreads, kOWaves = Shape::kWaves, kOBuf = Shape::kBuf, kOBlock = Shape::kBlock;
   extern __shared__ v4f lds4[];  // two block buffers of kOBuf 16-byte words; then the value cells
   float* cells = reinterpret_cast<float*>(lds4 + 2 * kOBuf);
@@ -349,9 +376,11 @@ __global__ __launch_bounds__(ObsShape<BB>::kThreads, 4) void observable_blocks_k
   }
   const uint32_t tid = threadIdx.x, t = tid & (kOH - 1u), hh = HALVES ? uni(tid >> 9) : 0u;
   const float2* ps = psi + (size_t(s_local) << n);
-  const v4f* own4 = reinterpret_cast<const v4f*>(ps + (size_t(bx) << BB)) + t;
+  const uint32_t own_row0 = BYROWS ? 4u * hh : 0u;   // the first row of the block this thread accumulates
+  const v4f* own4 = reinterpret_cast<const v4f*>(ps + (size_t(bx) << BITS)) + t + 512u * own_row0;
   ObsCtx<MODE> c;
   c.terms = terms; c.lds = reinterpret_cast<const char*>(lds4); c.cells = cells; c.n_ops = n_ops; c.bx = bx; c.t = t; c.tid = tid;
+  c.row_bytes = own_row0 << 13; c.second = BYROWS && hh;
   c.up = MODE == OBS_LAMBDA ? upstream + size_t(state0 + s_local) * n_ops : nullptr;
 
   v2f a[2 * NP];
@@ -361,8 +390,9 @@ __global__ __launch_bounds__(ObsShape<BB>::kThreads, 4) void observable_blocks_k
     for (uint32_t i = tid; i < kOWaves * n_ops; i += kOT) cells[i] = 0.f;
   }
   v4f r[NP];
+  [[maybe_unused]] v4f r2[NP];   // (rows split between the halves: the partner rows of a SECOND mask, read with the first's)
   ObsSet pfa, pfb;
-  obs_rows(r, c.lds, t << 4);  // (defined values before the first mask; never used)
+  obs_rows(r, c.lds, (t << 4) | c.row_bytes);  // (defined values before the first mask; never used)
   v2f d2 = v2f{0.f, 0.f};  // value modes: sum_k W_k (own . partner), both halves
   uint32_t cur_op = ~0u;  // (several observables: the one d2 is collecting, none yet)
   v2f dq[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
@@ -371,7 +401,7 @@ __global__ __launch_bounds__(ObsShape<BB>::kThreads, 4) void observable_blocks_k
   auto stage_a = [&] { obs_stage(lds4 + t + 512u * row0, pfa); };
   auto stage_b = [&] { obs_stage(lds4 + kOBuf + t + 512u * row0, pfb); };
   // the block a group pairs this one with (past the last group: the block itself -- no branch around the registers)
-  auto partner = [&](uint32_t g) { return ps + (size_t(bx ^ (g < n_groups ? groups[g].xout : 0u)) << BB); };
+  auto partner = [&](uint32_t g) { return ps + (size_t(bx ^ (g < n_groups ? groups[g].xout : 0u)) << BITS); };
 
   // groups of the next four steps
   uint32_t g0 = obs_next_group<HALVE>(groups, n_groups, 0u, bx, pivot_mask);
@@ -391,8 +421,36 @@ __global__ __launch_bounds__(ObsShape<BB>::kThreads, 4) void observable_blocks_k
   // with the block of g3, the masks of g0 (this half's share) are applied from the other buffer; one barrier.
   auto terms_of = [&](const ObsBGroup gr, uint32_t cur_bytes) {
     const float pair_weight = (!ACC && gr.xout != 0u) ? 2.f : 1.f;
-    uint32_t k = HALVES && hh ? gr.mid : gr.begin;
-    const uint32_t k1 = HALVES && !hh ? gr.mid : gr.end;  // this half's masks (blocks of 2^12: all of them)
+    uint32_t k = BYTERMS && hh ? gr.mid : gr.begin;
+    const uint32_t k1 = BYTERMS && !hh ? gr.mid : gr.end;  // this half's masks (the other shapes: all of them)
+    if constexpr (BYROWS && QHBM_OBS_ROWS_PAIRED) {
+      // Four pairs per thread leave registers for a second set of partner rows: the rows of TWO masks are read together and
+      // waited for once (a wave pays the LDS latency once per two terms).  A term on the mask of its predecessor re-reads
+      // the rows when the predecessor's sat in the second set.
+      if (k < k1) {
+        ObsBTerm ta = terms[k];
+        bool reread = false;
+        for (;;) {
+          const ObsBTerm tb = terms[k + 1u];
+          const bool pair = k + 1u < k1 && (tb.meta & kObsNewMask);
+          if ((ta.meta & kObsNewMask) || reread) obs_term_rows<MODE, NP>(c, ta, cur_bytes, r);
+          if (pair) obs_term_rows<MODE, NP>(c, tb, cur_bytes, r2);
+          obs_term_math<MODE, NP>(c, ta, pair_weight, a, r, d2, cur_op, dq);
+          if (pair) {
+            obs_term_math<MODE, NP>(c, tb, pair_weight, a, r2, d2, cur_op, dq);
+            k += 2u;
+            if (k >= k1) break;
+            ta = terms[k];
+            reread = true;
+          } else {
+            if (++k >= k1) break;
+            ta = tb;
+            reread = false;
+          }
+        }
+      }
+      return;
+    }
     // two records in flight: the scalar load of the next one runs behind the arithmetic of the current one (the
     // array is padded by one record)
     if (k < k1) {
@@ -470,14 +528,14 @@ __global__ __launch_bounds__(ObsShape<BB>::kThreads, 4) void observable_blocks_k
 
   v4f* const buf0 = lds4;
   if constexpr (ACC) {
-    if constexpr (HALVES) {
+    if constexpr (BYTERMS) {
       // the second half's accumulators join the first half's through an LDS buffer (every wave is past its last read)
       if (hh) obs_acc_out_(buf0 + t, a, std::make_integer_sequence<int, 8>{});
       __syncthreads();
       if (!hh) obs_acc_in_(a, buf0 + t, std::make_integer_sequence<int, 8>{});
     }
-    if (!hh && lam)
-      obs_store_(reinterpret_cast<v4f*>(lam + (size_t(s_local) << n) + (size_t(bx) << BB)) + t, a,
+    if ((!BYTERMS || !hh) && lam)
+      obs_store_(reinterpret_cast<v4f*>(lam + (size_t(s_local) << n) + (size_t(bx) << BITS)) + t + 512u * own_row0, a,
                  std::make_integer_sequence<int, NP>{});
   }
   if constexpr (MODE == OBS_LAMBDA) return;
@@ -507,7 +565,7 @@ __global__ __launch_bounds__(ObsShape<BB>::kThreads, 4) void observable_blocks_k
   } else {
     float e;
     if constexpr (MODE == OBS_LAMBDA_VALUE) {  // <psi|O|psi> = sum_j Re(conj(psi_j) lambda_j): the first half holds lambda
-      e = hh ? 0.f : obs_energy_(own4, a, std::make_integer_sequence<int, NP>{});
+      e = (BYTERMS && hh) ? 0.f : obs_energy_(own4, a, std::make_integer_sequence<int, NP>{});
     } else {
       e = d2.x + d2.y;
     }
@@ -569,9 +627,9 @@ hipError_t launch_observable_blocks_shape(int mode, const float2* psi, float2* l
                                     unsigned long long* out64, float* value_part, bool xcd_states, hipStream_t stream) {
   using Shape = ObsShape<BB>;
   constexpr uint32_t kOBlock = Shape::kBlock, kOWaves = Shape::kWaves, kOT = Shape::kThreads;
-  if (n < uint32_t(BB) || n_states == 0) return n_states ? hipErrorInvalidValue : hipSuccess;
+  if (n < uint32_t(Shape::kBits) || n_states == 0) return n_states ? hipErrorInvalidValue : hipSuccess;
   if (mode == OBS_VALUES_MULTI && n_ops > kObsMaxValueOps) return hipErrorInvalidValue;
-  const uint32_t nb = 1u << (n - uint32_t(BB));
+  const uint32_t nb = 1u << (n - uint32_t(Shape::kBits));
   // (a state must at least fill an XCD's workgroup slots: 32 CUs x the workgroups of a CU)
   const uint32_t xs = xcd_states && nb >= (Shape::kHalves ? 64u : 128u) ? 1u : 0u;
   // the largest cell area any mode uses, so that every instantiation is opted in once for the same size
@@ -616,6 +674,9 @@ hipError_t launch_observable_blocks(int mode, int block_bits, const float2* psi,
   if (block_bits == kObsBlockBitsSmall)
     return launch_observable_blocks_shape<kObsBlockBitsSmall>(mode, psi, lam, n, n_states, terms, groups, n_groups, upstream,
                                                               n_ops, state0, op_scale, out64, value_part, xcd_states, stream);
+  if (block_bits == kObsShapeRows)
+    return launch_observable_blocks_shape<kObsShapeRows>(mode, psi, lam, n, n_states, terms, groups, n_groups, upstream, n_ops,
+                                                         state0, op_scale, out64, value_part, xcd_states, stream);
   return hipErrorInvalidValue;
 }
 

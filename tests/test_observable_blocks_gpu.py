@@ -89,7 +89,7 @@ def test_random_pauli_sums_block_kernel_against_oracle(n, n_ops, block_bits):
   np.testing.assert_allclose(g_blk, g_ref.cpu().numpy(), atol=1e-4 * max(1.0, float(np.abs(g_blk).max())), rtol=0)
 
 
-@pytest.mark.parametrize("block_bits", [13, 12])
+@pytest.mark.parametrize("block_bits", [13, 12, 113])   # 113: blocks of 2^13, the halves split the rows (observable_split_rows)
 def test_every_sign_half_and_imaginary_variant_one_term_at_a_time(block_bits):
   """One observable per (slot Z bits, odd x, Y parity) combination at 13 qubits, i.e. one term per jump-table chunk:
   slot bits of the block layout are index bits 0, 10, 11, 12 = qubits 12, 2, 1, 0 (blocks of 2^12: bit 12 is a block bit)."""
@@ -120,12 +120,12 @@ def test_every_sign_half_and_imaginary_variant_one_term_at_a_time(block_bits):
         assert (bin(x & z).count("1") & 1) == imag
         ops.append([(float(rng.uniform(0.5, 1.5)), x, z)])
   eng = _engine(n, gates, len(names), ops, tile_qubits=10, adjoint_tile_qubits=10, observable_kernel=1,
-                multi_observable_values=1, observable_block_bits=block_bits)
+                multi_observable_values=1, observable_block_bits=min(block_bits, 13), observable_split_rows=int(block_bits == 113))
   up = rng.normal(size=(3, len(ops)))
   _check(eng, n, gates, params, bits, ops, up)
 
 
-@pytest.mark.parametrize("block_bits", [13, 12])
+@pytest.mark.parametrize("block_bits", [13, 12, 113])
 @pytest.mark.parametrize("xcd", [0, 1])
 def test_many_masks_at_19_qubits_values_lambda_and_both_xcd_maps(xcd, block_bits):
   """64 (128) blocks per state: partner blocks of other workgroups, the pair-halving of the value modes, the XCD maps."""
@@ -136,7 +136,8 @@ def test_many_masks_at_19_qubits_values_lambda_and_both_xcd_maps(xcd, block_bits
   ops = _random_ops(rng, n, 1, 96, p_identity=0.75)
   bits = rng.integers(0, 2, size=(9, n)).astype(np.int8)   # 9: one group of eight states and a remainder
   up = rng.normal(size=(9, 1))
-  eng = _engine(n, gates, len(names), ops, observable_kernel=1, observable_xcd_states=xcd, observable_block_bits=block_bits)
+  eng = _engine(n, gates, len(names), ops, observable_kernel=1, observable_xcd_states=xcd, observable_block_bits=min(block_bits, 13),
+                observable_split_rows=int(block_bits == 113))
   _check(eng, n, gates, params, bits, ops, up)
 
 

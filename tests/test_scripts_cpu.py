@@ -39,7 +39,7 @@ def test_the_block_observable_kernels_compile_without_register_spills():
     field = lambda name: int(re.search(name + r"[^:]*: (\d+)", b).group(1))
     assert field("VGPRs Spill") == 0 and field("SGPRs Spill") == 0 and field("ScratchSize") == 0, b[:400]
     assert field("VGPRs") <= 128 and field("Occupancy") >= 4, b[:400]
-  assert seen == 8   # four modes x the two shapes (blocks of 2^13 and of 2^12)
+  assert seen == 12   # four modes x the three shapes (blocks of 2^13 split by masks / by rows, blocks of 2^12)
 
 
 def test_published_counter_profiles_carry_the_hash_of_the_kernels_they_were_taken_on():
