@@ -171,9 +171,13 @@ __device__ __forceinline__ void obs_term(v2f (&a)[8], const v4f (&r)[4], v2f w, 
 // (Measured and dropped: the rows as immediate ds_read offsets behind an 8-way jump table like the term variants --
 // 15 vector instructions fewer per term, the LDS wait inside the asm statement -- 51.4 -> 52.5 ms on config 4: the mask
 // phase is bound by the LDS reads themselves, 8 KiB per wave and term, not by VALU issue.)
+// The reads go through ABSOLUTE LDS addresses (the workgroup's dynamic array starts at LDS byte 0: the kernel has no static
+// LDS, checked once per workgroup): `lds + offset` on the array's symbol costs a v_add_u32 with a link-time 0 per row -- eight
+// instructions per mask in a phase that is bound by instruction issue.
+typedef const v4f __attribute__((address_space(3))) * ObsLdsWord;
 template <int N, int... P>
-__device__ __forceinline__ void obs_rows_(v4f (&r)[N], const char* lds, uint32_t base, std::integer_sequence<int, P...>) {
-  ((r[P] = *reinterpret_cast<const v4f*>(lds + (base ^ uint32_t(P << 13)))), ...);
+__device__ __forceinline__ void obs_rows_(v4f (&r)[N], const char*, uint32_t base, std::integer_sequence<int, P...>) {
+  ((r[P] = *reinterpret_cast<ObsLdsWord>(uintptr_t(base ^ uint32_t(P << 13)))), ...);
 }
 template <int N>
 __device__ __forceinline__ void obs_rows(v4f (&r)[N], const char* lds, uint32_t base) {
@@ -356,6 +360,8 @@ __global__ __launch_bounds__(ObsShape<BB>::kThreads, 4) void observable_blocks_k
   constexpr uint32_t kOT = Shape::kThreads, kOWaves = Shape::kWaves, kOBuf = Shape::kBuf, kOBlock = Shape::kBlock;
   extern __shared__ v4f lds4[];  // two block buffers of kOBuf 16-byte words; then the value cells
   float* cells = reinterpret_cast<float*>(lds4 + 2 * kOBuf);
+  // (obs_rows reads absolute LDS addresses)
+  if (uint32_t(uintptr_t((__attribute__((address_space(3))) char*)(lds4))) != 0u) __builtin_trap();
   // Workgroup -> (state, block).  Workgroups are dealt round-robin to the 8 XCDs (linear id mod 8), each with its own L2:
   //   xcd_states: XCD k works on state 8 g + k, its blocks in index order;
   //   otherwise XCD k takes the k-th contiguous eighth of every state.
