@@ -575,6 +575,33 @@ __device__ __forceinline__ void round_store(float2* __restrict__ tile, uint32_t 
   round_store_<R>(reinterpret_cast<char*>(tile), T, DB, a, iseq<(1 << R)>{});
 }
 
+// The same exchange for a tile that starts at LDS byte 0 (the paired forward kernel and the exchange adjoint kernel: their
+// only LDS is the dynamic array, checked once per workgroup by lds_tile_at_zero): the accesses go through ABSOLUTE LDS
+// addresses.  `base + addr` on the array's symbol costs a v_add_u32 with a link-time 0 per access -- 2^R per exchange, none
+// of which the compiler can fold (the XOR walk keeps `addr` out of the instruction's offset field).
+typedef v2f __attribute__((address_space(3))) * LdsPair;
+__device__ __forceinline__ void lds_tile_at_zero(const void* tile) {
+  if (uint32_t(uintptr_t((__attribute__((address_space(3))) const char*)(tile))) != 0u) __builtin_trap();
+}
+template <int R, int... I>
+__device__ __forceinline__ void round_load0_(uint32_t addr, const uint32_t (&DB)[R], v2f (&a)[1 << R],
+                                             std::integer_sequence<int, I...>) {
+  ((addr ^= (I ? DB[I ? __builtin_ctz(I) : 0] : 0u), a[I ^ (I >> 1)] = *reinterpret_cast<LdsPair>(uintptr_t(addr))), ...);
+}
+template <int R>
+__device__ __forceinline__ void round_load0(uint32_t T, const uint32_t (&DB)[R], v2f (&a)[1 << R]) {
+  round_load0_<R>(T, DB, a, iseq<(1 << R)>{});
+}
+template <int R, int... I>
+__device__ __forceinline__ void round_store0_(uint32_t addr, const uint32_t (&DB)[R], const v2f (&a)[1 << R],
+                                              std::integer_sequence<int, I...>) {
+  ((addr ^= (I ? DB[I ? __builtin_ctz(I) : 0] : 0u), *reinterpret_cast<LdsPair>(uintptr_t(addr)) = a[I ^ (I >> 1)]), ...);
+}
+template <int R>
+__device__ __forceinline__ void round_store0(uint32_t T, const uint32_t (&DB)[R], const v2f (&a)[1 << R]) {
+  round_store0_<R>(T, DB, a, iseq<(1 << R)>{});
+}
+
 // Dense two-qubit gate applied directly on the LDS tile (not on the hot path of the
 // hardware-efficient ansatz; keeps the register rounds free of 4x4 code).
 // pos0/pos1 = local bit of the first/second qubit; matrix index = (b_q0 << 1) | b_q1.
@@ -1246,6 +1273,7 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_ker
   constexpr int NR = 1 << R;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* xt = reinterpret_cast<float2*>(smem);
+  lds_tile_at_zero(smem);   // (round_load0 / round_store0)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const uint32_t* recs = reinterpret_cast<const uint32_t*>(coef);
@@ -1282,11 +1310,11 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_ker
   v2f p[NR], q[NR];
   commit_tile<K, NT>(xt, ra, tid);
   __syncthreads();
-  round_load<R>(xt, T, DB, p);
+  round_load0<R>(T, DB, p);
   __syncthreads();
   commit_tile<K, NT>(xt, rb, tid);
   __syncthreads();
-  round_load<R>(xt, T, DB, q);
+  round_load0<R>(T, DB, q);
   for (;;) {
     const uint32_t n_inst = (w0 & ~kRoundNoBarrier) >> 8;
     for (uint32_t inst = 0; inst < n_inst; ++inst) {
@@ -1307,13 +1335,13 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_ker
       rec_off = next_off;
       rec_load<1>(recs, rec_off, lane, cur);
     }
-    round_store<R>(xt, T, DB, p);
+    round_store0<R>(T, DB, p);
     if (sync) __syncthreads();
-    round_load<R>(xt, Tn, DBn, p);
+    round_load0<R>(Tn, DBn, p);
     if (sync) __syncthreads();
-    round_store<R>(xt, T, DB, q);
+    round_store0<R>(T, DB, q);
     if (sync) __syncthreads();
-    round_load<R>(xt, Tn, DBn, q);
+    round_load0<R>(Tn, DBn, q);
 #pragma unroll
     for (int j = 0; j < R; ++j) DB[j] = DBn[j];
     T = Tn;
@@ -1321,12 +1349,12 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_fwd2_ker
     w0 = w1;
   }
   if (a.flags & PASS_STORE) {
-    round_store<R>(xt, T, DB, p);
+    round_store0<R>(T, DB, p);
     __syncthreads();
     const ThreadOff o = thread_offsets(t, tid);
     store_tile<K, NT>(xt, st_a, t, o, tid);
     __syncthreads();
-    round_store<R>(xt, T, DB, q);
+    round_store0<R>(T, DB, q);
     __syncthreads();
     if (s_b != s_a) store_tile<K, NT>(xt, st_b, t, o, tid);
   }
@@ -1530,6 +1558,7 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* xt = reinterpret_cast<float2*>(smem);
   float* cells = reinterpret_cast<float*>(xt + (1 << K));  // [kMaxSlotsPerPass][NW]
+  lds_tile_at_zero(smem);   // (round_load0 / round_store0)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1579,11 +1608,11 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   v2f p[NR], l[NR];
   commit_tile<K, NT>(xt, rp, tid);
   __syncthreads();
-  round_load<R>(xt, T, DB, p);
+  round_load0<R>(T, DB, p);
   __syncthreads();
   commit_tile<K, NT>(xt, rl, tid);
   __syncthreads();
-  round_load<R>(xt, T, DB, l);
+  round_load0<R>(T, DB, l);
   [[maybe_unused]] const unsigned long long tk2 = QHBM_TICK();
   [[maybe_unused]] unsigned long long tk_r = tk2;
   for (;;) {
@@ -1621,13 +1650,13 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
       rec_load<1>(recs, rec_off, lane, cur);
       rec_load<1>(recs, rec_off + L.slot0(), lane, sv);
     }
-    round_store<R>(xt, T, DB, p);
+    round_store0<R>(T, DB, p);
     if (sync) __syncthreads();
-    round_load<R>(xt, Tn, DBn, p);
+    round_load0<R>(Tn, DBn, p);
     if (sync) __syncthreads();
-    round_store<R>(xt, T, DB, l);
+    round_store0<R>(T, DB, l);
     if (sync) __syncthreads();
-    round_load<R>(xt, Tn, DBn, l);
+    round_load0<R>(Tn, DBn, l);
 #pragma unroll
     for (int j = 0; j < R; ++j) DB[j] = DBn[j];
     T = Tn;
@@ -1640,25 +1669,25 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
   // instantiations)
   if (a.flags & PASS_RELABEL) {
     const RelabelCtx rc = relabel_lookup<K>(a, tables, in_local, tid, lane);  // (in flight under the exchange below)
-    round_store<R>(xt, T, DB, p);
+    round_store0<R>(T, DB, p);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     store_tile_relabeled<K, NT>(xt, sp, a, rc, t.tile_base, tid);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    round_store<R>(xt, T, DB, l);
+    round_store0<R>(T, DB, l);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     store_tile_relabeled<K, NT>(xt, sl, a, rc, t.tile_base, tid);
   } else if (a.flags & PASS_STORE) {
     const ThreadOff o = thread_offsets<ROWS>(t, tid);
-    round_store<R>(xt, T, DB, p);
+    round_store0<R>(T, DB, p);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     store_tile<K, NT, ROWS>(xt, sp, t, o, tid);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    round_store<R>(xt, T, DB, l);
+    round_store0<R>(T, DB, l);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     store_tile<K, NT, ROWS>(xt, sl, t, o, tid);

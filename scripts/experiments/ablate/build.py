@@ -75,9 +75,9 @@ __device__ __forceinline__ void regs_to_global(const v2f (&a)[16], float2* __res
 }
 template <int K, int ROWS>
 __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_kernel("""),
-        "  commit_tile<K, NT>(xt, rp, tid);\n  __syncthreads();\n  round_load<R>(xt, T, DB, p);\n  __syncthreads();\n  commit_tile<K, NT>(xt, rl, tid);\n  __syncthreads();\n  round_load<R>(xt, T, DB, l);\n",
+        "  commit_tile<K, NT>(xt, rp, tid);\n  __syncthreads();\n  round_load0<R>(T, DB, p);\n  __syncthreads();\n  commit_tile<K, NT>(xt, rl, tid);\n  __syncthreads();\n  round_load0<R>(T, DB, l);\n",
         "  regs_from_tile(p, rp);\n  regs_from_tile(l, rl);\n  __syncthreads();\n"),
-        "    const ThreadOff o = thread_offsets<ROWS>(t, tid);\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    __builtin_amdgcn_sched_barrier(0);\n    store_tile<K, NT, ROWS>(xt, sp, t, o, tid);\n    __builtin_amdgcn_sched_barrier(0);\n    __syncthreads();\n    round_store<R>(xt, T, DB, l);\n    __syncthreads();\n    __builtin_amdgcn_sched_barrier(0);\n    store_tile<K, NT, ROWS>(xt, sl, t, o, tid);\n",
+        "    const ThreadOff o = thread_offsets<ROWS>(t, tid);\n    round_store0<R>(T, DB, p);\n    __syncthreads();\n    __builtin_amdgcn_sched_barrier(0);\n    store_tile<K, NT, ROWS>(xt, sp, t, o, tid);\n    __builtin_amdgcn_sched_barrier(0);\n    __syncthreads();\n    round_store0<R>(T, DB, l);\n    __syncthreads();\n    __builtin_amdgcn_sched_barrier(0);\n    store_tile<K, NT, ROWS>(xt, sl, t, o, tid);\n",
         "    regs_to_global<K, NT>(p, sp, t, tid);\n    regs_to_global<K, NT>(l, sl, t, tid);\n    __syncthreads();\n"),
     "no_x_inner": lambda t: in_instance(t, "g[J] = im_lam_x_psi<R, J>(p, l);", "g[J] = p[0].x;"),
     "no_x_on_lambda": lambda t: in_instance(t, "          apply_x<R, J>(l, cs);\n", ""),
@@ -87,25 +87,25 @@ __global__ __launch_bounds__(1 << (K - 4), adjx_min_waves(K)) void pass_adjx_ker
     "no_cph": lambda t: in_instance(t, "  if (h1 & 0xffu) {", "  if ((h1 & 0xffu) && lane == 77) {", 1),
     "no_ph1_ph2": lambda t: in_instance(in_instance(t, "  if ((h0 >> 16) & 0x3fu) {", "  if (((h0 >> 16) & 0x3fu) && lane == 77) {"),
                                         "  if ((h0 >> 8) & 0xfu) {", "  if (((h0 >> 8) & 0xfu) && lane == 77) {"),
-    "no_exchange": lambda t: once(t, """    round_store<R>(xt, T, DB, p);
+    "no_exchange": lambda t: once(t, """    round_store0<R>(T, DB, p);
     if (sync) __syncthreads();
-    round_load<R>(xt, Tn, DBn, p);
+    round_load0<R>(Tn, DBn, p);
     if (sync) __syncthreads();
-    round_store<R>(xt, T, DB, l);
+    round_store0<R>(T, DB, l);
     if (sync) __syncthreads();
-    round_load<R>(xt, Tn, DBn, l);
+    round_load0<R>(Tn, DBn, l);
 """, ""),
-    "no_barriers": lambda t: once(t, """    round_store<R>(xt, T, DB, p);
+    "no_barriers": lambda t: once(t, """    round_store0<R>(T, DB, p);
     if (sync) __syncthreads();
-    round_load<R>(xt, Tn, DBn, p);
+    round_load0<R>(Tn, DBn, p);
     if (sync) __syncthreads();
-    round_store<R>(xt, T, DB, l);
+    round_store0<R>(T, DB, l);
     if (sync) __syncthreads();
-    round_load<R>(xt, Tn, DBn, l);
-""", """    round_store<R>(xt, T, DB, p);
-    round_load<R>(xt, Tn, DBn, p);
-    round_store<R>(xt, T, DB, l);
-    round_load<R>(xt, Tn, DBn, l);
+    round_load0<R>(Tn, DBn, l);
+""", """    round_store0<R>(T, DB, p);
+    round_load0<R>(Tn, DBn, p);
+    round_store0<R>(T, DB, l);
+    round_load0<R>(Tn, DBn, l);
 """),
     "no_instances": lambda t: once(t, "        instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL | tile_hi, cells);\n        rec_off += L.words();\n        cur[0] = nxt[0];",
                                    "        if (lane == 77) instance_adj<R, NW, false>(cur, sv, recs, rec_off, lane, wave, p, l, TL | tile_hi, cells);\n        rec_off += L.words();\n        cur[0] = nxt[0];"),
@@ -227,15 +227,15 @@ VARIANTS.update({
                                         "      if (lane == 77) instance_fwd_pair<R, 1>(cur, recs, rec_off, p, q, TL | tile_hi);"),
     "fwd2_no_io": lambda t: once(once(t, "  prefetch_tile<K, NT>(ra, st_a, t, toff);\n  prefetch_tile<K, NT>(rb, st_b, t, toff);\n",
                                       "  ra = TileRegs{}; rb = TileRegs{}; ra.p0.x = 1e-3f; rb.p0.y = 1e-3f;\n"),
-                                 "  if (a.flags & PASS_STORE) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    const ThreadOff o = thread_offsets(t, tid);\n    store_tile<K, NT>(xt, st_a, t, o, tid);",
-                                 "  if ((a.flags & PASS_STORE) && tid == 100000) {\n    round_store<R>(xt, T, DB, p);\n    __syncthreads();\n    const ThreadOff o = thread_offsets(t, tid);\n    store_tile<K, NT>(xt, st_a, t, o, tid);"),
-    "fwd2_no_exchange": lambda t: once(t, """    round_store<R>(xt, T, DB, p);
+                                 "  if (a.flags & PASS_STORE) {\n    round_store0<R>(T, DB, p);\n    __syncthreads();\n    const ThreadOff o = thread_offsets(t, tid);\n    store_tile<K, NT>(xt, st_a, t, o, tid);",
+                                 "  if ((a.flags & PASS_STORE) && tid == 100000) {\n    round_store0<R>(T, DB, p);\n    __syncthreads();\n    const ThreadOff o = thread_offsets(t, tid);\n    store_tile<K, NT>(xt, st_a, t, o, tid);"),
+    "fwd2_no_exchange": lambda t: once(t, """    round_store0<R>(T, DB, p);
     if (sync) __syncthreads();
-    round_load<R>(xt, Tn, DBn, p);
+    round_load0<R>(Tn, DBn, p);
     if (sync) __syncthreads();
-    round_store<R>(xt, T, DB, q);
+    round_store0<R>(T, DB, q);
     if (sync) __syncthreads();
-    round_load<R>(xt, Tn, DBn, q);
+    round_load0<R>(Tn, DBn, q);
 """, ""),
 })
 
